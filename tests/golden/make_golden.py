@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (oracle/_ref, built by
+oracle/ref/build_ref.py from /root/reference).  Run in the build container only:
+
+    python oracle/ref/build_ref.py && python tests/golden/make_golden.py
+
+Each fixture stores the reference's own input (its generator), outputs
+(construct_R / construct_Rinv or construct_Q / construct_R dumps, column-major)
+and the value its own validator printed.  The GPU box has no /root/reference;
+tests read only these committed files.
+"""
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REFDIR = os.path.join(REPO, "oracle", "_ref")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+ENV = dict(os.environ, MKL_NUM_THREADS="1")
+
+
+def _kv(line):
+    return {k: v for k, v in re.findall(r"(\w+)=([-+.\dEe]+)", line)}
+
+
+def cholinv_case(name, n, ci, split, bc, pol=0):
+    with tempfile.TemporaryDirectory() as td:
+        dump = os.path.join(td, "d.bin")
+        out = subprocess.check_output([MPIEXEC, "-n", "1", os.path.join(REFDIR, "cholinv_ref"), str(n), str(ci),
+                                       str(split), str(bc), "0", "0", str(pol), dump, "1"], env=ENV).decode()
+        kv = _kv(out)
+        raw = np.fromfile(dump, dtype=np.float64).reshape(3, n, n)
+        # dumps are column-major n x n: raw[k] read row-major is the transpose
+        a, r, ri = (raw[k].T.copy() for k in range(3))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), A=a, R=r, Rinv=ri, n=n, complete_inv=ci, split=split,
+                        bc_mult_dim=bc, policy=pol, ref_residual=float(kv["residual"]), ref_stdout=out.strip())
+    print(name, out.strip())
+
+
+def cholinv_multirank_case(name, cases):
+    """8-rank (2x2x2) runs: only the validator's residual can be recorded (no dump upstream)."""
+    rows = []
+    for (n, ci, split, bc, pol) in cases:
+        out = subprocess.check_output([MPIEXEC, "-n", "8", os.path.join(REFDIR, "cholinv_ref"), str(n), str(ci),
+                                       str(split), str(bc), "0", "0", str(pol), "-", "1"], env=ENV).decode()
+        kv = _kv(out)
+        rows.append((n, ci, split, bc, pol, float(kv["residual"])))
+        print(name, out.strip())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), rows=np.array(rows, dtype=np.float64),
+                        columns="n,complete_inv,split,bc_mult_dim,policy,ref_residual")
+
+
+def cacqr_case(name, variant, m, n):
+    with tempfile.TemporaryDirectory() as td:
+        dump = os.path.join(td, "q.bin")
+        out = subprocess.check_output([MPIEXEC, "-n", "1", os.path.join(REFDIR, "cacqr_ref"), str(variant), str(m),
+                                       str(n), "1", "1", "1", "0", dump, "1"], env=ENV).decode()
+        kv = _kv(out)
+        raw = np.fromfile(dump, dtype=np.float64)
+        a = raw[: m * n].reshape(n, m).T.copy()
+        q = raw[m * n: 2 * m * n].reshape(n, m).T.copy()
+        r = raw[2 * m * n:].reshape(n, n).T.copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), A=a, Q=q, R=r, m=m, n=n, variant=variant,
+                        ref_residual=float(kv["residual"]), ref_orthogonality=float(kv["orthogonality"]),
+                        ref_stdout=out.strip())
+    print(name, out.strip())
+
+
+if __name__ == "__main__":
+    cholinv_case("cholinv_n64_ci0_s1_bc-2", 64, 0, 1, -2)
+    cholinv_case("cholinv_n64_ci1_s1_bc-3", 64, 1, 1, -3)
+    cholinv_case("cholinv_n96_ci1_s1_bc0", 96, 1, 1, 0)
+    cholinv_case("cholinv_n100_ci0_s2_bc-4", 100, 0, 2, -4)
+    cholinv_multirank_case("cholinv_p8_residuals", [(256, 0, 1, -2, 1), (250, 1, 1, -2, 1), (512, 0, 1, -3, 2),
+                                                    (257, 0, 1, -2, 3)])
+    cacqr_case("cacqr1_m192_n12", 1, 192, 12)
+    cacqr_case("cacqr2_m256_n16", 2, 256, 16)
