@@ -1,0 +1,98 @@
+"""ctypes loader for libcapital_amd.so - the product's only compute backend.
+
+Fails loudly if the HIP library is missing: there is no CPU fallback by design."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcapital_amd.so")
+
+_lib = None
+
+i64 = C.c_int64
+dbl = C.c_double
+ptr = C.c_void_p
+cint = C.c_int
+
+# name -> (restype, argtypes); mirrors include/capital_amd.h one to one
+SIGNATURES = {
+    "cap_status_string": (C.c_char_p, [cint]),
+    "cap_device_info": (cint, [C.c_char_p, cint, C.POINTER(cint), C.POINTER(i64)]),
+    "cap_dgemm": (cint, [cint, cint, i64, i64, i64, dbl, ptr, i64, ptr, i64, dbl, ptr, i64, ptr]),
+    "cap_dsyrk": (cint, [cint, cint, i64, i64, dbl, ptr, i64, dbl, ptr, i64, ptr]),
+    "cap_dtrmm": (cint, [cint, cint, cint, cint, i64, i64, dbl, ptr, i64, ptr, i64, ptr, ptr]),
+    "cap_dtrsm": (cint, [cint, cint, cint, i64, i64, dbl, ptr, i64, ptr, i64, ptr, ptr]),
+    "cap_dtrsm_work_size": (i64, [cint, i64, i64]),
+    "cap_dpotrf": (cint, [cint, i64, ptr, i64, ptr, ptr, ptr]),
+    "cap_dpotrf_work_size": (i64, [i64]),
+    "cap_dtrtri": (cint, [cint, i64, ptr, i64, ptr, ptr]),
+    "cap_dtrtri_work_size": (i64, [i64]),
+    "cap_fill_symmetric": (cint, [ptr, i64, i64, i64, i64, i64, cint, ptr]),
+    "cap_fill_random": (cint, [ptr, i64, i64, i64, i64, i64, i64, i64, i64, ptr]),
+    "cap_copy_window": (cint, [ptr, cint, i64, i64, i64, ptr, cint, i64, i64, i64, i64, i64, cint, cint, ptr]),
+    "cap_remove_triangle": (cint, [ptr, i64, i64, i64, i64, i64, i64, cint, ptr]),
+    "cap_cholesky_residual_terms": (cint, [ptr, i64, ptr, i64, i64, ptr, ptr, ptr]),
+    "cap_sumsq": (cint, [ptr, i64, i64, i64, cint, cint, ptr, ptr]),
+    "cap_comm_unique_id": (cint, [ptr]),
+    "cap_comm_create": (cint, [C.POINTER(ptr), ptr, cint, cint, ptr]),
+    "cap_comm_create_self": (cint, [C.POINTER(ptr)]),
+    "cap_comm_destroy": (cint, [ptr]),
+    "cap_comm_rank": (cint, [ptr]),
+    "cap_comm_size": (cint, [ptr]),
+    "cap_comm_allreduce_sum": (cint, [ptr, ptr, i64, ptr]),
+    "cap_comm_bcast": (cint, [ptr, ptr, i64, cint, ptr]),
+    "cap_comm_allgather": (cint, [ptr, ptr, ptr, i64, ptr]),
+    "cap_comm_barrier": (cint, [ptr, ptr]),
+    "cap_cholinv_plan_create": (cint, [C.POINTER(ptr), i64, cint, i64, i64, C.c_char, ptr]),
+    "cap_cholinv_plan_destroy": (cint, [ptr]),
+    "cap_cholinv_factor": (cint, [ptr, ptr, i64, ptr]),
+    "cap_cholinv_get_R": (cint, [ptr, ptr, i64, ptr]),
+    "cap_cholinv_get_Rinv": (cint, [ptr, ptr, i64, ptr]),
+    "cap_cholinv_R_ptr": (ptr, [ptr, C.POINTER(i64)]),
+    "cap_cholinv_Rinv_ptr": (ptr, [ptr, C.POINTER(i64)]),
+    "cap_cholinv_info": (cint, [ptr, ptr, C.POINTER(i64)]),
+    "cap_cholinv_set_option": (cint, [ptr, C.c_char_p, i64]),
+    "cap_cholinv_get_option": (i64, [ptr, C.c_char_p]),
+    "cap_cacqr_plan_create": (cint, [C.POINTER(ptr), i64, i64, cint, ptr]),
+    "cap_cacqr_plan_destroy": (cint, [ptr]),
+    "cap_cacqr_factor": (cint, [ptr, ptr, i64, ptr]),
+    "cap_cacqr_Q_ptr": (ptr, [ptr, C.POINTER(i64)]),
+    "cap_cacqr_R_ptr": (ptr, [ptr, C.POINTER(i64)]),
+    "cap_cacqr_info": (cint, [ptr, ptr, C.POINTER(i64)]),
+}
+
+
+class CapitalError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle with typed signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CapitalError(
+            "libcapital_amd.so not found at %s - build it with `python -m capital_amd.build` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    h = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            f = getattr(h, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        f.restype = res
+        f.argtypes = args
+    if missing:
+        raise CapitalError("libcapital_amd.so lacks symbols declared in include/capital_amd.h: %s" % missing)
+    _lib = h
+    return h
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().cap_status_string(status)
+        raise CapitalError("%s failed: status %d (%s)" % (what or "capital_amd call", status,
+                                                          msg.decode() if msg else "?"))

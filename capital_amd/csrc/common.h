@@ -1,0 +1,37 @@
+// Shared internals of libcapital_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/capital_amd.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+#define CAP_HIP(x)                                                                      \
+  do {                                                                                  \
+    hipError_t e_ = (x);                                                                \
+    if (e_ != hipSuccess) {                                                             \
+      fprintf(stderr, "capital_amd: HIP error '%s' at %s:%d\n", hipGetErrorString(e_),  \
+              __FILE__, __LINE__);                                                      \
+      return CAP_ERR_HIP;                                                               \
+    }                                                                                   \
+  } while (0)
+
+#define CAP_TRY(x)             \
+  do {                         \
+    int s_ = (x);              \
+    if (s_ != CAP_OK) return s_; \
+  } while (0)
+
+static inline hipStream_t cap_stream(void* s) { return (hipStream_t)s; }
+static inline int64_t cap_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t cap_round_up(int64_t a, int64_t b) { return cap_ceil_div(a, b) * b; }
+
+// internal launchers shared between translation units ---------------------------------------
+// C = alpha*op(A)*op(B) + beta*C with optional "upper tiles only" (SYRK-style) masking:
+// tri = 0 full, 1 = only tiles/elements with row <= col (upper), 2 = row >= col (lower).
+int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
+                    int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri,
+                    hipStream_t stream);

@@ -1,0 +1,295 @@
+// fp64 GEMM / SYRK on v_mfma_f64_16x16x4_f64 for gfx950 (MI355X).
+//
+// Replaces blas::engine::_gemm / _syrk (reference blas/interface.hpp:43-59, 81-97, which
+// call cblas_dgemm / cblas_dsyrk).  Column-major, device pointers.
+//
+// Kernel shape (v1):
+//   workgroup 256 threads = 4 waves (2 x 2), C tile 128 x 128, wave tile 64 x 64
+//   = 4 x 4 MFMA blocks of 16 x 16 (128 accumulator registers), K tile BK = 16.
+//   Operands are staged global -> VGPR (16-byte loads) -> LDS (double buffered, one
+//   barrier per K tile).  The LDS image of an operand follows its GLOBAL contiguity so
+//   that both the staging writes (ds_write_b128) and the fragment reads (ds_read_b64)
+//   are bank-conflict free:
+//     K-contiguous operand (op(A)=A^T, op(B)=B):  [outer][BK+2]   (LDK = 18)
+//     M-contiguous operand (op(A)=A,   op(B)=B^T): [k][128+16]    (LDO = 144)
+//   The MFMA is issued with the operands swapped (D' = B-frag x A-frag) so that a lane
+//   holds C[i = lane&15][j = (lane>>4)+4r]: 16 consecutive rows of a column -> 128-byte
+//   store segments in column-major C.
+//   Blocks are remapped XCD-aware: block b runs on XCD b%8; each XCD walks a contiguous
+//   range of 8x8-tile supertiles so its private L2 sees compact A/B panels.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, NTHREADS = 256;
+constexpr int LDK = BK + 2;       // K-contiguous LDS row stride (doubles)
+constexpr int LDO = 128 + 16;     // outer-contiguous LDS row stride (doubles)
+constexpr int TILE_ELEMS = 128 * LDK;  // == BK * LDO == 2304 doubles
+static_assert(128 * LDK == BK * LDO, "both LDS layouts use the same footprint");
+constexpr int ST = 8;             // supertile edge (tiles)
+
+struct GemmArgs {
+  const double* A; const double* B; double* C;
+  int64_t lda, ldb, ldc;
+  int64_t M, N, K;
+  double alpha, beta;
+  int tm, tn;       // tiles in M, N
+  int tri;          // 0 full, 1 upper (row<=col), 2 lower
+  int chunk;        // logical tiles per XCD
+  int nsm, nsn;     // supertiles in M, N
+};
+
+// logical slot -> tile coordinates (returns false when the slot is empty)
+__device__ __forceinline__ bool slot_to_tile(const GemmArgs& g, int L, int& ti, int& tj) {
+  int S = L / (ST * ST), w = L % (ST * ST);
+  int si, sj;
+  if (g.tri == 1) {  // upper triangle of supertiles, column-major: S = sj(sj+1)/2 + si
+    sj = (int)((__builtin_sqrtf(8.0f * (float)S + 1.0f) - 1.0f) * 0.5f);
+    while ((sj + 1) * (sj + 2) / 2 <= S) sj++;
+    while (sj * (sj + 1) / 2 > S) sj--;
+    si = S - sj * (sj + 1) / 2;
+  } else if (g.tri == 2) {
+    si = (int)((__builtin_sqrtf(8.0f * (float)S + 1.0f) - 1.0f) * 0.5f);
+    while ((si + 1) * (si + 2) / 2 <= S) si++;
+    while (si * (si + 1) / 2 > S) si--;
+    sj = S - si * (si + 1) / 2;
+  } else {
+    si = S % g.nsm; sj = S / g.nsm;
+  }
+  if (si >= g.nsm || sj >= g.nsn) return false;
+  ti = si * ST + (w % ST); tj = sj * ST + (w / ST);
+  if (ti >= g.tm || tj >= g.tn) return false;
+  if (g.tri == 1 && ti > tj) return false;
+  if (g.tri == 2 && ti < tj) return false;
+  return true;
+}
+
+// Stage one operand tile (128 outer x BK) from global into registers.
+// KC: element (o, k) at P[k + o*ld];  !KC: element (o, k) at P[o + k*ld].
+template <bool KC, bool EDGE>
+__device__ __forceinline__ void load_tile(const double* __restrict__ P, int64_t ld, int64_t o0, int64_t k0,
+                                          int64_t omax, int64_t kmax, d2 (&r)[4]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    int c = t + NTHREADS * s;
+    if (KC) {
+      int o = c >> 3, k2 = (c & 7) * 2;
+      if (!EDGE) {
+        r[s] = *reinterpret_cast<const d2*>(P + (o0 + o) * ld + k0 + k2);
+      } else {
+        double v0 = 0, v1 = 0;
+        if (o0 + o < omax) {
+          const double* p = P + (o0 + o) * ld + k0 + k2;
+          if (k0 + k2 < kmax) v0 = p[0];
+          if (k0 + k2 + 1 < kmax) v1 = p[1];
+        }
+        r[s] = (d2){v0, v1};
+      }
+    } else {
+      int k = c >> 6, o2 = (c & 63) * 2;
+      if (!EDGE) {
+        r[s] = *reinterpret_cast<const d2*>(P + (k0 + k) * ld + o0 + o2);
+      } else {
+        double v0 = 0, v1 = 0;
+        if (k0 + k < kmax) {
+          const double* p = P + (k0 + k) * ld + o0 + o2;
+          if (o0 + o2 < omax) v0 = p[0];
+          if (o0 + o2 + 1 < omax) v1 = p[1];
+        }
+        r[s] = (d2){v0, v1};
+      }
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(double* __restrict__ lds, const d2 (&r)[4]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    int c = t + NTHREADS * s;
+    int off = KC ? ((c >> 3) * LDK + (c & 7) * 2) : ((c >> 6) * LDO + (c & 63) * 2);
+    *reinterpret_cast<d2*>(lds + off) = r[s];
+  }
+}
+
+template <bool A_KC, bool B_KC, bool EDGE>
+__global__ void __launch_bounds__(NTHREADS, 2) dgemm_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  // block -> XCD-aware logical slot
+  const int b = blockIdx.x;
+  const int L = (b & 7) * g.chunk + (b >> 3);
+  int ti, tj;
+  if ((b >> 3) >= g.chunk || !slot_to_tile(g, L, ti, tj)) return;
+
+  const int64_t i0 = (int64_t)ti * BM, j0 = (int64_t)tj * BN;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wi = (wid & 1) * 64, wj = (wid >> 1) * 64;
+  const int lr = lane & 15, kg = lane >> 4;
+
+  // LDS carve: [A buf0][B buf0][A buf1][B buf1]
+  auto sA = [&](int buf) -> double* { return smem + buf * 2 * TILE_ELEMS; };
+  auto sB = [&](int buf) -> double* { return smem + buf * 2 * TILE_ELEMS + TILE_ELEMS; };
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  const int nk = (int)((g.K + BK - 1) / BK);
+  d2 ra[4], rb[4];
+  if (nk > 0) {
+    load_tile<A_KC, EDGE>(g.A, g.lda, i0, 0, g.M, g.K, ra);
+    load_tile<B_KC, EDGE>(g.B, g.ldb, j0, 0, g.N, g.K, rb);
+    store_tile<A_KC>(sA(0), ra);
+    store_tile<B_KC>(sB(0), rb);
+  }
+  __syncthreads();
+
+  // per-lane fragment base offsets inside an LDS tile
+  const int a_base = A_KC ? ((wi + lr) * LDK + kg) : (kg * LDO + wi + lr);
+  const int b_base = B_KC ? ((wj + lr) * LDK + kg) : (kg * LDO + wj + lr);
+  constexpr int A_SI = A_KC ? 16 * LDK : 16;      // +16 outer
+  constexpr int A_SK = A_KC ? 4 : 4 * LDO;        // +4 in k
+  constexpr int B_SI = B_KC ? 16 * LDK : 16;
+  constexpr int B_SK = B_KC ? 4 : 4 * LDO;
+
+  for (int kt = 0; kt < nk; kt++) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      load_tile<A_KC, EDGE>(g.A, g.lda, i0, (int64_t)(kt + 1) * BK, g.M, g.K, ra);
+      load_tile<B_KC, EDGE>(g.B, g.ldb, j0, (int64_t)(kt + 1) * BK, g.N, g.K, rb);
+    }
+    const double* pa = sA(cur) + a_base;
+    const double* pb = sB(cur) + b_base;
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ks++) {
+      double fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) fa[i] = pa[i * A_SI + ks * A_SK];
+#pragma unroll
+      for (int j = 0; j < 4; j++) fb[j] = pb[j * B_SI + ks * B_SK];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      store_tile<A_KC>(sA(cur ^ 1), ra);
+      store_tile<B_KC>(sB(cur ^ 1), rb);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds C[i0+wi+16i+lr][j0+wj+16j+kg+4r]
+  const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int64_t row = i0 + wi + 16 * i + lr;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int64_t col = j0 + wj + 16 * j + kg + 4 * r;
+        bool ok = true;
+        if (EDGE) ok = (row < g.M) && (col < g.N);
+        if (g.tri == 1) ok = ok && (row <= col);
+        if (g.tri == 2) ok = ok && (row >= col);
+        if (ok) {
+          double* pc = g.C + row + col * g.ldc;
+          double v = alpha * acc[i][j][r];
+          if (beta != 0.0) v += beta * (*pc);
+          *pc = v;
+        }
+      }
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC>
+int launch_variant(const GemmArgs& g, bool edge, int grid, hipStream_t stream) {
+  size_t lds = 4 * TILE_ELEMS * sizeof(double);
+  if (edge)
+    hipLaunchKernelGGL((dgemm_kernel<A_KC, B_KC, true>), dim3(grid), dim3(NTHREADS), lds, stream, g);
+  else
+    hipLaunchKernelGGL((dgemm_kernel<A_KC, B_KC, false>), dim3(grid), dim3(NTHREADS), lds, stream, g);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+// C = beta*C (alpha == 0 or k == 0), honouring the triangle mask
+__global__ void scale_kernel(double* C, int64_t ldc, int64_t m, int64_t n, double beta, int tri) {
+  int64_t col = blockIdx.y;
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < m; row += (int64_t)gridDim.x * blockDim.x) {
+    if (tri == 1 && row > col) continue;
+    if (tri == 2 && row < col) continue;
+    double* p = C + row + col * ldc;
+    *p = (beta == 0.0) ? 0.0 : beta * (*p);
+  }
+}
+
+}  // namespace
+
+int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
+                    int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri,
+                    hipStream_t stream) {
+  if (m < 0 || n < 0 || k < 0) return CAP_ERR_ARG;
+  if (m == 0 || n == 0) return CAP_OK;
+  if (ldc < m) return CAP_ERR_ARG;
+  if (alpha == 0.0 || k == 0) {
+    if (beta == 1.0) return CAP_OK;
+    dim3 grid((unsigned)cap_ceil_div(m, 256), (unsigned)n);
+    if (n > 65535) return CAP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(scale_kernel, grid, dim3(256), 0, stream, C, ldc, m, n, beta, tri);
+    CAP_HIP(hipGetLastError());
+    return CAP_OK;
+  }
+  if (!A || !B || !C) return CAP_ERR_ARG;
+  // op(A) is m x k: stored k x m when transposed
+  if (transa == CAP_TRANS ? lda < k : lda < m) return CAP_ERR_ARG;
+  if (transb == CAP_TRANS ? ldb < n : ldb < k) return CAP_ERR_ARG;
+
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.beta = beta; g.tri = tri;
+  g.tm = (int)cap_ceil_div(m, BM); g.tn = (int)cap_ceil_div(n, BN);
+  g.nsm = (int)cap_ceil_div(g.tm, ST); g.nsn = (int)cap_ceil_div(g.tn, ST);
+  int64_t nsuper;
+  if (tri == 0) nsuper = (int64_t)g.nsm * g.nsn;
+  else {
+    // triangular operands are square in tile space; enumerate the supertile triangle
+    int ns = g.nsm > g.nsn ? g.nsm : g.nsn;
+    nsuper = (int64_t)ns * (ns + 1) / 2;
+  }
+  int64_t slots = nsuper * ST * ST;
+  g.chunk = (int)cap_ceil_div(slots, 8);
+  int64_t grid = (int64_t)g.chunk * 8;
+  if (grid > 0x7fffffff) return CAP_ERR_UNSUPPORTED;
+
+  const bool a_kc = (transa == CAP_TRANS);   // op(A)=A^T: k contiguous
+  const bool b_kc = (transb != CAP_TRANS);   // op(B)=B:   k contiguous
+  auto aligned16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  bool edge = (m % BM) || (n % BN) || (k % BK) || (lda & 1) || (ldb & 1) || !aligned16(A) || !aligned16(B);
+
+  if (a_kc && b_kc) return launch_variant<true, true>(g, edge, (int)grid, stream);
+  if (a_kc && !b_kc) return launch_variant<true, false>(g, edge, (int)grid, stream);
+  if (!a_kc && b_kc) return launch_variant<false, true>(g, edge, (int)grid, stream);
+  return launch_variant<false, false>(g, edge, (int)grid, stream);
+}
+
+extern "C" int cap_dgemm(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
+                         int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, void* stream) {
+  return cap_gemm_launch(transa, transb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0, cap_stream(stream));
+}
+
+extern "C" int cap_dsyrk(int uplo, int trans, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
+                         double beta, double* C, int64_t ldc, void* stream) {
+  // trans: C = alpha*A^T*A + beta*C with A k x n;  notrans: C = alpha*A*A^T + beta*C with A n x k
+  int tri = (uplo == CAP_UPPER) ? 1 : 2;
+  if (trans == CAP_TRANS)
+    return cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n, n, k, alpha, A, lda, A, lda, beta, C, ldc, tri, cap_stream(stream));
+  return cap_gemm_launch(CAP_NOTRANS, CAP_TRANS, n, n, k, alpha, A, lda, A, lda, beta, C, ldc, tri, cap_stream(stream));
+}

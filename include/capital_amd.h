@@ -1,0 +1,201 @@
+/* capital_amd.h - C ABI of the MI355X-native CAPITAL hot path (libcapital_amd.so).
+ *
+ * This is the drop-in boundary.  The reference (tbennun/capital) has no FFI: its seam is
+ * C++ static-template call signatures.  Each entry point below names the reference
+ * interface it replaces (file:line relative to the reference tree).  INTEGRATION.md shows
+ * the reference-side binding a maintainer would add.
+ *
+ * Conventions
+ *  - all matrices are COLUMN-MAJOR fp64 in DEVICE memory (HBM), caller owned;
+ *  - dimensions / leading dimensions are int64_t (blas/interface.h:58-66 uses int64_t);
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call is
+ *    asynchronous on that stream unless stated otherwise;
+ *  - every function returns a cap_status (0 = ok).  The reference has no error channel
+ *    (LAPACKE info is dropped, lapack/interface.hpp:39,54); here POTRF's `info` is
+ *    propagated through a device-resident int the caller can read back.
+ *  - enums use the reference's own numeric values (blas/engine.h:23-52,
+ *    lapack/engine.h:23-52) so ArgPacks map 1:1.
+ */
+#ifndef CAPITAL_AMD_H_
+#define CAPITAL_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  CAP_OK = 0,
+  CAP_ERR_ARG = 1,        /* bad argument */
+  CAP_ERR_HIP = 2,        /* a HIP runtime call failed */
+  CAP_ERR_NOT_SPD = 3,    /* potrf met a non-positive pivot (info > 0) */
+  CAP_ERR_UNSUPPORTED = 4,
+  CAP_ERR_COMM = 5,       /* RCCL failure */
+  CAP_ERR_ALLOC = 6
+} cap_status;
+
+/* blas/engine.h:23-52 */
+enum { CAP_NOTRANS = 0, CAP_TRANS = 1 };
+enum { CAP_LEFT = 0, CAP_RIGHT = 1 };
+enum { CAP_LOWER = 0, CAP_UPPER = 1 };
+enum { CAP_NONUNIT = 0, CAP_UNIT = 1 };
+
+const char* cap_status_string(int status);
+/* library / device info: fills name (<= len bytes), CU count, HBM bytes. */
+int cap_device_info(char* name, int len, int* cus, int64_t* hbm_bytes);
+
+/* ------------------------------------------------------------------------------------
+ * Operator seam  (replaces blas::engine / lapack::engine, device pointers + status)
+ * ---------------------------------------------------------------------------------- */
+
+/* blas::engine::_gemm  - blas/interface.h:58-60, interface.hpp:43-59 (cblas_dgemm).
+ * C[m x n] = alpha * op(A)[m x k] * op(B)[k x n] + beta * C.                          */
+int cap_dgemm(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha,
+              const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
+              double* C, int64_t ldc, void* stream);
+
+/* blas::engine::_syrk  - blas/interface.h:65-66, interface.hpp:81-97 (cblas_dsyrk).
+ * C[n x n](uplo triangle only) = alpha * op(A) op(A)^T + beta * C;
+ * trans == CAP_TRANS: A is k x n and C = alpha*A^T*A + beta*C (the form cacqr.hpp:15 and
+ * the trailing update cholinv.hpp:128-137 use).                                        */
+int cap_dsyrk(int uplo, int trans, int64_t n, int64_t k, double alpha, const double* A,
+              int64_t lda, double beta, double* C, int64_t ldc, void* stream);
+
+/* blas::engine::_trmm  - blas/interface.h:62-63, interface.hpp:61-79 (cblas_dtrmm).
+ * B[m x n] = alpha * op(T) * B (side = LEFT, T m x m) or alpha * B * op(T) (RIGHT, T n x n).
+ * In place like the reference; `work` is device scratch of >= m*n doubles (the reference
+ * hides the same copy inside MKL); work == NULL -> CAP_ERR_ARG.                          */
+int cap_dtrmm(int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
+              const double* T, int64_t ldt, double* B, int64_t ldb, double* work, void* stream);
+
+/* Real triangular solve (not in the reference, which inverts then multiplies - SURVEY 2b;
+ * trsm/diaginvert/diaginvert.hpp:7-10 is a static_assert stub).  Solves
+ * op(T) X = alpha B (LEFT) or X op(T) = alpha B (RIGHT) in place; T upper or lower, non-unit.
+ * `work`: device scratch >= m*n + 2*nb*max(m,n)... see cap_dtrsm_work_size.               */
+int cap_dtrsm(int side, int uplo, int trans, int64_t m, int64_t n, double alpha, const double* T,
+              int64_t ldt, double* B, int64_t ldb, double* work, void* stream);
+int64_t cap_dtrsm_work_size(int side, int64_t m, int64_t n);
+
+/* lapack::engine::_potrf - lapack/interface.h:49-50, interface.hpp:30-43 (LAPACKE_dpotrf).
+ * In-place A = R^T R (uplo = UPPER) or L L^T (LOWER) of the n x n block; the other triangle
+ * is not referenced.  `info` (device int, may be NULL): 0 or 1-based index of the first
+ * non-positive pivot.  `work`: device scratch >= cap_dpotrf_work_size(n) doubles.         */
+int cap_dpotrf(int uplo, int64_t n, double* A, int64_t lda, int* info, double* work, void* stream);
+int64_t cap_dpotrf_work_size(int64_t n);
+
+/* lapack::engine::_trtri - lapack/interface.h:52-53, interface.hpp:45-58 (LAPACKE_dtrtri).
+ * In-place inverse of the triangular n x n block (non-unit).  work >= cap_dtrtri_work_size. */
+int cap_dtrtri(int uplo, int64_t n, double* A, int64_t lda, double* work, void* stream);
+int64_t cap_dtrtri_work_size(int64_t n);
+
+/* ------------------------------------------------------------------------------------
+ * Matrix descriptor helpers (replaces src/matrix/: generators, serialize, structure)
+ * ---------------------------------------------------------------------------------- */
+
+/* rect::_distribute_symmetric - structure.hpp:68-103.  Fills the local element-cyclic piece
+ * (grid position x,y of a d x d grid) of the N x N SPD test matrix directly on the GPU:
+ * A[gy,gx] = u(max + N*min) (+N on the diagonal), u = srand48/drand48 closed form.
+ * local: ceil(N/d) x ceil(N/d) column-major with leading dimension ld; padding zero-filled. */
+int cap_fill_symmetric(double* local, int64_t ld, int64_t n_global, int64_t x, int64_t y, int64_t d,
+                       int diagonally_dominant, void* stream);
+/* rect::_distribute_random - structure.hpp:105-129 (sequential drand48 stream per rank,
+ * key = rank / c; jump-ahead LCG so every element is computed independently, bit-exact).   */
+int cap_fill_random(double* local, int64_t ld, int64_t m_global, int64_t n_global, int64_t x, int64_t y,
+                    int64_t dx, int64_t dy, int64_t key, void* stream);
+
+/* serialize<S1,S2>::invoke - serialize.hpp:12-150: copy a window between rect / packed-upper
+ * buffers.  src/dst are either column-major rect (packed = 0, leading dim ld) or packed upper
+ * (packed = 1: column x at x(x+1)/2, structure.h:39; ld ignored).  Copies the n x n window's
+ * upper triangle (tri_only = 1) or the full rows x cols window (tri_only = 0).
+ * zero_lower = 1 additionally zero-fills the strictly lower part of a rect destination.     */
+int cap_copy_window(const double* src, int src_packed, int64_t src_ld, int64_t src_row0, int64_t src_col0,
+                    double* dst, int dst_packed, int64_t dst_ld, int64_t dst_row0, int64_t dst_col0,
+                    int64_t rows, int64_t cols, int tri_only, int zero_lower, void* stream);
+
+/* util::remove_triangle - util.hpp:266-318: zero the entries of a local element-cyclic piece
+ * that are globally strictly below (dir 'U') / above ('L') the diagonal.                   */
+int cap_remove_triangle(double* local, int64_t ld, int64_t rows_local, int64_t cols_local, int64_t x, int64_t y,
+                        int64_t d, int dir_upper, void* stream);
+
+/* util::residual_local pieces (util.hpp:25-53) + the validators' GEMMs
+ * (test/cholesky/validate.hpp:33-46): writes out[0] = sum_{upper}(R^T R - A)^2,
+ * out[1] = sum_{upper} A^2 (device doubles) for single-rank (d = 1) matrices.
+ * work >= n*n doubles.                                                                    */
+int cap_cholesky_residual_terms(const double* A, int64_t lda, const double* R, int64_t ldr, int64_t n,
+                                double* work, double* out2, void* stream);
+/* sum of squares of (alpha*X + beta*Y) over an m x n window, optional identity subtraction:
+ * out[0] = sum (X - (sub_identity ? I : 0))^2 ; used by qr residual / orthogonality
+ * (test/qr/validate.hpp:24-31,46-51).                                                      */
+int cap_sumsq(const double* X, int64_t ldx, int64_t m, int64_t n, int sub_identity, int upper_only,
+              double* out1, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Communicator bundle (replaces topo::square / topo::rect, util/topology.h:16-143)
+ * RCCL over xGMI, one process per GPU.  The 128-byte unique id is produced on rank 0 by
+ * cap_comm_unique_id and shipped to the other ranks by the host (torch.distributed / MPI).
+ * ---------------------------------------------------------------------------------- */
+typedef struct cap_comm cap_comm;
+int cap_comm_unique_id(void* id128);
+int cap_comm_create(cap_comm** comm, const void* id128, int rank, int size, void* stream);
+int cap_comm_create_self(cap_comm** comm);           /* P = 1, no RCCL */
+int cap_comm_destroy(cap_comm* comm);
+int cap_comm_rank(const cap_comm* comm);
+int cap_comm_size(const cap_comm* comm);
+int cap_comm_allreduce_sum(cap_comm* comm, double* buf, int64_t count, void* stream);
+int cap_comm_bcast(cap_comm* comm, double* buf, int64_t count, int root, void* stream);
+int cap_comm_allgather(cap_comm* comm, const double* send, double* recv, int64_t count_per_rank, void* stream);
+int cap_comm_barrier(cap_comm* comm, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Algorithm seam (replaces src/alg/cholesky/cholinv, src/alg/qr/cacqr)
+ * ---------------------------------------------------------------------------------- */
+
+/* cholesky::cholinv<...>::info + factor - cholinv.h:16-53, cholinv.hpp:6-28.
+ * A plan handle (like `info`: create once, factor many times; owns R, Rinv and workspace).
+ * Knobs keep the reference's meaning:
+ *   complete_inv: 1 = full R^-1; 0 = skip the root-level Rinv12 (cholinv.hpp:147);
+ *                 -1 (extension) = do not build R^-1 at all: blocked right-looking Cholesky
+ *                 with real DTRSM/DSYRK - the headline "fp64 Cholesky" path;
+ *   split:        root partition is n >> split (cholinv.hpp:107);
+ *   bc_mult_dim:  base-case size knob (cholinv.hpp:15-18) -> panel width of the GPU schedule;
+ *   dir:          'U' only, as upstream (cholinv.hpp:9).
+ * Single-GPU plans take comm = NULL or a self comm.  Multi-GPU plans (1 x P block-cyclic
+ * column distribution) are created with cap_cholinv_plan_create_dist.                      */
+typedef struct cap_cholinv_plan cap_cholinv_plan;
+int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv, int64_t split,
+                            int64_t bc_mult_dim, char dir, cap_comm* comm);
+int cap_cholinv_plan_destroy(cap_cholinv_plan* plan);
+/* factor: A (n x n col-major, lda) is read-only (only its upper triangle is consumed,
+ * cholinv.hpp:13).  Results stay resident in the plan.                                     */
+int cap_cholinv_factor(cap_cholinv_plan* plan, const double* A, int64_t lda, void* stream);
+/* construct_R / construct_Rinv - cholinv.hpp:30-46: copy the upper-triangular result into a
+ * caller rect buffer (strictly lower part zero-filled).                                    */
+int cap_cholinv_get_R(cap_cholinv_plan* plan, double* out, int64_t ld, void* stream);
+int cap_cholinv_get_Rinv(cap_cholinv_plan* plan, double* out, int64_t ld, void* stream);
+/* device pointers to the resident factors (leading dimension returned through *ld).        */
+double* cap_cholinv_R_ptr(cap_cholinv_plan* plan, int64_t* ld);
+double* cap_cholinv_Rinv_ptr(cap_cholinv_plan* plan, int64_t* ld);
+/* host-readable status of the last factor: 0, or 1-based index of the failing pivot.
+ * Synchronises the stream.                                                                 */
+int cap_cholinv_info(cap_cholinv_plan* plan, void* stream, int64_t* info);
+/* tuning knobs of the GPU schedule (panel width nb, leaf size, look-ahead on/off).         */
+int cap_cholinv_set_option(cap_cholinv_plan* plan, const char* key, int64_t value);
+int64_t cap_cholinv_get_option(cap_cholinv_plan* plan, const char* key);
+
+/* qr::cacqr<...>::info + factor, 1D path - cacqr.h:18-49, cacqr.hpp:5-29,172-193,217-248.
+ * A is the local row-cyclic piece (m_local x n, column-major); R (n x n) is replicated;
+ * num_iter = 1 (CholeskyQR) or 2 (CholeskyQR2).  comm == NULL -> single rank.              */
+typedef struct cap_cacqr_plan cap_cacqr_plan;
+int cap_cacqr_plan_create(cap_cacqr_plan** plan, int64_t m_local, int64_t n, int num_iter, cap_comm* comm);
+int cap_cacqr_plan_destroy(cap_cacqr_plan* plan);
+int cap_cacqr_factor(cap_cacqr_plan* plan, const double* A, int64_t lda, void* stream);
+double* cap_cacqr_Q_ptr(cap_cacqr_plan* plan, int64_t* ld);
+double* cap_cacqr_R_ptr(cap_cacqr_plan* plan, int64_t* ld);
+int cap_cacqr_info(cap_cacqr_plan* plan, void* stream, int64_t* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPITAL_AMD_H_ */
