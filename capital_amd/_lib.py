@@ -21,6 +21,7 @@ SIGNATURES = {
     "cap_dgemm": (cint, [cint, cint, i64, i64, i64, dbl, ptr, i64, ptr, i64, dbl, ptr, i64, ptr]),
     "cap_dsyrk": (cint, [cint, cint, i64, i64, dbl, ptr, i64, dbl, ptr, i64, ptr]),
     "cap_dtrmm": (cint, [cint, cint, cint, cint, i64, i64, dbl, ptr, i64, ptr, i64, ptr, ptr]),
+    "cap_dtrmm_work_size": (i64, [cint, i64, i64]),
     "cap_dtrsm": (cint, [cint, cint, cint, i64, i64, dbl, ptr, i64, ptr, i64, ptr, ptr]),
     "cap_dtrsm_work_size": (i64, [cint, i64, i64]),
     "cap_dpotrf": (cint, [cint, i64, ptr, i64, ptr, ptr, ptr]),

@@ -1,0 +1,99 @@
+"""cholesky::cholinv mirror (reference src/alg/cholesky/cholinv/cholinv.h:16-53, cholinv.hpp:6-46).
+
+    pack = cholinv.info(complete_inv, split, bc_mult_dim, 'U')     # plan handle (create once)
+    cholinv.factor(A, pack, topo)                                   # A: matrix (read-only)
+    R = cholinv.construct_R(pack, topo); Rinv = cholinv.construct_Rinv(pack, topo)
+
+`info` keeps upstream's four user knobs.  complete_inv = -1 is the documented extension:
+blocked right-looking Cholesky (real TRSM/SYRK, no explicit inverse) - the headline
+"fp64 Cholesky" path; 0 / 1 reproduce upstream's R + R^-1 semantics."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._util import cur_stream
+from .matrix import matrix, rect
+
+
+class info:
+    def __init__(self, complete_inv, split, bc_mult_dim, dir='U'):
+        self.complete_inv, self.split, self.bc_mult_dim, self.dir = int(complete_inv), int(split), int(bc_mult_dim), dir
+        self._plan = None
+        self._n = None
+        self.options = {}
+
+    def set_option(self, key, value):
+        """GPU-schedule knobs: nb (panel width), leaf (<= 64), lookahead (0/1)."""
+        self.options[key] = int(value)
+        if self._plan:
+            _lib.check(_lib.lib().cap_cholinv_set_option(self._plan, key.encode(), int(value)), "set_option")
+
+    def get_option(self, key):
+        if not self._plan:
+            return self.options.get(key)
+        return _lib.lib().cap_cholinv_get_option(self._plan, key.encode())
+
+    def _ensure(self, n):
+        if self._plan is not None and self._n == n:
+            return
+        self._release()
+        L = _lib.lib()
+        h = C.c_void_p()
+        # args.R/_Rinv._register_: allocated once, later calls are no-ops (cholinv.hpp:11-12)
+        _lib.check(L.cap_cholinv_plan_create(C.byref(h), n, self.complete_inv, self.split, self.bc_mult_dim,
+                                             self.dir.encode()[0:1], None), "cap_cholinv_plan_create")
+        self._plan, self._n = h, n
+        for k, v in self.options.items():
+            _lib.check(L.cap_cholinv_set_option(self._plan, k.encode(), v), "set_option")
+
+    def _release(self):
+        if self._plan is not None:
+            _lib.lib().cap_cholinv_plan_destroy(self._plan)
+            self._plan = None
+
+    def last_info(self):
+        """0, or the 1-based index of the first non-positive pivot (upstream drops this, lapack/interface.hpp:39)."""
+        v = C.c_int64(0)
+        _lib.lib().cap_cholinv_info(self._plan, cur_stream(), C.byref(v))
+        return v.value
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+
+def factor(A, args, CommInfo=None):
+    """cholinv::factor (cholinv.hpp:6-28). Asynchronous on the current stream."""
+    if args.dir != 'U':
+        raise _lib.CapitalError("dir must be 'U' (upstream asserts the same, cholinv.hpp:9)")
+    if args.split <= 0:
+        raise _lib.CapitalError("split must be > 0 (cholinv.hpp:9)")
+    if CommInfo is not None and getattr(CommInfo, "size", 1) != 1:
+        raise _lib.CapitalError("cholinv on this build runs one GPU per factorization (P = 1); "
+                                "upstream supports only cubic grids P = 1, 8, 27 (SURVEY 3.3)")
+    n = A.num_rows_global()
+    if n != A.num_columns_global():
+        raise _lib.CapitalError("cholinv needs a square matrix")
+    args._ensure(n)
+    _lib.check(_lib.lib().cap_cholinv_factor(args._plan, A.data_ptr(), A.ld(), cur_stream()), "cholinv::factor")
+
+
+def _construct(args, which):
+    n = args._n
+    out = matrix(n, n, 1, 1, rect)
+    fn = _lib.lib().cap_cholinv_get_R if which == "R" else _lib.lib().cap_cholinv_get_Rinv
+    _lib.check(fn(args._plan, out.data_ptr(), out.ld(), cur_stream()), "construct_" + which)
+    return out
+
+
+def construct_R(args, CommInfo=None):
+    """cholinv.hpp:30-37: fresh rect matrix holding the upper-triangular factor."""
+    return _construct(args, "R")
+
+
+def construct_Rinv(args, CommInfo=None):
+    """cholinv.hpp:39-46."""
+    return _construct(args, "Rinv")

@@ -1,0 +1,241 @@
+// HBM-bound helper kernels: generators, window copies (serialize), triangle masks, norms.
+// Replaces src/matrix/structure.hpp:68-129 (generators), src/matrix/serialize.hpp:12-150,
+// src/util/util.hpp:25-53,266-318.  All coalesced along the column-major fast axis.
+#include "common.h"
+
+namespace {
+
+constexpr uint64_t MASK48 = (1ull << 48) - 1;
+constexpr uint64_t LCG_A = 0x5DEECE66Dull;
+constexpr uint64_t LCG_C = 0xBull;
+
+// srand48(seed); drand48()  - glibc closed form (structure.hpp:80-88 calls the pair per element)
+__device__ __forceinline__ double drand48_of_seed(uint64_t seed) {
+  uint64_t x0 = ((seed & 0xFFFFFFFFull) << 16) | 0x330Eull;
+  uint64_t x1 = (LCG_A * x0 + LCG_C) & MASK48;   // 64-bit wrap keeps the low 48 bits exact
+  return (double)x1 * (1.0 / 281474976710656.0);
+}
+
+__global__ void fill_symmetric_kernel(double* out, int64_t ld, int64_t nl, int64_t n, int64_t x, int64_t y, int64_t d,
+                                      int dom) {
+  int64_t il = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;   // local row
+  int64_t jl = blockIdx.y;                                       // local column
+  if (il >= nl) return;
+  int64_t gy = y + il * d, gx = x + jl * d;
+  double v = 0.0;   // zero padding (matrix.hpp:8-11, structure.hpp:92-101)
+  if (gy < n && gx < n) {
+    int64_t hi = gx > gy ? gx : gy, lo = gx > gy ? gy : gx;
+    v = drand48_of_seed((uint64_t)(hi + n * lo));
+    if (dom && gx == gy) v += (double)n;
+  }
+  out[il + jl * ld] = v;
+}
+
+// X_{k} after k steps of the LCG from X0: affine map power by squaring
+__device__ __forceinline__ uint64_t lcg_jump(uint64_t x0, uint64_t k) {
+  uint64_t a = LCG_A, c = LCG_C, ra = 1, rc = 0;
+  while (k) {
+    if (k & 1) { ra = (ra * a) & MASK48; rc = (rc * a + c) & MASK48; }
+    c = (c * a + c) & MASK48;
+    a = (a * a) & MASK48;
+    k >>= 1;
+  }
+  return (ra * x0 + rc) & MASK48;
+}
+
+__global__ void fill_random_kernel(double* out, int64_t ld, int64_t ml, int64_t nl, int64_t pad_y, int64_t pad_x,
+                                   uint64_t x0) {
+  int64_t il = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t jl = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (il >= ml || jl >= nl) return;
+  double v = 0.0;
+  if (il < pad_y && jl < pad_x) {
+    uint64_t idx = (uint64_t)(jl * pad_y + il);   // column-major stream position (structure.hpp:111-117)
+    v = (double)lcg_jump(x0, idx + 1) * (1.0 / 281474976710656.0);
+  }
+  out[il + jl * ld] = v;
+}
+
+__device__ __forceinline__ int64_t addr(int packed, int64_t ld, int64_t r, int64_t c) {
+  return packed ? (c * (c + 1) / 2 + r) : (r + c * ld);   // uppertri::_offset structure.h:39 / rect :13
+}
+
+__global__ void copy_window_kernel(const double* src, int sp, int64_t sld, int64_t sr0, int64_t sc0, double* dst, int dp,
+                                   int64_t dld, int64_t dr0, int64_t dc0, int64_t rows, int64_t cols, int tri, int zl) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t c = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (r >= rows || c >= cols) return;
+  if (tri && r > c) {
+    if (zl && !dp) dst[addr(0, dld, dr0 + r, dc0 + c)] = 0.0;
+    return;
+  }
+  dst[addr(dp, dld, dr0 + r, dc0 + c)] = src[addr(sp, sld, sr0 + r, sc0 + c)];
+}
+
+__global__ void zero_rect_kernel(double* dst, int64_t ld, int64_t rows, int64_t cols) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t c = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (r < rows && c < cols) dst[r + c * ld] = 0.0;
+}
+
+__global__ void remove_triangle_kernel(double* a, int64_t ld, int64_t rows, int64_t cols, int64_t x, int64_t y, int64_t d,
+                                       int upper) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t c = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (r >= rows || c >= cols) return;
+  int64_t gy = y + r * d, gx = x + c * d;
+  if (upper ? (gy > gx) : (gy < gx)) a[r + c * ld] = 0.0;
+}
+
+// out[0] += sum over window of (X[r,c] - (sub_id && r==c))^2 ; upper_only: r <= c
+__global__ void sumsq_kernel(const double* X, int64_t ld, int64_t m, int64_t n, int sub_id, int upper, double* out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  int64_t c = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (c < n) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < m; r += (int64_t)gridDim.x * blockDim.x) {
+      if (upper && r > c) break;
+      double v = X[r + c * ld];
+      if (sub_id && r == c) v -= 1.0;
+      s += v * v;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = red[0] + red[1] + red[2] + red[3];
+    if (tot != 0.0) atomicAdd(out, tot);
+  }
+}
+
+inline dim3 grid2d(int64_t rows, int64_t cols, int bx) {
+  unsigned gy = (unsigned)(cols < 65535 ? cols : 65535);
+  unsigned gz = (unsigned)cap_ceil_div(cols, 65535);
+  return dim3((unsigned)cap_ceil_div(rows, bx), gy ? gy : 1, gz ? gz : 1);
+}
+
+}  // namespace
+
+int cap_copy_rect(const double* src, int64_t sld, double* dst, int64_t dld, int64_t rows, int64_t cols, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return CAP_OK;
+  hipLaunchKernelGGL(copy_window_kernel, grid2d(rows, cols, 256), dim3(256), 0, s, src, 0, sld, (int64_t)0, (int64_t)0, dst,
+                     0, dld, (int64_t)0, (int64_t)0, rows, cols, 0, 0);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+int cap_zero_rect(double* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return CAP_OK;
+  hipLaunchKernelGGL(zero_rect_kernel, grid2d(rows, cols, 256), dim3(256), 0, s, dst, ldd, rows, cols);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+extern "C" {
+
+int cap_fill_symmetric(double* local, int64_t ld, int64_t n_global, int64_t x, int64_t y, int64_t d,
+                       int diagonally_dominant, void* stream) {
+  if (!local || d <= 0 || x < 0 || y < 0 || x >= d || y >= d || n_global <= 0) return CAP_ERR_ARG;
+  int64_t nl = cap_ceil_div(n_global, d);
+  if (ld < nl || nl > 65535ll * 65535ll) return CAP_ERR_ARG;
+  if (nl > 65535) {  // column index rides in blockIdx.y only; split launches for very wide pieces
+    for (int64_t c0 = 0; c0 < nl; c0 += 65535) {
+      int64_t nc = nl - c0 < 65535 ? nl - c0 : 65535;
+      hipLaunchKernelGGL(fill_symmetric_kernel, dim3((unsigned)cap_ceil_div(nl, 256), (unsigned)nc), dim3(256), 0,
+                         cap_stream(stream), local + c0 * ld, ld, nl, n_global, x + c0 * d, y, d, diagonally_dominant);
+    }
+  } else {
+    hipLaunchKernelGGL(fill_symmetric_kernel, dim3((unsigned)cap_ceil_div(nl, 256), (unsigned)nl), dim3(256), 0,
+                       cap_stream(stream), local, ld, nl, n_global, x, y, d, diagonally_dominant);
+  }
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+int cap_fill_random(double* local, int64_t ld, int64_t m_global, int64_t n_global, int64_t x, int64_t y, int64_t dx,
+                    int64_t dy, int64_t key, void* stream) {
+  if (!local || dx <= 0 || dy <= 0 || m_global <= 0 || n_global <= 0) return CAP_ERR_ARG;
+  int64_t ml = cap_ceil_div(m_global, dy), nl = cap_ceil_div(n_global, dx);
+  if (ld < ml) return CAP_ERR_ARG;
+  // structure.hpp:109-110: the last local row/col is padding when the global dim is not divisible
+  int64_t pad_x = ((n_global % dx != 0) && ((nl - 1) * dx + x >= n_global)) ? nl - 1 : nl;
+  int64_t pad_y = ((m_global % dy != 0) && ((ml - 1) * dy + y >= m_global)) ? ml - 1 : ml;
+  uint64_t x0 = ((((uint64_t)key) & 0xFFFFFFFFull) << 16) | 0x330Eull;
+  hipLaunchKernelGGL(fill_random_kernel, grid2d(ml, nl, 256), dim3(256), 0, cap_stream(stream), local, ld, ml, nl, pad_y,
+                     pad_x, x0);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+int cap_copy_window(const double* src, int src_packed, int64_t src_ld, int64_t src_row0, int64_t src_col0, double* dst,
+                    int dst_packed, int64_t dst_ld, int64_t dst_row0, int64_t dst_col0, int64_t rows, int64_t cols,
+                    int tri_only, int zero_lower, void* stream) {
+  if (rows < 0 || cols < 0 || !src || !dst) return CAP_ERR_ARG;
+  if (rows == 0 || cols == 0) return CAP_OK;
+  if ((src_packed || dst_packed) && !tri_only) return CAP_ERR_ARG;   // packed buffers only hold the upper triangle
+  hipLaunchKernelGGL(copy_window_kernel, grid2d(rows, cols, 256), dim3(256), 0, cap_stream(stream), src, src_packed, src_ld,
+                     src_row0, src_col0, dst, dst_packed, dst_ld, dst_row0, dst_col0, rows, cols, tri_only, zero_lower);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+int cap_remove_triangle(double* local, int64_t ld, int64_t rows_local, int64_t cols_local, int64_t x, int64_t y, int64_t d,
+                        int dir_upper, void* stream) {
+  if (!local || d <= 0) return CAP_ERR_ARG;
+  if (rows_local <= 0 || cols_local <= 0) return CAP_OK;
+  hipLaunchKernelGGL(remove_triangle_kernel, grid2d(rows_local, cols_local, 256), dim3(256), 0, cap_stream(stream), local,
+                     ld, rows_local, cols_local, x, y, d, dir_upper);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+int cap_sumsq(const double* X, int64_t ldx, int64_t m, int64_t n, int sub_identity, int upper_only, double* out1,
+              void* stream) {
+  if (!X || !out1 || m < 0 || n < 0) return CAP_ERR_ARG;
+  CAP_HIP(hipMemsetAsync(out1, 0, sizeof(double), cap_stream(stream)));
+  if (m == 0 || n == 0) return CAP_OK;
+  int64_t gx = cap_ceil_div(m, 256); if (gx > 64) gx = 64;
+  dim3 g = grid2d(m, n, 256); g.x = (unsigned)gx;
+  hipLaunchKernelGGL(sumsq_kernel, g, dim3(256), 0, cap_stream(stream), X, ldx, m, n, sub_identity, upper_only, out1);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+int cap_cholesky_residual_terms(const double* A, int64_t lda, const double* R, int64_t ldr, int64_t n, double* work,
+                                double* out2, void* stream) {
+  if (!A || !R || !work || !out2 || n <= 0) return CAP_ERR_ARG;
+  hipStream_t s = cap_stream(stream);
+  // work = upper(A);  work = R^T R - work (upper tiles only);  out = { sum work^2, sum A^2 } over the upper triangle
+  CAP_TRY(cap_copy_window(A, 0, lda, 0, 0, work, 0, n, 0, 0, n, n, 1, 1, stream));
+  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n, n, n, 1.0, R, ldr, R, ldr, -1.0, work, n, 1, s));
+  CAP_TRY(cap_sumsq(work, n, n, n, 0, 1, out2, stream));
+  CAP_TRY(cap_sumsq(A, lda, n, n, 0, 1, out2 + 1, stream));
+  return CAP_OK;
+}
+
+const char* cap_status_string(int status) {
+  switch (status) {
+    case CAP_OK: return "ok";
+    case CAP_ERR_ARG: return "bad argument";
+    case CAP_ERR_HIP: return "HIP runtime error";
+    case CAP_ERR_NOT_SPD: return "matrix is not positive definite";
+    case CAP_ERR_UNSUPPORTED: return "unsupported configuration";
+    case CAP_ERR_COMM: return "RCCL error";
+    case CAP_ERR_ALLOC: return "device allocation failed";
+  }
+  return "unknown status";
+}
+
+int cap_device_info(char* name, int len, int* cus, int64_t* hbm_bytes) {
+  int dev = 0;
+  CAP_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  CAP_HIP(hipGetDeviceProperties(&p, dev));
+  if (name && len > 0) snprintf(name, len, "%s (%s)", p.name, p.gcnArchName);
+  if (cus) *cus = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+  return CAP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,447 @@
+// Host-side factorization schedule (C++ behind the C ABI) for the Cholesky hot path.
+//
+// Replaces cholesky::cholinv::factor / invoke / base_case (reference
+// src/alg/cholesky/cholinv/cholinv.hpp:6-183) and the SUMMA carrier it calls
+// (src/alg/matmult/summa/summa.hpp) for a GPU-resident matrix.
+//
+// Two schedules share the same kernels:
+//  * reference-shaped recursion (complete_inv = 0 / 1): cholinv.hpp:85-165 restated for
+//    one device - recurse on A11, R12 = Ri11^T A12 ("TRSM by inverse", :118-121),
+//    A22 -= R12^T R12 (:128-137), recurse on A22, Ri12 = -Ri11 R12 Ri22 (:150-154, skipped
+//    at the root when complete_inv == 0, :147).  Produces R and R^-1 like upstream.
+//  * blocked right-looking Cholesky with look-ahead (complete_inv = -1):
+//    panel width nb; the nb x nb diagonal block is factored AND inverted by the recursion
+//    above (exactly upstream's "invert then multiply" at tile granularity), the block row
+//    is solved with one GEMM against the inverse, the trailing matrix is updated by a
+//    SYRK on upper tiles only.  The update of the NEXT block row runs first on a
+//    high-priority stream followed by the next panel factorization, overlapping with the
+//    bulk of the trailing update on the main stream (HIP events, no host sync).
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "common.h"
+
+namespace {
+
+// ---- reference-shaped recursion on the window [off, off+n) of R (in place) and Ri ----------
+// Ri's strictly-lower part must be zero (it is a GEMM operand as a full square).
+struct RecCtx {
+  double* R; int64_t ldr;
+  double* Ri; int64_t ldi;
+  double* W; int64_t wcap;   // scratch >= max n1*n2 doubles
+  int* info;
+  int64_t leaf;
+  int64_t split;             // root split shift (cholinv.hpp:107)
+  int complete_inv;
+  hipStream_t s;
+};
+
+int64_t pick_split(int64_t n, int64_t leaf) {
+  // below the root the partition is free: keep blocks multiples of 128 so the fast GEMM path applies
+  int64_t h = n / 2;
+  int64_t q = n >= 512 ? 128 : leaf;
+  h = (h / q) * q;
+  if (h <= 0) h = std::min<int64_t>(leaf, n - 1);
+  return h;
+}
+
+int rec_cholinv(const RecCtx& c, int64_t off, int64_t n, bool is_root, int64_t info_base) {
+  double* R = c.R + off + off * c.ldr;
+  double* Ri = c.Ri + off + off * c.ldi;
+  // is_root is only set when upstream itself would partition the root (see cap_cholinv_factor):
+  // then the n >> split partition is honoured even for tiny matrices, because with
+  // complete_inv == 0 it decides which block of R^-1 stays empty (cholinv.hpp:107,147)
+  if (n <= c.leaf && !is_root) return cap_leaf_cholinv(R, c.ldr, Ri, c.ldi, (int)n, 1, c.info, (int)(info_base + off), c.s);
+  int64_t n1 = is_root ? (n >> c.split) : pick_split(n, c.leaf);
+  if (n1 <= 0 || n1 >= n) n1 = pick_split(n, c.leaf);
+  int64_t n2 = n - n1;
+  CAP_TRY(rec_cholinv(c, off, n1, false, info_base));
+  double* R12 = R + n1 * c.ldr;
+  double* R22 = R + n1 + n1 * c.ldr;
+  double* Ri12 = Ri + n1 * c.ldi;
+  double* Ri22 = Ri + n1 + n1 * c.ldi;
+  if (n1 * n2 > c.wcap) return CAP_ERR_ALLOC;
+  // R12 = Ri11^T * A12  (out of place into W, then back: the reference serializes through
+  // rect_table1 the same way, cholinv.hpp:122-125)
+  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n1, n2, n1, 1.0, Ri, c.ldi, R12, c.ldr, 0.0, c.W, n1, 0, c.s));
+  CAP_TRY(cap_copy_rect(c.W, n1, R12, c.ldr, n1, n2, c.s));
+  // A22 -= R12^T R12 on upper tiles
+  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n2, n2, n1, -1.0, R12, c.ldr, R12, c.ldr, 1.0, R22, c.ldr, 1, c.s));
+  CAP_TRY(rec_cholinv(c, off + n1, n2, false, info_base));
+  if (!(is_root && c.complete_inv == 0)) {
+    // Ri12 = -Ri11 * (R12 * Ri22)
+    CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, n1, n2, n2, 1.0, R12, c.ldr, Ri22, c.ldi, 0.0, c.W, n1, 0, c.s));
+    CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, n1, n2, n1, -1.0, Ri, c.ldi, c.W, n1, 0.0, Ri12, c.ldi, 0, c.s));
+  }
+  return CAP_OK;
+}
+
+int64_t rec_work_size(int64_t n) { return cap_round_up((n / 2 + 1) * (n / 2 + 1), 2); }
+
+// ---- in-place triangular inverse (upper): R <- R^-1, recursion + leaf kernel -----------------
+int rec_trtri(double* R, int64_t ldr, int64_t n, double* W, int64_t wcap, int64_t leaf, hipStream_t s) {
+  if (n <= leaf) return cap_leaf_trtri(R, ldr, R, ldr, (int)n, s);
+  int64_t n1 = pick_split(n, leaf), n2 = n - n1;
+  double* R12 = R + n1 * ldr;
+  double* R22 = R + n1 + n1 * ldr;
+  CAP_TRY(rec_trtri(R, ldr, n1, W, wcap, leaf, s));
+  CAP_TRY(rec_trtri(R22, ldr, n2, W, wcap, leaf, s));
+  if (n1 * n2 > wcap) return CAP_ERR_ALLOC;
+  // R12 <- -Ri11 * (R12 * Ri22); the strictly-lower parts of R11/R22 must be zero
+  CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, n1, n2, n2, 1.0, R12, ldr, R22, ldr, 0.0, W, n1, 0, s));
+  CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, n1, n2, n1, -1.0, R, ldr, W, n1, 0.0, R12, ldr, 0, s));
+  return CAP_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// plan
+// =================================================================================================
+struct cap_cholinv_plan {
+  int64_t n; int complete_inv; int64_t split, bc_mult_dim; char dir;
+  cap_comm* comm;
+  // schedule knobs
+  int64_t nb, leaf; int lookahead;
+  // device state
+  double* R; int64_t ldr;
+  double* Rinv; int64_t ldi;      // n x n (complete_inv >= 0) or nb x nb diagonal-block inverse
+  double* work; int64_t work_elems;
+  int* info_dev;
+  hipStream_t s_panel; hipEvent_t ev_panel[2], ev_update[2], ev_fork, ev_join;
+  bool streams_ready;
+};
+
+namespace {
+
+int64_t default_nb(int64_t n, int64_t bc_mult_dim) {
+  // bcDimension of cholinv.hpp:15-18 with c = d = 1, used as the panel-width hint
+  int64_t bc = 1;
+  if (bc_mult_dim < 0) for (int64_t i = 0; i < -bc_mult_dim && bc < n; i++) bc *= 2;
+  bc = std::max<int64_t>(1, std::min<int64_t>(n, bc));
+  int64_t hint = n / bc;
+  if (bc_mult_dim >= 0) hint = 0;            // "whole matrix is one base case" makes no sense on a GPU
+  int64_t nb = hint > 0 ? hint : 512;
+  nb = std::max<int64_t>(128, std::min<int64_t>(nb, 2048));
+  nb = (nb / 128) * 128;
+  if (n < 2048) nb = std::min<int64_t>(nb, 256);
+  return nb;
+}
+
+int plan_alloc(cap_cholinv_plan* p) {
+  const int64_t n = p->n;
+  p->ldr = cap_round_up(n, 2);
+  CAP_HIP(hipMalloc((void**)&p->R, sizeof(double) * p->ldr * n));
+  if (p->complete_inv >= 0) {
+    p->ldi = cap_round_up(n, 2);
+    CAP_HIP(hipMalloc((void**)&p->Rinv, sizeof(double) * p->ldi * n));
+    CAP_HIP(hipMemset(p->Rinv, 0, sizeof(double) * p->ldi * n));
+    p->work_elems = rec_work_size(n);
+  } else {
+    p->ldi = p->nb;
+    CAP_HIP(hipMalloc((void**)&p->Rinv, sizeof(double) * p->nb * p->nb));
+    CAP_HIP(hipMemset(p->Rinv, 0, sizeof(double) * p->nb * p->nb));
+    p->work_elems = rec_work_size(p->nb) + cap_round_up(p->nb * n, 2);
+  }
+  CAP_HIP(hipMalloc((void**)&p->work, sizeof(double) * p->work_elems));
+  CAP_HIP(hipMalloc((void**)&p->info_dev, sizeof(int)));
+  CAP_HIP(hipMemset(p->info_dev, 0, sizeof(int)));
+  return CAP_OK;
+}
+
+int ensure_streams(cap_cholinv_plan* p) {
+  if (p->streams_ready) return CAP_OK;
+  int lo = 0, hi = 0;
+  CAP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  CAP_HIP(hipStreamCreateWithPriority(&p->s_panel, hipStreamNonBlocking, hi));
+  for (int i = 0; i < 2; i++) {
+    CAP_HIP(hipEventCreateWithFlags(&p->ev_panel[i], hipEventDisableTiming));
+    CAP_HIP(hipEventCreateWithFlags(&p->ev_update[i], hipEventDisableTiming));
+  }
+  CAP_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+  CAP_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+  p->streams_ready = true;
+  return CAP_OK;
+}
+
+// factor the nb-wide panel starting at j0: diagonal block (R, Dinv), then the block row solve
+int panel_factor(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t j0, int64_t jb, hipStream_t s) {
+  double* Dinv = p->Rinv;                       // jb x jb, ld = nb, strictly-lower part stays zero
+  double* Wrec = p->work;                       // rec scratch
+  double* Wpan = p->work + rec_work_size(p->nb);  // jb x m panel scratch
+  RecCtx c{R + j0 + j0 * ldr, ldr, Dinv, p->ldi, Wrec, rec_work_size(p->nb), p->info_dev, p->leaf, 1, 1, s};
+  CAP_TRY(rec_cholinv(c, 0, jb, false, j0));
+  const int64_t m = n - j0 - jb;
+  if (m > 0) {
+    double* Rpan = R + j0 + (j0 + jb) * ldr;
+    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, m, jb, 1.0, Dinv, p->ldi, Rpan, ldr, 0.0, Wpan, jb, 0, s));
+    CAP_TRY(cap_copy_rect(Wpan, jb, Rpan, ldr, jb, m, s));
+  }
+  return CAP_OK;
+}
+
+// blocked right-looking Cholesky (upper) in place on R (n x n, ldr), optional look-ahead
+int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStream_t s0) {
+  const int64_t nb = p->nb;
+  const int64_t nblk = cap_ceil_div(n, nb);
+  const bool la = p->lookahead && nblk > 2;
+  if (!la) {
+    for (int64_t k = 0; k < nblk; k++) {
+      const int64_t j0 = k * nb, jb = std::min(nb, n - j0), m = n - j0 - jb;
+      CAP_TRY(panel_factor(p, R, ldr, n, j0, jb, s0));
+      if (m > 0) {
+        double* Rpan = R + j0 + (j0 + jb) * ldr;
+        double* R22 = R + (j0 + jb) + (j0 + jb) * ldr;
+        CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, m, m, jb, -1.0, Rpan, ldr, Rpan, ldr, 1.0, R22, ldr, 1, s0));
+      }
+    }
+    return CAP_OK;
+  }
+  CAP_TRY(ensure_streams(p));
+  hipStream_t s1 = p->s_panel;
+  // fork: the panel stream joins the caller's stream
+  CAP_HIP(hipEventRecord(p->ev_fork, s0));
+  CAP_HIP(hipStreamWaitEvent(s1, p->ev_fork, 0));
+  // panel 0 on the panel stream
+  CAP_TRY(panel_factor(p, R, ldr, n, 0, std::min(nb, n), s1));
+  CAP_HIP(hipEventRecord(p->ev_panel[0], s1));
+  for (int64_t k = 0; k < nblk; k++) {
+    const int64_t j0 = k * nb, jb = std::min(nb, n - j0), m = n - j0 - jb;
+    if (m <= 0) break;
+    const int64_t j1 = j0 + jb, jb1 = std::min(nb, n - j1), m2 = m - jb1;
+    double* Rpan = R + j0 + j1 * ldr;             // block row k: jb x m, columns j1..n
+    // (a) panel stream: update block row k+1 (upper part), factor panel k+1
+    //     needs: panel k (same stream) and the bulk update of step k-1 (main stream)
+    if (k > 0) CAP_HIP(hipStreamWaitEvent(s1, p->ev_update[(k - 1) & 1], 0));
+    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb1, m, jb, -1.0, Rpan, ldr, Rpan, ldr, 1.0, R + j1 + j1 * ldr, ldr, 1, s1));
+    CAP_TRY(panel_factor(p, R, ldr, n, j1, jb1, s1));
+    CAP_HIP(hipEventRecord(p->ev_panel[(k + 1) & 1], s1));
+    // (b) main stream: bulk of the trailing update (rows below block row k+1)
+    CAP_HIP(hipStreamWaitEvent(s0, p->ev_panel[k & 1], 0));
+    if (m2 > 0) {
+      double* Rp2 = Rpan + jb1 * ldr;             // columns j1+jb1..n of block row k
+      double* R33 = R + (j1 + jb1) + (j1 + jb1) * ldr;
+      CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, m2, m2, jb, -1.0, Rp2, ldr, Rp2, ldr, 1.0, R33, ldr, 1, s0));
+    }
+    CAP_HIP(hipEventRecord(p->ev_update[k & 1], s0));
+  }
+  // join
+  CAP_HIP(hipEventRecord(p->ev_join, s1));
+  CAP_HIP(hipStreamWaitEvent(s0, p->ev_join, 0));
+  return CAP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv, int64_t split, int64_t bc_mult_dim,
+                            char dir, cap_comm* comm) {
+  if (!plan || n <= 0 || split <= 0) return CAP_ERR_ARG;          // assert(args.split>0), cholinv.hpp:9
+  if (dir != 'U') return CAP_ERR_UNSUPPORTED;                      // assert(args.dir == 'U'), cholinv.hpp:9
+  if (complete_inv < -1 || complete_inv > 1) return CAP_ERR_ARG;
+  if (comm && cap_comm_size(comm) > 1) return CAP_ERR_UNSUPPORTED;  // distributed plans: cap_cholinv_plan_create_dist (dist.hip)
+  cap_cholinv_plan* p = new (std::nothrow) cap_cholinv_plan();
+  if (!p) return CAP_ERR_ALLOC;
+  memset(p, 0, sizeof(*p));
+  p->n = n; p->complete_inv = complete_inv; p->split = split; p->bc_mult_dim = bc_mult_dim; p->dir = dir; p->comm = comm;
+  p->nb = default_nb(n, bc_mult_dim); p->leaf = CAP_LEAF_MAX; p->lookahead = 1;
+  int st = plan_alloc(p);
+  if (st != CAP_OK) { cap_cholinv_plan_destroy(p); return st; }
+  *plan = p;
+  return CAP_OK;
+}
+
+int cap_cholinv_plan_destroy(cap_cholinv_plan* p) {
+  if (!p) return CAP_OK;
+  if (p->R) (void)hipFree(p->R);
+  if (p->Rinv) (void)hipFree(p->Rinv);
+  if (p->work) (void)hipFree(p->work);
+  if (p->info_dev) (void)hipFree(p->info_dev);
+  if (p->streams_ready) {
+    (void)hipStreamDestroy(p->s_panel);
+    for (int i = 0; i < 2; i++) { (void)hipEventDestroy(p->ev_panel[i]); (void)hipEventDestroy(p->ev_update[i]); }
+    (void)hipEventDestroy(p->ev_fork); (void)hipEventDestroy(p->ev_join);
+  }
+  delete p;
+  return CAP_OK;
+}
+
+int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) {
+  if (!p || !key) return CAP_ERR_ARG;
+  std::string k(key);
+  if (k == "nb") {
+    if (p->complete_inv >= 0) { p->nb = value; return CAP_OK; }
+    if (value < 64 || value % 64) return CAP_ERR_ARG;
+    if (value == p->nb) return CAP_OK;
+    // workspace depends on nb: reallocate
+    (void)hipFree(p->Rinv); (void)hipFree(p->work);
+    p->Rinv = nullptr; p->work = nullptr;
+    p->nb = value; p->ldi = value;
+    CAP_HIP(hipMalloc((void**)&p->Rinv, sizeof(double) * p->nb * p->nb));
+    CAP_HIP(hipMemset(p->Rinv, 0, sizeof(double) * p->nb * p->nb));
+    p->work_elems = rec_work_size(p->nb) + cap_round_up(p->nb * p->n, 2);
+    CAP_HIP(hipMalloc((void**)&p->work, sizeof(double) * p->work_elems));
+    return CAP_OK;
+  }
+  if (k == "leaf") { if (value < 1 || value > CAP_LEAF_MAX) return CAP_ERR_ARG; p->leaf = value; return CAP_OK; }
+  if (k == "lookahead") { p->lookahead = value != 0; return CAP_OK; }
+  return CAP_ERR_ARG;
+}
+
+int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
+  if (!p || !key) return -1;
+  std::string k(key);
+  if (k == "nb") return p->nb;
+  if (k == "leaf") return p->leaf;
+  if (k == "lookahead") return p->lookahead;
+  if (k == "n") return p->n;
+  if (k == "complete_inv") return p->complete_inv;
+  if (k == "split") return p->split;
+  if (k == "bc_mult_dim") return p->bc_mult_dim;
+  return -1;
+}
+
+int cap_cholinv_factor(cap_cholinv_plan* p, const double* A, int64_t lda, void* stream) {
+  if (!p || !A || lda < p->n) return CAP_ERR_ARG;
+  hipStream_t s = cap_stream(stream);
+  const int64_t n = p->n;
+  CAP_HIP(hipMemsetAsync(p->info_dev, 0, sizeof(int), s));
+  // serialize<uppertri,uppertri>(A -> R), cholinv.hpp:13: only A's upper triangle is consumed
+  CAP_TRY(cap_copy_window(A, 0, lda, 0, 0, p->R, 0, p->ldr, 0, 0, n, n, 1, 1, stream));
+  if (p->complete_inv < 0) return right_looking(p, p->R, p->ldr, n, s);
+  RecCtx c{p->R, p->ldr, p->Rinv, p->ldi, p->work, p->work_elems, p->info_dev, p->leaf, p->split, p->complete_inv, s};
+  // upstream's leaf test at the root (cholinv.hpp:93 with c = d = 1): a root that is itself a base
+  // case gets the full inverse whatever complete_inv says (policy.h:199-201 always runs trtri)
+  int64_t bc = 1;
+  if (p->bc_mult_dim < 0) for (int64_t i = 0; i < -p->bc_mult_dim && bc < n; i++) bc *= 2;
+  bc = std::max<int64_t>(1, std::min<int64_t>(n, bc));
+  const int64_t bc_dim = n / bc;
+  const bool root_is_base = (n <= bc_dim) || ((n >> p->split) < p->split);
+  return rec_cholinv(c, 0, n, !root_is_base, 0);
+}
+
+int cap_cholinv_get_R(cap_cholinv_plan* p, double* out, int64_t ld, void* stream) {
+  if (!p || !out || ld < p->n) return CAP_ERR_ARG;
+  return cap_copy_window(p->R, 0, p->ldr, 0, 0, out, 0, ld, 0, 0, p->n, p->n, 1, 1, stream);
+}
+
+int cap_cholinv_get_Rinv(cap_cholinv_plan* p, double* out, int64_t ld, void* stream) {
+  if (!p || !out || ld < p->n) return CAP_ERR_ARG;
+  if (p->complete_inv < 0) return CAP_ERR_UNSUPPORTED;   // this mode never builds R^-1
+  return cap_copy_window(p->Rinv, 0, p->ldi, 0, 0, out, 0, ld, 0, 0, p->n, p->n, 1, 1, stream);
+}
+
+double* cap_cholinv_R_ptr(cap_cholinv_plan* p, int64_t* ld) { if (!p) return nullptr; if (ld) *ld = p->ldr; return p->R; }
+double* cap_cholinv_Rinv_ptr(cap_cholinv_plan* p, int64_t* ld) {
+  if (!p || p->complete_inv < 0) return nullptr;
+  if (ld) *ld = p->ldi;
+  return p->Rinv;
+}
+
+int cap_cholinv_info(cap_cholinv_plan* p, void* stream, int64_t* info) {
+  if (!p || !info) return CAP_ERR_ARG;
+  int h = 0;
+  CAP_HIP(hipMemcpyAsync(&h, p->info_dev, sizeof(int), hipMemcpyDeviceToHost, cap_stream(stream)));
+  CAP_HIP(hipStreamSynchronize(cap_stream(stream)));
+  *info = h;
+  return h == 0 ? CAP_OK : CAP_ERR_NOT_SPD;
+}
+
+// -------------------------------------------------------------------------------------------------
+// operator seam built from the same blocks (lapack::engine::_potrf/_trtri, blas::engine::_trmm, DTRSM)
+// -------------------------------------------------------------------------------------------------
+int64_t cap_dpotrf_work_size(int64_t n) {
+  int64_t nb = default_nb(n, -100);
+  nb = std::min<int64_t>(nb, cap_round_up(std::max<int64_t>(n, 1), 64));
+  return nb * nb + rec_work_size(nb) + cap_round_up(nb * n, 2) + 8;
+}
+
+int cap_dpotrf(int uplo, int64_t n, double* A, int64_t lda, int* info, double* work, void* stream) {
+  if (n < 0 || (n > 0 && (!A || lda < n || !work))) return CAP_ERR_ARG;
+  if (uplo != CAP_UPPER) return CAP_ERR_UNSUPPORTED;    // upstream removed 'L' as well (cholinv.hpp:9)
+  if (n == 0) return CAP_OK;
+  hipStream_t s = cap_stream(stream);
+  // a throw-away single-stream plan view over caller memory
+  cap_cholinv_plan p;
+  memset(&p, 0, sizeof(p));
+  p.n = n; p.complete_inv = -1; p.leaf = CAP_LEAF_MAX; p.lookahead = 0;
+  p.nb = std::min<int64_t>(default_nb(n, -100), cap_round_up(n, 64));
+  p.ldi = p.nb;
+  p.Rinv = work;                                // nb x nb
+  p.work = work + p.nb * p.nb;                  // rec scratch + panel scratch
+  p.info_dev = info;
+  CAP_HIP(hipMemsetAsync(p.Rinv, 0, sizeof(double) * p.nb * p.nb, s));
+  if (info) CAP_HIP(hipMemsetAsync(info, 0, sizeof(int), s));
+  return right_looking(&p, A, lda, n, s);
+}
+
+int64_t cap_dtrtri_work_size(int64_t n) { return n * n + rec_work_size(n); }
+
+int cap_dtrtri(int uplo, int64_t n, double* A, int64_t lda, double* work, void* stream) {
+  if (n < 0 || (n > 0 && (!A || lda < n || !work))) return CAP_ERR_ARG;
+  if (uplo != CAP_UPPER) return CAP_ERR_UNSUPPORTED;
+  if (n == 0) return CAP_OK;
+  hipStream_t s = cap_stream(stream);
+  // work on a zero-lower copy (LAPACK does not reference the other triangle), then copy the upper part back
+  double* T = work; double* W = work + n * n;
+  CAP_TRY(cap_copy_window(A, 0, lda, 0, 0, T, 0, n, 0, 0, n, n, 1, 1, stream));
+  CAP_TRY(rec_trtri(T, n, n, W, rec_work_size(n), CAP_LEAF_MAX, s));
+  return cap_copy_window(T, 0, n, 0, 0, A, 0, lda, 0, 0, n, n, 1, 0, stream);
+}
+
+// B = alpha op(T) B  or  alpha B op(T): copy triangle to a zero-filled square, GEMM out of place, copy back.
+// work layout: [tdim*tdim triangle copy][m*n result]
+static int trmm_like(int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha, const double* T,
+                     int64_t ldt, double* B, int64_t ldb, double* work, hipStream_t s, bool solve) {
+  if (m < 0 || n < 0) return CAP_ERR_ARG;
+  if (m == 0 || n == 0) return CAP_OK;
+  if (!T || !B || !work || ldb < m) return CAP_ERR_ARG;
+  if (uplo != CAP_UPPER || diag != CAP_NONUNIT) return CAP_ERR_UNSUPPORTED;
+  const int64_t td = side == CAP_LEFT ? m : n;
+  if (ldt < td) return CAP_ERR_ARG;
+  double* Tc = work; double* Out = work + cap_round_up(td * td, 2);
+  CAP_TRY(cap_copy_window(T, 0, ldt, 0, 0, Tc, 0, td, 0, 0, td, td, 1, 1, (void*)s));
+  if (solve) {
+    double* W = Out + cap_round_up(m * n, 2);
+    CAP_TRY(rec_trtri(Tc, td, td, W, rec_work_size(td), CAP_LEAF_MAX, s));
+  }
+  if (side == CAP_LEFT)
+    CAP_TRY(cap_gemm_launch(trans, CAP_NOTRANS, m, n, m, alpha, Tc, td, B, ldb, 0.0, Out, m, 0, s));
+  else
+    CAP_TRY(cap_gemm_launch(CAP_NOTRANS, trans, m, n, n, alpha, B, ldb, Tc, td, 0.0, Out, m, 0, s));
+  return cap_copy_rect(Out, m, B, ldb, m, n, s);
+}
+
+int64_t cap_dtrmm_work_size(int side, int64_t m, int64_t n) {
+  const int64_t td = side == CAP_LEFT ? m : n;
+  return cap_round_up(td * td, 2) + cap_round_up(m * n, 2);
+}
+
+int cap_dtrmm(int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha, const double* T, int64_t ldt,
+              double* B, int64_t ldb, double* work, void* stream) {
+  return trmm_like(side, uplo, trans, diag, m, n, alpha, T, ldt, B, ldb, work, cap_stream(stream), false);
+}
+
+int64_t cap_dtrsm_work_size(int side, int64_t m, int64_t n) {
+  const int64_t td = side == CAP_LEFT ? m : n;
+  return cap_round_up(td * td, 2) + cap_round_up(m * n, 2) + rec_work_size(td);
+}
+
+int cap_dtrsm(int side, int uplo, int trans, int64_t m, int64_t n, double alpha, const double* T, int64_t ldt, double* B,
+              int64_t ldb, double* work, void* stream) {
+  // op(T) X = alpha B  <=>  X = alpha op(T^-1) B: invert the (small) triangle once, then one GEMM on MFMA
+  return trmm_like(side, uplo, trans, CAP_NONUNIT, m, n, alpha, T, ldt, B, ldb, work, cap_stream(stream), true);
+}
+
+}  // extern "C"
+
+// used by cacqr.hip: full cholinv (R in place, Ri = R^-1) of an n x n block on one stream
+int cap_rec_cholinv_full(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, double* W, int64_t wcap, int* info,
+                         hipStream_t s) {
+  RecCtx c{R, ldr, Ri, ldi, W, wcap, info, CAP_LEAF_MAX, 1, 1, s};
+  return rec_cholinv(c, 0, n, false, 0);
+}
+int64_t cap_rec_work_size(int64_t n) { return rec_work_size(n); }

@@ -35,3 +35,14 @@ static inline int64_t cap_round_up(int64_t a, int64_t b) { return cap_ceil_div(a
 int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
                     int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri,
                     hipStream_t stream);
+
+// leaf.hip: in-LDS cholinv (potrf + trtri) / trtri of one n <= 64 block
+constexpr int CAP_LEAF_MAX = 64;
+int cap_leaf_cholinv(double* A, int64_t lda, double* Rinv, int64_t ldr, int n, int zero_lower, int* info,
+                     int info_base, hipStream_t stream);
+int cap_leaf_trtri(const double* R, int64_t ldr, double* Rinv, int64_t ldi, int n, hipStream_t stream);
+
+// aux.hip
+int cap_copy_rect(const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s);
+int cap_zero_rect(double* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s);
+double* cap_scratch(int64_t elems);  // gemm.hip: library-owned device scratch (split-K partials)

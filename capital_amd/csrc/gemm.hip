@@ -34,21 +34,25 @@ struct GemmArgs {
   int64_t M, N, K;
   double alpha, beta;
   int tm, tn;       // tiles in M, N
-  int tri;          // 0 full, 1 upper (row<=col), 2 lower
+  int tri;          // element mask: 0 full, 1 upper (row<=col), 2 lower
+  int etri;         // tile enumeration: 0 full grid, 1/2 triangular (square tile spaces only)
   int chunk;        // logical tiles per XCD
   int nsm, nsn;     // supertiles in M, N
+  // split-K (tall-skinny Gram / few-tile problems): blockIdx.y = K slice; partial tiles go to
+  // slab kz of P (column-major, ld = M) and a second kernel reduces them deterministically
+  int ksplit; int64_t kchunk; double* P; int64_t slab;
 };
 
 // logical slot -> tile coordinates (returns false when the slot is empty)
 __device__ __forceinline__ bool slot_to_tile(const GemmArgs& g, int L, int& ti, int& tj) {
   int S = L / (ST * ST), w = L % (ST * ST);
   int si, sj;
-  if (g.tri == 1) {  // upper triangle of supertiles, column-major: S = sj(sj+1)/2 + si
+  if (g.etri == 1) {  // upper triangle of supertiles, column-major: S = sj(sj+1)/2 + si
     sj = (int)((__builtin_sqrtf(8.0f * (float)S + 1.0f) - 1.0f) * 0.5f);
     while ((sj + 1) * (sj + 2) / 2 <= S) sj++;
     while (sj * (sj + 1) / 2 > S) sj--;
     si = S - sj * (sj + 1) / 2;
-  } else if (g.tri == 2) {
+  } else if (g.etri == 2) {
     si = (int)((__builtin_sqrtf(8.0f * (float)S + 1.0f) - 1.0f) * 0.5f);
     while ((si + 1) * (si + 2) / 2 <= S) si++;
     while (si * (si + 1) / 2 > S) si--;
@@ -138,11 +142,14 @@ __global__ void __launch_bounds__(NTHREADS, 2) dgemm_kernel(const GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
-  const int nk = (int)((g.K + BK - 1) / BK);
+  const int kz = blockIdx.y;
+  const int64_t kbeg = (int64_t)kz * g.kchunk;
+  const int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+  const int nk = (int)((kend - kbeg + BK - 1) / BK);
   d2 ra[4], rb[4];
   if (nk > 0) {
-    load_tile<A_KC, EDGE>(g.A, g.lda, i0, 0, g.M, g.K, ra);
-    load_tile<B_KC, EDGE>(g.B, g.ldb, j0, 0, g.N, g.K, rb);
+    load_tile<A_KC, EDGE>(g.A, g.lda, i0, kbeg, g.M, kend, ra);
+    load_tile<B_KC, EDGE>(g.B, g.ldb, j0, kbeg, g.N, kend, rb);
     store_tile<A_KC>(sA(0), ra);
     store_tile<B_KC>(sB(0), rb);
   }
@@ -159,8 +166,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) dgemm_kernel(const GemmArgs g) {
   for (int kt = 0; kt < nk; kt++) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      load_tile<A_KC, EDGE>(g.A, g.lda, i0, (int64_t)(kt + 1) * BK, g.M, g.K, ra);
-      load_tile<B_KC, EDGE>(g.B, g.ldb, j0, (int64_t)(kt + 1) * BK, g.N, g.K, rb);
+      load_tile<A_KC, EDGE>(g.A, g.lda, i0, kbeg + (int64_t)(kt + 1) * BK, g.M, kend, ra);
+      load_tile<B_KC, EDGE>(g.B, g.ldb, j0, kbeg + (int64_t)(kt + 1) * BK, g.N, kend, rb);
     }
     const double* pa = sA(cur) + a_base;
     const double* pb = sB(cur) + b_base;
@@ -199,10 +206,14 @@ __global__ void __launch_bounds__(NTHREADS, 2) dgemm_kernel(const GemmArgs g) {
         if (g.tri == 1) ok = ok && (row <= col);
         if (g.tri == 2) ok = ok && (row >= col);
         if (ok) {
-          double* pc = g.C + row + col * g.ldc;
           double v = alpha * acc[i][j][r];
-          if (beta != 0.0) v += beta * (*pc);
-          *pc = v;
+          if (g.ksplit > 1) {
+            g.P[(int64_t)kz * g.slab + row + col * g.M] = v;
+          } else {
+            double* pc = g.C + row + col * g.ldc;
+            if (beta != 0.0) v += beta * (*pc);
+            *pc = v;
+          }
         }
       }
     }
@@ -213,9 +224,9 @@ template <bool A_KC, bool B_KC>
 int launch_variant(const GemmArgs& g, bool edge, int grid, hipStream_t stream) {
   size_t lds = 4 * TILE_ELEMS * sizeof(double);
   if (edge)
-    hipLaunchKernelGGL((dgemm_kernel<A_KC, B_KC, true>), dim3(grid), dim3(NTHREADS), lds, stream, g);
+    hipLaunchKernelGGL((dgemm_kernel<A_KC, B_KC, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
   else
-    hipLaunchKernelGGL((dgemm_kernel<A_KC, B_KC, false>), dim3(grid), dim3(NTHREADS), lds, stream, g);
+    hipLaunchKernelGGL((dgemm_kernel<A_KC, B_KC, false>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
@@ -231,7 +242,33 @@ __global__ void scale_kernel(double* C, int64_t ldc, int64_t m, int64_t n, doubl
   }
 }
 
+// C = beta*C + sum_z P[z]  (fixed summation order -> run-to-run deterministic)
+__global__ void splitk_reduce_kernel(double* C, int64_t ldc, const double* P, int64_t slab, int ksplit, int64_t m, int64_t n,
+                                     double beta, int tri) {
+  int64_t col = blockIdx.y;
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < m; row += (int64_t)gridDim.x * blockDim.x) {
+    if (tri == 1 && row > col) continue;
+    if (tri == 2 && row < col) continue;
+    double s = 0.0;
+    for (int z = 0; z < ksplit; z++) s += P[(int64_t)z * slab + row + col * m];
+    double* pc = C + row + col * ldc;
+    *pc = (beta == 0.0) ? s : s + beta * (*pc);
+  }
+}
+
+// library-owned scratch for split-K partials (grown on demand; first use synchronises)
+double* g_scratch = nullptr;
+int64_t g_scratch_elems = 0;
+
 }  // namespace
+
+double* cap_scratch(int64_t elems) {
+  if (elems <= g_scratch_elems) return g_scratch;
+  if (g_scratch) { (void)hipDeviceSynchronize(); (void)hipFree(g_scratch); g_scratch = nullptr; g_scratch_elems = 0; }
+  if (hipMalloc((void**)&g_scratch, sizeof(double) * elems) != hipSuccess) return nullptr;
+  g_scratch_elems = elems;
+  return g_scratch;
+}
 
 int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
                     int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri,
@@ -258,26 +295,46 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   g.tm = (int)cap_ceil_div(m, BM); g.tn = (int)cap_ceil_div(n, BN);
   g.nsm = (int)cap_ceil_div(g.tm, ST); g.nsn = (int)cap_ceil_div(g.tn, ST);
   int64_t nsuper;
-  if (tri == 0) nsuper = (int64_t)g.nsm * g.nsn;
-  else {
-    // triangular operands are square in tile space; enumerate the supertile triangle
-    int ns = g.nsm > g.nsn ? g.nsm : g.nsn;
-    nsuper = (int64_t)ns * (ns + 1) / 2;
-  }
+  g.etri = (tri != 0 && g.nsm == g.nsn) ? tri : 0;
+  if (g.etri == 0) nsuper = (int64_t)g.nsm * g.nsn;   // strips keep the element mask but walk the full grid
+  else nsuper = (int64_t)g.nsm * (g.nsm + 1) / 2;      // square tile space: enumerate the supertile triangle
   int64_t slots = nsuper * ST * ST;
   g.chunk = (int)cap_ceil_div(slots, 8);
   int64_t grid = (int64_t)g.chunk * 8;
   if (grid > 0x7fffffff) return CAP_ERR_UNSUPPORTED;
+
+  // split-K when the tile grid cannot fill the chip and K is long (Gram matrices, cacqr.hpp:15)
+  g.ksplit = 1; g.kchunk = cap_round_up(k, BK); g.P = nullptr; g.slab = 0;
+  {
+    int64_t tiles = (tri == 0) ? (int64_t)g.tm * g.tn : ((int64_t)g.tm * (g.tm + 1)) / 2;
+    if (tiles < 128 && k >= 4096 && n <= 65535) {
+      int64_t want = cap_ceil_div(768, tiles);
+      int64_t maxs = k / 1024;
+      int64_t ks = want < maxs ? want : maxs;
+      if (ks > 1) {
+        int64_t kc = cap_round_up(cap_ceil_div(k, ks), BK);
+        ks = cap_ceil_div(k, kc);
+        double* P = cap_scratch(ks * m * n);
+        if (P && ks > 1) { g.ksplit = (int)ks; g.kchunk = kc; g.P = P; g.slab = m * n; }
+      }
+    }
+  }
 
   const bool a_kc = (transa == CAP_TRANS);   // op(A)=A^T: k contiguous
   const bool b_kc = (transb != CAP_TRANS);   // op(B)=B:   k contiguous
   auto aligned16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   bool edge = (m % BM) || (n % BN) || (k % BK) || (lda & 1) || (ldb & 1) || !aligned16(A) || !aligned16(B);
 
-  if (a_kc && b_kc) return launch_variant<true, true>(g, edge, (int)grid, stream);
-  if (a_kc && !b_kc) return launch_variant<true, false>(g, edge, (int)grid, stream);
-  if (!a_kc && b_kc) return launch_variant<false, true>(g, edge, (int)grid, stream);
-  return launch_variant<false, false>(g, edge, (int)grid, stream);
+  int st;
+  if (a_kc && b_kc) st = launch_variant<true, true>(g, edge, (int)grid, stream);
+  else if (a_kc && !b_kc) st = launch_variant<true, false>(g, edge, (int)grid, stream);
+  else if (!a_kc && b_kc) st = launch_variant<false, true>(g, edge, (int)grid, stream);
+  else st = launch_variant<false, false>(g, edge, (int)grid, stream);
+  if (st != CAP_OK || g.ksplit == 1) return st;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cap_ceil_div(m, 256), (unsigned)n), dim3(256), 0, stream, C, ldc,
+                     g.P, g.slab, g.ksplit, m, n, beta, tri);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
 }
 
 extern "C" int cap_dgemm(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,

@@ -1,0 +1,108 @@
+"""GPU-resident element-cyclic matrix descriptor (reference src/matrix/matrix.h:9-97,
+structure.h:8-72, structure.hpp:68-129, serialize.hpp).
+
+Same constructor argument order and accessor names as upstream:
+    matrix(globalDimensionX = #columns, globalDimensionY = #rows, globalPgridX, globalPgridY)
+X = column index, Y = row index everywhere (matrix.h:19,47).  Local storage is column-major
+in HBM with the reference's ceil(N/d) zero-padded local dims (matrix.hpp:8-11).  The
+reference's three raw buffers data/scratch/pad (pointer-rotation protocol, matrix.h:55-56)
+do not exist here: workspaces are owned by plans behind the C ABI."""
+import numpy as np
+import torch
+
+from . import _lib
+from ._util import cur_stream
+
+
+class rect:
+    name = "rect"
+
+    @staticmethod
+    def _offset(x, y, dimX, dimY):   # structure.h:13
+        return x * dimY + y
+
+    @staticmethod
+    def _num_elems(dimX, dimY):
+        return dimX * dimY
+
+
+class uppertri:
+    name = "uppertri"
+
+    @staticmethod
+    def _offset(x, y, dimX, dimY):   # structure.h:39
+        return (x * (x + 1)) // 2 + y
+
+    @staticmethod
+    def _num_elems(dimX, dimY):      # structure.h:37
+        return (dimY * (dimY + 1)) // 2
+
+
+def _local(n_global, p):
+    return n_global // p + (1 if n_global % p else 0)
+
+
+class matrix:
+    def __init__(self, globalDimensionX, globalDimensionY, globalPgridX=1, globalPgridY=1, structure=rect, device=None):
+        if structure is not rect:
+            raise _lib.CapitalError("device matrices are rect; packed-upper windows are handled by serialize()")
+        self._globalDimensionX, self._globalDimensionY = int(globalDimensionX), int(globalDimensionY)
+        self._dimensionX = _local(self._globalDimensionX, globalPgridX)
+        self._dimensionY = _local(self._globalDimensionY, globalPgridY)
+        self._pgridX, self._pgridY = int(globalPgridX), int(globalPgridY)
+        self.structure = structure
+        self.device = torch.device(device if device is not None else ("cuda:%d" % torch.cuda.current_device()))
+        if self.device.type != "cuda":
+            raise _lib.CapitalError("capital_amd matrices live in HBM; no CPU path")
+        self._ld = self._dimensionY + (self._dimensionY & 1)          # even ld keeps 16-byte loads aligned
+        self._buf = torch.zeros(self._dimensionX, self._ld, dtype=torch.float64, device=self.device)
+
+    # --- accessors with upstream names (matrix.h:44-51) ---
+    def num_rows_local(self): return self._dimensionY
+    def num_columns_local(self): return self._dimensionX
+    def num_rows_global(self): return self._globalDimensionY
+    def num_columns_global(self): return self._globalDimensionX
+    def num_elems(self): return self._dimensionX * self._dimensionY
+    def ld(self): return self._ld
+    def data(self): return self._buf           # device buffer (columns, ld); data().data_ptr() is the raw address
+    def data_ptr(self): return self._buf.data_ptr()
+
+    def view(self):
+        """[row, col] indexed device view of the local piece."""
+        return self._buf[:, :self._dimensionY].t()
+
+    # --- generators (structure.hpp:68-129), computed on the GPU ---
+    def distribute_symmetric(self, localPgridX, localPgridY, globalPgridX, globalPgridY, key=0, diagonallyDominant=True):
+        if globalPgridX != globalPgridY or self._globalDimensionX != self._globalDimensionY:
+            raise _lib.CapitalError("distribute_symmetric needs a square matrix on a square grid")
+        st = _lib.lib().cap_fill_symmetric(self._buf.data_ptr(), self._ld, self._globalDimensionX, localPgridX, localPgridY,
+                                           globalPgridX, 1 if diagonallyDominant else 0, cur_stream())
+        _lib.check(st, "distribute_symmetric")
+
+    def distribute_random(self, localPgridX, localPgridY, globalPgridX, globalPgridY, key=0):
+        st = _lib.lib().cap_fill_random(self._buf.data_ptr(), self._ld, self._globalDimensionY, self._globalDimensionX,
+                                        localPgridX, localPgridY, globalPgridX, globalPgridY, key, cur_stream())
+        _lib.check(st, "distribute_random")
+
+    # --- host transfer (tests / drivers; pinned staging is the caller's business) ---
+    def to_numpy(self):
+        return self.view().cpu().numpy().copy()
+
+    def from_numpy(self, a):
+        a = np.asarray(a, dtype=np.float64)
+        assert a.shape == (self._dimensionY, self._dimensionX), (a.shape, self._dimensionY, self._dimensionX)
+        self.view().copy_(torch.from_numpy(np.ascontiguousarray(a)).to(self.device))
+        return self
+
+
+def serialize(src, dst, src_window, dst_origin, tri_only=False, zero_lower=False, src_packed=False, dst_packed=False,
+              src_ld=None, dst_ld=None):
+    """serialize<S1,S2>::invoke (serialize.hpp:12-150) on device buffers.
+
+    src/dst: torch tensors (device); window = (row0, row1, col0, col1) in the source; origin = (row0, col0) in dst.
+    packed buffers use uppertri::_offset (structure.h:39)."""
+    r0, r1, c0, c1 = src_window
+    st = _lib.lib().cap_copy_window(src.data_ptr(), int(src_packed), src_ld or 0, r0, c0, dst.data_ptr(), int(dst_packed),
+                                    dst_ld or 0, dst_origin[0], dst_origin[1], r1 - r0, c1 - c0, int(tri_only), int(zero_lower),
+                                    cur_stream())
+    _lib.check(st, "serialize")

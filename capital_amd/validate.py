@@ -1,0 +1,65 @@
+"""Residual functors computed on the GPU (reference test/cholesky/validate.hpp:7-49,
+test/qr/validate.hpp:7-52, src/util/util.hpp:25-53) - the parity metrics of the hot path."""
+import math
+
+import torch
+
+from . import _lib
+from ._util import cur_stream
+from . import cholinv as _cholinv
+from . import cacqr as _cacqr
+
+
+class cholesky:
+    @staticmethod
+    def residual(A, args, CommInfo=None):
+        """sqrt(sum_upper (R^T R - A)^2) / sqrt(sum_upper A^2)  (validate.hpp:33-46)."""
+        n = A.num_rows_global()
+        R = _cholinv.construct_R(args, CommInfo)
+        work = torch.empty(n * n, dtype=torch.float64, device=A.device)
+        out = torch.zeros(2, dtype=torch.float64, device=A.device)
+        st = _lib.lib().cap_cholesky_residual_terms(A.data_ptr(), A.ld(), R.data_ptr(), R.ld(), n, work.data_ptr(),
+                                                    out.data_ptr(), cur_stream())
+        _lib.check(st, "cholesky::validate::residual")
+        e, c = out.tolist()
+        return math.sqrt(e) / math.sqrt(c)
+
+
+class qr:
+    @staticmethod
+    def _sumsq(t, ld, m, n, sub_identity=False):
+        out = torch.zeros(1, dtype=torch.float64, device=t.device)
+        _lib.check(_lib.lib().cap_sumsq(t.data_ptr(), ld, m, n, int(sub_identity), 0, out.data_ptr(), cur_stream()), "sumsq")
+        return out
+
+    @staticmethod
+    def residual(A, args, CommInfo=None):
+        """||QR - A||_F / ||A||_F (test/qr/validate.hpp:37-52); partial sums all-reduced over ranks."""
+        Q = _cacqr.construct_Q(args, CommInfo); R = _cacqr.construct_R(args, CommInfo)
+        m, n = A.num_rows_local(), A.num_columns_local()
+        E = torch.empty_like(A.data()); E.copy_(A.data())
+        L = _lib.lib()
+        _lib.check(L.cap_dgemm(0, 0, m, n, n, 1.0, Q.data_ptr(), Q.ld(), R.data_ptr(), R.ld(), -1.0, E.data_ptr(), A.ld(),
+                               cur_stream()), "QR - A")
+        num = qr._sumsq(E, A.ld(), m, n); den = qr._sumsq(A.data(), A.ld(), m, n)
+        v = torch.cat([num, den])
+        comm = getattr(CommInfo, "world", None) if CommInfo is not None else None
+        if comm is not None and getattr(CommInfo, "size", 1) > 1:
+            _lib.check(L.cap_comm_allreduce_sum(comm, v.data_ptr(), 2, cur_stream()), "allreduce")
+        e, c = v.tolist()
+        return math.sqrt(e) / math.sqrt(c)
+
+    @staticmethod
+    def orthogonality(A, args, CommInfo=None):
+        """||Q^T Q - I||_F / sqrt(n*n): upstream normalises by control = 1 per entry (validate.hpp:24-31)."""
+        Q = _cacqr.construct_Q(args, CommInfo)
+        m, n = Q.num_rows_local(), Q.num_columns_local()
+        G = torch.zeros(n, n, dtype=torch.float64, device=Q.device)
+        L = _lib.lib()
+        _lib.check(L.cap_dgemm(1, 0, n, n, m, 1.0, Q.data_ptr(), Q.ld(), Q.data_ptr(), Q.ld(), 0.0, G.data_ptr(), n,
+                               cur_stream()), "Q^T Q")
+        comm = getattr(CommInfo, "world", None) if CommInfo is not None else None
+        if comm is not None and getattr(CommInfo, "size", 1) > 1:
+            _lib.check(L.cap_comm_allreduce_sum(comm, G.data_ptr(), n * n, cur_stream()), "allreduce")
+        e = qr._sumsq(G, n, n, n, sub_identity=True).item()
+        return math.sqrt(e) / math.sqrt(n * n)

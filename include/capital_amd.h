@@ -65,22 +65,25 @@ int cap_dsyrk(int uplo, int trans, int64_t n, int64_t k, double alpha, const dou
 
 /* blas::engine::_trmm  - blas/interface.h:62-63, interface.hpp:61-79 (cblas_dtrmm).
  * B[m x n] = alpha * op(T) * B (side = LEFT, T m x m) or alpha * B * op(T) (RIGHT, T n x n).
- * In place like the reference; `work` is device scratch of >= m*n doubles (the reference
- * hides the same copy inside MKL); work == NULL -> CAP_ERR_ARG.                          */
+ * In place like the reference; `work` is device scratch of >= cap_dtrmm_work_size doubles
+ * (the reference hides the same copy inside MKL).  uplo = UPPER, diag = NONUNIT only (all
+ * upstream call sites); other values return CAP_ERR_UNSUPPORTED.               */
 int cap_dtrmm(int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
               const double* T, int64_t ldt, double* B, int64_t ldb, double* work, void* stream);
+int64_t cap_dtrmm_work_size(int side, int64_t m, int64_t n);
 
 /* Real triangular solve (not in the reference, which inverts then multiplies - SURVEY 2b;
  * trsm/diaginvert/diaginvert.hpp:7-10 is a static_assert stub).  Solves
- * op(T) X = alpha B (LEFT) or X op(T) = alpha B (RIGHT) in place; T upper or lower, non-unit.
- * `work`: device scratch >= m*n + 2*nb*max(m,n)... see cap_dtrsm_work_size.               */
+ * op(T) X = alpha B (LEFT) or X op(T) = alpha B (RIGHT) in place; T upper, non-unit.  Done as
+ * "invert the triangle (recursive TRTRI), then one MFMA GEMM" - upstream's invert-then-multiply.
+ * `work`: device scratch >= cap_dtrsm_work_size doubles.                                   */
 int cap_dtrsm(int side, int uplo, int trans, int64_t m, int64_t n, double alpha, const double* T,
               int64_t ldt, double* B, int64_t ldb, double* work, void* stream);
 int64_t cap_dtrsm_work_size(int side, int64_t m, int64_t n);
 
 /* lapack::engine::_potrf - lapack/interface.h:49-50, interface.hpp:30-43 (LAPACKE_dpotrf).
- * In-place A = R^T R (uplo = UPPER) or L L^T (LOWER) of the n x n block; the other triangle
- * is not referenced.  `info` (device int, may be NULL): 0 or 1-based index of the first
+ * In-place A = R^T R (uplo = UPPER; LOWER returns CAP_ERR_UNSUPPORTED - upstream removed
+ * 'L' too, cholinv.hpp:9) of the n x n block; the other triangle is not referenced.  `info` (device int, may be NULL): 0 or 1-based index of the first
  * non-positive pivot.  `work`: device scratch >= cap_dpotrf_work_size(n) doubles.         */
 int cap_dpotrf(int uplo, int64_t n, double* A, int64_t lda, int* info, double* work, void* stream);
 int64_t cap_dpotrf_work_size(int64_t n);

@@ -1,0 +1,144 @@
+"""-m gpu: cholinv (factor / construct_R / construct_Rinv) through the C ABI vs the real reference's
+dumps (tests/golden) and the oracle, plus size-independent properties at BASELINE sizes."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import capital_oracle as orc  # noqa: E402
+from tests.gpu_util import relerr  # noqa: E402
+
+RES_TOL = 1e-14      # ||A - R^T R||_F / ||A||_F (upper), fp64: SURVEY App. A suggested bar
+GOLD = sorted(os.path.basename(p) for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "cholinv_n*.npz")))
+
+
+def _factor(n, ci, split=1, bc=-2, a=None, opts=None):
+    from capital_amd import cholinv
+    from capital_amd.matrix import matrix
+    A = matrix(n, n, 1, 1)
+    if a is None:
+        A.distribute_symmetric(0, 0, 1, 1, 0, True)
+    else:
+        A.from_numpy(a)
+    pack = cholinv.info(ci, split, bc, 'U')
+    for k, v in (opts or {}).items():
+        pack.set_option(k, v)
+    cholinv.factor(A, pack, None)
+    return A, pack
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_matches_reference_dump(golden_dir, name):
+    """Same input, same knobs as the REAL reference run -> same R and R^-1 (incl. which Rinv block stays empty)."""
+    from capital_amd import cholinv
+    g = np.load(os.path.join(golden_dir, name))
+    n, ci, split, bc = int(g["n"]), int(g["complete_inv"]), int(g["split"]), int(g["bc_mult_dim"])
+    A, pack = _factor(n, ci, split, bc)
+    assert np.array_equal(A.to_numpy(), g["A"])
+    R = cholinv.construct_R(pack).to_numpy(); Ri = cholinv.construct_Rinv(pack).to_numpy()
+    assert pack.last_info() == 0
+    assert relerr(R, np.triu(g["R"])) < 1e-14
+    assert relerr(Ri, np.triu(g["Rinv"])) < 1e-13
+    assert np.array_equal(Ri != 0, np.triu(g["Rinv"]) != 0)
+    assert np.array_equal(np.tril(R, -1), np.zeros_like(R))
+    res = orc.cholesky_residual(g["A"], R)
+    assert res < RES_TOL and res < 10 * float(g["ref_residual"])
+    # the extension mode (no inverse) gives the same R
+    _, pack2 = _factor(n, -1, split, bc)
+    assert relerr(cholinv.construct_R(pack2).to_numpy(), np.triu(g["R"])) < 1e-14
+
+
+@pytest.mark.parametrize("n,ci,split,bc", [(512, 1, 1, -2), (1000, 0, 1, -3), (1000, 1, 2, -3), (777, -1, 1, -2),
+                                           (2048, 0, 1, -2), (2048, -1, 1, -3), (1, 1, 1, 0), (3, 0, 1, 0), (130, 1, 1, -1)])
+def test_matches_oracle(n, ci, split, bc):
+    from capital_amd import cholinv, validate
+    A, pack = _factor(n, ci, split, bc)
+    a = orc.symmetric_global(n, True)
+    r_ref, ri_ref = orc.cholinv(a, max(ci, 0), split, bc, 1, 1)
+    R = cholinv.construct_R(pack).to_numpy()
+    assert pack.last_info() == 0
+    assert relerr(R, r_ref) < 1e-13
+    res_gpu = validate.cholesky.residual(A, pack)            # GPU-side validator == oracle's metric
+    res = orc.cholesky_residual(a, R)
+    assert abs(res_gpu - res) < 1e-16 + 1e-3 * res
+    assert res < RES_TOL and res < 10 * orc.cholesky_residual(a, r_ref)
+    if ci >= 0:
+        Ri = cholinv.construct_Rinv(pack).to_numpy()
+        assert relerr(Ri, ri_ref) < 1e-12
+        assert np.array_equal(Ri != 0, ri_ref != 0)
+    else:
+        from capital_amd import _lib
+        with pytest.raises(_lib.CapitalError):
+            cholinv.construct_Rinv(pack)
+
+
+@pytest.mark.parametrize("opts", [{"lookahead": 0}, {"lookahead": 1, "nb": 128}, {"nb": 256}, {"nb": 512, "leaf": 32}, {"leaf": 16}])
+def test_schedule_knobs_do_not_change_the_answer(opts):
+    from capital_amd import cholinv
+    n = 1536
+    a = orc.symmetric_global(n, True)
+    _, pack = _factor(n, -1, 1, -2, opts=opts)
+    R = cholinv.construct_R(pack).to_numpy()
+    assert orc.cholesky_residual(a, R) < RES_TOL
+    assert relerr(R, np.linalg.cholesky(a).T) < 1e-13
+
+
+def test_harder_spd_input():
+    """A = B^T B + eps I (kappa ~ 1e6): residual stays at fp64 level relative to ||A||."""
+    from capital_amd import cholinv
+    n = 768
+    b = np.random.default_rng(3).standard_normal((n, n))
+    a = b.T @ b + 1e-3 * np.eye(n)
+    for ci in (-1, 1):
+        _, pack = _factor(n, ci, 1, -2, a=a)
+        R = cholinv.construct_R(pack).to_numpy()
+        assert orc.cholesky_residual(a, R) < 1e-13
+        if ci == 1:
+            Ri = cholinv.construct_Rinv(pack).to_numpy()
+            assert np.linalg.norm(Ri @ R - np.eye(n)) / np.sqrt(n) < 1e-8
+
+
+def test_not_spd_is_reported():
+    from capital_amd import cholinv
+    n = 300
+    a = orc.symmetric_global(n, True); a[200, 200] = -5.0
+    for ci in (-1, 1):
+        _, pack = _factor(n, ci, 1, -2, a=a)
+        assert pack.last_info() == 201
+
+
+def test_plan_is_reusable_and_input_is_read_only():
+    """factor many times on one `info` (bench/cholesky/cholinv.cpp:42-53); A is never modified."""
+    from capital_amd import cholinv
+    n = 640
+    A, pack = _factor(n, 0, 1, -2)
+    a0 = A.to_numpy()
+    r0 = cholinv.construct_R(pack).to_numpy()
+    for _ in range(3):
+        cholinv.factor(A, pack, None)
+    assert np.array_equal(A.to_numpy(), a0)
+    assert np.array_equal(cholinv.construct_R(pack).to_numpy(), r0)      # deterministic, bit for bit
+
+
+@pytest.mark.parametrize("n,ci", [(8192, -1), (8192, 0), (16384, -1), (32768, -1)])
+def test_large_sizes_by_properties(n, ci):
+    """BASELINE sizes: too big for the oracle in seconds -> size-independent properties on the GPU:
+    residual (reference metric), diag(R) > 0, R upper, and sum of logs of diag(R)^2 == logdet(A) via a
+    second independent factorization path (right-looking vs recursive share only the kernels)."""
+    from capital_amd import cholinv, validate
+    A, pack = _factor(n, ci, 1, -3)
+    assert pack.last_info() == 0
+    res = validate.cholesky.residual(A, pack)
+    assert res < RES_TOL, res
+    R = cholinv.construct_R(pack)
+    d = torch.diagonal(R.view())
+    assert bool((d > 0).all())
+    assert float(torch.tril(R.view()[:2048, :2048], -1).abs().max()) == 0.0
+    if n <= 8192:
+        _, pack2 = _factor(n, 1 if ci < 0 else -1, 1, -2)
+        d2 = torch.diagonal(cholinv.construct_R(pack2).view())
+        assert abs(float(torch.log(d).sum() - torch.log(d2).sum())) < 1e-9 * n

@@ -1,0 +1,86 @@
+"""-m gpu: device generators / serialize / triangle masks vs the oracle (bit-exact: integer LCG + one division)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import capital_oracle as orc  # noqa: E402
+from tests.gpu_util import DEV, to_dev, to_host  # noqa: E402
+
+
+@pytest.mark.parametrize("n,d", [(64, 1), (100, 1), (37, 2), (64, 2), (101, 3), (256, 4)])
+def test_distribute_symmetric_bit_exact(n, d):
+    from capital_amd.matrix import matrix
+    for x in range(d):
+        for y in range(d):
+            A = matrix(n, n, d, d)
+            A.distribute_symmetric(x, y, d, d, 0, True)
+            assert np.array_equal(A.to_numpy(), orc.symmetric_local(n, x, y, d, True))
+
+
+def test_distribute_symmetric_matches_reference_dump(golden_dir):
+    import os
+    from capital_amd.matrix import matrix
+    g = np.load(os.path.join(golden_dir, "cholinv_n100_ci0_s2_bc-4.npz"))
+    A = matrix(100, 100, 1, 1); A.distribute_symmetric(0, 0, 1, 1, 0, True)
+    assert np.array_equal(A.to_numpy(), g["A"])      # the REAL reference's generator output
+
+
+def test_distribute_symmetric_seed_wrap():
+    """N^2 > 2^32: seeds wrap mod 2^32 exactly like srand48 - checked on the last rows of N = 70000."""
+    from capital_amd import _lib
+    from capital_amd._util import cur_stream
+    n, d = 70000, 8          # local piece 8750 x 8750 on grid position (7, 7)
+    nl = orc.local_dim(n, d)
+    buf = torch.empty(nl, nl, dtype=torch.float64, device=DEV)
+    _lib.check(_lib.lib().cap_fill_symmetric(buf.data_ptr(), nl, n, 7, 7, d, 1, cur_stream()))
+    got = buf.t()[-3:, -3:].cpu().numpy()
+    gy = 7 + (np.arange(nl - 3, nl)) * d; gx = gy.copy()
+    ref = np.zeros((3, 3))
+    for i, r in enumerate(gy):
+        for j, c in enumerate(gx):
+            if r < n and c < n:
+                ref[i, j] = float(orc.drand48_of_seed(max(r, c) + n * min(r, c))) + (n if r == c else 0)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("m,n,dx,dy,key", [(256, 16, 1, 1, 0), (192, 12, 1, 1, 0), (1000, 8, 1, 4, 3), (37, 5, 1, 2, 1), (64, 6, 2, 2, 7)])
+def test_distribute_random_bit_exact(m, n, dx, dy, key):
+    from capital_amd.matrix import matrix
+    for x in range(dx):
+        for y in range(dy):
+            A = matrix(n, m, dx, dy)
+            A.distribute_random(x, y, dx, dy, key)
+            assert np.array_equal(A.to_numpy(), orc.random_local(m, n, x, y, dx, dy, key))
+
+
+def test_serialize_packed_roundtrip_and_windows():
+    from capital_amd.matrix import serialize
+    n = 50
+    a = np.triu(np.random.default_rng(0).standard_normal((n, n)))
+    A, Av = to_dev(a)
+    packed = torch.zeros(n * (n + 1) // 2, dtype=torch.float64, device=DEV)
+    serialize(A, packed, (0, n, 0, n), (0, 0), tri_only=True, src_ld=n, dst_packed=True)
+    assert np.array_equal(packed.cpu().numpy(), orc.pack_upper(a))            # uppertri::_offset, structure.h:39
+    B = torch.full((n, n), 3.0, dtype=torch.float64, device=DEV)
+    serialize(packed, B, (0, n, 0, n), (0, 0), tri_only=True, zero_lower=True, src_packed=True, dst_ld=n)
+    assert np.array_equal(to_host(B.t()), a)
+    # rect window copy (serialize<rect,rect> with offsets, as cholinv.hpp:122)
+    W = torch.zeros((20, 30), dtype=torch.float64, device=DEV)                # 30 x 20 column-major, ld 30
+    serialize(A, W, (5, 25, 10, 30), (3, 0), src_ld=n, dst_ld=30)
+    assert np.array_equal(to_host(W.t())[3:23, :20], a[5:25, 10:30])
+
+
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_remove_triangle(d):
+    from capital_amd import _lib
+    from capital_amd._util import cur_stream
+    n = 23
+    full = np.random.default_rng(d).standard_normal((n, n))
+    for x in range(d):
+        for y in range(d):
+            loc = orc.cyclic_local(full, x, y, d, d)
+            L, Lv = to_dev(loc)
+            _lib.check(_lib.lib().cap_remove_triangle(L.data_ptr(), loc.shape[0], loc.shape[0], loc.shape[1], x, y, d, 1, cur_stream()))
+            assert np.array_equal(to_host(Lv), orc.cyclic_local(np.triu(full), x, y, d, d))
