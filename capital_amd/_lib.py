@@ -4,6 +4,9 @@ Fails loudly if the HIP library is missing: there is no CPU fallback by design."
 import ctypes as C
 import os
 
+import torch  # noqa: F401  - MUST load first: torch bundles its own libamdhip64/librccl with the same sonames as
+              # /opt/rocm; loading ours first leaves the process with a HIP runtime that sees no device.
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcapital_amd.so")
 
@@ -54,6 +57,7 @@ SIGNATURES = {
     "cap_cholinv_info": (cint, [ptr, ptr, C.POINTER(i64)]),
     "cap_cholinv_set_option": (cint, [ptr, C.c_char_p, i64]),
     "cap_cholinv_get_option": (i64, [ptr, C.c_char_p]),
+    "cap_cholinv_profile": (cint, [ptr, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]),
     "cap_cacqr_plan_create": (cint, [C.POINTER(ptr), i64, i64, cint, ptr]),
     "cap_cacqr_plan_destroy": (cint, [ptr]),
     "cap_cacqr_factor": (cint, [ptr, ptr, i64, ptr]),

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -112,6 +113,10 @@ struct cap_cholinv_plan {
   int* info_dev;
   hipStream_t s_panel; hipEvent_t ev_panel[2], ev_update[2], ev_fork, ev_join;
   bool streams_ready;
+  // optional live profile of the dominant kernel (trailing-update SYRK): HIP events on the stream
+  // it is launched on, algorithmic flops m(m+1)k per launch
+  int profile;
+  std::vector<hipEvent_t>* prof_ev; std::vector<double>* prof_flops; int prof_used;
 };
 
 namespace {
@@ -182,11 +187,32 @@ int panel_factor(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t
   return CAP_OK;
 }
 
+// trailing update R33 -= Rp^T Rp on upper tiles (the dominant kernel), optionally bracketed by events
+int trailing_update(cap_cholinv_plan* p, int64_t m, int64_t k, const double* Rp, double* R33, int64_t ldr, hipStream_t s) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (p->profile && p->prof_ev) {
+    if ((size_t)p->prof_used + 2 > p->prof_ev->size()) {
+      for (int i = 0; i < 64; i++) { hipEvent_t e; CAP_HIP(hipEventCreate(&e)); p->prof_ev->push_back(e); }
+    }
+    e0 = (*p->prof_ev)[p->prof_used]; e1 = (*p->prof_ev)[p->prof_used + 1];
+    CAP_HIP(hipEventRecord(e0, s));
+  }
+  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, m, m, k, -1.0, Rp, ldr, Rp, ldr, 1.0, R33, ldr, 1, s, 1));
+  if (e0) {
+    CAP_HIP(hipEventRecord(e1, s));
+    p->prof_used += 2;
+    p->prof_flops->push_back((double)m * (double)(m + 1) * (double)k);
+  }
+  return CAP_OK;
+}
+
 // blocked right-looking Cholesky (upper) in place on R (n x n, ldr), optional look-ahead
 int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStream_t s0) {
   const int64_t nb = p->nb;
   const int64_t nblk = cap_ceil_div(n, nb);
   const bool la = p->lookahead && nblk > 2;
+  p->prof_used = 0;
+  if (p->prof_flops) p->prof_flops->clear();
   if (!la) {
     for (int64_t k = 0; k < nblk; k++) {
       const int64_t j0 = k * nb, jb = std::min(nb, n - j0), m = n - j0 - jb;
@@ -194,7 +220,7 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
       if (m > 0) {
         double* Rpan = R + j0 + (j0 + jb) * ldr;
         double* R22 = R + (j0 + jb) + (j0 + jb) * ldr;
-        CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, m, m, jb, -1.0, Rpan, ldr, Rpan, ldr, 1.0, R22, ldr, 1, s0));
+        CAP_TRY(trailing_update(p, m, jb, Rpan, R22, ldr, s0));
       }
     }
     return CAP_OK;
@@ -223,7 +249,7 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
     if (m2 > 0) {
       double* Rp2 = Rpan + jb1 * ldr;             // columns j1+jb1..n of block row k
       double* R33 = R + (j1 + jb1) + (j1 + jb1) * ldr;
-      CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, m2, m2, jb, -1.0, Rp2, ldr, Rp2, ldr, 1.0, R33, ldr, 1, s0));
+      CAP_TRY(trailing_update(p, m2, jb, Rp2, R33, ldr, s0));
     }
     CAP_HIP(hipEventRecord(p->ev_update[k & 1], s0));
   }
@@ -265,6 +291,7 @@ int cap_cholinv_plan_destroy(cap_cholinv_plan* p) {
     for (int i = 0; i < 2; i++) { (void)hipEventDestroy(p->ev_panel[i]); (void)hipEventDestroy(p->ev_update[i]); }
     (void)hipEventDestroy(p->ev_fork); (void)hipEventDestroy(p->ev_join);
   }
+  if (p->prof_ev) { for (hipEvent_t e : *p->prof_ev) (void)hipEventDestroy(e); delete p->prof_ev; delete p->prof_flops; }
   delete p;
   return CAP_OK;
 }
@@ -288,6 +315,11 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
   }
   if (k == "leaf") { if (value < 1 || value > CAP_LEAF_MAX) return CAP_ERR_ARG; p->leaf = value; return CAP_OK; }
   if (k == "lookahead") { p->lookahead = value != 0; return CAP_OK; }
+  if (k == "profile") {
+    p->profile = value != 0;
+    if (p->profile && !p->prof_ev) { p->prof_ev = new std::vector<hipEvent_t>(); p->prof_flops = new std::vector<double>(); }
+    return CAP_OK;
+  }
   return CAP_ERR_ARG;
 }
 
@@ -348,6 +380,21 @@ int cap_cholinv_info(cap_cholinv_plan* p, void* stream, int64_t* info) {
   CAP_HIP(hipStreamSynchronize(cap_stream(stream)));
   *info = h;
   return h == 0 ? CAP_OK : CAP_ERR_NOT_SPD;
+}
+
+// live profile of the last factor call: launches of the trailing-update kernel, their summed
+// duration (ms, HIP events on the launch stream) and summed algorithmic flops.  Synchronises.
+int cap_cholinv_profile(cap_cholinv_plan* p, int64_t* launches, double* ms_total, double* flops_total) {
+  if (!p || !launches || !ms_total || !flops_total) return CAP_ERR_ARG;
+  *launches = 0; *ms_total = 0; *flops_total = 0;
+  if (!p->prof_ev) return CAP_OK;
+  for (int i = 0; i + 1 < p->prof_used; i += 2) {
+    CAP_HIP(hipEventSynchronize((*p->prof_ev)[i + 1]));
+    float ms = 0;
+    CAP_HIP(hipEventElapsedTime(&ms, (*p->prof_ev)[i], (*p->prof_ev)[i + 1]));
+    *ms_total += ms; *flops_total += (*p->prof_flops)[i / 2]; (*launches)++;
+  }
+  return CAP_OK;
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -17,6 +17,9 @@
 //   store segments in column-major C.
 //   Blocks are remapped XCD-aware: block b runs on XCD b%8; each XCD walks a contiguous
 //   range of 8x8-tile supertiles so its private L2 sees compact A/B panels.
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -118,7 +121,9 @@ __device__ __forceinline__ void store_tile(double* __restrict__ lds, const d2 (&
   }
 }
 
-template <bool A_KC, bool B_KC, bool EDGE>
+// TAG only changes the kernel's NAME (same code): TAG 1 = the trailing update of the blocked
+// Cholesky, so rocprofv3 --stats reports the dominant kernel separately from panel-sized launches.
+template <bool A_KC, bool B_KC, bool EDGE, int TAG>
 __global__ void __launch_bounds__(NTHREADS, 2) dgemm_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // block -> XCD-aware logical slot
@@ -220,13 +225,188 @@ __global__ void __launch_bounds__(NTHREADS, 2) dgemm_kernel(const GemmArgs g) {
   }
 }
 
-template <bool A_KC, bool B_KC>
+
+// ---------------------------------------------------------------------------------------------
+// v2 hot kernel: TN (both operands K-contiguous), aligned shapes.  Differences from the generic
+// kernel above:
+//  * operand tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction):
+//    no staging VGPRs, no ds_write pass, no vmcnt->ds_write dependency in the loop;
+//  * the LDS image is the lane-linear [row][8 x 16 B] tile, bank-conflict free through an XOR
+//    swizzle applied to the per-lane SOURCE address and to the fragment read (chunk ^= (row>>1)&7);
+//  * fragments are read with ds_read_b128: a lane gets k = 2kg, 2kg+1 of an 8-deep half tile; the
+//    MFMA pair {x, y} then contracts k = {0,2,4,6} and {1,3,5,7} - the same permutation on both
+//    operands, so the sum over k is unchanged;
+//  * fragment registers are double buffered per half tile and the single barrier per K tile sits
+//    in the middle of the tile, so LDS latency, DMA landing and barrier skew all hide behind 32 MFMAs.
+// ---------------------------------------------------------------------------------------------
+constexpr int DMA_TILE = 128 * BK;   // doubles per operand tile (16 KiB), unpadded
+
+__device__ __forceinline__ void dma_tile(const double* __restrict__ P, int64_t ld, int64_t o0, int64_t k0, double* lds_tile) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int rsub = lane >> 3, p = lane & 7;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int r0 = (wid * 4 + q) * 8;
+    const int row = r0 + rsub;
+    const int c = p ^ ((row >> 1) & 7);
+    const double* src = P + (o0 + row) * ld + k0 + c * 2;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds_tile + r0 * BK), 16, 0, 0);
+  }
+}
+
+template <int TAG>
+__global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = blockIdx.x;
+  const int L = (b & 7) * g.chunk + (b >> 3);
+  int ti, tj;
+  if ((b >> 3) >= g.chunk || !slot_to_tile(g, L, ti, tj)) return;
+
+  const int64_t i0 = (int64_t)ti * BM, j0 = (int64_t)tj * BN;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wi = (wid & 1) * 64, wj = (wid >> 1) * 64;
+  const int lr = lane & 15, kg = lane >> 4;
+
+  // LDS carve: [A0][B0][A1][B1], 16 KiB each
+  auto sA = [&](int buf) -> double* { return smem + buf * 2 * DMA_TILE; };
+  auto sB = [&](int buf) -> double* { return smem + buf * 2 * DMA_TILE + DMA_TILE; };
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  const int kz = blockIdx.y;
+  const int64_t kbeg = (int64_t)kz * g.kchunk;
+  const int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+  const int nk = (int)((kend - kbeg) / BK);
+
+  // per-lane fragment offsets (doubles) for the two half tiles; +16 rows = +16*BK doubles per block
+  const int sw = lr >> 1;
+  const int a_off0 = (wi + lr) * BK + ((0 + kg) ^ sw) * 2, a_off1 = (wi + lr) * BK + ((4 + kg) ^ sw) * 2;
+  const int b_off0 = (wj + lr) * BK + ((0 + kg) ^ sw) * 2, b_off1 = (wj + lr) * BK + ((4 + kg) ^ sw) * 2;
+
+  d2 fa0[4], fb0[4], fa1[4], fb1[4];
+  auto read_frags = [&](const double* tA, const double* tB, int aoff, int boff, d2 (&fa)[4], d2 (&fb)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) fa[i] = *reinterpret_cast<const d2*>(tA + aoff + i * 16 * BK);
+#pragma unroll
+    for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const d2*>(tB + boff + j * 16 * BK);
+  };
+  auto mma32 = [&](const d2 (&fa)[4], const d2 (&fb)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
+  };
+
+  // Software pipeline, rotated so that every fragment set is consumed in the basic block that issued
+  // its reads or right behind a barrier (hipcc's waitcnt pass falls back to lgkmcnt(0) on loop-carried
+  // LDS reads otherwise):
+  //   prologue : DMA t0 | sync | read F0(t0,h0) | DMA t1 | read F1(t0,h1) | MMA(F0)
+  //   loop kt  : sync | read F0(t(kt+1),h0) | MMA(F1) | DMA t(kt+2) | read F1(t(kt+1),h1) | MMA(F0)
+  //   tail     : MMA(F1)
+  // The barrier at the top of iteration kt proves: all reads of tile kt are done (buffer kt&1 may be
+  // refilled) and tile kt+1 has landed (each wave drained its own DMA share with vmcnt(0) before it).
+  if (nk > 0) {
+    dma_tile(g.A, g.lda, i0, kbeg, sA(0));
+    dma_tile(g.B, g.ldb, j0, kbeg, sB(0));
+    __syncthreads();
+    read_frags(sA(0), sB(0), a_off0, b_off0, fa0, fb0);
+    {
+      const int64_t k1 = kbeg + (int64_t)(nk > 1 ? 1 : 0) * BK;
+      dma_tile(g.A, g.lda, i0, k1, sA(1));
+      dma_tile(g.B, g.ldb, j0, k1, sB(1));
+    }
+    read_frags(sA(0), sB(0), a_off1, b_off1, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma32(fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = 0; kt + 1 < nk; kt++) {
+      const int nxt = (kt + 1) & 1;
+      __builtin_amdgcn_s_waitcnt(0xc07f);                // F1 (issued 32 MFMAs ago) is complete: tell the compiler
+      __syncthreads();
+      read_frags(sA(nxt), sB(nxt), a_off0, b_off0, fa0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma32(fa1, fb1);                                   // second half of tile kt
+      __builtin_amdgcn_sched_barrier(0);
+      // F0's reads returned long ago; saying so keeps hipcc from emitting lgkmcnt(0) after the F1 reads
+      // below (16 LDS reads in flight would overflow its 4-bit lgkmcnt model)
+      __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0) only
+      {
+        const int kn = (kt + 2 < nk) ? kt + 2 : nk - 1;  // clamp: the last refill is redundant but branch-free
+        dma_tile(g.A, g.lda, i0, kbeg + (int64_t)kn * BK, sA(nxt ^ 1));
+        dma_tile(g.B, g.ldb, j0, kbeg + (int64_t)kn * BK, sB(nxt ^ 1));
+      }
+      read_frags(sA(nxt), sB(nxt), a_off1, b_off1, fa1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma32(fa0, fb0);                                   // first half of tile kt+1
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mma32(fa1, fb1);
+  }
+
+  // epilogue: lane holds C[i0+wi+16i+lr][j0+wj+16j+kg+4r]; all branches are block-uniform
+  const double alpha = g.alpha, beta = g.beta;
+  const bool diag_tile = (g.tri != 0) && (ti == tj);
+  auto epilogue = [&](auto masked, auto with_beta, auto split) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int64_t row = i0 + wi + 16 * i + lr;
+      double cin[4][4];
+      if (with_beta.value && !split.value) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int64_t col = j0 + wj + 16 * j + kg + 4 * r;
+            bool ok = !masked.value || (g.tri == 1 ? row <= col : row >= col);
+            cin[j][r] = ok ? g.C[row + col * g.ldc] : 0.0;
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int64_t col = j0 + wj + 16 * j + kg + 4 * r;
+          bool ok = !masked.value || (g.tri == 1 ? row <= col : row >= col);
+          double v = alpha * acc[i][j][r];
+          if (split.value) {
+            if (ok) g.P[(int64_t)kz * g.slab + row + col * g.M] = v;
+          } else {
+            if (with_beta.value) v += beta * cin[j][r];
+            if (ok) g.C[row + col * g.ldc] = v;
+          }
+        }
+    }
+  };
+  using T = std::true_type; using F = std::false_type;
+  if (g.ksplit > 1) { if (diag_tile) epilogue(T{}, F{}, T{}); else epilogue(F{}, F{}, T{}); }
+  else if (beta != 0.0) { if (diag_tile) epilogue(T{}, T{}, F{}); else epilogue(F{}, T{}, F{}); }
+  else { if (diag_tile) epilogue(T{}, F{}, F{}); else epilogue(F{}, F{}, F{}); }
+}
+
+template <int TAG>
+int launch_tn_dma(const GemmArgs& g, int grid, hipStream_t stream) {
+  size_t lds = 4 * DMA_TILE * sizeof(double);
+  hipLaunchKernelGGL((dgemm_tn_dma_kernel<TAG>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+template <bool A_KC, bool B_KC, int TAG = 0>
 int launch_variant(const GemmArgs& g, bool edge, int grid, hipStream_t stream) {
   size_t lds = 4 * TILE_ELEMS * sizeof(double);
   if (edge)
-    hipLaunchKernelGGL((dgemm_kernel<A_KC, B_KC, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+    hipLaunchKernelGGL((dgemm_kernel<A_KC, B_KC, true, TAG>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
   else
-    hipLaunchKernelGGL((dgemm_kernel<A_KC, B_KC, false>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+    hipLaunchKernelGGL((dgemm_kernel<A_KC, B_KC, false, TAG>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
@@ -272,7 +452,7 @@ double* cap_scratch(int64_t elems) {
 
 int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
                     int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri,
-                    hipStream_t stream) {
+                    hipStream_t stream, int tag) {
   if (m < 0 || n < 0 || k < 0) return CAP_ERR_ARG;
   if (m == 0 || n == 0) return CAP_OK;
   if (ldc < m) return CAP_ERR_ARG;
@@ -326,7 +506,10 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   bool edge = (m % BM) || (n % BN) || (k % BK) || (lda & 1) || (ldb & 1) || !aligned16(A) || !aligned16(B);
 
   int st;
-  if (a_kc && b_kc) st = launch_variant<true, true>(g, edge, (int)grid, stream);
+  static const bool use_v1 = getenv("CAP_GEMM_V1") != nullptr;   // A/B switch for profiling
+  if (a_kc && b_kc && !edge && !use_v1) st = (tag == 1) ? launch_tn_dma<1>(g, (int)grid, stream) : launch_tn_dma<0>(g, (int)grid, stream);
+  else if (a_kc && b_kc && tag == 1) st = launch_variant<true, true, 1>(g, edge, (int)grid, stream);
+  else if (a_kc && b_kc) st = launch_variant<true, true>(g, edge, (int)grid, stream);
   else if (a_kc && !b_kc) st = launch_variant<true, false>(g, edge, (int)grid, stream);
   else if (!a_kc && b_kc) st = launch_variant<false, true>(g, edge, (int)grid, stream);
   else st = launch_variant<false, false>(g, edge, (int)grid, stream);

@@ -186,6 +186,11 @@ int cap_cholinv_info(cap_cholinv_plan* plan, void* stream, int64_t* info);
 /* tuning knobs of the GPU schedule (panel width nb, leaf size, look-ahead on/off).         */
 int cap_cholinv_set_option(cap_cholinv_plan* plan, const char* key, int64_t value);
 int64_t cap_cholinv_get_option(cap_cholinv_plan* plan, const char* key);
+/* Live measurement of the dominant kernel (trailing-update DSYRK) of the LAST factor call, enabled
+ * with cap_cholinv_set_option(plan, "profile", 1): number of launches, their summed duration in ms
+ * (HIP events recorded on the stream each launch went to) and summed algorithmic flops
+ * (m(m+1)k per launch).  Synchronises on the recorded events.                               */
+int cap_cholinv_profile(cap_cholinv_plan* plan, int64_t* launches, double* ms_total, double* flops_total);
 
 /* qr::cacqr<...>::info + factor, 1D path - cacqr.h:18-49, cacqr.hpp:5-29,172-193,217-248.
  * A is the local row-cyclic piece (m_local x n, column-major); R (n x n) is replicated;
