@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=65536, help="matrix dimension (BASELINE metric: 65536)")
     ap.add_argument("--nb", type=int, default=0, help="panel width override (0 = library default)")
+    ap.add_argument("--outer", type=int, default=0, help="outer strip height NB override (0 = library default)")
+    ap.add_argument("--tail", type=int, default=-1, help="trailing size below which strips are nb wide (-1 = default)")
     ap.add_argument("--complete-inv", type=int, default=-1,
                     help="-1 blocked Cholesky (headline), 0/1 reference cholinv semantics (R and R^-1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -107,6 +109,10 @@ def main():
         pack = cholinv.info(args.complete_inv, 1, -7, 'U')      # bcMult -7: N/128 = 512-wide panels at N = 65536
         if args.nb:
             pack.set_option("nb", args.nb)
+        if args.outer:
+            pack.set_option("outer", args.outer)
+        if args.tail >= 0:
+            pack.set_option("tail", args.tail)
         run = lambda: cholinv.factor(A, pack, None)
         finish = lambda: pack.last_info()
         parallelism = "1 GPU"

@@ -106,6 +106,8 @@ struct cap_cholinv_plan {
   cap_comm* comm;
   // schedule knobs
   int64_t nb, leaf; int lookahead;
+  int64_t outer;   // outer strip height NB (multiple of nb): K of the big trailing SYRK
+  int64_t tail;    // trailing sizes <= tail fall back to nb-wide strips
   // device state
   double* R; int64_t ldr;
   double* Rinv; int64_t ldi;      // n x n (complete_inv >= 0) or nb x nb diagonal-block inverse
@@ -206,21 +208,50 @@ int trailing_update(cap_cholinv_plan* p, int64_t m, int64_t k, const double* Rp,
   return CAP_OK;
 }
 
-// blocked right-looking Cholesky (upper) in place on R (n x n, ldr), optional look-ahead
+// Factor the strip R[J0 : J0+rows, J0 : n] (its leading rows x rows block is diagonal), assuming every
+// update from earlier strips has been applied: inner right-looking sweep with nb-wide panels whose
+// trailing update is confined to the strip's own rows.  One stream.
+int factor_strip(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t J0, int64_t rows, hipStream_t s) {
+  const int64_t nb = p->nb, Jend = J0 + rows;
+  for (int64_t j0 = J0; j0 < Jend; j0 += nb) {
+    const int64_t jb = std::min(nb, Jend - j0);
+    CAP_TRY(panel_factor(p, R, ldr, n, j0, jb, s));
+    const int64_t j1 = j0 + jb, rows_left = Jend - j1, cols = n - j1;
+    if (rows_left > 0 && cols > 0) {
+      double* Rpan = R + j0 + j1 * ldr;            // jb x cols block row just solved
+      CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows_left, cols, jb, -1.0, Rpan, ldr, Rpan, ldr, 1.0,
+                              R + j1 + j1 * ldr, ldr, 1, s));
+    }
+  }
+  return CAP_OK;
+}
+
+// Blocked right-looking Cholesky (upper) in place on R (n x n, ldr), two-level blocking:
+// outer strips of NB rows (factored by factor_strip with nb-wide panels), one K = NB trailing
+// SYRK per strip, look-ahead of one strip on the high-priority stream.
 int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStream_t s0) {
   const int64_t nb = p->nb;
-  const int64_t nblk = cap_ceil_div(n, nb);
-  const bool la = p->lookahead && nblk > 2;
+  int64_t NB = std::max(nb, (p->outer / nb) * nb);
+  // strip boundaries: wide strips while the trailing matrix is large, nb-wide ones in the tail where the
+  // strip chain could no longer hide behind the trailing update
+  std::vector<int64_t> bnd;
+  bnd.push_back(0);
+  while (bnd.back() < n) {
+    const int64_t j = bnd.back(), rest = n - j;
+    int64_t w = (rest > p->tail) ? NB : nb;
+    bnd.push_back(std::min(n, j + w));
+  }
+  const int64_t nstrip = (int64_t)bnd.size() - 1;
+  const bool la = p->lookahead && nstrip > 2;
   p->prof_used = 0;
   if (p->prof_flops) p->prof_flops->clear();
   if (!la) {
-    for (int64_t k = 0; k < nblk; k++) {
-      const int64_t j0 = k * nb, jb = std::min(nb, n - j0), m = n - j0 - jb;
-      CAP_TRY(panel_factor(p, R, ldr, n, j0, jb, s0));
+    for (int64_t k = 0; k < nstrip; k++) {
+      const int64_t J0 = bnd[k], rows = bnd[k + 1] - J0, m = n - bnd[k + 1];
+      CAP_TRY(factor_strip(p, R, ldr, n, J0, rows, s0));
       if (m > 0) {
-        double* Rpan = R + j0 + (j0 + jb) * ldr;
-        double* R22 = R + (j0 + jb) + (j0 + jb) * ldr;
-        CAP_TRY(trailing_update(p, m, jb, Rpan, R22, ldr, s0));
+        double* S = R + J0 + bnd[k + 1] * ldr;
+        CAP_TRY(trailing_update(p, m, rows, S, R + bnd[k + 1] + bnd[k + 1] * ldr, ldr, s0));
       }
     }
     return CAP_OK;
@@ -230,26 +261,24 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
   // fork: the panel stream joins the caller's stream
   CAP_HIP(hipEventRecord(p->ev_fork, s0));
   CAP_HIP(hipStreamWaitEvent(s1, p->ev_fork, 0));
-  // panel 0 on the panel stream
-  CAP_TRY(panel_factor(p, R, ldr, n, 0, std::min(nb, n), s1));
+  CAP_TRY(factor_strip(p, R, ldr, n, 0, bnd[1], s1));
   CAP_HIP(hipEventRecord(p->ev_panel[0], s1));
-  for (int64_t k = 0; k < nblk; k++) {
-    const int64_t j0 = k * nb, jb = std::min(nb, n - j0), m = n - j0 - jb;
+  for (int64_t k = 0; k < nstrip; k++) {
+    const int64_t J0 = bnd[k], rows = bnd[k + 1] - J0, m = n - bnd[k + 1];
     if (m <= 0) break;
-    const int64_t j1 = j0 + jb, jb1 = std::min(nb, n - j1), m2 = m - jb1;
-    double* Rpan = R + j0 + j1 * ldr;             // block row k: jb x m, columns j1..n
-    // (a) panel stream: update block row k+1 (upper part), factor panel k+1
-    //     needs: panel k (same stream) and the bulk update of step k-1 (main stream)
+    const int64_t J1 = bnd[k + 1], rows1 = bnd[k + 2] - J1, m2 = m - rows1;
+    double* S = R + J0 + J1 * ldr;                 // strip k right of its diagonal block: rows x m
+    // (a) panel stream: bring strip k+1 up to date (K = rows, upper part), then factor it.
+    //     needs strip k (same stream) and the bulk update of step k-1 (main stream)
     if (k > 0) CAP_HIP(hipStreamWaitEvent(s1, p->ev_update[(k - 1) & 1], 0));
-    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb1, m, jb, -1.0, Rpan, ldr, Rpan, ldr, 1.0, R + j1 + j1 * ldr, ldr, 1, s1));
-    CAP_TRY(panel_factor(p, R, ldr, n, j1, jb1, s1));
+    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows1, m, rows, -1.0, S, ldr, S, ldr, 1.0, R + J1 + J1 * ldr, ldr, 1, s1));
+    CAP_TRY(factor_strip(p, R, ldr, n, J1, rows1, s1));
     CAP_HIP(hipEventRecord(p->ev_panel[(k + 1) & 1], s1));
-    // (b) main stream: bulk of the trailing update (rows below block row k+1)
+    // (b) main stream: bulk of the trailing update (rows below strip k+1)
     CAP_HIP(hipStreamWaitEvent(s0, p->ev_panel[k & 1], 0));
     if (m2 > 0) {
-      double* Rp2 = Rpan + jb1 * ldr;             // columns j1+jb1..n of block row k
-      double* R33 = R + (j1 + jb1) + (j1 + jb1) * ldr;
-      CAP_TRY(trailing_update(p, m2, jb, Rp2, R33, ldr, s0));
+      double* S2 = S + rows1 * ldr;
+      CAP_TRY(trailing_update(p, m2, rows, S2, R + (J1 + rows1) + (J1 + rows1) * ldr, ldr, s0));
     }
     CAP_HIP(hipEventRecord(p->ev_update[k & 1], s0));
   }
@@ -274,6 +303,7 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   memset(p, 0, sizeof(*p));
   p->n = n; p->complete_inv = complete_inv; p->split = split; p->bc_mult_dim = bc_mult_dim; p->dir = dir; p->comm = comm;
   p->nb = default_nb(n, bc_mult_dim); p->leaf = CAP_LEAF_MAX; p->lookahead = 1;
+  p->outer = p->nb; p->tail = 0;
   int st = plan_alloc(p);
   if (st != CAP_OK) { cap_cholinv_plan_destroy(p); return st; }
   *plan = p;
@@ -315,6 +345,8 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
   }
   if (k == "leaf") { if (value < 1 || value > CAP_LEAF_MAX) return CAP_ERR_ARG; p->leaf = value; return CAP_OK; }
   if (k == "lookahead") { p->lookahead = value != 0; return CAP_OK; }
+  if (k == "outer") { if (value < 64) return CAP_ERR_ARG; p->outer = value; return CAP_OK; }
+  if (k == "tail") { if (value < 0) return CAP_ERR_ARG; p->tail = value; return CAP_OK; }
   if (k == "profile") {
     p->profile = value != 0;
     if (p->profile && !p->prof_ev) { p->prof_ev = new std::vector<hipEvent_t>(); p->prof_flops = new std::vector<double>(); }
@@ -329,6 +361,8 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
   if (k == "nb") return p->nb;
   if (k == "leaf") return p->leaf;
   if (k == "lookahead") return p->lookahead;
+  if (k == "outer") return p->outer;
+  if (k == "tail") return p->tail;
   if (k == "n") return p->n;
   if (k == "complete_inv") return p->complete_inv;
   if (k == "split") return p->split;
@@ -416,6 +450,7 @@ int cap_dpotrf(int uplo, int64_t n, double* A, int64_t lda, int* info, double* w
   memset(&p, 0, sizeof(p));
   p.n = n; p.complete_inv = -1; p.leaf = CAP_LEAF_MAX; p.lookahead = 0;
   p.nb = std::min<int64_t>(default_nb(n, -100), cap_round_up(n, 64));
+  p.outer = p.nb; p.tail = 0;
   p.ldi = p.nb;
   p.Rinv = work;                                // nb x nb
   p.work = work + p.nb * p.nb;                  // rec scratch + panel scratch

@@ -330,23 +330,34 @@ __global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArg
     __builtin_amdgcn_sched_barrier(0);
     for (int kt = 0; kt + 1 < nk; kt++) {
       const int nxt = (kt + 1) & 1;
-      __builtin_amdgcn_s_waitcnt(0xc07f);                // F1 (issued 32 MFMAs ago) is complete: tell the compiler
+      __builtin_amdgcn_s_waitcnt(0xc07f);                // F1 (issued during the previous MFMA block) is complete
       __syncthreads();
-      read_frags(sA(nxt), sB(nxt), a_off0, b_off0, fa0, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma32(fa1, fb1);                                   // second half of tile kt
-      __builtin_amdgcn_sched_barrier(0);
-      // F0's reads returned long ago; saying so keeps hipcc from emitting lgkmcnt(0) after the F1 reads
-      // below (16 LDS reads in flight would overflow its 4-bit lgkmcnt model)
-      __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0) only
+      // ---- phase A: refill the buffer tile kt just vacated, fetch F0 of tile kt+1, contract 2nd half of tile kt.
+      // The DMA pieces and LDS reads are interleaved INTO the MFMA stream (one of each per 4 MFMAs) so that
+      // a single wave keeps the matrix pipe busy while it issues them (sched_group_barrier pipeline).
       {
         const int kn = (kt + 2 < nk) ? kt + 2 : nk - 1;  // clamp: the last refill is redundant but branch-free
         dma_tile(g.A, g.lda, i0, kbeg + (int64_t)kn * BK, sA(nxt ^ 1));
         dma_tile(g.B, g.ldb, j0, kbeg + (int64_t)kn * BK, sB(nxt ^ 1));
       }
-      read_frags(sA(nxt), sB(nxt), a_off1, b_off1, fa1, fb1);
+      read_frags(sA(nxt), sB(nxt), a_off0, b_off0, fa0, fb0);
+      mma32(fa1, fb1);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // 1 VMEM (LDS-DMA piece)
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+      }
       __builtin_amdgcn_sched_barrier(0);
-      mma32(fa0, fb0);                                   // first half of tile kt+1
+      // ---- phase B: fetch F1 of tile kt+1, contract its first half
+      __builtin_amdgcn_s_waitcnt(0xc07f);                // F0 has landed (last read issued >= 4 MFMAs ago)
+      read_frags(sA(nxt), sB(nxt), a_off1, b_off1, fa1, fb1);
+      mma32(fa0, fb0);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     mma32(fa1, fb1);
