@@ -40,6 +40,7 @@ SIGNATURES = {
     "cap_comm_unique_id": (cint, [ptr]),
     "cap_comm_create": (cint, [C.POINTER(ptr), ptr, cint, cint, ptr]),
     "cap_comm_create_self": (cint, [C.POINTER(ptr)]),
+    "cap_comm_create_callbacks": (cint, [C.POINTER(ptr), cint, cint, ptr, ptr, ptr, ptr]),
     "cap_comm_destroy": (cint, [ptr]),
     "cap_comm_rank": (cint, [ptr]),
     "cap_comm_size": (cint, [ptr]),
@@ -58,6 +59,16 @@ SIGNATURES = {
     "cap_cholinv_set_option": (cint, [ptr, C.c_char_p, i64]),
     "cap_cholinv_get_option": (i64, [ptr, C.c_char_p]),
     "cap_cholinv_profile": (cint, [ptr, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]),
+    "cap_dist_plan_create": (cint, [C.POINTER(ptr), i64, i64, ptr]),
+    "cap_dist_plan_destroy": (cint, [ptr]),
+    "cap_dist_local_cols": (i64, [ptr]),
+    "cap_dist_factor": (cint, [ptr, ptr, i64, ptr]),
+    "cap_dist_R_ptr": (ptr, [ptr, C.POINTER(i64)]),
+    "cap_dist_info": (cint, [ptr, ptr, C.POINTER(i64)]),
+    "cap_fill_symmetric_bc": (cint, [ptr, i64, i64, i64, cint, cint, cint, ptr]),
+    "cap_bc_owner": (cint, [i64, cint]),
+    "cap_bc_local_block": (i64, [i64, cint]),
+    "cap_bc_num_local_cols": (i64, [i64, i64, cint, cint]),
     "cap_cacqr_plan_create": (cint, [C.POINTER(ptr), i64, i64, cint, ptr]),
     "cap_cacqr_plan_destroy": (cint, [ptr]),
     "cap_cacqr_factor": (cint, [ptr, ptr, i64, ptr]),

@@ -17,7 +17,7 @@
 
 // from cholinv.hip
 int cap_rec_cholinv_full(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, double* W, int64_t wcap, int* info,
-                         hipStream_t s);
+                         hipStream_t s, int64_t info_base = 0);
 int64_t cap_rec_work_size(int64_t n);
 
 struct cap_cacqr_plan {

@@ -522,8 +522,8 @@ int cap_dtrsm(int side, int uplo, int trans, int64_t m, int64_t n, double alpha,
 
 // used by cacqr.hip: full cholinv (R in place, Ri = R^-1) of an n x n block on one stream
 int cap_rec_cholinv_full(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, double* W, int64_t wcap, int* info,
-                         hipStream_t s) {
+                         hipStream_t s, int64_t info_base) {
   RecCtx c{R, ldr, Ri, ldi, W, wcap, info, CAP_LEAF_MAX, 1, 1, s};
-  return rec_cholinv(c, 0, n, false, 0);
+  return rec_cholinv(c, 0, n, false, info_base);
 }
 int64_t cap_rec_work_size(int64_t n) { return rec_work_size(n); }

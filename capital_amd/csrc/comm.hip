@@ -16,6 +16,9 @@ struct cap_comm {
   ncclComm_t nccl;
   int rank, size;
   bool self;
+  // host-staged backend (tests: several ranks sharing ONE GPU, collectives run by the host through
+  // torch.distributed/gloo callbacks).  The factorization schedule is identical; only these hooks differ.
+  cap_allgather_fn cb_allgather; cap_bcast_fn cb_bcast; cap_allreduce_fn cb_allreduce; void* cb_ctx;
 };
 
 #define CAP_NCCL(x)                                                                          \
@@ -45,6 +48,7 @@ int cap_comm_create(cap_comm** comm, const void* id128, int rank, int size, void
   cap_comm* c = new (std::nothrow) cap_comm();
   if (!c) return CAP_ERR_ALLOC;
   c->rank = rank; c->size = size; c->self = false; c->nccl = nullptr;
+  c->cb_allgather = nullptr; c->cb_bcast = nullptr; c->cb_allreduce = nullptr; c->cb_ctx = nullptr;
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   ncclResult_t r = ncclCommInitRank(&c->nccl, size, id, rank);
@@ -62,6 +66,18 @@ int cap_comm_create_self(cap_comm** comm) {
   cap_comm* c = new (std::nothrow) cap_comm();
   if (!c) return CAP_ERR_ALLOC;
   c->rank = 0; c->size = 1; c->self = true; c->nccl = nullptr;
+  c->cb_allgather = nullptr; c->cb_bcast = nullptr; c->cb_allreduce = nullptr; c->cb_ctx = nullptr;
+  *comm = c;
+  return CAP_OK;
+}
+
+int cap_comm_create_callbacks(cap_comm** comm, int rank, int size, cap_allgather_fn ag, cap_bcast_fn bc,
+                              cap_allreduce_fn ar, void* ctx) {
+  if (!comm || size < 1 || rank < 0 || rank >= size || !ag || !bc || !ar) return CAP_ERR_ARG;
+  cap_comm* c = new (std::nothrow) cap_comm();
+  if (!c) return CAP_ERR_ALLOC;
+  c->rank = rank; c->size = size; c->self = false; c->nccl = nullptr;
+  c->cb_allgather = ag; c->cb_bcast = bc; c->cb_allreduce = ar; c->cb_ctx = ctx;
   *comm = c;
   return CAP_OK;
 }
@@ -79,6 +95,7 @@ int cap_comm_size(const cap_comm* c) { return c ? c->size : 1; }
 // MPI_Allreduce(MPI_IN_PLACE, SUM) - summa.hpp:236, cacqr/policy.h:22,82
 int cap_comm_allreduce_sum(cap_comm* c, double* buf, int64_t count, void* stream) {
   if (!c || c->size == 1 || count == 0) return CAP_OK;
+  if (c->cb_allreduce) return c->cb_allreduce(c->cb_ctx, buf, count, stream) ? CAP_ERR_COMM : CAP_OK;
   CAP_NCCL(ncclAllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->nccl, cap_stream(stream)));
   return CAP_OK;
 }
@@ -87,6 +104,7 @@ int cap_comm_allreduce_sum(cap_comm* c, double* buf, int64_t count, void* stream
 int cap_comm_bcast(cap_comm* c, double* buf, int64_t count, int root, void* stream) {
   if (!c || c->size == 1 || count == 0) return CAP_OK;
   if (root < 0 || root >= c->size) return CAP_ERR_ARG;
+  if (c->cb_bcast) return c->cb_bcast(c->cb_ctx, buf, count, root, stream) ? CAP_ERR_COMM : CAP_OK;
   CAP_NCCL(ncclBroadcast(buf, buf, (size_t)count, ncclDouble, root, c->nccl, cap_stream(stream)));
   return CAP_OK;
 }
@@ -98,12 +116,18 @@ int cap_comm_allgather(cap_comm* c, const double* send, double* recv, int64_t co
       CAP_HIP(hipMemcpyAsync(recv, send, sizeof(double) * count_per_rank, hipMemcpyDeviceToDevice, cap_stream(stream)));
     return CAP_OK;
   }
+  if (c->cb_allgather) return c->cb_allgather(c->cb_ctx, send, recv, count_per_rank, stream) ? CAP_ERR_COMM : CAP_OK;
   CAP_NCCL(ncclAllGather(send, recv, (size_t)count_per_rank, ncclDouble, c->nccl, cap_stream(stream)));
   return CAP_OK;
 }
 
 int cap_comm_barrier(cap_comm* c, void* stream) {
   if (!c || c->size == 1) return CAP_OK;
+  if (c->cb_allreduce) {
+    static double* tok = nullptr;
+    if (!tok) { CAP_HIP(hipMalloc((void**)&tok, sizeof(double))); CAP_HIP(hipMemset(tok, 0, sizeof(double))); }
+    return c->cb_allreduce(c->cb_ctx, tok, 1, stream) ? CAP_ERR_COMM : CAP_OK;
+  }
   static double* token = nullptr;
   if (!token) { CAP_HIP(hipMalloc((void**)&token, sizeof(double))); CAP_HIP(hipMemset(token, 0, sizeof(double))); }
   CAP_NCCL(ncclAllReduce(token, token, 1, ncclDouble, ncclSum, c->nccl, cap_stream(stream)));

@@ -44,7 +44,25 @@ struct GemmArgs {
   // split-K (tall-skinny Gram / few-tile problems): blockIdx.y = K slice; partial tiles go to
   // slab kz of P (column-major, ld = M) and a second kernel reduces them deterministically
   int ksplit; int64_t kchunk; double* P; int64_t slab;
+  // distributed trailing update (dist.hip): C = my block-cyclic block columns (1 x P grid, block width
+  // nbT tiles), rows are global.  stair: upper mask follows the staircase  row_tile <= global tile of
+  // my local column tile;  gather: operand A is the all-gathered block row, stored as P pieces in
+  // (rank, local block) order - row tile ti lives in piece (J % P) at local block J / P - gstart[r].
+  int stair, gather, sP, sp, snbT, sJ0, slb0;
+  int64_t gpiece; int gstart[8];
 };
+
+// global tile index (relative to the row origin) of local column tile tj under the staircase view
+__device__ __forceinline__ int stair_gtj(const GemmArgs& g, int tj) {
+  const int J = g.sp + g.sP * (g.slb0 + tj / g.snbT);
+  return (J - g.sJ0) * g.snbT + tj % g.snbT;
+}
+// base of A's rows for row tile ti (K-contiguous operand, lda doubles per row)
+__device__ __forceinline__ const double* a_tile_base(const GemmArgs& g, int ti) {
+  if (!g.gather) return g.A + (int64_t)ti * 128 * g.lda;
+  const int J = g.sJ0 + ti / g.snbT, r = J % g.sP, lb = J / g.sP - g.gstart[r];
+  return g.A + (int64_t)r * g.gpiece + ((int64_t)(lb * g.snbT + ti % g.snbT) * 128) * g.lda;
+}
 
 // logical slot -> tile coordinates (returns false when the slot is empty)
 __device__ __forceinline__ bool slot_to_tile(const GemmArgs& g, int L, int& ti, int& tj) {
@@ -66,6 +84,7 @@ __device__ __forceinline__ bool slot_to_tile(const GemmArgs& g, int L, int& ti, 
   if (si >= g.nsm || sj >= g.nsn) return false;
   ti = si * ST + (w % ST); tj = sj * ST + (w / ST);
   if (ti >= g.tm || tj >= g.tn) return false;
+  if (g.stair) return ti <= stair_gtj(g, tj);
   if (g.tri == 1 && ti > tj) return false;
   if (g.tri == 2 && ti < tj) return false;
   return true;
@@ -314,14 +333,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArg
   //   tail     : MMA(F1)
   // The barrier at the top of iteration kt proves: all reads of tile kt are done (buffer kt&1 may be
   // refilled) and tile kt+1 has landed (each wave drained its own DMA share with vmcnt(0) before it).
+  const double* Abase = a_tile_base(g, ti);   // rows of this tile start at Abase (row offset 0 below)
   if (nk > 0) {
-    dma_tile(g.A, g.lda, i0, kbeg, sA(0));
+    dma_tile(Abase, g.lda, 0, kbeg, sA(0));
     dma_tile(g.B, g.ldb, j0, kbeg, sB(0));
     __syncthreads();
     read_frags(sA(0), sB(0), a_off0, b_off0, fa0, fb0);
     {
       const int64_t k1 = kbeg + (int64_t)(nk > 1 ? 1 : 0) * BK;
-      dma_tile(g.A, g.lda, i0, k1, sA(1));
+      dma_tile(Abase, g.lda, 0, k1, sA(1));
       dma_tile(g.B, g.ldb, j0, k1, sB(1));
     }
     read_frags(sA(0), sB(0), a_off1, b_off1, fa1, fb1);
@@ -337,7 +357,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArg
       // a single wave keeps the matrix pipe busy while it issues them (sched_group_barrier pipeline).
       {
         const int kn = (kt + 2 < nk) ? kt + 2 : nk - 1;  // clamp: the last refill is redundant but branch-free
-        dma_tile(g.A, g.lda, i0, kbeg + (int64_t)kn * BK, sA(nxt ^ 1));
+        dma_tile(Abase, g.lda, 0, kbeg + (int64_t)kn * BK, sA(nxt ^ 1));
         dma_tile(g.B, g.ldb, j0, kbeg + (int64_t)kn * BK, sB(nxt ^ 1));
       }
       read_frags(sA(nxt), sB(nxt), a_off0, b_off0, fa0, fb0);
@@ -365,7 +385,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArg
 
   // epilogue: lane holds C[i0+wi+16i+lr][j0+wj+16j+kg+4r]; all branches are block-uniform
   const double alpha = g.alpha, beta = g.beta;
-  const bool diag_tile = (g.tri != 0) && (ti == tj);
+  const bool diag_tile = g.stair ? (ti == stair_gtj(g, tj)) : ((g.tri != 0) && (ti == tj));
   auto epilogue = [&](auto masked, auto with_beta, auto split) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -377,7 +397,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArg
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int64_t col = j0 + wj + 16 * j + kg + 4 * r;
-            bool ok = !masked.value || (g.tri == 1 ? row <= col : row >= col);
+            // diagonal tiles: compare WITHIN-tile offsets (under the staircase view rows and columns have different origins)
+            bool ok = !masked.value || (g.tri == 1 ? (row - i0) <= (col - j0) : (row - i0) >= (col - j0));
             cin[j][r] = ok ? g.C[row + col * g.ldc] : 0.0;
           }
       }
@@ -386,7 +407,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArg
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int64_t col = j0 + wj + 16 * j + kg + 4 * r;
-          bool ok = !masked.value || (g.tri == 1 ? row <= col : row >= col);
+          bool ok = !masked.value || (g.tri == 1 ? (row - i0) <= (col - j0) : (row - i0) >= (col - j0));
           double v = alpha * acc[i][j][r];
           if (split.value) {
             if (ok) g.P[(int64_t)kz * g.slab + row + col * g.M] = v;
@@ -483,6 +504,8 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.beta = beta; g.tri = tri;
+  g.stair = 0; g.gather = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0;
+  for (int i = 0; i < 8; i++) g.gstart[i] = 0;
   g.tm = (int)cap_ceil_div(m, BM); g.tn = (int)cap_ceil_div(n, BN);
   g.nsm = (int)cap_ceil_div(g.tm, ST); g.nsn = (int)cap_ceil_div(g.tn, ST);
   int64_t nsuper;
@@ -529,6 +552,29 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
                      g.P, g.slab, g.ksplit, m, n, beta, tri);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
+}
+
+// Distributed trailing update on a 1 x P block-column-cyclic matrix (see GemmArgs::stair):
+//   C[m x nloc] -= G^T * B  restricted to the global upper triangle, K = nb.
+// G: gathered block row (P pieces of `piece` doubles, each nb x cols_r column-major with ld = k),
+// B: this rank's own solved columns (nb x nloc, ld = k), C: local columns, rows are global (ldc).
+// Requires m, nloc multiples of 128, nb multiple of 128, k multiple of 16.
+int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, int64_t piece, const int* gstart,
+                           const double* B, double* C, int64_t ldc, int P, int p, int nb, int J0, int lb0,
+                           hipStream_t stream) {
+  if (m <= 0 || nloc <= 0) return CAP_OK;
+  if ((m % BM) || (nloc % BN) || (k % BK) || (nb % 128) || P < 1 || P > 8) return CAP_ERR_UNSUPPORTED;
+  GemmArgs g;
+  g.A = G; g.B = B; g.C = C; g.lda = k; g.ldb = k; g.ldc = ldc;
+  g.M = m; g.N = nloc; g.K = k; g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.etri = 0;
+  g.tm = (int)(m / BM); g.tn = (int)(nloc / BN);
+  g.nsm = (int)cap_ceil_div(g.tm, ST); g.nsn = (int)cap_ceil_div(g.tn, ST);
+  g.ksplit = 1; g.kchunk = k; g.P = nullptr; g.slab = 0;
+  g.stair = 1; g.gather = 1; g.sP = P; g.sp = p; g.snbT = nb / 128; g.sJ0 = J0; g.slb0 = lb0; g.gpiece = piece;
+  for (int i = 0; i < 8; i++) g.gstart[i] = i < P ? gstart[i] : 0;
+  int64_t slots = (int64_t)g.nsm * g.nsn * ST * ST;
+  g.chunk = (int)cap_ceil_div(slots, 8);
+  return launch_tn_dma<1>(g, g.chunk * 8, stream);
 }
 
 extern "C" int cap_dgemm(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,

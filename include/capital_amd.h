@@ -143,6 +143,14 @@ typedef struct cap_comm cap_comm;
 int cap_comm_unique_id(void* id128);
 int cap_comm_create(cap_comm** comm, const void* id128, int rank, int size, void* stream);
 int cap_comm_create_self(cap_comm** comm);           /* P = 1, no RCCL */
+/* Host-staged communicator: the three collectives are provided by the caller (device pointers in,
+ * 0 = success).  Used by the tests to run the multi-rank schedule with several processes sharing one
+ * GPU (gloo over host memory); the product uses cap_comm_create (RCCL).                         */
+typedef int (*cap_allgather_fn)(void* ctx, const double* send, double* recv, int64_t count_per_rank, void* stream);
+typedef int (*cap_bcast_fn)(void* ctx, double* buf, int64_t count, int root, void* stream);
+typedef int (*cap_allreduce_fn)(void* ctx, double* buf, int64_t count, void* stream);
+int cap_comm_create_callbacks(cap_comm** comm, int rank, int size, cap_allgather_fn allgather, cap_bcast_fn bcast,
+                              cap_allreduce_fn allreduce, void* ctx);
 int cap_comm_destroy(cap_comm* comm);
 int cap_comm_rank(const cap_comm* comm);
 int cap_comm_size(const cap_comm* comm);
@@ -191,6 +199,28 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* plan, const char* key);
  * (HIP events recorded on the stream each launch went to) and summed algorithmic flops
  * (m(m+1)k per launch).  Synchronises on the recorded events.                               */
 int cap_cholinv_profile(cap_cholinv_plan* plan, int64_t* launches, double* ms_total, double* flops_total);
+
+/* Multi-GPU blocked Cholesky on a 1 x P block-column-cyclic matrix (the 2D block-cyclic descriptor with
+ * Pr = 1): global block column J (width nb) lives on rank J % P as local block J / P; rows are not
+ * distributed.  Per step: the owner factors + inverts the diagonal block, broadcasts
+ * [R(k,k+1) | Dinv(k+1)], every rank solves its own part of block row k with one GEMM, the solved rows
+ * are all-gathered and each rank applies the rank-nb update to its own columns (upper staircase only).
+ * Replaces the MPI_Bcast / MPI_Allgather schedule of summa.hpp:163-253 + policy.h:160-305 with RCCL
+ * over xGMI; one process per GPU.  Inputs/outputs are the LOCAL column blocks (n rows, ld >= n).     */
+typedef struct cap_dist_plan cap_dist_plan;
+int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* comm);
+int cap_dist_plan_destroy(cap_dist_plan* plan);
+int64_t cap_dist_local_cols(const cap_dist_plan* plan);                 /* columns stored on this rank   */
+int cap_dist_factor(cap_dist_plan* plan, const double* Alocal, int64_t lda, void* stream);
+double* cap_dist_R_ptr(cap_dist_plan* plan, int64_t* ld);               /* local columns of R (n x lc)   */
+int cap_dist_info(cap_dist_plan* plan, void* stream, int64_t* info);    /* agreed on all ranks           */
+/* distribute_symmetric (structure.hpp:68-103) for this layout: fills the local block columns.            */
+int cap_fill_symmetric_bc(double* local, int64_t ld, int64_t n, int64_t nb, int P, int p, int diagonally_dominant,
+                          void* stream);
+/* pure index helpers (no GPU): owner / local block / local column offset of global block column J    */
+int cap_bc_owner(int64_t J, int P);
+int64_t cap_bc_local_block(int64_t J, int P);
+int64_t cap_bc_num_local_cols(int64_t n, int64_t nb, int P, int p);
 
 /* qr::cacqr<...>::info + factor, 1D path - cacqr.h:18-49, cacqr.hpp:5-29,172-193,217-248.
  * A is the local row-cyclic piece (m_local x n, column-major); R (n x n) is replicated;
