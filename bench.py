@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--nb", type=int, default=0, help="panel width override (0 = library default)")
     ap.add_argument("--outer", type=int, default=0, help="outer strip height NB override (0 = library default)")
     ap.add_argument("--tail", type=int, default=-1, help="trailing size below which strips are nb wide (-1 = default)")
+    ap.add_argument("--reserve", type=int, default=-1, help="CUs reserved for the panel chain (-1 = library default)")
     ap.add_argument("--complete-inv", type=int, default=-1,
                     help="-1 blocked Cholesky (headline), 0/1 reference cholinv semantics (R and R^-1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -113,6 +114,8 @@ def main():
             pack.set_option("outer", args.outer)
         if args.tail >= 0:
             pack.set_option("tail", args.tail)
+        if args.reserve >= 0:
+            pack.set_option("reserve", args.reserve)
         run = lambda: cholinv.factor(A, pack, None)
         finish = lambda: pack.last_info()
         parallelism = "1 GPU"

@@ -17,6 +17,7 @@
 //    high-priority stream followed by the next panel factorization, overlapping with the
 //    bulk of the trailing update on the main stream (HIP events, no host sync).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -66,15 +67,15 @@ int rec_cholinv(const RecCtx& c, int64_t off, int64_t n, bool is_root, int64_t i
   if (n1 * n2 > c.wcap) return CAP_ERR_ALLOC;
   // R12 = Ri11^T * A12  (out of place into W, then back: the reference serializes through
   // rect_table1 the same way, cholinv.hpp:122-125)
-  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n1, n2, n1, 1.0, Ri, c.ldi, R12, c.ldr, 0.0, c.W, n1, 0, c.s));
+  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n1, n2, n1, 1.0, Ri, c.ldi, R12, c.ldr, 0.0, c.W, n1, 0, c.s, 2));
   CAP_TRY(cap_copy_rect(c.W, n1, R12, c.ldr, n1, n2, c.s));
   // A22 -= R12^T R12 on upper tiles
-  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n2, n2, n1, -1.0, R12, c.ldr, R12, c.ldr, 1.0, R22, c.ldr, 1, c.s));
+  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n2, n2, n1, -1.0, R12, c.ldr, R12, c.ldr, 1.0, R22, c.ldr, 1, c.s, 2));
   CAP_TRY(rec_cholinv(c, off + n1, n2, false, info_base));
   if (!(is_root && c.complete_inv == 0)) {
     // Ri12 = -Ri11 * (R12 * Ri22)
-    CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, n1, n2, n2, 1.0, R12, c.ldr, Ri22, c.ldi, 0.0, c.W, n1, 0, c.s));
-    CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, n1, n2, n1, -1.0, Ri, c.ldi, c.W, n1, 0.0, Ri12, c.ldi, 0, c.s));
+    CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, n1, n2, n2, 1.0, R12, c.ldr, Ri22, c.ldi, 0.0, c.W, n1, 0, c.s, 2));
+    CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, n1, n2, n1, -1.0, Ri, c.ldi, c.W, n1, 0.0, Ri12, c.ldi, 0, c.s, 2));
   }
   return CAP_OK;
 }
@@ -114,6 +115,10 @@ struct cap_cholinv_plan {
   double* work; int64_t work_elems;
   int* info_dev;
   hipStream_t s_panel; hipEvent_t ev_panel[2], ev_update[2], ev_fork, ev_join;
+  // bulk updates run on an internal stream whose CU mask leaves `reserve` CUs (one per XCD per 8) to the
+  // panel stream, so the latency-bound diagonal-block chain is not time-sliced against 512 resident bulk
+  // workgroups (hipExtStreamCreateWithCUMask: bit i -> XCD i % 8, tools/cumask_probe.hip)
+  hipStream_t s_bulk; hipEvent_t ev_join_b; int64_t reserve; bool bulk_ready;
   bool streams_ready;
   // optional live profile of the dominant kernel (trailing-update SYRK): HIP events on the stream
   // it is launched on, algorithmic flops m(m+1)k per launch
@@ -139,7 +144,7 @@ int64_t default_nb(int64_t n, int64_t bc_mult_dim) {
 
 int plan_alloc(cap_cholinv_plan* p) {
   const int64_t n = p->n;
-  p->ldr = cap_round_up(n, 2);
+  p->ldr = cap_round_up(n, 2);   // power-of-two column strides were measured harmless (HBM address hashing)
   CAP_HIP(hipMalloc((void**)&p->R, sizeof(double) * p->ldr * n));
   if (p->complete_inv >= 0) {
     p->ldi = cap_round_up(n, 2);
@@ -169,7 +174,18 @@ int ensure_streams(cap_cholinv_plan* p) {
   }
   CAP_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
   CAP_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+  CAP_HIP(hipEventCreateWithFlags(&p->ev_join_b, hipEventDisableTiming));
   p->streams_ready = true;
+  return CAP_OK;
+}
+
+int ensure_bulk_stream(cap_cholinv_plan* p) {
+  if (p->bulk_ready || p->reserve <= 0) return CAP_OK;
+  uint32_t mask[8];
+  for (int i = 0; i < 8; i++) mask[i] = 0xffffffffu;
+  for (int64_t b = 0; b < p->reserve && b < 128; b++) mask[b / 32] &= ~(1u << (b % 32));
+  CAP_HIP(hipExtStreamCreateWithCUMask(&p->s_bulk, 8, mask));
+  p->bulk_ready = true;
   return CAP_OK;
 }
 
@@ -183,7 +199,7 @@ int panel_factor(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t
   const int64_t m = n - j0 - jb;
   if (m > 0) {
     double* Rpan = R + j0 + (j0 + jb) * ldr;
-    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, m, jb, 1.0, Dinv, p->ldi, Rpan, ldr, 0.0, Wpan, jb, 0, s));
+    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, m, jb, 1.0, Dinv, p->ldi, Rpan, ldr, 0.0, Wpan, jb, 0, s, 2));
     CAP_TRY(cap_copy_rect(Wpan, jb, Rpan, ldr, jb, m, s));
   }
   return CAP_OK;
@@ -257,10 +273,13 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
     return CAP_OK;
   }
   CAP_TRY(ensure_streams(p));
+  CAP_TRY(ensure_bulk_stream(p));
   hipStream_t s1 = p->s_panel;
-  // fork: the panel stream joins the caller's stream
+  hipStream_t s_user = s0;
+  // fork: the panel stream (and the CU-masked bulk stream) join the caller's stream
   CAP_HIP(hipEventRecord(p->ev_fork, s0));
   CAP_HIP(hipStreamWaitEvent(s1, p->ev_fork, 0));
+  if (p->bulk_ready) { s0 = p->s_bulk; CAP_HIP(hipStreamWaitEvent(s0, p->ev_fork, 0)); }
   CAP_TRY(factor_strip(p, R, ldr, n, 0, bnd[1], s1));
   CAP_HIP(hipEventRecord(p->ev_panel[0], s1));
   for (int64_t k = 0; k < nstrip; k++) {
@@ -284,7 +303,8 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
   }
   // join
   CAP_HIP(hipEventRecord(p->ev_join, s1));
-  CAP_HIP(hipStreamWaitEvent(s0, p->ev_join, 0));
+  CAP_HIP(hipStreamWaitEvent(s_user, p->ev_join, 0));
+  if (s0 != s_user) { CAP_HIP(hipEventRecord(p->ev_join_b, s0)); CAP_HIP(hipStreamWaitEvent(s_user, p->ev_join_b, 0)); }
   return CAP_OK;
 }
 
@@ -303,7 +323,7 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   memset(p, 0, sizeof(*p));
   p->n = n; p->complete_inv = complete_inv; p->split = split; p->bc_mult_dim = bc_mult_dim; p->dir = dir; p->comm = comm;
   p->nb = default_nb(n, bc_mult_dim); p->leaf = CAP_LEAF_MAX; p->lookahead = 1;
-  p->outer = p->nb; p->tail = 0;
+  p->outer = p->nb; p->tail = 0; p->reserve = 0;
   int st = plan_alloc(p);
   if (st != CAP_OK) { cap_cholinv_plan_destroy(p); return st; }
   *plan = p;
@@ -319,8 +339,9 @@ int cap_cholinv_plan_destroy(cap_cholinv_plan* p) {
   if (p->streams_ready) {
     (void)hipStreamDestroy(p->s_panel);
     for (int i = 0; i < 2; i++) { (void)hipEventDestroy(p->ev_panel[i]); (void)hipEventDestroy(p->ev_update[i]); }
-    (void)hipEventDestroy(p->ev_fork); (void)hipEventDestroy(p->ev_join);
+    (void)hipEventDestroy(p->ev_fork); (void)hipEventDestroy(p->ev_join); (void)hipEventDestroy(p->ev_join_b);
   }
+  if (p->bulk_ready) (void)hipStreamDestroy(p->s_bulk);
   if (p->prof_ev) { for (hipEvent_t e : *p->prof_ev) (void)hipEventDestroy(e); delete p->prof_ev; delete p->prof_flops; }
   delete p;
   return CAP_OK;
@@ -347,6 +368,11 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
   if (k == "lookahead") { p->lookahead = value != 0; return CAP_OK; }
   if (k == "outer") { if (value < 64) return CAP_ERR_ARG; p->outer = value; return CAP_OK; }
   if (k == "tail") { if (value < 0) return CAP_ERR_ARG; p->tail = value; return CAP_OK; }
+  if (k == "reserve") {   // CUs kept free for the panel chain (multiple of 8 keeps the XCDs balanced); 0 = off
+    if (value < 0 || value > 64) return CAP_ERR_ARG;
+    if (p->bulk_ready) { (void)hipStreamSynchronize(p->s_bulk); (void)hipStreamDestroy(p->s_bulk); p->bulk_ready = false; }
+    p->reserve = value; return CAP_OK;
+  }
   if (k == "profile") {
     p->profile = value != 0;
     if (p->profile && !p->prof_ev) { p->prof_ev = new std::vector<hipEvent_t>(); p->prof_flops = new std::vector<double>(); }
@@ -363,6 +389,7 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
   if (k == "lookahead") return p->lookahead;
   if (k == "outer") return p->outer;
   if (k == "tail") return p->tail;
+  if (k == "reserve") return p->reserve;
   if (k == "n") return p->n;
   if (k == "complete_inv") return p->complete_inv;
   if (k == "split") return p->split;

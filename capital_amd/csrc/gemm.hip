@@ -48,6 +48,7 @@ struct GemmArgs {
   // nbT tiles), rows are global.  stair: upper mask follows the staircase  row_tile <= global tile of
   // my local column tile;  gather: operand A is the all-gathered block row, stored as P pieces in
   // (rank, local block) order - row tile ti lives in piece (J % P) at local block J / P - gstart[r].
+  int hiprio;       // panel-stream launches: raise the waves' issue priority (they share CUs with the bulk update)
   int stair, gather, sP, sp, snbT, sJ0, slb0;
   int64_t gpiece; int gstart[8];
 };
@@ -92,7 +93,9 @@ __device__ __forceinline__ bool slot_to_tile(const GemmArgs& g, int L, int& ti, 
 
 // Stage one operand tile (128 outer x BK) from global into registers.
 // KC: element (o, k) at P[k + o*ld];  !KC: element (o, k) at P[o + k*ld].
-template <bool KC, bool EDGE>
+// EDGE: 0 = aligned interior (no checks), 1 = ragged extents but 16-byte aligned even geometry (predicated
+// vector loads), 2 = anything (scalar loads).
+template <bool KC, int EDGE>
 __device__ __forceinline__ void load_tile(const double* __restrict__ P, int64_t ld, int64_t o0, int64_t k0,
                                           int64_t omax, int64_t kmax, d2 (&r)[4]) {
   const int t = threadIdx.x;
@@ -101,12 +104,14 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ P, int64_t 
     int c = t + NTHREADS * s;
     if (KC) {
       int o = c >> 3, k2 = (c & 7) * 2;
-      if (!EDGE) {
-        r[s] = *reinterpret_cast<const d2*>(P + (o0 + o) * ld + k0 + k2);
+      const double* p = P + (o0 + o) * ld + k0 + k2;
+      if (EDGE == 0) {
+        r[s] = *reinterpret_cast<const d2*>(p);
+      } else if (EDGE == 1) {          // kmax even: a k pair is in or out as a whole
+        r[s] = (o0 + o < omax && k0 + k2 < kmax) ? *reinterpret_cast<const d2*>(p) : (d2){0.0, 0.0};
       } else {
         double v0 = 0, v1 = 0;
         if (o0 + o < omax) {
-          const double* p = P + (o0 + o) * ld + k0 + k2;
           if (k0 + k2 < kmax) v0 = p[0];
           if (k0 + k2 + 1 < kmax) v1 = p[1];
         }
@@ -114,12 +119,14 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ P, int64_t 
       }
     } else {
       int k = c >> 6, o2 = (c & 63) * 2;
-      if (!EDGE) {
-        r[s] = *reinterpret_cast<const d2*>(P + (k0 + k) * ld + o0 + o2);
+      const double* p = P + (k0 + k) * ld + o0 + o2;
+      if (EDGE == 0) {
+        r[s] = *reinterpret_cast<const d2*>(p);
+      } else if (EDGE == 1) {          // omax even: an outer pair is in or out as a whole
+        r[s] = (k0 + k < kmax && o0 + o2 < omax) ? *reinterpret_cast<const d2*>(p) : (d2){0.0, 0.0};
       } else {
         double v0 = 0, v1 = 0;
         if (k0 + k < kmax) {
-          const double* p = P + (k0 + k) * ld + o0 + o2;
           if (o0 + o2 < omax) v0 = p[0];
           if (o0 + o2 + 1 < omax) v1 = p[1];
         }
@@ -142,14 +149,16 @@ __device__ __forceinline__ void store_tile(double* __restrict__ lds, const d2 (&
 
 // TAG only changes the kernel's NAME (same code): TAG 1 = the trailing update of the blocked
 // Cholesky, so rocprofv3 --stats reports the dominant kernel separately from panel-sized launches.
-template <bool A_KC, bool B_KC, bool EDGE, int TAG>
+template <bool A_KC, bool B_KC, int EDGE, int TAG>
 __global__ void __launch_bounds__(NTHREADS, 2) dgemm_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  // block -> XCD-aware logical slot
-  const int b = blockIdx.x;
+  // block -> XCD-aware logical slot.  Under split-K every K slice would put the same few tiles on the same
+  // XCDs (block b runs on XCD b % 8 for every blockIdx.y when gridDim.x % 8 == 0): rotate by the slice index.
+  const int b = (int)((blockIdx.x + blockIdx.y) % gridDim.x);
   const int L = (b & 7) * g.chunk + (b >> 3);
   int ti, tj;
   if ((b >> 3) >= g.chunk || !slot_to_tile(g, L, ti, tj)) return;
+  if (g.hiprio) __builtin_amdgcn_s_setprio(3);
 
   const int64_t i0 = (int64_t)ti * BM, j0 = (int64_t)tj * BN;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -226,7 +235,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) dgemm_kernel(const GemmArgs g) {
       for (int r = 0; r < 4; r++) {
         const int64_t col = j0 + wj + 16 * j + kg + 4 * r;
         bool ok = true;
-        if (EDGE) ok = (row < g.M) && (col < g.N);
+        if (EDGE != 0) ok = (row < g.M) && (col < g.N);
         if (g.tri == 1) ok = ok && (row <= col);
         if (g.tri == 2) ok = ok && (row >= col);
         if (ok) {
@@ -277,10 +286,11 @@ __device__ __forceinline__ void dma_tile(const double* __restrict__ P, int64_t l
 template <int TAG>
 __global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int b = blockIdx.x;
+  const int b = (int)((blockIdx.x + blockIdx.y) % gridDim.x);   // split-K: rotate tiles over the XCDs (see dgemm_kernel)
   const int L = (b & 7) * g.chunk + (b >> 3);
   int ti, tj;
   if ((b >> 3) >= g.chunk || !slot_to_tile(g, L, ti, tj)) return;
+  if (g.hiprio) __builtin_amdgcn_s_setprio(3);
 
   const int64_t i0 = (int64_t)ti * BM, j0 = (int64_t)tj * BN;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -433,12 +443,115 @@ int launch_tn_dma(const GemmArgs& g, int grid, hipStream_t stream) {
 }
 
 template <bool A_KC, bool B_KC, int TAG = 0>
-int launch_variant(const GemmArgs& g, bool edge, int grid, hipStream_t stream) {
+int launch_variant(const GemmArgs& g, int edge, int grid, hipStream_t stream) {
   size_t lds = 4 * TILE_ELEMS * sizeof(double);
-  if (edge)
-    hipLaunchKernelGGL((dgemm_kernel<A_KC, B_KC, true, TAG>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+  if (edge == 2)
+    hipLaunchKernelGGL((dgemm_kernel<A_KC, B_KC, 2, TAG>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+  else if (edge == 1)
+    hipLaunchKernelGGL((dgemm_kernel<A_KC, B_KC, 1, TAG>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
   else
-    hipLaunchKernelGGL((dgemm_kernel<A_KC, B_KC, false, TAG>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+    hipLaunchKernelGGL((dgemm_kernel<A_KC, B_KC, 0, TAG>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Small-problem kernel (the diagonal-block recursion issues dozens of 64...256-sized products that are
+// pure latency): 64 x 64 C tile per 256-thread workgroup, 4 waves x (2 x 2 MFMA blocks), K chunks of 32
+// staged through LDS as [k][64 + 16] (fragment reads: 16 consecutive doubles per k row, the +16 pad puts
+// the second k row of a half-wave on the other 32 banks).  Scalar predicated loads: any shape / alignment.
+// ---------------------------------------------------------------------------------------------
+constexpr int SM_T = 64, SM_K = 32, SM_LD = SM_T + 16;
+
+struct SmallArgs {
+  const double* A; const double* B; double* C;
+  int64_t lda, ldb, ldc;
+  int M, N, K;
+  double alpha, beta;
+  int tri, hiprio;
+};
+
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256) dgemm_small_kernel(const SmallArgs g) {
+  __shared__ __attribute__((aligned(16))) double As[SM_K * SM_LD];
+  __shared__ __attribute__((aligned(16))) double Bs[SM_K * SM_LD];
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (g.tri == 1 && ti > tj) return;
+  if (g.tri == 2 && ti < tj) return;
+  if (g.hiprio) __builtin_amdgcn_s_setprio(3);
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int lr = lane & 15, kg = lane >> 4;
+  const int wi = (wid & 1) * 32, wj = (wid >> 1) * 32;
+  const int i0 = ti * SM_T, j0 = tj * SM_T;
+  d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  for (int k0 = 0; k0 < g.K; k0 += SM_K) {
+    // stage op(A)[i0.., k0..] -> As[k][m], op(B)[k0.., j0..] -> Bs[k][n]; threads walk the contiguous global axis
+#pragma unroll
+    for (int s = 0; s < (SM_T * SM_K) / 256; s++) {
+      const int e = t + 256 * s;
+      int m, k;
+      if (TA) { k = e % SM_K; m = e / SM_K; } else { m = e % SM_T; k = e / SM_T; }
+      double v = 0.0;
+      if (i0 + m < g.M && k0 + k < g.K) v = TA ? g.A[(int64_t)(i0 + m) * g.lda + k0 + k] : g.A[(int64_t)(k0 + k) * g.lda + i0 + m];
+      As[k * SM_LD + m] = v;
+      int n, kb;
+      if (TB) { n = e % SM_T; kb = e / SM_T; } else { kb = e % SM_K; n = e / SM_K; }
+      double w = 0.0;
+      if (j0 + n < g.N && k0 + kb < g.K) w = TB ? g.B[(int64_t)(k0 + kb) * g.ldb + j0 + n] : g.B[(int64_t)(j0 + n) * g.ldb + k0 + kb];
+      Bs[kb * SM_LD + n] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < SM_K / 4; ks++) {
+      double fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) fa[i] = As[(ks * 4 + kg) * SM_LD + wi + 16 * i + lr];
+#pragma unroll
+      for (int j = 0; j < 2; j++) fb[j] = Bs[(ks * 4 + kg) * SM_LD + wj + 16 * j + lr];
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // lane holds C[i0+wi+16i+lr][j0+wj+16j+kg+4r]
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int row = i0 + wi + 16 * i + lr;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int col = j0 + wj + 16 * j + kg + 4 * r;
+        bool ok = row < g.M && col < g.N;
+        if (g.tri == 1) ok = ok && row <= col;
+        if (g.tri == 2) ok = ok && row >= col;
+        if (ok) {
+          double* pc = g.C + row + (int64_t)col * g.ldc;
+          double v = g.alpha * acc[i][j][r];
+          if (g.beta != 0.0) v += g.beta * (*pc);
+          *pc = v;
+        }
+      }
+  }
+}
+
+int launch_small(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
+                 const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, int hiprio, hipStream_t stream) {
+  SmallArgs g{A, B, C, lda, ldb, ldc, (int)m, (int)n, (int)k, alpha, beta, tri, hiprio};
+  dim3 grid((unsigned)cap_ceil_div(m, SM_T), (unsigned)cap_ceil_div(n, SM_T));
+  const bool ta = transa == CAP_TRANS, tb = transb == CAP_TRANS;
+  if (ta && !tb) hipLaunchKernelGGL((dgemm_small_kernel<true, false>), grid, dim3(256), 0, stream, g);
+  else if (!ta && !tb) hipLaunchKernelGGL((dgemm_small_kernel<false, false>), grid, dim3(256), 0, stream, g);
+  else if (ta && tb) hipLaunchKernelGGL((dgemm_small_kernel<true, true>), grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((dgemm_small_kernel<false, true>), grid, dim3(256), 0, stream, g);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
@@ -501,9 +614,14 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   if (transa == CAP_TRANS ? lda < k : lda < m) return CAP_ERR_ARG;
   if (transb == CAP_TRANS ? ldb < n : ldb < k) return CAP_ERR_ARG;
 
+  // latency-bound little products (diagonal-block recursion): 64 x 64 tiles, no setup cost
+  if (m <= 512 && n <= 512 && k <= 1024 && m * n <= 256 * 256)
+    return launch_small(transa, transb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, (tag & 2) ? 1 : 0, stream);
+
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.beta = beta; g.tri = tri;
+  g.hiprio = (tag & 2) ? 1 : 0; tag &= 1;
   g.stair = 0; g.gather = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0;
   for (int i = 0; i < 8; i++) g.gstart[i] = 0;
   g.tm = (int)cap_ceil_div(m, BM); g.tn = (int)cap_ceil_div(n, BN);
@@ -537,7 +655,15 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   const bool a_kc = (transa == CAP_TRANS);   // op(A)=A^T: k contiguous
   const bool b_kc = (transb != CAP_TRANS);   // op(B)=B:   k contiguous
   auto aligned16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
-  bool edge = (m % BM) || (n % BN) || (k % BK) || (lda & 1) || (ldb & 1) || !aligned16(A) || !aligned16(B);
+  // 0: aligned interior; 1: ragged extents with 16-byte-aligned even geometry (vector loads); 2: scalar
+  int edge = 0;
+  if ((m % BM) || (n % BN) || (k % BK)) edge = 1;
+  {
+    bool vec_ok = !(lda & 1) && !(ldb & 1) && aligned16(A) && aligned16(B) && !(k & 1);
+    if (!a_kc && (m & 1)) vec_ok = false;     // outer-contiguous operands need an even outer extent
+    if (!b_kc && (n & 1)) vec_ok = false;
+    if (!vec_ok) edge = 2;
+  }
 
   int st;
   static const bool use_v1 = getenv("CAP_GEMM_V1") != nullptr;   // A/B switch for profiling
@@ -570,6 +696,7 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   g.tm = (int)(m / BM); g.tn = (int)(nloc / BN);
   g.nsm = (int)cap_ceil_div(g.tm, ST); g.nsn = (int)cap_ceil_div(g.tn, ST);
   g.ksplit = 1; g.kchunk = k; g.P = nullptr; g.slab = 0;
+  g.hiprio = 0;
   g.stair = 1; g.gather = 1; g.sP = P; g.sp = p; g.snbT = nb / 128; g.sJ0 = J0; g.slb0 = lb0; g.gpiece = piece;
   for (int i = 0; i < 8; i++) g.gstart[i] = i < P ? gstart[i] : 0;
   int64_t slots = (int64_t)g.nsm * g.nsn * ST * ST;

@@ -55,7 +55,9 @@ __device__ __forceinline__ void lds_mm(double* C, const double* A, const double*
 }
 
 // 16 x 16 base: unblocked right-looking potrf on S[off.., off..] (upper), then inverse into T.
-__device__ __forceinline__ void base16(double* S, double* T, int off, int* bad) {
+// One reciprocal per pivot (1/r), multiplications everywhere else; the reciprocals are kept in `dinv`
+// for the back substitution, whose dependent chain then has no division.
+__device__ __forceinline__ void base16(double* S, double* T, double* dinv, int off, int* bad) {
   const int t = threadIdx.x;
   const int i = t & 15, j = t >> 4;  // one (i,j) pair per thread
   for (int k = 0; k < 16; k++) {
@@ -63,10 +65,12 @@ __device__ __forceinline__ void base16(double* S, double* T, int off, int* bad) 
     double d = SM(S, off + k, off + k);
     if (!(d > 0.0) && t == 0 && *bad == 0) *bad = off + k + 1;
     double r = __builtin_sqrt(d);
-    double rowi = SM(S, off + k, off + i), rowj = SM(S, off + k, off + j);
+    double rinv = 1.0 / r;
+    double rowi = SM(S, off + k, off + i) * rinv, rowj = SM(S, off + k, off + j) * rinv;
     __syncthreads();
-    if (i == k && j >= k) SM(S, off + k, off + j) = (j == k) ? r : rowj / r;
-    if (i > k && j >= i) SM(S, off + i, off + j) -= (rowi / r) * (rowj / r);
+    if (i == k && j >= k) SM(S, off + k, off + j) = (j == k) ? r : rowj;
+    if (i > k && j >= i) SM(S, off + i, off + j) -= rowi * rowj;
+    if (t == 0) dinv[off + k] = rinv;
   }
   __syncthreads();
   // inverse: thread c solves R x = e_c by back substitution (column c of R^-1)
@@ -80,7 +84,7 @@ __device__ __forceinline__ void base16(double* S, double* T, int off, int* bad) 
       double s = (ii == c) ? 1.0 : 0.0;
 #pragma unroll
       for (int l = ii + 1; l < 16; l++) s -= SM(S, off + ii, off + l) * x[l];
-      double v = s / SM(S, off + ii, off + ii);
+      double v = s * dinv[off + ii];
       x[ii] = (ii <= c) ? v : 0.0;
     }
 #pragma unroll
@@ -90,12 +94,12 @@ __device__ __forceinline__ void base16(double* S, double* T, int off, int* bad) 
 }
 
 template <int N>
-__device__ void cholinv_lds(double* S, double* T, int off, int* bad) {
+__device__ void cholinv_lds(double* S, double* T, double* dinv, int off, int* bad) {
   if constexpr (N == 16) {
-    base16(S, T, off, bad);
+    base16(S, T, dinv, off, bad);
   } else {
     constexpr int H = N / 2;
-    cholinv_lds<H>(S, T, off, bad);
+    cholinv_lds<H>(S, T, dinv, off, bad);
     double* S11 = &SM(S, off, off);        (void)S11;
     double* S12 = &SM(S, off, off + H);
     double* S21 = &SM(S, off + H, off);     // scratch: the unused lower block
@@ -111,7 +115,7 @@ __device__ void cholinv_lds(double* S, double* T, int off, int* bad) {
     // A22 -= R12^T R12     (SYRK Upper/Trans alpha=-1 beta=1, cholinv.hpp:128-137)
     lds_mm<true, true, true>(S22, S12, S12, H, H, H, -1.0);
     __syncthreads();
-    cholinv_lds<H>(S, T, off + H, bad);
+    cholinv_lds<H>(S, T, dinv, off + H, bad);
     // Ri12 = -Ri11 * R12 * Ri22   (two TRMMs, cholinv.hpp:150-154)
     lds_mm<false, false, false>(S21, S12, T22, H, H, H, 1.0);
     __syncthreads();
@@ -130,8 +134,10 @@ __global__ void __launch_bounds__(LTHREADS) leaf_cholinv_kernel(double* A, int64
   double* S = lds;
   double* T = lds + LMAX * LLD;
   int& bad = *reinterpret_cast<int*>(lds + 2 * LMAX * LLD);   // keep ALL LDS in the dynamic region (16-B aligned base)
+  double* dinv = lds + 2 * LMAX * LLD + 2;                    // 1/R[k][k], 64 doubles
   const int t = threadIdx.x;
   const int np = n <= 16 ? 16 : (n <= 32 ? 32 : 64);
+  __builtin_amdgcn_s_setprio(3);      // latency-critical single workgroup: win issue arbitration against co-resident bulk waves
   if (t == 0) bad = 0;
   for (int e = t; e < np * np; e += LTHREADS) {
     int i = e % np, j = e / np;
@@ -142,9 +148,9 @@ __global__ void __launch_bounds__(LTHREADS) leaf_cholinv_kernel(double* A, int64
     SM(T, i, j) = 0.0;
   }
   __syncthreads();
-  if (np == 16) cholinv_lds<16>(S, T, 0, &bad);
-  else if (np == 32) cholinv_lds<32>(S, T, 0, &bad);
-  else cholinv_lds<64>(S, T, 0, &bad);
+  if (np == 16) cholinv_lds<16>(S, T, dinv, 0, &bad);
+  else if (np == 32) cholinv_lds<32>(S, T, dinv, 0, &bad);
+  else cholinv_lds<64>(S, T, dinv, 0, &bad);
   __syncthreads();
   for (int e = t; e < n * n; e += LTHREADS) {
     int i = e % n, j = e / n;
@@ -178,15 +184,15 @@ __global__ void __launch_bounds__(LTHREADS) leaf_trtri_kernel(const double* R, i
   const int nblk = np / 16;
   if (t < 16 * nblk) {
     const int off = (t >> 4) * 16, c = t & 15;
-    double x[16];
+    double x[16], rd[16];
 #pragma unroll
-    for (int q = 0; q < 16; q++) x[q] = 0.0;
+    for (int q = 0; q < 16; q++) { x[q] = 0.0; rd[q] = 1.0 / SM(S, off + q, off + q); }   // independent divisions, off the chain
 #pragma unroll
     for (int ii = 15; ii >= 0; ii--) {
       double s = (ii == c) ? 1.0 : 0.0;
 #pragma unroll
       for (int l = ii + 1; l < 16; l++) s -= SM(S, off + ii, off + l) * x[l];
-      double v = s / SM(S, off + ii, off + ii);
+      double v = s * rd[ii];
       x[ii] = (ii <= c) ? v : 0.0;
     }
 #pragma unroll
@@ -212,7 +218,7 @@ __global__ void __launch_bounds__(LTHREADS) leaf_trtri_kernel(const double* R, i
 
 }  // namespace
 
-constexpr size_t LEAF_LDS_BYTES = 2 * LMAX * LLD * sizeof(double) + 16;
+constexpr size_t LEAF_LDS_BYTES = (2 * LMAX * LLD + 2 + LMAX) * sizeof(double);
 
 int cap_leaf_cholinv(double* A, int64_t lda, double* Rinv, int64_t ldr, int n, int zero_lower, int* info,
                      int info_base, hipStream_t stream) {

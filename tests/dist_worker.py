@@ -54,6 +54,35 @@ def main():
         assert int(t.item()) == n
         if rank == 0:
             print("INDEX-OK world=%d n=%d nb=%d" % (size, n, nb), flush=True)
+    elif args.mode == "cacqr":
+        # CholeskyQR2 on the 1D grid (c = 1, d = world): rows cyclic over ranks, Gram all-reduce through the communicator
+        torch.cuda.set_device(0)
+        from capital_amd import cacqr, cholinv, validate, dist_cholesky as dc
+        from capital_amd.matrix import matrix
+
+        class Topo:                      # the fields cacqr/validate read from topo::rect (topology.h:62-64)
+            pass
+        comm = dc.HostStagedComm()
+        topo = Topo(); topo.c, topo.d, topo.x, topo.y, topo.z = 1, size, 0, rank, 0
+        topo.rank, topo.size, topo.world = rank, size, comm.handle
+        m, ncol = args.n, args.nb        # --size = global rows, --nb = columns here
+        A = matrix(ncol, m, 1, size)
+        A.distribute_random(0, rank, 1, size, rank)      # key = rank / c (bench/qr/cacqr.cpp:34)
+        a_loc = A.to_numpy()
+        assert np.array_equal(a_loc, orc.random_local(m, ncol, 0, rank, 1, size, rank))
+        pack = cacqr.info(2, cholinv.info(1, 1, 0, 'U'))
+        cacqr.factor(A, pack, topo)
+        res = validate.qr.residual(A, pack, topo); orth = validate.qr.orthogonality(A, pack, topo)
+        q_loc = cacqr.construct_Q(pack, topo).to_numpy(); r = cacqr.construct_R(pack, topo).to_numpy()
+        pieces = [None] * size
+        dist.all_gather_object(pieces, (a_loc, q_loc))
+        if rank == 0:
+            q_ref, r_ref = orc.cacqr_1d([p[0] for p in pieces], 2)
+            assert np.linalg.norm(r - r_ref) / np.linalg.norm(r_ref) < 1e-11
+            for y in range(size):
+                assert np.linalg.norm(pieces[y][1] - q_ref[y]) / np.linalg.norm(q_ref[y]) < 1e-10
+            assert res < 1e-13 and orth < 1e-15, (res, orth)
+            print("CACQR-OK world=%d m=%d n=%d residual=%.2e orth=%.2e collectives=%s" % (size, m, ncol, res, orth, comm.calls), flush=True)
     else:
         torch.cuda.set_device(0)
         from capital_amd import dist_cholesky as dc

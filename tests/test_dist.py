@@ -70,3 +70,12 @@ def test_single_rank_dist_path_matches_single_gpu_plan():
     R2 = cholinv.construct_R(pack).to_numpy()
     assert np.linalg.norm(R1 - R2) / np.linalg.norm(R2) < 1e-14
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,m,n", [(2, 4096, 64), (4, 10000, 48), (3, 6000, 128)])
+def test_multirank_cacqr_on_one_gpu(nproc, m, n):
+    """CholeskyQR2 1D: row-cyclic pieces on several ranks, Gram all-reduce through the (host-staged) communicator."""
+    r = _launch(nproc, "cacqr", m, n, 29641 + nproc)
+    assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    assert "CACQR-OK" in r.stdout, r.stdout[-2000:]
