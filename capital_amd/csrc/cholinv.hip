@@ -323,7 +323,9 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   memset(p, 0, sizeof(*p));
   p->n = n; p->complete_inv = complete_inv; p->split = split; p->bc_mult_dim = bc_mult_dim; p->dir = dir; p->comm = comm;
   p->nb = default_nb(n, bc_mult_dim); p->leaf = CAP_LEAF_MAX; p->lookahead = 1;
-  p->outer = p->nb; p->tail = 0; p->reserve = 0;
+  // two-level blocking defaults (tools/sweep.sh on MI355X): K = 2 nb bulk updates while the trailing matrix is
+  // large, nb-wide strips for the last n/8 columns where the strip chain could no longer hide
+  p->outer = n >= 8192 ? 2 * p->nb : p->nb; p->tail = n >= 8192 ? n / 8 : 0; p->reserve = 0;
   int st = plan_alloc(p);
   if (st != CAP_OK) { cap_cholinv_plan_destroy(p); return st; }
   *plan = p;

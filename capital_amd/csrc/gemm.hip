@@ -462,7 +462,8 @@ int launch_variant(const GemmArgs& g, int edge, int grid, hipStream_t stream) {
 // staged through LDS as [k][64 + 16] (fragment reads: 16 consecutive doubles per k row, the +16 pad puts
 // the second k row of a half-wave on the other 32 banks).  Scalar predicated loads: any shape / alignment.
 // ---------------------------------------------------------------------------------------------
-constexpr int SM_T = 64, SM_K = 32, SM_LD = SM_T + 16;
+constexpr int SM_T = 64, SM_K = 64, SM_LD = SM_T + 16;
+constexpr int SM_PER_THREAD = (SM_T * SM_K) / 256;   // elements of each operand chunk staged per thread
 
 struct SmallArgs {
   const double* A; const double* B; double* C;
@@ -474,8 +475,9 @@ struct SmallArgs {
 
 template <bool TA, bool TB>
 __global__ void __launch_bounds__(256) dgemm_small_kernel(const SmallArgs g) {
-  __shared__ __attribute__((aligned(16))) double As[SM_K * SM_LD];
-  __shared__ __attribute__((aligned(16))) double Bs[SM_K * SM_LD];
+  extern __shared__ __attribute__((aligned(16))) double sm_lds[];
+  double* As = sm_lds;
+  double* Bs = sm_lds + SM_K * SM_LD;
   const int ti = blockIdx.x, tj = blockIdx.y;
   if (g.tri == 1 && ti > tj) return;
   if (g.tri == 2 && ti < tj) return;
@@ -490,23 +492,39 @@ __global__ void __launch_bounds__(256) dgemm_small_kernel(const SmallArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
-  for (int k0 = 0; k0 < g.K; k0 += SM_K) {
-    // stage op(A)[i0.., k0..] -> As[k][m], op(B)[k0.., j0..] -> Bs[k][n]; threads walk the contiguous global axis
+  // global -> registers for one K chunk (threads walk the contiguous global axis; all loads of a chunk are
+  // issued back to back, and the NEXT chunk's loads fly while the current one is contracted)
+  double ra[SM_PER_THREAD], rb[SM_PER_THREAD];
+  auto fetch = [&](int k0) {
 #pragma unroll
-    for (int s = 0; s < (SM_T * SM_K) / 256; s++) {
+    for (int s = 0; s < SM_PER_THREAD; s++) {
       const int e = t + 256 * s;
       int m, k;
       if (TA) { k = e % SM_K; m = e / SM_K; } else { m = e % SM_T; k = e / SM_T; }
-      double v = 0.0;
-      if (i0 + m < g.M && k0 + k < g.K) v = TA ? g.A[(int64_t)(i0 + m) * g.lda + k0 + k] : g.A[(int64_t)(k0 + k) * g.lda + i0 + m];
-      As[k * SM_LD + m] = v;
+      ra[s] = (i0 + m < g.M && k0 + k < g.K) ? (TA ? g.A[(int64_t)(i0 + m) * g.lda + k0 + k] : g.A[(int64_t)(k0 + k) * g.lda + i0 + m]) : 0.0;
       int n, kb;
       if (TB) { n = e % SM_T; kb = e / SM_T; } else { kb = e % SM_K; n = e / SM_K; }
-      double w = 0.0;
-      if (j0 + n < g.N && k0 + kb < g.K) w = TB ? g.B[(int64_t)(k0 + kb) * g.ldb + j0 + n] : g.B[(int64_t)(j0 + n) * g.ldb + k0 + kb];
-      Bs[kb * SM_LD + n] = w;
+      rb[s] = (j0 + n < g.N && k0 + kb < g.K) ? (TB ? g.B[(int64_t)(k0 + kb) * g.ldb + j0 + n] : g.B[(int64_t)(j0 + n) * g.ldb + k0 + kb]) : 0.0;
     }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int s = 0; s < SM_PER_THREAD; s++) {
+      const int e = t + 256 * s;
+      int m, k;
+      if (TA) { k = e % SM_K; m = e / SM_K; } else { m = e % SM_T; k = e / SM_T; }
+      As[k * SM_LD + m] = ra[s];
+      int n, kb;
+      if (TB) { n = e % SM_T; kb = e / SM_T; } else { kb = e % SM_K; n = e / SM_K; }
+      Bs[kb * SM_LD + n] = rb[s];
+    }
+  };
+
+  fetch(0);
+  for (int k0 = 0; k0 < g.K; k0 += SM_K) {
+    stash();
     __syncthreads();
+    if (k0 + SM_K < g.K) fetch(k0 + SM_K);
 #pragma unroll
     for (int ks = 0; ks < SM_K / 4; ks++) {
       double fa[2], fb[2];
@@ -548,10 +566,11 @@ int launch_small(int transa, int transb, int64_t m, int64_t n, int64_t k, double
   SmallArgs g{A, B, C, lda, ldb, ldc, (int)m, (int)n, (int)k, alpha, beta, tri, hiprio};
   dim3 grid((unsigned)cap_ceil_div(m, SM_T), (unsigned)cap_ceil_div(n, SM_T));
   const bool ta = transa == CAP_TRANS, tb = transb == CAP_TRANS;
-  if (ta && !tb) hipLaunchKernelGGL((dgemm_small_kernel<true, false>), grid, dim3(256), 0, stream, g);
-  else if (!ta && !tb) hipLaunchKernelGGL((dgemm_small_kernel<false, false>), grid, dim3(256), 0, stream, g);
-  else if (ta && tb) hipLaunchKernelGGL((dgemm_small_kernel<true, true>), grid, dim3(256), 0, stream, g);
-  else hipLaunchKernelGGL((dgemm_small_kernel<false, true>), grid, dim3(256), 0, stream, g);
+  const size_t lds = 2 * SM_K * SM_LD * sizeof(double);
+  if (ta && !tb) hipLaunchKernelGGL((dgemm_small_kernel<true, false>), grid, dim3(256), lds, stream, g);
+  else if (!ta && !tb) hipLaunchKernelGGL((dgemm_small_kernel<false, false>), grid, dim3(256), lds, stream, g);
+  else if (ta && tb) hipLaunchKernelGGL((dgemm_small_kernel<true, true>), grid, dim3(256), lds, stream, g);
+  else hipLaunchKernelGGL((dgemm_small_kernel<false, true>), grid, dim3(256), lds, stream, g);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }

@@ -54,72 +54,109 @@ __device__ __forceinline__ void lds_mm(double* C, const double* A, const double*
   }
 }
 
-// 16 x 16 base: unblocked right-looking potrf on S[off.., off..] (upper), then inverse into T.
-// One reciprocal per pivot (1/r), multiplications everywhere else; the reciprocals are kept in `dinv`
-// for the back substitution, whose dependent chain then has no division.
-__device__ __forceinline__ void base16(double* S, double* T, double* dinv, int off, int* bad) {
-  const int t = threadIdx.x;
-  const int i = t & 15, j = t >> 4;  // one (i,j) pair per thread
+// 1/sqrt(d) from v_rsq_f64 + two Newton steps (full fp64 accuracy, ~20 dependent ops instead of the ~80 of
+// sqrt followed by a division); d <= 0 yields NaN/Inf which the caller reports through `bad`.
+__device__ __forceinline__ double fast_rsqrt(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  y = y * (1.5 - h * y * y);
+  y = y * (1.5 - h * y * y);
+  return y;
+}
+
+// 16 x 16 Cholesky of S[off.., off..] by ONE wave, block held in registers: lane (j = lane & 15, q = lane >> 4)
+// owns rows 4q..4q+3 of column j.  Per pivot only the pivot row travels through LDS (rowbuf, double
+// buffered); no workgroup barrier inside.  Also leaves 1/R[k][k] in dinv.
+__device__ __forceinline__ void potrf16_wave(double* S, double* dinv, double* rowbuf, int off, int* bad) {
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15, q = lane >> 4;
+  double a[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) a[e] = SM(S, off + 4 * q + e, off + j);
+#pragma unroll
   for (int k = 0; k < 16; k++) {
-    __syncthreads();
-    double d = SM(S, off + k, off + k);
-    if (!(d > 0.0) && t == 0 && *bad == 0) *bad = off + k + 1;
-    double r = __builtin_sqrt(d);
-    double rinv = 1.0 / r;
-    double rowi = SM(S, off + k, off + i) * rinv, rowj = SM(S, off + k, off + j) * rinv;
-    __syncthreads();
-    if (i == k && j >= k) SM(S, off + k, off + j) = (j == k) ? r : rowj;
-    if (i > k && j >= i) SM(S, off + i, off + j) -= rowi * rowj;
-    if (t == 0) dinv[off + k] = rinv;
+    const int kq = k >> 2, ke = k & 3;
+    double* rb = rowbuf + (k & 1) * 16;
+    if (q == kq) rb[j] = a[ke];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double d = rb[k], rj = rb[j];
+    const d2 r01 = *reinterpret_cast<const d2*>(rb + 4 * q), r23 = *reinterpret_cast<const d2*>(rb + 4 * q + 2);
+    const double ri[4] = {r01.x, r01.y, r23.x, r23.y};
+    if (!(d > 0.0) && lane == 0 && *bad == 0) *bad = off + k + 1;
+    const double rinv = fast_rsqrt(d);
+    const double rjs = rj * rinv;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int i = 4 * q + e;
+      if (i > k && j >= i) a[e] -= (ri[e] * rinv) * rjs;
+    }
+    if (q == kq) a[ke] = (j == k) ? d * rinv : (j > k ? rjs : a[ke]);
+    if (lane == 0) dinv[off + k] = rinv;
   }
-  __syncthreads();
-  // inverse: thread c solves R x = e_c by back substitution (column c of R^-1)
-  if (t < 16) {
-    const int c = t;
+#pragma unroll
+  for (int e = 0; e < 4; e++) SM(S, off + 4 * q + e, off + j) = a[e];
+}
+
+// Right-looking blocked Cholesky of the np x np (np = 16, 32 or 64) block in S, 16-wide panels:
+//   potrf16 (wave 0, registers) | row panel by forward substitution (one lane per column, R11 broadcast from LDS)
+//   | rank-16 update of the trailing blocks on MFMA.
+__device__ void potrf_lds(double* S, double* dinv, double* rowbuf, int np, int* bad) {
+  const int t = threadIdx.x;
+  for (int off = 0; off < np; off += 16) {
+    if (t < 64) potrf16_wave(S, dinv, rowbuf, off, bad);
+    __syncthreads();
+    const int rest = np - off - 16;
+    if (rest > 0) {
+      if (t < rest) {   // X = R11^-T * A12, column t of the panel
+        const int c = off + 16 + t;
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          double sacc = SM(S, off + i, c);
+#pragma unroll
+          for (int l = 0; l < i; l++) sacc -= SM(S, off + l, off + i) * x[l];
+          x[i] = sacc * dinv[off + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) SM(S, off + i, c) = x[i];
+      }
+      __syncthreads();
+      lds_mm<true, true, true>(&SM(S, off + 16, off + 16), &SM(S, off, off + 16), &SM(S, off, off + 16), rest, rest, 16, -1.0);
+      __syncthreads();
+    }
+  }
+}
+
+// T = R^-1 for the np x np upper-triangular block in S (T zero on entry): the 16 x 16 diagonal blocks by back
+// substitution (all blocks in parallel, reciprocals from dinv), then Ri12 = -Ri11 R12 Ri22 level by level on MFMA;
+// S's strictly-lower blocks serve as scratch.
+__device__ void trtri_lds(double* S, double* T, const double* dinv, int np) {
+  const int t = threadIdx.x;
+  const int nblk = np / 16;
+  if (t < 16 * nblk) {
+    const int off = (t >> 4) * 16, c = t & 15;
     double x[16];
 #pragma unroll
     for (int q = 0; q < 16; q++) x[q] = 0.0;
 #pragma unroll
     for (int ii = 15; ii >= 0; ii--) {
-      double s = (ii == c) ? 1.0 : 0.0;
+      double sacc = (ii == c) ? 1.0 : 0.0;
 #pragma unroll
-      for (int l = ii + 1; l < 16; l++) s -= SM(S, off + ii, off + l) * x[l];
-      double v = s * dinv[off + ii];
+      for (int l = ii + 1; l < 16; l++) sacc -= SM(S, off + ii, off + l) * x[l];
+      double v = sacc * dinv[off + ii];
       x[ii] = (ii <= c) ? v : 0.0;
     }
 #pragma unroll
     for (int q = 0; q < 16; q++) SM(T, off + q, off + c) = x[q];
   }
   __syncthreads();
-}
-
-template <int N>
-__device__ void cholinv_lds(double* S, double* T, double* dinv, int off, int* bad) {
-  if constexpr (N == 16) {
-    base16(S, T, dinv, off, bad);
-  } else {
-    constexpr int H = N / 2;
-    cholinv_lds<H>(S, T, dinv, off, bad);
-    double* S11 = &SM(S, off, off);        (void)S11;
-    double* S12 = &SM(S, off, off + H);
-    double* S21 = &SM(S, off + H, off);     // scratch: the unused lower block
-    double* S22 = &SM(S, off + H, off + H);
-    double* T11 = &SM(T, off, off);
-    double* T12 = &SM(T, off, off + H);
-    double* T22 = &SM(T, off + H, off + H);
-    // R12 = Ri11^T * A12   (TRMM Left/Upper/Trans of cholinv.hpp:118-121)
-    lds_mm<true, false, false>(S21, T11, S12, H, H, H, 1.0);
+  for (int h = 16; h < np; h *= 2) {
+    for (int off = 0; off < np; off += 2 * h)
+      lds_mm<false, false, false>(&SM(S, off + h, off), &SM(S, off, off + h), &SM(T, off + h, off + h), h, h, h, 1.0);
     __syncthreads();
-    for (int e = threadIdx.x; e < H * H; e += LTHREADS) SM(S12, e % H, e / H) = SM(S21, e % H, e / H);
-    __syncthreads();
-    // A22 -= R12^T R12     (SYRK Upper/Trans alpha=-1 beta=1, cholinv.hpp:128-137)
-    lds_mm<true, true, true>(S22, S12, S12, H, H, H, -1.0);
-    __syncthreads();
-    cholinv_lds<H>(S, T, dinv, off + H, bad);
-    // Ri12 = -Ri11 * R12 * Ri22   (two TRMMs, cholinv.hpp:150-154)
-    lds_mm<false, false, false>(S21, S12, T22, H, H, H, 1.0);
-    __syncthreads();
-    lds_mm<false, false, false>(T12, T11, S21, H, H, H, -1.0);
+    for (int off = 0; off < np; off += 2 * h)
+      lds_mm<false, false, false>(&SM(T, off, off + h), &SM(T, off, off), &SM(S, off + h, off), h, h, h, -1.0);
     __syncthreads();
   }
 }
@@ -135,27 +172,38 @@ __global__ void __launch_bounds__(LTHREADS) leaf_cholinv_kernel(double* A, int64
   double* T = lds + LMAX * LLD;
   int& bad = *reinterpret_cast<int*>(lds + 2 * LMAX * LLD);   // keep ALL LDS in the dynamic region (16-B aligned base)
   double* dinv = lds + 2 * LMAX * LLD + 2;                    // 1/R[k][k], 64 doubles
+  double* rowbuf = dinv + LMAX;                               // pivot-row exchange, 2 x 16 doubles
   const int t = threadIdx.x;
   const int np = n <= 16 ? 16 : (n <= 32 ? 32 : 64);
   __builtin_amdgcn_s_setprio(3);      // latency-critical single workgroup: win issue arbitration against co-resident bulk waves
   if (t == 0) bad = 0;
-  for (int e = t; e < np * np; e += LTHREADS) {
-    int i = e % np, j = e / np;
-    double v = 0.0;
-    if (i < n && j < n) { if (i <= j) v = A[i + (int64_t)j * lda]; }
-    else if (i == j) v = 1.0;
-    SM(S, i, j) = v;
-    SM(T, i, j) = 0.0;
+  for (int e0 = 0; e0 < np * np; e0 += 4 * LTHREADS) {   // 4 independent loads in flight per thread
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + u * LTHREADS + t;
+      const int i = e % np, j = e / np;
+      const bool in = (e < np * np) && i < n && j < n && i <= j;
+      v[u] = in ? A[i + (int64_t)j * lda] : ((i == j && i >= n) ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + u * LTHREADS + t;
+      if (e < np * np) { SM(S, e % np, e / np) = v[u]; SM(T, e % np, e / np) = 0.0; }
+    }
   }
   __syncthreads();
-  if (np == 16) cholinv_lds<16>(S, T, dinv, 0, &bad);
-  else if (np == 32) cholinv_lds<32>(S, T, dinv, 0, &bad);
-  else cholinv_lds<64>(S, T, dinv, 0, &bad);
+  potrf_lds(S, dinv, rowbuf, np, &bad);
+  // R goes out first (the scratch use of S's lower blocks below never touches the upper triangle)
+  for (int e = t; e < n * n; e += LTHREADS) {
+    int i = e % n, j = e / n;
+    if (i <= j) A[i + (int64_t)j * lda] = SM(S, i, j);
+  }
+  if (Rinv) trtri_lds(S, T, dinv, np);
   __syncthreads();
   for (int e = t; e < n * n; e += LTHREADS) {
     int i = e % n, j = e / n;
     if (i <= j) {
-      A[i + (int64_t)j * lda] = SM(S, i, j);
       if (Rinv) Rinv[i + (int64_t)j * ldr] = SM(T, i, j);
     } else if (Rinv && zero_lower) {
       Rinv[i + (int64_t)j * ldr] = 0.0;
@@ -180,36 +228,10 @@ __global__ void __launch_bounds__(LTHREADS) leaf_trtri_kernel(const double* R, i
     SM(T, i, j) = 0.0;
   }
   __syncthreads();
-  // invert the 16x16 diagonal blocks (thread c of group g solves column c of block g)
-  const int nblk = np / 16;
-  if (t < 16 * nblk) {
-    const int off = (t >> 4) * 16, c = t & 15;
-    double x[16], rd[16];
-#pragma unroll
-    for (int q = 0; q < 16; q++) { x[q] = 0.0; rd[q] = 1.0 / SM(S, off + q, off + q); }   // independent divisions, off the chain
-#pragma unroll
-    for (int ii = 15; ii >= 0; ii--) {
-      double s = (ii == c) ? 1.0 : 0.0;
-#pragma unroll
-      for (int l = ii + 1; l < 16; l++) s -= SM(S, off + ii, off + l) * x[l];
-      double v = s * rd[ii];
-      x[ii] = (ii <= c) ? v : 0.0;
-    }
-#pragma unroll
-    for (int q = 0; q < 16; q++) SM(T, off + q, off + c) = x[q];
-  }
+  double* dinv = lds + 2 * LMAX * LLD + 2;
+  if (t < np) dinv[t] = 1.0 / SM(S, t, t);
   __syncthreads();
-  // combine: for block size h = 16, 32: Ri12 = -Ri11 R12 Ri22 for every aligned pair
-  for (int h = 16; h < np; h *= 2) {
-    for (int off = 0; off < np; off += 2 * h) {
-      lds_mm<false, false, false>(&SM(S, off + h, off), &SM(S, off, off + h), &SM(T, off + h, off + h), h, h, h, 1.0);
-    }
-    __syncthreads();
-    for (int off = 0; off < np; off += 2 * h) {
-      lds_mm<false, false, false>(&SM(T, off, off + h), &SM(T, off, off), &SM(S, off + h, off), h, h, h, -1.0);
-    }
-    __syncthreads();
-  }
+  trtri_lds(S, T, dinv, np);
   for (int e = t; e < n * n; e += LTHREADS) {
     int i = e % n, j = e / n;
     if (i <= j) Rinv[i + (int64_t)j * ldi] = SM(T, i, j);
@@ -218,7 +240,7 @@ __global__ void __launch_bounds__(LTHREADS) leaf_trtri_kernel(const double* R, i
 
 }  // namespace
 
-constexpr size_t LEAF_LDS_BYTES = (2 * LMAX * LLD + 2 + LMAX) * sizeof(double);
+constexpr size_t LEAF_LDS_BYTES = (2 * LMAX * LLD + 2 + LMAX + 32) * sizeof(double);
 
 int cap_leaf_cholinv(double* A, int64_t lda, double* Rinv, int64_t ldr, int n, int zero_lower, int* info,
                      int info_base, hipStream_t stream) {
