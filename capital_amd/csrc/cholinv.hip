@@ -129,16 +129,18 @@ struct cap_cholinv_plan {
 namespace {
 
 int64_t default_nb(int64_t n, int64_t bc_mult_dim) {
-  // bcDimension of cholinv.hpp:15-18 with c = d = 1, used as the panel-width hint
-  int64_t bc = 1;
-  if (bc_mult_dim < 0) for (int64_t i = 0; i < -bc_mult_dim && bc < n; i++) bc *= 2;
-  bc = std::max<int64_t>(1, std::min<int64_t>(n, bc));
-  int64_t hint = n / bc;
-  if (bc_mult_dim >= 0) hint = 0;            // "whole matrix is one base case" makes no sense on a GPU
-  int64_t nb = hint > 0 ? hint : 512;
-  nb = std::max<int64_t>(128, std::min<int64_t>(nb, 2048));
-  nb = (nb / 128) * 128;
-  if (n < 2048) nb = std::min<int64_t>(nb, 256);
+  // Panel width of the GPU schedule.  The sweet spot on MI355X is 512 (256 for small matrices): wider panels
+  // lengthen the latency-bound diagonal-block chain, narrower ones starve the MFMA update of K.  upstream's
+  // base-case knob (bcDimension of cholinv.hpp:15-18 with c = d = 1) can only narrow it.
+  int64_t nb = n >= 8192 ? 512 : 256;
+  if (bc_mult_dim < 0) {
+    int64_t bc = 1;
+    for (int64_t i = 0; i < -bc_mult_dim && bc < n; i++) bc *= 2;
+    bc = std::max<int64_t>(1, std::min<int64_t>(n, bc));
+    const int64_t hint = ((n / bc) / 128) * 128;
+    if (hint >= 128) nb = std::min(nb, hint);
+    else nb = std::min<int64_t>(nb, 128);
+  }
   return nb;
 }
 
