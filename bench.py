@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--nb", type=int, default=0, help="panel width override (0 = library default)")
     ap.add_argument("--outer", type=int, default=0, help="outer strip height NB override (0 = library default)")
     ap.add_argument("--tail", type=int, default=-1, help="trailing size below which strips are nb wide (-1 = default)")
+    ap.add_argument("--bulk-wgs", type=int, default=-1, help="persistent bulk-update grid size (-1 = library default, 0 = off)")
     ap.add_argument("--reserve", type=int, default=-1, help="CUs reserved for the panel chain (-1 = library default)")
     ap.add_argument("--complete-inv", type=int, default=-1,
                     help="-1 blocked Cholesky (headline), 0/1 reference cholinv semantics (R and R^-1)")
@@ -116,6 +117,8 @@ def main():
             pack.set_option("tail", args.tail)
         if args.reserve >= 0:
             pack.set_option("reserve", args.reserve)
+        if args.bulk_wgs >= 0:
+            pack.set_option("bulk_wgs", args.bulk_wgs)
         run = lambda: cholinv.factor(A, pack, None)
         finish = lambda: pack.last_info()
         parallelism = "1 GPU"
@@ -168,7 +171,7 @@ def main():
             pack.set_option("profile", 0)
             if nl.value:
                 ach = fl.value / (ms.value * 1e-3) / 1e12
-                out["roofline"] = {"bound": "mfma", "kernel": "dgemm_kernel<TN,...,TAG=1> (trailing-update DSYRK, upper tiles)",
+                out["roofline"] = {"bound": "mfma", "kernel": "dgemm_tn_dma_kernel<1> (trailing-update DSYRK, upper tiles)",
                                    "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF,
                                    "launches": nl.value, "avg_launch_ms": ms.value / nl.value,
                                    "algorithmic_flops_per_launch_avg": fl.value / nl.value, "traffic": None}

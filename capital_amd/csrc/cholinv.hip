@@ -109,6 +109,7 @@ struct cap_cholinv_plan {
   int64_t nb, leaf; int lookahead;
   int64_t outer;   // outer strip height NB (multiple of nb): K of the big trailing SYRK
   int64_t tail;    // trailing sizes <= tail fall back to nb-wide strips
+  int64_t bulk_wgs; // > 0: bulk updates run as a persistent grid of this many workgroups (512 slots on the chip)
   // device state
   double* R; int64_t ldr;
   double* Rinv; int64_t ldi;      // n x n (complete_inv >= 0) or nb x nb diagonal-block inverse
@@ -148,6 +149,9 @@ int plan_alloc(cap_cholinv_plan* p) {
   const int64_t n = p->n;
   p->ldr = cap_round_up(n, 2);   // power-of-two column strides were measured harmless (HBM address hashing)
   CAP_HIP(hipMalloc((void**)&p->R, sizeof(double) * p->ldr * n));
+  // R's strictly-lower triangle is zeroed ONCE here: no kernel of either schedule ever writes below the
+  // diagonal (upper-tile masks everywhere), so factor() only has to copy A's upper triangle in
+  CAP_HIP(hipMemset(p->R, 0, sizeof(double) * p->ldr * n));
   if (p->complete_inv >= 0) {
     p->ldi = cap_round_up(n, 2);
     CAP_HIP(hipMalloc((void**)&p->Rinv, sizeof(double) * p->ldi * n));
@@ -217,7 +221,7 @@ int trailing_update(cap_cholinv_plan* p, int64_t m, int64_t k, const double* Rp,
     e0 = (*p->prof_ev)[p->prof_used]; e1 = (*p->prof_ev)[p->prof_used + 1];
     CAP_HIP(hipEventRecord(e0, s));
   }
-  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, m, m, k, -1.0, Rp, ldr, Rp, ldr, 1.0, R33, ldr, 1, s, 1));
+  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, m, m, k, -1.0, Rp, ldr, Rp, ldr, 1.0, R33, ldr, 1, s, 1, (int)p->bulk_wgs));
   if (e0) {
     CAP_HIP(hipEventRecord(e1, s));
     p->prof_used += 2;
@@ -372,6 +376,7 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
   if (k == "lookahead") { p->lookahead = value != 0; return CAP_OK; }
   if (k == "outer") { if (value < 64) return CAP_ERR_ARG; p->outer = value; return CAP_OK; }
   if (k == "tail") { if (value < 0) return CAP_ERR_ARG; p->tail = value; return CAP_OK; }
+  if (k == "bulk_wgs") { if (value < 0 || value > 2048) return CAP_ERR_ARG; p->bulk_wgs = value; return CAP_OK; }
   if (k == "reserve") {   // CUs kept free for the panel chain (multiple of 8 keeps the XCDs balanced); 0 = off
     if (value < 0 || value > 64) return CAP_ERR_ARG;
     if (p->bulk_ready) { (void)hipStreamSynchronize(p->s_bulk); (void)hipStreamDestroy(p->s_bulk); p->bulk_ready = false; }
@@ -393,6 +398,7 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
   if (k == "lookahead") return p->lookahead;
   if (k == "outer") return p->outer;
   if (k == "tail") return p->tail;
+  if (k == "bulk_wgs") return p->bulk_wgs;
   if (k == "reserve") return p->reserve;
   if (k == "n") return p->n;
   if (k == "complete_inv") return p->complete_inv;
@@ -407,7 +413,7 @@ int cap_cholinv_factor(cap_cholinv_plan* p, const double* A, int64_t lda, void* 
   const int64_t n = p->n;
   CAP_HIP(hipMemsetAsync(p->info_dev, 0, sizeof(int), s));
   // serialize<uppertri,uppertri>(A -> R), cholinv.hpp:13: only A's upper triangle is consumed
-  CAP_TRY(cap_copy_window(A, 0, lda, 0, 0, p->R, 0, p->ldr, 0, 0, n, n, 1, 1, stream));
+  CAP_TRY(cap_copy_window(A, 0, lda, 0, 0, p->R, 0, p->ldr, 0, 0, n, n, 1, 0, stream));
   if (p->complete_inv < 0) return right_looking(p, p->R, p->ldr, n, s);
   RecCtx c{p->R, p->ldr, p->Rinv, p->ldi, p->work, p->work_elems, p->info_dev, p->leaf, p->split, p->complete_inv, s};
   // upstream's leaf test at the root (cholinv.hpp:93 with c = d = 1): a root that is itself a base

@@ -34,7 +34,7 @@ static inline int64_t cap_round_up(int64_t a, int64_t b) { return cap_ceil_div(a
 // tri = 0 full, 1 = only tiles/elements with row <= col (upper), 2 = row >= col (lower).
 int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
                     int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri,
-                    hipStream_t stream, int tag = 0);
+                    hipStream_t stream, int tag = 0, int persist_wgs = 0);
 
 // leaf.hip: in-LDS cholinv (potrf + trtri) / trtri of one n <= 64 block
 constexpr int CAP_LEAF_MAX = 64;
@@ -50,4 +50,4 @@ double* cap_scratch(int64_t elems);  // gemm.hip: library-owned device scratch (
 // gemm.hip: distributed (1 x P block-column-cyclic) trailing update with staircase mask + gathered A operand
 int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, int64_t piece, const int* gstart,
                            const double* B, double* C, int64_t ldc, int P, int p, int nb, int J0, int lb0,
-                           hipStream_t stream);
+                           hipStream_t stream, int persist_wgs = 0);

@@ -48,6 +48,7 @@ struct GemmArgs {
   // nbT tiles), rows are global.  stair: upper mask follows the staircase  row_tile <= global tile of
   // my local column tile;  gather: operand A is the all-gathered block row, stored as P pieces in
   // (rank, local block) order - row tile ti lives in piece (J % P) at local block J / P - gstart[r].
+  int* ctr;         // persistent launches: 8 per-XCD slot counters (zeroed on the stream before the launch)
   int hiprio;       // panel-stream launches: raise the waves' issue priority (they share CUs with the bulk update)
   int stair, gather, sP, sp, snbT, sJ0, slb0;
   int64_t gpiece; int gstart[8];
@@ -283,15 +284,7 @@ __device__ __forceinline__ void dma_tile(const double* __restrict__ P, int64_t l
   }
 }
 
-template <int TAG>
-__global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int b = (int)((blockIdx.x + blockIdx.y) % gridDim.x);   // split-K: rotate tiles over the XCDs (see dgemm_kernel)
-  const int L = (b & 7) * g.chunk + (b >> 3);
-  int ti, tj;
-  if ((b >> 3) >= g.chunk || !slot_to_tile(g, L, ti, tj)) return;
-  if (g.hiprio) __builtin_amdgcn_s_setprio(3);
-
+__device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, const int tj, const int kz, double* smem) {
   const int64_t i0 = (int64_t)ti * BM, j0 = (int64_t)tj * BN;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wi = (wid & 1) * 64, wj = (wid >> 1) * 64;
@@ -307,7 +300,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArg
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
-  const int kz = blockIdx.y;
   const int64_t kbeg = (int64_t)kz * g.kchunk;
   const int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
   const int nk = (int)((kend - kbeg) / BK);
@@ -434,10 +426,55 @@ __global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArg
   else { if (diag_tile) epilogue(T{}, F{}, F{}); else epilogue(F{}, F{}, F{}); }
 }
 
+// One tile per workgroup (PERSIST = false), or a persistent workgroup that pulls tiles from its XCD's slot
+// range through an atomic counter and steals from the other XCDs when its own range is drained (PERSIST =
+// true).  The persistent form is launched with FEWER workgroups than the chip has slots (2 per CU): the
+// slots left free are what the latency-bound panel chain on the other stream runs in, instead of waiting
+// for (and time-slicing against) one of 512 resident bulk workgroups.
+template <int TAG, bool PERSIST>
+__global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (!PERSIST) {
+    const int b = (int)((blockIdx.x + blockIdx.y) % gridDim.x);   // split-K: rotate tiles over the XCDs (see dgemm_kernel)
+    const int L = (b & 7) * g.chunk + (b >> 3);
+    int ti, tj;
+    if ((b >> 3) >= g.chunk || !slot_to_tile(g, L, ti, tj)) return;
+    if (g.hiprio) __builtin_amdgcn_s_setprio(3);
+    tn_dma_tile(g, ti, tj, (int)blockIdx.y, smem);
+    return;
+  }
+  int* slot_word = reinterpret_cast<int*>(smem + 4 * DMA_TILE);
+  const int xcd = blockIdx.x & 7;          // block b is placed on XCD b % 8 (speed only; correctness does not depend on it)
+  for (int pass = 0; pass < 8; pass++) {
+    const int q = (xcd + pass) & 7;
+    for (;;) {
+      if (threadIdx.x == 0) *slot_word = atomicAdd(&g.ctr[q], 1);
+      __syncthreads();
+      const int r = *slot_word;
+      __syncthreads();                     // also fences the previous tile's LDS reads against the next tile's DMA
+      if (r >= g.chunk) break;
+      int ti, tj;
+      if (slot_to_tile(g, q * g.chunk + r, ti, tj)) tn_dma_tile(g, ti, tj, 0, smem);
+    }
+  }
+}
+
+// ring of per-launch counter sets for persistent launches
+int* g_ctr_ring = nullptr;
+int g_ctr_next = 0;
+constexpr int CTR_RING = 256;
+
 template <int TAG>
-int launch_tn_dma(const GemmArgs& g, int grid, hipStream_t stream) {
+int launch_tn_dma(GemmArgs g, int grid, hipStream_t stream, int persist_wgs = 0) {
   size_t lds = 4 * DMA_TILE * sizeof(double);
-  hipLaunchKernelGGL((dgemm_tn_dma_kernel<TAG>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+  if (persist_wgs > 0 && g.ksplit == 1 && grid > persist_wgs) {
+    if (!g_ctr_ring) CAP_HIP(hipMalloc((void**)&g_ctr_ring, sizeof(int) * 8 * CTR_RING));
+    g.ctr = g_ctr_ring + 8 * (g_ctr_next++ % CTR_RING);
+    CAP_HIP(hipMemsetAsync(g.ctr, 0, sizeof(int) * 8, stream));
+    hipLaunchKernelGGL((dgemm_tn_dma_kernel<TAG, true>), dim3((persist_wgs / 8) * 8), dim3(NTHREADS), lds + 16, stream, g);
+  } else {
+    hipLaunchKernelGGL((dgemm_tn_dma_kernel<TAG, false>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+  }
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
@@ -616,7 +653,7 @@ double* cap_scratch(int64_t elems) {
 
 int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
                     int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri,
-                    hipStream_t stream, int tag) {
+                    hipStream_t stream, int tag, int persist_wgs) {
   if (m < 0 || n < 0 || k < 0) return CAP_ERR_ARG;
   if (m == 0 || n == 0) return CAP_OK;
   if (ldc < m) return CAP_ERR_ARG;
@@ -640,7 +677,7 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.beta = beta; g.tri = tri;
-  g.hiprio = (tag & 2) ? 1 : 0; tag &= 1;
+  g.hiprio = (tag & 2) ? 1 : 0; tag &= 1; g.ctr = nullptr;
   g.stair = 0; g.gather = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0;
   for (int i = 0; i < 8; i++) g.gstart[i] = 0;
   g.tm = (int)cap_ceil_div(m, BM); g.tn = (int)cap_ceil_div(n, BN);
@@ -686,7 +723,7 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
 
   int st;
   static const bool use_v1 = getenv("CAP_GEMM_V1") != nullptr;   // A/B switch for profiling
-  if (a_kc && b_kc && !edge && !use_v1) st = (tag == 1) ? launch_tn_dma<1>(g, (int)grid, stream) : launch_tn_dma<0>(g, (int)grid, stream);
+  if (a_kc && b_kc && !edge && !use_v1) st = (tag == 1) ? launch_tn_dma<1>(g, (int)grid, stream, persist_wgs) : launch_tn_dma<0>(g, (int)grid, stream, 0);
   else if (a_kc && b_kc && tag == 1) st = launch_variant<true, true, 1>(g, edge, (int)grid, stream);
   else if (a_kc && b_kc) st = launch_variant<true, true>(g, edge, (int)grid, stream);
   else if (a_kc && !b_kc) st = launch_variant<true, false>(g, edge, (int)grid, stream);
@@ -706,7 +743,7 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
 // Requires m, nloc multiples of 128, nb multiple of 128, k multiple of 16.
 int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, int64_t piece, const int* gstart,
                            const double* B, double* C, int64_t ldc, int P, int p, int nb, int J0, int lb0,
-                           hipStream_t stream) {
+                           hipStream_t stream, int persist_wgs) {
   if (m <= 0 || nloc <= 0) return CAP_OK;
   if ((m % BM) || (nloc % BN) || (k % BK) || (nb % 128) || P < 1 || P > 8) return CAP_ERR_UNSUPPORTED;
   GemmArgs g;
@@ -715,12 +752,12 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   g.tm = (int)(m / BM); g.tn = (int)(nloc / BN);
   g.nsm = (int)cap_ceil_div(g.tm, ST); g.nsn = (int)cap_ceil_div(g.tn, ST);
   g.ksplit = 1; g.kchunk = k; g.P = nullptr; g.slab = 0;
-  g.hiprio = 0;
+  g.hiprio = 0; g.ctr = nullptr;
   g.stair = 1; g.gather = 1; g.sP = P; g.sp = p; g.snbT = nb / 128; g.sJ0 = J0; g.slb0 = lb0; g.gpiece = piece;
   for (int i = 0; i < 8; i++) g.gstart[i] = i < P ? gstart[i] : 0;
   int64_t slots = (int64_t)g.nsm * g.nsn * ST * ST;
   g.chunk = (int)cap_ceil_div(slots, 8);
-  return launch_tn_dma<1>(g, g.chunk * 8, stream);
+  return launch_tn_dma<1>(g, g.chunk * 8, stream, persist_wgs);
 }
 
 extern "C" int cap_dgemm(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
