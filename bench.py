@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--nb", type=int, default=0, help="panel width override (0 = library default)")
     ap.add_argument("--outer", type=int, default=0, help="outer strip height NB override (0 = library default)")
     ap.add_argument("--tail", type=int, default=-1, help="trailing size below which strips are nb wide (-1 = default)")
+    ap.add_argument("--depth2", type=int, default=-1, help="look-ahead depth 2 (split bulk updates): 1/0, -1 = library default")
     ap.add_argument("--bulk-wgs", type=int, default=-1, help="persistent bulk-update grid size (-1 = library default, 0 = off)")
     ap.add_argument("--reserve", type=int, default=-1, help="CUs reserved for the panel chain (-1 = library default)")
     ap.add_argument("--complete-inv", type=int, default=-1,
@@ -117,6 +118,8 @@ def main():
             pack.set_option("tail", args.tail)
         if args.reserve >= 0:
             pack.set_option("reserve", args.reserve)
+        if args.depth2 >= 0:
+            pack.set_option("depth2", args.depth2)
         if args.bulk_wgs >= 0:
             pack.set_option("bulk_wgs", args.bulk_wgs)
         run = lambda: cholinv.factor(A, pack, None)

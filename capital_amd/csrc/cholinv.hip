@@ -109,6 +109,7 @@ struct cap_cholinv_plan {
   int64_t nb, leaf; int lookahead;
   int64_t outer;   // outer strip height NB (multiple of nb): K of the big trailing SYRK
   int64_t tail;    // trailing sizes <= tail fall back to nb-wide strips
+  int depth2;       // split each bulk update into head (next-next strip's rows) + rest: look-ahead depth 2
   int64_t bulk_wgs; // > 0: bulk updates run as a persistent grid of this many workgroups (512 slots on the chip)
   // device state
   double* R; int64_t ldr;
@@ -211,8 +212,11 @@ int panel_factor(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t
   return CAP_OK;
 }
 
-// trailing update R33 -= Rp^T Rp on upper tiles (the dominant kernel), optionally bracketed by events
-int trailing_update(cap_cholinv_plan* p, int64_t m, int64_t k, const double* Rp, double* R33, int64_t ldr, hipStream_t s) {
+// trailing update C[M x N] -= A^T B on upper tiles (the dominant kernel), optionally bracketed by events.
+// M == N, A == B: the SYRK on the bulk of the trailing matrix; M < N: the strip of rows updated first so
+// that the panel chain of the step after next can start early (look-ahead depth 2).
+int trailing_update(cap_cholinv_plan* p, int64_t M, int64_t N, int64_t k, const double* A, const double* B, double* C,
+                    int64_t ldr, hipStream_t s) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (p->profile && p->prof_ev) {
     if ((size_t)p->prof_used + 2 > p->prof_ev->size()) {
@@ -221,11 +225,12 @@ int trailing_update(cap_cholinv_plan* p, int64_t m, int64_t k, const double* Rp,
     e0 = (*p->prof_ev)[p->prof_used]; e1 = (*p->prof_ev)[p->prof_used + 1];
     CAP_HIP(hipEventRecord(e0, s));
   }
-  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, m, m, k, -1.0, Rp, ldr, Rp, ldr, 1.0, R33, ldr, 1, s, 1, (int)p->bulk_wgs));
+  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, M, N, k, -1.0, A, ldr, B, ldr, 1.0, C, ldr, 1, s, 1, (int)p->bulk_wgs));
   if (e0) {
     CAP_HIP(hipEventRecord(e1, s));
     p->prof_used += 2;
-    p->prof_flops->push_back((double)m * (double)(m + 1) * (double)k);
+    // algorithmic flops: 2k per element of the upper staircase  sum_{i<M} (N - i)
+    p->prof_flops->push_back(2.0 * (double)k * ((double)M * (double)N - 0.5 * (double)M * (double)(M - 1)));
   }
   return CAP_OK;
 }
@@ -273,7 +278,7 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
       CAP_TRY(factor_strip(p, R, ldr, n, J0, rows, s0));
       if (m > 0) {
         double* S = R + J0 + bnd[k + 1] * ldr;
-        CAP_TRY(trailing_update(p, m, rows, S, R + bnd[k + 1] + bnd[k + 1] * ldr, ldr, s0));
+        CAP_TRY(trailing_update(p, m, m, rows, S, S, R + bnd[k + 1] + bnd[k + 1] * ldr, ldr, s0));
       }
     }
     return CAP_OK;
@@ -294,7 +299,8 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
     const int64_t J1 = bnd[k + 1], rows1 = bnd[k + 2] - J1, m2 = m - rows1;
     double* S = R + J0 + J1 * ldr;                 // strip k right of its diagonal block: rows x m
     // (a) panel stream: bring strip k+1 up to date (K = rows, upper part), then factor it.
-    //     needs strip k (same stream) and the bulk update of step k-1 (main stream)
+    //     needs strip k (same stream) and the HEAD of the bulk update of step k-1 (main stream): the head is the
+    //     part of that update that touches strip k+1's rows, so the chain runs one more step ahead of the bulk
     if (k > 0) CAP_HIP(hipStreamWaitEvent(s1, p->ev_update[(k - 1) & 1], 0));
     CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows1, m, rows, -1.0, S, ldr, S, ldr, 1.0, R + J1 + J1 * ldr, ldr, 1, s1));
     CAP_TRY(factor_strip(p, R, ldr, n, J1, rows1, s1));
@@ -303,9 +309,22 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
     CAP_HIP(hipStreamWaitEvent(s0, p->ev_panel[k & 1], 0));
     if (m2 > 0) {
       double* S2 = S + rows1 * ldr;
-      CAP_TRY(trailing_update(p, m2, rows, S2, R + (J1 + rows1) + (J1 + rows1) * ldr, ldr, s0));
+      const int64_t J2 = J1 + rows1;
+      const int64_t rows2 = (k + 3 <= nstrip) ? bnd[k + 3] - bnd[k + 2] : m2;   // height of strip k+2
+      if (p->depth2 && rows2 < m2) {
+        // head: strip k+2's rows first, then signal the panel stream; rest: everything below
+        CAP_TRY(trailing_update(p, rows2, m2, rows, S2, S2, R + J2 + J2 * ldr, ldr, s0));
+        CAP_HIP(hipEventRecord(p->ev_update[k & 1], s0));
+        const int64_t m3 = m2 - rows2;
+        double* S3 = S2 + rows2 * ldr;
+        CAP_TRY(trailing_update(p, m3, m3, rows, S3, S3, R + (J2 + rows2) + (J2 + rows2) * ldr, ldr, s0));
+      } else {
+        CAP_TRY(trailing_update(p, m2, m2, rows, S2, S2, R + J2 + J2 * ldr, ldr, s0));
+        CAP_HIP(hipEventRecord(p->ev_update[k & 1], s0));
+      }
+    } else {
+      CAP_HIP(hipEventRecord(p->ev_update[k & 1], s0));
     }
-    CAP_HIP(hipEventRecord(p->ev_update[k & 1], s0));
   }
   // join
   CAP_HIP(hipEventRecord(p->ev_join, s1));
@@ -332,6 +351,7 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   // two-level blocking defaults (tools/sweep.sh on MI355X): K = 2 nb bulk updates while the trailing matrix is
   // large, nb-wide strips for the last n/8 columns where the strip chain could no longer hide
   p->outer = n >= 8192 ? 2 * p->nb : p->nb; p->tail = n >= 8192 ? n / 8 : 0; p->reserve = 0;
+  p->depth2 = n >= 24576;     // look-ahead depth 2 pays once a bulk update is long enough to split (+2 % at N = 32768)
   int st = plan_alloc(p);
   if (st != CAP_OK) { cap_cholinv_plan_destroy(p); return st; }
   *plan = p;
@@ -377,6 +397,7 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
   if (k == "outer") { if (value < 64) return CAP_ERR_ARG; p->outer = value; return CAP_OK; }
   if (k == "tail") { if (value < 0) return CAP_ERR_ARG; p->tail = value; return CAP_OK; }
   if (k == "bulk_wgs") { if (value < 0 || value > 2048) return CAP_ERR_ARG; p->bulk_wgs = value; return CAP_OK; }
+  if (k == "depth2") { p->depth2 = value != 0; return CAP_OK; }
   if (k == "reserve") {   // CUs kept free for the panel chain (multiple of 8 keeps the XCDs balanced); 0 = off
     if (value < 0 || value > 64) return CAP_ERR_ARG;
     if (p->bulk_ready) { (void)hipStreamSynchronize(p->s_bulk); (void)hipStreamDestroy(p->s_bulk); p->bulk_ready = false; }
@@ -399,6 +420,7 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
   if (k == "outer") return p->outer;
   if (k == "tail") return p->tail;
   if (k == "bulk_wgs") return p->bulk_wgs;
+  if (k == "depth2") return p->depth2;
   if (k == "reserve") return p->reserve;
   if (k == "n") return p->n;
   if (k == "complete_inv") return p->complete_inv;

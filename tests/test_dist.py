@@ -47,7 +47,8 @@ def test_index_helpers_match_library_when_built():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproc,n,nb", [(1, 1024, 128), (2, 1024, 128), (4, 2048, 128), (3, 1536, 256), (2, 2048, 512)])
+@pytest.mark.parametrize("nproc,n,nb", [(1, 1024, 128), (2, 1024, 128), (4, 2048, 128), (3, 1536, 256), (2, 2048, 512),
+                                        (8, 8192, 512)])   # the driver's 8-GPU shape: P = 8, nb = 512 (2 block columns per rank)
 def test_multirank_schedule_on_one_gpu(nproc, n, nb):
     r = _launch(nproc, "gpu", n, nb, 29621 + nproc)
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
