@@ -80,7 +80,44 @@ int rec_cholinv(const RecCtx& c, int64_t off, int64_t n, bool is_root, int64_t i
   return CAP_OK;
 }
 
-int64_t rec_work_size(int64_t n) { return cap_round_up((n / 2 + 1) * (n / 2 + 1), 2); }
+int64_t rec_work_size(int64_t n) { return cap_round_up(std::max<int64_t>((n / 2 + 1) * (n / 2 + 1), 64 * n), 2); }
+
+// Diagonal-block fast path (n = 64 * nblk <= 1024): 64-blocked right-looking potrf with ONE fused launch per step
+// (cap_panel64_solve_update) + the inverse assembled level by level with batched products - 3 nblk - 1 + 2 log2(nblk)
+// dependent launches instead of the recursion's ~5.4 nblk (21 instead of 43 at n = 512).  Same arithmetic,
+// different association order.  Ri's strictly-lower blocks must be zero on entry (they are never written).
+int blocked_cholinv(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, double* W, int64_t wcap, int* info,
+                    int64_t info_base, hipStream_t s) {
+  const int nblk = (int)(n / 64);
+  if (64 * n > wcap) return CAP_ERR_ALLOC;
+  double* Xs = W;      // block row solved by the fused step, moved into R by the NEXT leaf launch (W is free until the inverse phase)
+  for (int i = 0; i < nblk; i++) {
+    double* Rii = R + (int64_t)i * 64 * (ldr + 1);
+    double* Dii = Ri + (int64_t)i * 64 * (ldi + 1);
+    if (i == 0) CAP_TRY(cap_leaf_cholinv(Rii, ldr, Dii, ldi, 64, 1, info, (int)(info_base + i * 64), s));
+    else CAP_TRY(cap_leaf_cholinv(Rii, ldr, Dii, ldi, 64, 1, info, (int)(info_base + i * 64), s, Xs,
+                                  R + (int64_t)(i - 1) * 64 + (int64_t)i * 64 * ldr, ldr, (nblk - i) * 64));
+    CAP_TRY(cap_panel64_solve_update(R, ldr, Dii, ldi, i, nblk, Xs, s));
+  }
+  for (int64_t h = 64; h < n; h *= 2) {
+    const int npairs = (int)(n / (2 * h));
+    if (h * h * npairs > wcap) return CAP_ERR_ALLOC;
+    if (h <= 256) {
+      // W_z = R12_z * Ri22_z ;  Ri12_z = -Ri11_z * W_z   for every aligned pair z at once
+      CAP_TRY(cap_gemm_small_batched(CAP_NOTRANS, CAP_NOTRANS, h, h, h, 1.0, R + h * ldr, ldr, 2 * h * (ldr + 1),
+                                     Ri + h + h * ldi, ldi, 2 * h * (ldi + 1), 0.0, W, h, h * h, npairs, s));
+      CAP_TRY(cap_gemm_small_batched(CAP_NOTRANS, CAP_NOTRANS, h, h, h, -1.0, Ri, ldi, 2 * h * (ldi + 1), W, h, h * h, 0.0,
+                                     Ri + h * ldi, ldi, 2 * h * (ldi + 1), npairs, s));
+    } else {
+      for (int z = 0; z < npairs; z++) {
+        double* Rz = R + (int64_t)z * 2 * h * (ldr + 1); double* Iz = Ri + (int64_t)z * 2 * h * (ldi + 1);
+        CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, h, h, h, 1.0, Rz + h * ldr, ldr, Iz + h + h * ldi, ldi, 0.0, W, h, 0, s, 2));
+        CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, h, h, h, -1.0, Iz, ldi, W, h, 0.0, Iz + h * ldi, ldi, 0, s, 2));
+      }
+    }
+  }
+  return CAP_OK;
+}
 
 // ---- in-place triangular inverse (upper): R <- R^-1, recursion + leaf kernel -----------------
 int rec_trtri(double* R, int64_t ldr, int64_t n, double* W, int64_t wcap, int64_t leaf, hipStream_t s) {
@@ -109,6 +146,7 @@ struct cap_cholinv_plan {
   int64_t nb, leaf; int lookahead;
   int64_t outer;   // outer strip height NB (multiple of nb): K of the big trailing SYRK
   int64_t tail;    // trailing sizes <= tail fall back to nb-wide strips
+  int fastdiag;     // diagonal blocks by the 64-blocked fused path (default) instead of the recursion
   int depth2;       // split each bulk update into head (next-next strip's rows) + rest: look-ahead depth 2
   int64_t bulk_wgs; // > 0: bulk updates run as a persistent grid of this many workgroups (512 slots on the chip)
   // device state
@@ -201,8 +239,12 @@ int panel_factor(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t
   double* Dinv = p->Rinv;                       // jb x jb, ld = nb, strictly-lower part stays zero
   double* Wrec = p->work;                       // rec scratch
   double* Wpan = p->work + rec_work_size(p->nb);  // jb x m panel scratch
-  RecCtx c{R + j0 + j0 * ldr, ldr, Dinv, p->ldi, Wrec, rec_work_size(p->nb), p->info_dev, p->leaf, 1, 1, s};
-  CAP_TRY(rec_cholinv(c, 0, jb, false, j0));
+  if (p->fastdiag && jb % 64 == 0 && jb >= 128 && jb <= 1024 && (jb & (jb - 1)) == 0 && p->leaf == CAP_LEAF_MAX) {
+    CAP_TRY(blocked_cholinv(R + j0 + j0 * ldr, ldr, Dinv, p->ldi, jb, Wrec, rec_work_size(p->nb), p->info_dev, j0, s));
+  } else {
+    RecCtx c{R + j0 + j0 * ldr, ldr, Dinv, p->ldi, Wrec, rec_work_size(p->nb), p->info_dev, p->leaf, 1, 1, s};
+    CAP_TRY(rec_cholinv(c, 0, jb, false, j0));
+  }
   const int64_t m = n - j0 - jb;
   if (m > 0) {
     double* Rpan = R + j0 + (j0 + jb) * ldr;
@@ -351,6 +393,10 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   // two-level blocking defaults (tools/sweep.sh on MI355X): K = 2 nb bulk updates while the trailing matrix is
   // large, nb-wide strips for the last n/8 columns where the strip chain could no longer hide
   p->outer = n >= 8192 ? 2 * p->nb : p->nb; p->tail = n >= 8192 ? n / 8 : 0; p->reserve = 0;
+  // fused 64-blocked diagonal-block path: 25 % faster alone (N = 8192: 20.8 -> 15.5 ms) but its 135 KiB-LDS
+  // workgroups need a CU with BOTH bulk workgroups retired, so under a concurrent bulk update it loses
+  // (N = 65536: 65.3 -> 62.8 TF).  Off by default; see DESIGN.md section 6.
+  p->fastdiag = 0;
   p->depth2 = n >= 24576;     // look-ahead depth 2 pays once a bulk update is long enough to split (+2 % at N = 32768)
   int st = plan_alloc(p);
   if (st != CAP_OK) { cap_cholinv_plan_destroy(p); return st; }
@@ -398,6 +444,7 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
   if (k == "tail") { if (value < 0) return CAP_ERR_ARG; p->tail = value; return CAP_OK; }
   if (k == "bulk_wgs") { if (value < 0 || value > 2048) return CAP_ERR_ARG; p->bulk_wgs = value; return CAP_OK; }
   if (k == "depth2") { p->depth2 = value != 0; return CAP_OK; }
+  if (k == "fastdiag") { p->fastdiag = value != 0; return CAP_OK; }
   if (k == "reserve") {   // CUs kept free for the panel chain (multiple of 8 keeps the XCDs balanced); 0 = off
     if (value < 0 || value > 64) return CAP_ERR_ARG;
     if (p->bulk_ready) { (void)hipStreamSynchronize(p->s_bulk); (void)hipStreamDestroy(p->s_bulk); p->bulk_ready = false; }
@@ -421,6 +468,7 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
   if (k == "tail") return p->tail;
   if (k == "bulk_wgs") return p->bulk_wgs;
   if (k == "depth2") return p->depth2;
+  if (k == "fastdiag") return p->fastdiag;
   if (k == "reserve") return p->reserve;
   if (k == "n") return p->n;
   if (k == "complete_inv") return p->complete_inv;
@@ -509,7 +557,7 @@ int cap_dpotrf(int uplo, int64_t n, double* A, int64_t lda, int* info, double* w
   memset(&p, 0, sizeof(p));
   p.n = n; p.complete_inv = -1; p.leaf = CAP_LEAF_MAX; p.lookahead = 0;
   p.nb = std::min<int64_t>(default_nb(n, -100), cap_round_up(n, 64));
-  p.outer = p.nb; p.tail = 0;
+  p.outer = p.nb; p.tail = 0; p.fastdiag = 1;   // cap_dpotrf runs alone on its stream: the fused path wins
   p.ldi = p.nb;
   p.Rinv = work;                                // nb x nb
   p.work = work + p.nb * p.nb;                  // rec scratch + panel scratch
@@ -582,6 +630,8 @@ int cap_dtrsm(int side, int uplo, int trans, int64_t m, int64_t n, double alpha,
 // used by cacqr.hip: full cholinv (R in place, Ri = R^-1) of an n x n block on one stream
 int cap_rec_cholinv_full(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, double* W, int64_t wcap, int* info,
                          hipStream_t s, int64_t info_base) {
+  static const bool fast = getenv("CAP_FASTDIAG") != nullptr;   // see cap_cholinv_plan::fastdiag
+  if (fast && n % 64 == 0 && n >= 128 && n <= 1024 && (n & (n - 1)) == 0) return blocked_cholinv(R, ldr, Ri, ldi, n, W, wcap, info, info_base, s);
   RecCtx c{R, ldr, Ri, ldi, W, wcap, info, CAP_LEAF_MAX, 1, 1, s};
   return rec_cholinv(c, 0, n, false, info_base);
 }

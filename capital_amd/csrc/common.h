@@ -39,7 +39,8 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
 // leaf.hip: in-LDS cholinv (potrf + trtri) / trtri of one n <= 64 block
 constexpr int CAP_LEAF_MAX = 64;
 int cap_leaf_cholinv(double* A, int64_t lda, double* Rinv, int64_t ldr, int n, int zero_lower, int* info,
-                     int info_base, hipStream_t stream);
+                     int info_base, hipStream_t stream, const double* cjob_src = nullptr, double* cjob_dst = nullptr,
+                     int64_t cjob_ld = 0, int cjob_cols = 0);
 int cap_leaf_trtri(const double* R, int64_t ldr, double* Rinv, int64_t ldi, int n, hipStream_t stream);
 
 // aux.hip
@@ -51,3 +52,11 @@ double* cap_scratch(int64_t elems);  // gemm.hip: library-owned device scratch (
 int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, int64_t piece, const int* gstart,
                            const double* B, double* C, int64_t ldc, int P, int p, int nb, int J0, int lb0,
                            hipStream_t stream, int persist_wgs = 0);
+
+// leaf.hip: fused block-row solve + rank-64 trailing update of the 64-blocked diagonal-block factorization
+int cap_panel64_solve_update(double* R, int64_t ldr, const double* Dinv, int64_t ldi, int i, int nblk, double* Xs,
+                             hipStream_t stream);
+// gemm.hip: batched 64x64-tile products (batch = blockIdx.z, affine strides)
+int cap_gemm_small_batched(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
+                           int64_t sa, const double* B, int64_t ldb, int64_t sb, double beta, double* C, int64_t ldc, int64_t sc,
+                           int nbatch, hipStream_t stream);

@@ -508,11 +508,13 @@ struct SmallArgs {
   int M, N, K;
   double alpha, beta;
   int tri, hiprio;
+  int64_t sa, sb, sc;   // batch strides (blockIdx.z)
 };
 
 template <bool TA, bool TB>
-__global__ void __launch_bounds__(256) dgemm_small_kernel(const SmallArgs g) {
+__global__ void __launch_bounds__(256) dgemm_small_kernel(SmallArgs g) {
   extern __shared__ __attribute__((aligned(16))) double sm_lds[];
+  g.A += (int64_t)blockIdx.z * g.sa; g.B += (int64_t)blockIdx.z * g.sb; g.C += (int64_t)blockIdx.z * g.sc;
   double* As = sm_lds;
   double* Bs = sm_lds + SM_K * SM_LD;
   const int ti = blockIdx.x, tj = blockIdx.y;
@@ -599,9 +601,10 @@ __global__ void __launch_bounds__(256) dgemm_small_kernel(const SmallArgs g) {
 }
 
 int launch_small(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
-                 const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, int hiprio, hipStream_t stream) {
-  SmallArgs g{A, B, C, lda, ldb, ldc, (int)m, (int)n, (int)k, alpha, beta, tri, hiprio};
-  dim3 grid((unsigned)cap_ceil_div(m, SM_T), (unsigned)cap_ceil_div(n, SM_T));
+                 const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, int hiprio, hipStream_t stream,
+                 int nbatch = 1, int64_t sa = 0, int64_t sb = 0, int64_t sc = 0) {
+  SmallArgs g{A, B, C, lda, ldb, ldc, (int)m, (int)n, (int)k, alpha, beta, tri, hiprio, sa, sb, sc};
+  dim3 grid((unsigned)cap_ceil_div(m, SM_T), (unsigned)cap_ceil_div(n, SM_T), (unsigned)nbatch);
   const bool ta = transa == CAP_TRANS, tb = transb == CAP_TRANS;
   const size_t lds = 2 * SM_K * SM_LD * sizeof(double);
   if (ta && !tb) hipLaunchKernelGGL((dgemm_small_kernel<true, false>), grid, dim3(256), lds, stream, g);
@@ -758,6 +761,15 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   int64_t slots = (int64_t)g.nsm * g.nsn * ST * ST;
   g.chunk = (int)cap_ceil_div(slots, 8);
   return launch_tn_dma<1>(g, g.chunk * 8, stream, persist_wgs);
+}
+
+// batched small products (blockIdx.z = batch, affine pointer strides) - the level-by-level inverse assembly
+int cap_gemm_small_batched(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
+                           int64_t sa, const double* B, int64_t ldb, int64_t sb, double beta, double* C, int64_t ldc, int64_t sc,
+                           int nbatch, hipStream_t stream) {
+  if (m <= 0 || n <= 0 || nbatch <= 0) return CAP_OK;
+  if (nbatch > 65535) return CAP_ERR_UNSUPPORTED;
+  return launch_small(transa, transb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0, 1, stream, nbatch, sa, sb, sc);
 }
 
 extern "C" int cap_dgemm(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,

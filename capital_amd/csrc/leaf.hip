@@ -165,9 +165,14 @@ __device__ void trtri_lds(double* S, double* T, const double* dinv, int np) {
 // untouched).  Rinv (may be NULL): n x n, ldr; upper triangle written, strictly lower part
 // zero-filled when zero_lower != 0.  info: device int, set to info_base + (1-based pivot
 // index) on the first non-positive pivot if currently 0.
+// Optional side job (cjob_cols > 0): copy the 64 x cjob_cols block row solved by the previous fused step from its
+// scratch (ld 64) to its final place in R - issued first so the traffic overlaps the factorization below.
 __global__ void __launch_bounds__(LTHREADS) leaf_cholinv_kernel(double* A, int64_t lda, double* Rinv, int64_t ldr,
-                                                                int n, int zero_lower, int* info, int info_base) {
+                                                                int n, int zero_lower, int* info, int info_base,
+                                                                const double* cjob_src, double* cjob_dst, int64_t cjob_ld,
+                                                                int cjob_cols) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  for (int e = threadIdx.x; e < 64 * cjob_cols; e += LTHREADS) cjob_dst[(e & 63) + (int64_t)(e >> 6) * cjob_ld] = cjob_src[e];
   double* S = lds;
   double* T = lds + LMAX * LLD;
   int& bad = *reinterpret_cast<int*>(lds + 2 * LMAX * LLD);   // keep ALL LDS in the dynamic region (16-B aligned base)
@@ -238,16 +243,104 @@ __global__ void __launch_bounds__(LTHREADS) leaf_trtri_kernel(const double* R, i
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused step of the 64-blocked right-looking factorization of one nb x nb diagonal block (nb = 64 * nblk):
+// after leaf i produced R_ii and Dinv_i = R_ii^-1, ONE launch solves the block row i and applies its rank-64
+// update to every trailing 64 x 64 block (a, b), i < a <= b:
+//     X_a = Dinv_i^T A_ia,  X_b = Dinv_i^T A_ib   (recomputed by every workgroup that needs them - 2 x 64^3
+//     flops of redundancy buy the removal of a grid-wide dependency, i.e. of one kernel launch per step)
+//     A_ab -= X_a^T X_b                          (upper part only on diagonal blocks)
+// and the workgroup of the diagonal block (a, a) also stores X_a as the final R_ia.
+// Replaces 3-4 dependent launches of the recursive formulation per step (cholinv.hpp:113-137 at tile scale).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(LTHREADS) panel64_solve_update_kernel(double* R, int64_t ldr, const double* Dinv, int64_t ldi,
+                                                                       int i, int nblk, double* Xs) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* Dm = lds;                       // Dinv_i
+  double* B0 = lds + 1 * LMAX * LLD;      // A_ia  -> later X_b
+  double* B1 = lds + 2 * LMAX * LLD;      // A_ib  -> later the update tile
+  double* Xa = lds + 3 * LMAX * LLD;      // X_a
+  __builtin_amdgcn_s_setprio(3);
+  const int t = threadIdx.x;
+  // triangular decode of blockIdx.x -> (a, b), i < a <= b < nblk, column-major over the r x r upper triangle
+  const int r = nblk - 1 - i;
+  int q = blockIdx.x, bj = 0;
+  while (q >= bj + 1) { q -= bj + 1; bj++; }
+  const int a = i + 1 + q, b = i + 1 + bj;
+  (void)r;
+  const double* Aia = R + (int64_t)i * 64 + (int64_t)a * 64 * ldr;
+  const double* Aib = R + (int64_t)i * 64 + (int64_t)b * 64 * ldr;
+  for (int e0 = 0; e0 < 64 * 64; e0 += 4 * LTHREADS) {
+    double v0[4], v1[4], v2[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
+      v0[u] = Dinv[ii + (int64_t)jj * ldi];
+      v1[u] = Aia[ii + (int64_t)jj * ldr];
+      v2[u] = Aib[ii + (int64_t)jj * ldr];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
+      SM(Dm, ii, jj) = (ii <= jj) ? v0[u] : 0.0;     // the inverse is upper triangular; do not trust what lies below
+      SM(B0, ii, jj) = v1[u];
+      SM(B1, ii, jj) = v2[u];
+    }
+  }
+  __syncthreads();
+  lds_mm<true, false, false>(Xa, Dm, B0, 64, 64, 64, 1.0);        // X_a = Dinv^T A_ia
+  __syncthreads();
+  if (a == b) {
+    // the solved block R_ia goes to scratch (other workgroups of this launch still read the unsolved A_ia from R);
+    // the next leaf launch moves the whole block row into place
+    double* dst = Xs + (int64_t)(a - i - 1) * 64 * 64;
+    for (int e = t; e < 64 * 64; e += LTHREADS) dst[e] = SM(Xa, e & 63, e >> 6);
+  }
+  const double* Xb = Xa;
+  if (a != b) {
+    lds_mm<true, false, false>(B0, Dm, B1, 64, 64, 64, 1.0);      // X_b = Dinv^T A_ib  (A_ia is dead)
+    __syncthreads();
+    Xb = B0;
+  }
+  lds_mm<true, false, false>(B1, Xa, Xb, 64, 64, 64, 1.0);        // X_a^T X_b          (A_ib is dead)
+  __syncthreads();
+  double* C = R + (int64_t)a * 64 + (int64_t)b * 64 * ldr;
+  for (int e0 = 0; e0 < 64 * 64; e0 += 4 * LTHREADS) {
+    double c[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
+      c[u] = (a != b || ii <= jj) ? C[ii + (int64_t)jj * ldr] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
+      if (a != b || ii <= jj) C[ii + (int64_t)jj * ldr] = c[u] - SM(B1, ii, jj);
+    }
+  }
+}
+
 }  // namespace
+
+int cap_panel64_solve_update(double* R, int64_t ldr, const double* Dinv, int64_t ldi, int i, int nblk, double* Xs,
+                             hipStream_t stream) {
+  const int r = nblk - 1 - i;
+  if (r <= 0) return CAP_OK;
+  const size_t lds_bytes = 4 * LMAX * LLD * sizeof(double);
+  hipLaunchKernelGGL(panel64_solve_update_kernel, dim3(r * (r + 1) / 2), dim3(LTHREADS), lds_bytes, stream, R, ldr, Dinv, ldi, i, nblk, Xs);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
 
 constexpr size_t LEAF_LDS_BYTES = (2 * LMAX * LLD + 2 + LMAX + 32) * sizeof(double);
 
 int cap_leaf_cholinv(double* A, int64_t lda, double* Rinv, int64_t ldr, int n, int zero_lower, int* info,
-                     int info_base, hipStream_t stream) {
+                     int info_base, hipStream_t stream, const double* cjob_src, double* cjob_dst, int64_t cjob_ld,
+                     int cjob_cols) {
   if (n <= 0) return CAP_OK;
   if (n > LMAX) return CAP_ERR_ARG;
   hipLaunchKernelGGL(leaf_cholinv_kernel, dim3(1), dim3(LTHREADS), LEAF_LDS_BYTES, stream, A, lda, Rinv, ldr, n,
-                     zero_lower, info, info_base);
+                     zero_lower, info, info_base, cjob_src, cjob_dst, cjob_ld, cjob_cols);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
