@@ -109,7 +109,7 @@ def main():
         from capital_amd.matrix import matrix
         A = matrix(n, n, 1, 1)
         A.distribute_symmetric(0, 0, 1, 1, 0, True)
-        pack = cholinv.info(args.complete_inv, 1, -7, 'U')      # bcMult -7: N/128 = 512-wide panels at N = 65536
+        pack = cholinv.info(args.complete_inv, 1, -5, 'U')      # bcMult -5: base-case hint N/32 >= 512 -> the library's 512-wide panels
         if args.nb:
             pack.set_option("nb", args.nb)
         if args.outer:

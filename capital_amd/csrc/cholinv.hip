@@ -393,10 +393,10 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   // two-level blocking defaults (tools/sweep.sh on MI355X): K = 2 nb bulk updates while the trailing matrix is
   // large, nb-wide strips for the last n/8 columns where the strip chain could no longer hide
   p->outer = n >= 8192 ? 2 * p->nb : p->nb; p->tail = n >= 8192 ? n / 8 : 0; p->reserve = 0;
-  // fused 64-blocked diagonal-block path: 25 % faster alone (N = 8192: 20.8 -> 15.5 ms) but its 135 KiB-LDS
-  // workgroups need a CU with BOTH bulk workgroups retired, so under a concurrent bulk update it loses
-  // (N = 65536: 65.3 -> 62.8 TF).  Off by default; see DESIGN.md section 6.
-  p->fastdiag = 0;
+  // fused 64-blocked diagonal-block path (28 dependent launches per 512 panel instead of 43; N = 8192 alone:
+  // 20.8 -> 15.5 ms).  Its workgroups use 84 KiB of LDS so that they fit into ONE slot vacated by a bulk
+  // workgroup - a first 135 KiB version needed a fully idle CU and lost 4 % under a concurrent bulk update.
+  p->fastdiag = getenv("CAP_FASTDIAG") ? atoi(getenv("CAP_FASTDIAG")) : 1;
   p->depth2 = n >= 24576;     // look-ahead depth 2 pays once a bulk update is long enough to split (+2 % at N = 32768)
   int st = plan_alloc(p);
   if (st != CAP_OK) { cap_cholinv_plan_destroy(p); return st; }
@@ -630,7 +630,7 @@ int cap_dtrsm(int side, int uplo, int trans, int64_t m, int64_t n, double alpha,
 // used by cacqr.hip: full cholinv (R in place, Ri = R^-1) of an n x n block on one stream
 int cap_rec_cholinv_full(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, double* W, int64_t wcap, int* info,
                          hipStream_t s, int64_t info_base) {
-  static const bool fast = getenv("CAP_FASTDIAG") != nullptr;   // see cap_cholinv_plan::fastdiag
+  static const bool fast = getenv("CAP_FASTDIAG") ? atoi(getenv("CAP_FASTDIAG")) != 0 : true;   // see cap_cholinv_plan::fastdiag
   if (fast && n % 64 == 0 && n >= 128 && n <= 1024 && (n & (n - 1)) == 0) return blocked_cholinv(R, ldr, Ri, ldi, n, W, wcap, info, info_base, s);
   RecCtx c{R, ldr, Ri, ldi, W, wcap, info, CAP_LEAF_MAX, 1, 1, s};
   return rec_cholinv(c, 0, n, false, info_base);

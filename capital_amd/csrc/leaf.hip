@@ -253,21 +253,22 @@ __global__ void __launch_bounds__(LTHREADS) leaf_trtri_kernel(const double* R, i
 // and the workgroup of the diagonal block (a, a) also stores X_a as the final R_ia.
 // Replaces 3-4 dependent launches of the recursive formulation per step (cholinv.hpp:113-137 at tile scale).
 // ---------------------------------------------------------------------------------------------
+// LDS budget: Dinv_i packed upper (16.6 KB) + two 64 x 64 panels (33.8 KB each) = 84 KB, so the workgroup fits
+// into ONE slot vacated by a bulk-update workgroup (96 KB); a 4-buffer version (135 KB) needed a whole idle CU
+// and lost 4 % end to end under a concurrent bulk update.  Products stay in registers between phases.
 __global__ void __launch_bounds__(LTHREADS) panel64_solve_update_kernel(double* R, int64_t ldr, const double* Dinv, int64_t ldi,
                                                                        int i, int nblk, double* Xs) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* Dm = lds;                       // Dinv_i
-  double* B0 = lds + 1 * LMAX * LLD;      // A_ia  -> later X_b
-  double* B1 = lds + 2 * LMAX * LLD;      // A_ib  -> later the update tile
-  double* Xa = lds + 3 * LMAX * LLD;      // X_a
+  double* B0 = lds;                       // A_ia -> X_a
+  double* B1 = lds + LMAX * LLD;          // A_ib -> X_b
+  double* Dp = lds + 2 * LMAX * LLD;      // Dinv_i, packed upper: (k, p), k <= p, at p(p+1)/2 + k
   __builtin_amdgcn_s_setprio(3);
-  const int t = threadIdx.x;
-  // triangular decode of blockIdx.x -> (a, b), i < a <= b < nblk, column-major over the r x r upper triangle
-  const int r = nblk - 1 - i;
-  int q = blockIdx.x, bj = 0;
-  while (q >= bj + 1) { q -= bj + 1; bj++; }
-  const int a = i + 1 + q, b = i + 1 + bj;
-  (void)r;
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int lr = lane & 15, kg = lane >> 4;
+  int q = blockIdx.x, bjt = 0;            // triangular decode -> (a, b), i < a <= b < nblk
+  while (q >= bjt + 1) { q -= bjt + 1; bjt++; }
+  const int a = i + 1 + q, b = i + 1 + bjt;
+  const bool diag = (a == b);
   const double* Aia = R + (int64_t)i * 64 + (int64_t)a * 64 * ldr;
   const double* Aib = R + (int64_t)i * 64 + (int64_t)b * 64 * ldr;
   for (int e0 = 0; e0 < 64 * 64; e0 += 4 * LTHREADS) {
@@ -275,47 +276,75 @@ __global__ void __launch_bounds__(LTHREADS) panel64_solve_update_kernel(double* 
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
-      v0[u] = Dinv[ii + (int64_t)jj * ldi];
+      v0[u] = (ii <= jj) ? Dinv[ii + (int64_t)jj * ldi] : 0.0;
       v1[u] = Aia[ii + (int64_t)jj * ldr];
-      v2[u] = Aib[ii + (int64_t)jj * ldr];
+      v2[u] = diag ? 0.0 : Aib[ii + (int64_t)jj * ldr];
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
-      SM(Dm, ii, jj) = (ii <= jj) ? v0[u] : 0.0;     // the inverse is upper triangular; do not trust what lies below
+      if (ii <= jj) Dp[jj * (jj + 1) / 2 + ii] = v0[u];
       SM(B0, ii, jj) = v1[u];
-      SM(B1, ii, jj) = v2[u];
+      if (!diag) SM(B1, ii, jj) = v2[u];
     }
   }
   __syncthreads();
-  lds_mm<true, false, false>(Xa, Dm, B0, 64, 64, 64, 1.0);        // X_a = Dinv^T A_ia
+  // X = Dinv^T * B for the wave's four 16 x 16 output blocks (block id = wid + 4 s: bi = id & 3, bj = id >> 2);
+  // Dinv upper triangular -> rows k > p of column p vanish: only k < 16 (bi + 1) contributes to row block bi
+  auto solve = [&](const double* B, d4 (&acc)[4]) {
+#pragma unroll
+    for (int sblk = 0; sblk < 4; sblk++) {
+      const int id = wid + 4 * sblk, bi = id & 3, bj = id >> 2;
+      d4 c = {0.0, 0.0, 0.0, 0.0};
+      const int p = bi * 16 + lr;
+      for (int k0 = 0; k0 < 16 * (bi + 1); k0 += 4) {
+        const int k = k0 + kg;
+        const double av = (k <= p) ? Dp[p * (p + 1) / 2 + k] : 0.0;     // Dinv[k][p]
+        const double bv = SM(B, k, bj * 16 + lr);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);    // rows p (= kg + 4r), cols lr
+      }
+      acc[sblk] = c;
+    }
+  };
+  auto put = [&](double* B, const d4 (&acc)[4]) {
+#pragma unroll
+    for (int sblk = 0; sblk < 4; sblk++) {
+      const int id = wid + 4 * sblk, bi = id & 3, bj = id >> 2;
+#pragma unroll
+      for (int r = 0; r < 4; r++) SM(B, bi * 16 + kg + 4 * r, bj * 16 + lr) = acc[sblk][r];
+    }
+  };
+  d4 xa[4], xb[4];
+  solve(B0, xa);
+  if (!diag) solve(B1, xb);
+  __syncthreads();                 // every read of the unsolved panels is done
+  put(B0, xa);
+  if (!diag) put(B1, xb);
   __syncthreads();
-  if (a == b) {
+  if (diag) {
     // the solved block R_ia goes to scratch (other workgroups of this launch still read the unsolved A_ia from R);
     // the next leaf launch moves the whole block row into place
     double* dst = Xs + (int64_t)(a - i - 1) * 64 * 64;
-    for (int e = t; e < 64 * 64; e += LTHREADS) dst[e] = SM(Xa, e & 63, e >> 6);
+    for (int e = t; e < 64 * 64; e += LTHREADS) dst[e] = SM(B0, e & 63, e >> 6);
   }
-  const double* Xb = Xa;
-  if (a != b) {
-    lds_mm<true, false, false>(B0, Dm, B1, 64, 64, 64, 1.0);      // X_b = Dinv^T A_ib  (A_ia is dead)
-    __syncthreads();
-    Xb = B0;
-  }
-  lds_mm<true, false, false>(B1, Xa, Xb, 64, 64, 64, 1.0);        // X_a^T X_b          (A_ib is dead)
-  __syncthreads();
+  // C_ab -= X_a^T X_b, computed transposed (MFMA rows <- columns of C) so that a lane owns 16 consecutive ROWS of C
+  const double* XB = diag ? B0 : B1;
   double* C = R + (int64_t)a * 64 + (int64_t)b * 64 * ldr;
-  for (int e0 = 0; e0 < 64 * 64; e0 += 4 * LTHREADS) {
-    double c[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
-      c[u] = (a != b || ii <= jj) ? C[ii + (int64_t)jj * ldr] : 0.0;
+  for (int sblk = 0; sblk < 4; sblk++) {
+    const int id = wid + 4 * sblk, bi = id & 3, bj = id >> 2;     // bi: row block of C (from X_a), bj: column block (from X_b)
+    if (diag && bi > bj) continue;
+    d4 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k0 = 0; k0 < 64; k0 += 4) {
+      const double colv = SM(XB, k0 + kg, bj * 16 + lr);    // MFMA "A": index lr -> column of C
+      const double rowv = SM(B0, k0 + kg, bi * 16 + lr);    // MFMA "B": index lr -> row of C
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(colv, rowv, c, 0, 0, 0);   // result: (col = kg + 4r, row = lr)
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
-      if (a != b || ii <= jj) C[ii + (int64_t)jj * ldr] = c[u] - SM(B1, ii, jj);
+    for (int r = 0; r < 4; r++) {
+      const int row = bi * 16 + lr, col = bj * 16 + kg + 4 * r;
+      if (!diag || row <= col) C[row + (int64_t)col * ldr] -= c[r];
     }
   }
 }
@@ -326,7 +355,7 @@ int cap_panel64_solve_update(double* R, int64_t ldr, const double* Dinv, int64_t
                              hipStream_t stream) {
   const int r = nblk - 1 - i;
   if (r <= 0) return CAP_OK;
-  const size_t lds_bytes = 4 * LMAX * LLD * sizeof(double);
+  const size_t lds_bytes = (2 * LMAX * LLD + LMAX * (LMAX + 1) / 2) * sizeof(double);
   hipLaunchKernelGGL(panel64_solve_update_kernel, dim3(r * (r + 1) / 2), dim3(LTHREADS), lds_bytes, stream, R, ldr, Dinv, ldi, i, nblk, Xs);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
