@@ -85,6 +85,20 @@ def cpu_baseline(cpu_n):
             "sample": "N=%d numpy.linalg.cholesky (OpenBLAS, all host threads), %.3f s" % (n, t)}
 
 
+def traffic_from_profile(n, args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
+    (profiles/r01_traffic_bench_n65536.json, produced by tools/prof_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate
+    runs, FETCH_SIZE doubled per the gfx950 correction).  Counters cannot be collected inside the timed run; the
+    number is only reported for the exact configuration it was measured on, else null."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_bench_n65536.json")))
+        if d["config"]["n"] == n and d["config"]["complete_inv"] == args.complete_inv and not (args.nb or args.outer or args.tail >= 0):
+            return d["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     args = parse()
     import torch
@@ -177,7 +191,7 @@ def main():
                 out["roofline"] = {"bound": "mfma", "kernel": "dgemm_tn_dma_kernel<1> (trailing-update DSYRK, upper tiles)",
                                    "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF,
                                    "launches": nl.value, "avg_launch_ms": ms.value / nl.value,
-                                   "algorithmic_flops_per_launch_avg": fl.value / nl.value, "traffic": None}
+                                   "algorithmic_flops_per_launch_avg": fl.value / nl.value, "traffic": traffic_from_profile(n, args)}
         if args.check:
             out["config"]["residual"] = validate.cholesky.residual(A, pack)
     if rank == 0:
