@@ -41,6 +41,7 @@ struct GemmArgs {
   int etri;         // tile enumeration: 0 full grid, 1/2 triangular (square tile spaces only)
   int chunk;        // logical tiles per XCD
   int nsm, nsn;     // supertiles in M, N
+  int st;           // supertile edge in tiles (tiles of one supertile are co-scheduled on one XCD)
   // split-K (tall-skinny Gram / few-tile problems): blockIdx.y = K slice; partial tiles go to
   // slab kz of P (column-major, ld = M) and a second kernel reduces them deterministically
   int ksplit; int64_t kchunk; double* P; int64_t slab;
@@ -68,6 +69,7 @@ __device__ __forceinline__ const double* a_tile_base(const GemmArgs& g, int ti) 
 
 // logical slot -> tile coordinates (returns false when the slot is empty)
 __device__ __forceinline__ bool slot_to_tile(const GemmArgs& g, int L, int& ti, int& tj) {
+  const int ST = g.st;
   int S = L / (ST * ST), w = L % (ST * ST);
   int si, sj;
   if (g.etri == 1) {  // upper triangle of supertiles, column-major: S = sj(sj+1)/2 + si
@@ -684,12 +686,14 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   g.stair = 0; g.gather = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0;
   for (int i = 0; i < 8; i++) g.gstart[i] = 0;
   g.tm = (int)cap_ceil_div(m, BM); g.tn = (int)cap_ceil_div(n, BN);
-  g.nsm = (int)cap_ceil_div(g.tm, ST); g.nsn = (int)cap_ceil_div(g.tn, ST);
+  static const int st_env = getenv("CAP_ST") ? atoi(getenv("CAP_ST")) : ST;
+  g.st = st_env;
+  g.nsm = (int)cap_ceil_div(g.tm, g.st); g.nsn = (int)cap_ceil_div(g.tn, g.st);
   int64_t nsuper;
   g.etri = (tri != 0 && g.nsm == g.nsn) ? tri : 0;
   if (g.etri == 0) nsuper = (int64_t)g.nsm * g.nsn;   // strips keep the element mask but walk the full grid
   else nsuper = (int64_t)g.nsm * (g.nsm + 1) / 2;      // square tile space: enumerate the supertile triangle
-  int64_t slots = nsuper * ST * ST;
+  int64_t slots = nsuper * g.st * g.st;
   g.chunk = (int)cap_ceil_div(slots, 8);
   int64_t grid = (int64_t)g.chunk * 8;
   if (grid > 0x7fffffff) return CAP_ERR_UNSUPPORTED;
@@ -753,6 +757,7 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   g.A = G; g.B = B; g.C = C; g.lda = k; g.ldb = k; g.ldc = ldc;
   g.M = m; g.N = nloc; g.K = k; g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.etri = 0;
   g.tm = (int)(m / BM); g.tn = (int)(nloc / BN);
+  g.st = ST;
   g.nsm = (int)cap_ceil_div(g.tm, ST); g.nsn = (int)cap_ceil_div(g.tn, ST);
   g.ksplit = 1; g.kchunk = k; g.P = nullptr; g.slab = 0;
   g.hiprio = 0; g.ctr = nullptr;
