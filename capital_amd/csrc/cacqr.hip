@@ -40,7 +40,8 @@ int sweep(cap_cacqr_plan* p, hipStream_t s) {
   CAP_TRY(cap_zero_rect(p->Gi, n, n, n, s));
   CAP_TRY(cap_rec_cholinv_full(p->G, n, p->Gi, n, n, p->W, p->wcap, p->info_dev, s));
   // Q <- Q * R^-1 (cacqr.hpp:24-25)
-  CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, m, n, n, 1.0, Qin, p->ldq, p->Gi, n, 0.0, Qout, p->ldq, 0, s));
+  // tag 8: R^-1 is upper triangular -> a column tile only contracts the rows above its diagonal block
+  CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, m, n, n, 1.0, Qin, p->ldq, p->Gi, n, 0.0, Qout, p->ldq, 0, s, 8));
   p->cur ^= 1;
   return CAP_OK;
 }

@@ -49,6 +49,7 @@ struct GemmArgs {
   // nbT tiles), rows are global.  stair: upper mask follows the staircase  row_tile <= global tile of
   // my local column tile;  gather: operand A is the all-gathered block row, stored as P pieces in
   // (rank, local block) order - row tile ti lives in piece (J % P) at local block J / P - gstart[r].
+  int bupper;       // op(B) is upper triangular (k x n, zero for k > column): K range of a column tile stops at its diagonal
   int* ctr;         // persistent launches: 8 per-XCD slot counters (zeroed on the stream before the launch)
   int hiprio;       // panel-stream launches: raise the waves' issue priority (they share CUs with the bulk update)
   int stair, gather, sP, sp, snbT, sJ0, slb0;
@@ -286,6 +287,23 @@ __device__ __forceinline__ void dma_tile(const double* __restrict__ P, int64_t l
   }
 }
 
+// M-contiguous A operand (op(A) = A, column-major m x k): a K tile is 16 rows (k) of 128 consecutive doubles.
+// One wave-instruction moves one k row (1 KiB); the LDS image is [k][128], with the two 128-byte halves of a
+// row swapped when (k >> 1) is odd (source-side XOR) so that the four k rows a fragment read touches
+// alternate between the two halves of the 64-bank row: ds_read_b64 stays conflict free.
+__device__ __forceinline__ void dma_tile_mc(const double* __restrict__ P, int64_t ld, int64_t i0, int64_t k0, double* lds_tile) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int kr = wid * 4 + q;
+    const int c = lane ^ (((kr >> 1) & 1) << 3);
+    const double* src = P + (k0 + kr) * ld + i0 + c * 2;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds_tile + kr * 128), 16, 0, 0);
+  }
+}
+
+template <bool A_MC>
 __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, const int tj, const int kz, double* smem) {
   const int64_t i0 = (int64_t)ti * BM, j0 = (int64_t)tj * BN;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -303,7 +321,8 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
     for (int j = 0; j < 4; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
   const int64_t kbeg = (int64_t)kz * g.kchunk;
-  const int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+  int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+  if (g.bupper && kend > j0 + BN) kend = j0 + BN;      // op(B) upper triangular: rows k > column vanish
   const int nk = (int)((kend - kbeg) / BK);
 
   // per-lane fragment offsets (doubles) for the two half tiles; +16 rows = +16*BK doubles per block
@@ -312,9 +331,19 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
   const int b_off0 = (wj + lr) * BK + ((0 + kg) ^ sw) * 2, b_off1 = (wj + lr) * BK + ((4 + kg) ^ sw) * 2;
 
   d2 fa0[4], fb0[4], fa1[4], fb1[4];
+  // M-contiguous A: x/y steps take k = 8h + 2kg and 8h + 2kg + 1 (the k permutation of the B operand's b128 read)
+  const int amc_flip = ((kg & 1) << 4);                 // rows with (k >> 1) odd are stored half-swapped
   auto read_frags = [&](const double* tA, const double* tB, int aoff, int boff, d2 (&fa)[4], d2 (&fb)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) fa[i] = *reinterpret_cast<const d2*>(tA + aoff + i * 16 * BK);
+    for (int i = 0; i < 4; i++) {
+      if (A_MC) {
+        const int h8 = (aoff == a_off0) ? 0 : 8;       // a_off0 / a_off1 select the half tile
+        const int m = (wi + 16 * i + lr) ^ amc_flip;
+        fa[i] = (d2){tA[(h8 + 2 * kg) * 128 + m], tA[(h8 + 2 * kg + 1) * 128 + m]};
+      } else {
+        fa[i] = *reinterpret_cast<const d2*>(tA + aoff + i * 16 * BK);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const d2*>(tB + boff + j * 16 * BK);
   };
@@ -338,14 +367,15 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
   // The barrier at the top of iteration kt proves: all reads of tile kt are done (buffer kt&1 may be
   // refilled) and tile kt+1 has landed (each wave drained its own DMA share with vmcnt(0) before it).
   const double* Abase = a_tile_base(g, ti);   // rows of this tile start at Abase (row offset 0 below)
+  auto dma_a = [&](int64_t k0, double* dst) { if (A_MC) dma_tile_mc(g.A, g.lda, i0, k0, dst); else dma_tile(Abase, g.lda, 0, k0, dst); };
   if (nk > 0) {
-    dma_tile(Abase, g.lda, 0, kbeg, sA(0));
+    dma_a(kbeg, sA(0));
     dma_tile(g.B, g.ldb, j0, kbeg, sB(0));
     __syncthreads();
     read_frags(sA(0), sB(0), a_off0, b_off0, fa0, fb0);
     {
       const int64_t k1 = kbeg + (int64_t)(nk > 1 ? 1 : 0) * BK;
-      dma_tile(Abase, g.lda, 0, k1, sA(1));
+      dma_a(k1, sA(1));
       dma_tile(g.B, g.ldb, j0, k1, sB(1));
     }
     read_frags(sA(0), sB(0), a_off1, b_off1, fa1, fb1);
@@ -361,7 +391,7 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
       // a single wave keeps the matrix pipe busy while it issues them (sched_group_barrier pipeline).
       {
         const int kn = (kt + 2 < nk) ? kt + 2 : nk - 1;  // clamp: the last refill is redundant but branch-free
-        dma_tile(Abase, g.lda, 0, kbeg + (int64_t)kn * BK, sA(nxt ^ 1));
+        dma_a(kbeg + (int64_t)kn * BK, sA(nxt ^ 1));
         dma_tile(g.B, g.ldb, j0, kbeg + (int64_t)kn * BK, sB(nxt ^ 1));
       }
       read_frags(sA(nxt), sB(nxt), a_off0, b_off0, fa0, fb0);
@@ -433,7 +463,7 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
 // true).  The persistent form is launched with FEWER workgroups than the chip has slots (2 per CU): the
 // slots left free are what the latency-bound panel chain on the other stream runs in, instead of waiting
 // for (and time-slicing against) one of 512 resident bulk workgroups.
-template <int TAG, bool PERSIST>
+template <int TAG, bool PERSIST, bool A_MC = false>
 __global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (!PERSIST) {
@@ -442,7 +472,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArg
     int ti, tj;
     if ((b >> 3) >= g.chunk || !slot_to_tile(g, L, ti, tj)) return;
     if (g.hiprio) __builtin_amdgcn_s_setprio(3);
-    tn_dma_tile(g, ti, tj, (int)blockIdx.y, smem);
+    tn_dma_tile<A_MC>(g, ti, tj, (int)blockIdx.y, smem);
     return;
   }
   int* slot_word = reinterpret_cast<int*>(smem + 4 * DMA_TILE);
@@ -456,9 +486,16 @@ __global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArg
       __syncthreads();                     // also fences the previous tile's LDS reads against the next tile's DMA
       if (r >= g.chunk) break;
       int ti, tj;
-      if (slot_to_tile(g, q * g.chunk + r, ti, tj)) tn_dma_tile(g, ti, tj, 0, smem);
+      if (slot_to_tile(g, q * g.chunk + r, ti, tj)) tn_dma_tile<A_MC>(g, ti, tj, 0, smem);
     }
   }
+}
+
+int launch_nn_dma(const GemmArgs& g, int grid, hipStream_t stream) {
+  size_t lds = 4 * DMA_TILE * sizeof(double);
+  hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, false, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
 }
 
 // ring of per-launch counter sets for persistent launches
@@ -682,7 +719,7 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.beta = beta; g.tri = tri;
-  g.hiprio = (tag & 2) ? 1 : 0; tag &= 1; g.ctr = nullptr;
+  g.hiprio = (tag & 2) ? 1 : 0; g.bupper = (tag & 8) ? 1 : 0; tag &= 1; g.ctr = nullptr;
   g.stair = 0; g.gather = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0;
   for (int i = 0; i < 8; i++) g.gstart[i] = 0;
   g.tm = (int)cap_ceil_div(m, BM); g.tn = (int)cap_ceil_div(n, BN);
@@ -731,6 +768,7 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   int st;
   static const bool use_v1 = getenv("CAP_GEMM_V1") != nullptr;   // A/B switch for profiling
   if (a_kc && b_kc && !edge && !use_v1) st = (tag == 1) ? launch_tn_dma<1>(g, (int)grid, stream, persist_wgs) : launch_tn_dma<0>(g, (int)grid, stream, 0);
+  else if (!a_kc && b_kc && !edge && !use_v1 && g.ksplit == 1) st = launch_nn_dma(g, (int)grid, stream);
   else if (a_kc && b_kc && tag == 1) st = launch_variant<true, true, 1>(g, edge, (int)grid, stream);
   else if (a_kc && b_kc) st = launch_variant<true, true>(g, edge, (int)grid, stream);
   else if (a_kc && !b_kc) st = launch_variant<true, false>(g, edge, (int)grid, stream);
@@ -760,7 +798,7 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   g.st = ST;
   g.nsm = (int)cap_ceil_div(g.tm, ST); g.nsn = (int)cap_ceil_div(g.tn, ST);
   g.ksplit = 1; g.kchunk = k; g.P = nullptr; g.slab = 0;
-  g.hiprio = 0; g.ctr = nullptr;
+  g.hiprio = 0; g.ctr = nullptr; g.bupper = 0;
   g.stair = 1; g.gather = 1; g.sP = P; g.sp = p; g.snbT = nb / 128; g.sJ0 = J0; g.slb0 = lb0; g.gpiece = piece;
   for (int i = 0; i < 8; i++) g.gstart[i] = i < P ? gstart[i] : 0;
   int64_t slots = (int64_t)g.nsm * g.nsn * ST * ST;
