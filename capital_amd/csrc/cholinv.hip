@@ -67,15 +67,16 @@ int rec_cholinv(const RecCtx& c, int64_t off, int64_t n, bool is_root, int64_t i
   if (n1 * n2 > c.wcap) return CAP_ERR_ALLOC;
   // R12 = Ri11^T * A12  (out of place into W, then back: the reference serializes through
   // rect_table1 the same way, cholinv.hpp:122-125)
-  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n1, n2, n1, 1.0, Ri, c.ldi, R12, c.ldr, 0.0, c.W, n1, 0, c.s, 2));
+  // tags: 2 panel-chain priority, 8 / 16 / 32 triangular operand hints (K ranges that only see zeros are skipped)
+  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n1, n2, n1, 1.0, Ri, c.ldi, R12, c.ldr, 0.0, c.W, n1, 0, c.s, 2 | 16));
   CAP_TRY(cap_copy_rect(c.W, n1, R12, c.ldr, n1, n2, c.s));
   // A22 -= R12^T R12 on upper tiles
   CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n2, n2, n1, -1.0, R12, c.ldr, R12, c.ldr, 1.0, R22, c.ldr, 1, c.s, 2));
   CAP_TRY(rec_cholinv(c, off + n1, n2, false, info_base));
   if (!(is_root && c.complete_inv == 0)) {
     // Ri12 = -Ri11 * (R12 * Ri22)
-    CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, n1, n2, n2, 1.0, R12, c.ldr, Ri22, c.ldi, 0.0, c.W, n1, 0, c.s, 2));
-    CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, n1, n2, n1, -1.0, Ri, c.ldi, c.W, n1, 0.0, Ri12, c.ldi, 0, c.s, 2));
+    CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, n1, n2, n2, 1.0, R12, c.ldr, Ri22, c.ldi, 0.0, c.W, n1, 0, c.s, 2 | 8));
+    CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, n1, n2, n1, -1.0, Ri, c.ldi, c.W, n1, 0.0, Ri12, c.ldi, 0, c.s, 2 | 32));
   }
   return CAP_OK;
 }
@@ -248,7 +249,7 @@ int panel_factor(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t
   const int64_t m = n - j0 - jb;
   if (m > 0) {
     double* Rpan = R + j0 + (j0 + jb) * ldr;
-    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, m, jb, 1.0, Dinv, p->ldi, Rpan, ldr, 0.0, Wpan, jb, 0, s, 2));
+    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, m, jb, 1.0, Dinv, p->ldi, Rpan, ldr, 0.0, Wpan, jb, 0, s, 2 | 16));
     CAP_TRY(cap_copy_rect(Wpan, jb, Rpan, ldr, jb, m, s));
   }
   return CAP_OK;

@@ -195,7 +195,7 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
     if (nloc_k > 0) {
       if (k >= 2) CAP_HIP(hipStreamWaitEvent(s1, d->ev_gather[k - 2], 0));   // S[par] was the all-gather source of step k-2
       double* Rrow = d->R + k * nb + lb0 * nb * ld;
-      CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, nloc_k, nb, 1.0, Dinv, nb, Rrow, ld, 0.0, d->S[par], nb, 0, s1));
+      CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, nloc_k, nb, 1.0, Dinv, nb, Rrow, ld, 0.0, d->S[par], nb, 0, s1, 2 | 16));
       CAP_TRY(cap_copy_rect(d->S[par], nb, Rrow, ld, nb, nloc_k, s1));
     }
     CAP_HIP(hipEventRecord(d->ev_solved[k], s1));

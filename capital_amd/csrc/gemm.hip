@@ -49,6 +49,7 @@ struct GemmArgs {
   // nbT tiles), rows are global.  stair: upper mask follows the staircase  row_tile <= global tile of
   // my local column tile;  gather: operand A is the all-gathered block row, stored as P pieces in
   // (rank, local block) order - row tile ti lives in piece (J % P) at local block J / P - gstart[r].
+  int aupt, aupn;   // op(A) comes from an upper-triangular A (Trans / NoTrans form): see tn_dma_tile
   int bupper;       // op(B) is upper triangular (k x n, zero for k > column): K range of a column tile stops at its diagonal
   int* ctr;         // persistent launches: 8 per-XCD slot counters (zeroed on the stream before the launch)
   int hiprio;       // panel-stream launches: raise the waves' issue priority (they share CUs with the bulk update)
@@ -320,10 +321,13 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
-  const int64_t kbeg = (int64_t)kz * g.kchunk;
+  int64_t kbeg = (int64_t)kz * g.kchunk;
   int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
-  if (g.bupper && kend > j0 + BN) kend = j0 + BN;      // op(B) upper triangular: rows k > column vanish
-  const int nk = (int)((kend - kbeg) / BK);
+  // triangular operands stored as full squares with explicit zeros: skip the K range that only multiplies zeros
+  if (g.bupper && kend > j0 + BN) kend = j0 + BN;      // op(B)[k][j] = 0 for k > j   (B upper, NoTrans)
+  if (g.aupt && kend > i0 + BM) kend = i0 + BM;        // op(A)[i][k] = A[k][i] = 0 for k > i   (A upper, Trans)
+  if (g.aupn && kbeg < i0) kbeg = i0;                  // op(A)[i][k] = A[i][k] = 0 for k < i   (A upper, NoTrans)
+  const int nk = kend > kbeg ? (int)((kend - kbeg) / BK) : 0;
 
   // per-lane fragment offsets (doubles) for the two half tiles; +16 rows = +16*BK doubles per block
   const int sw = lr >> 1;
@@ -719,7 +723,9 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.beta = beta; g.tri = tri;
-  g.hiprio = (tag & 2) ? 1 : 0; g.bupper = (tag & 8) ? 1 : 0; tag &= 1; g.ctr = nullptr;
+  g.hiprio = (tag & 2) ? 1 : 0; g.bupper = (tag & 8) ? 1 : 0;
+  g.aupt = ((tag & 16) && transa == CAP_TRANS) ? 1 : 0; g.aupn = ((tag & 32) && transa != CAP_TRANS) ? 1 : 0;
+  tag &= 1; g.ctr = nullptr;
   g.stair = 0; g.gather = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0;
   for (int i = 0; i < 8; i++) g.gstart[i] = 0;
   g.tm = (int)cap_ceil_div(m, BM); g.tn = (int)cap_ceil_div(n, BN);
@@ -798,7 +804,7 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   g.st = ST;
   g.nsm = (int)cap_ceil_div(g.tm, ST); g.nsn = (int)cap_ceil_div(g.tn, ST);
   g.ksplit = 1; g.kchunk = k; g.P = nullptr; g.slab = 0;
-  g.hiprio = 0; g.ctr = nullptr; g.bupper = 0;
+  g.hiprio = 0; g.ctr = nullptr; g.bupper = 0; g.aupt = 0; g.aupn = 0;
   g.stair = 1; g.gather = 1; g.sP = P; g.sp = p; g.snbT = nb / 128; g.sJ0 = J0; g.slb0 = lb0; g.gpiece = piece;
   for (int i = 0; i < 8; i++) g.gstart[i] = i < P ? gstart[i] : 0;
   int64_t slots = (int64_t)g.nsm * g.nsn * ST * ST;
