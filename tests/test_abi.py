@@ -75,3 +75,18 @@ def test_reference_enum_values_and_topology_maps():
     assert len(seen) == 8
     r = topo.rect_coords(5, 8, 1)            # the 1D CholeskyQR grid: c = 1, d = 8, rows cyclic over y
     assert (r["c"], r["d"], r["x"], r["y"], r["z"]) == (1, 8, 0, 5, 0)
+
+
+def test_plain_c_host_compiles_against_the_header(built, tmp_path):
+    """north_star: "host code stays C" - a C (not C++) translation unit includes the header and links the library."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc") or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("gcc / ROCm headers not available")
+    exe = tmp_path / "cholinv_driver.bin"
+    cmd = ["gcc", "-std=c99", "-D_POSIX_C_SOURCE=199309L", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "cholinv_driver.c"), "-L" + os.path.dirname(built), "-lcapital_amd", "-L/opt/rocm/lib",
+           "-lamdhip64", "-lm", "-Wl,-rpath," + os.path.dirname(built), "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert exe.exists()
