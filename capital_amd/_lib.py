@@ -34,6 +34,8 @@ SIGNATURES = {
     "cap_fill_symmetric": (cint, [ptr, i64, i64, i64, i64, i64, cint, ptr]),
     "cap_fill_random": (cint, [ptr, i64, i64, i64, i64, i64, i64, i64, i64, ptr]),
     "cap_copy_window": (cint, [ptr, cint, i64, i64, i64, ptr, cint, i64, i64, i64, i64, i64, cint, cint, ptr]),
+    "cap_cyclic_import": (cint, [ptr, i64, ptr, i64, i64, i64, i64, i64, i64, i64, ptr]),
+    "cap_cyclic_export": (cint, [ptr, i64, ptr, i64, i64, i64, i64, i64, i64, i64, ptr]),
     "cap_remove_triangle": (cint, [ptr, i64, i64, i64, i64, i64, i64, cint, ptr]),
     "cap_cholesky_residual_terms": (cint, [ptr, i64, ptr, i64, i64, ptr, ptr, ptr]),
     "cap_sumsq": (cint, [ptr, i64, i64, i64, cint, cint, ptr, ptr]),

@@ -109,6 +109,19 @@ __global__ void sumsq_kernel(const double* X, int64_t ld, int64_t m, int64_t n, 
   }
 }
 
+// element-cyclic piece (x, y) of a dx x dy grid  <->  dense global matrix (the map of matrix.hpp:8-11 / util.hpp:135-164):
+// piece[r, c] = dense[y + r*dy, x + c*dx]; rows/cols past the global extent are the reference's zero padding.
+__global__ void cyclic_piece_kernel(double* piece, int64_t ldp, int64_t rl, int64_t cl, double* dense, int64_t ldd, int64_t m,
+                                    int64_t n, int64_t x, int64_t y, int64_t dx, int64_t dy, int to_dense) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t c = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (r >= rl || c >= cl) return;
+  const int64_t gy = y + r * dy, gx = x + c * dx;
+  const bool in = gy < m && gx < n;
+  if (to_dense) { if (in) dense[gy + gx * ldd] = piece[r + c * ldp]; }
+  else piece[r + c * ldp] = in ? dense[gy + gx * ldd] : 0.0;
+}
+
 inline dim3 grid2d(int64_t rows, int64_t cols, int bx) {
   unsigned gy = (unsigned)(cols < 65535 ? cols : 65535);
   unsigned gz = (unsigned)cap_ceil_div(cols, 65535);
@@ -176,6 +189,28 @@ int cap_copy_window(const double* src, int src_packed, int64_t src_ld, int64_t s
   if ((src_packed || dst_packed) && !tri_only) return CAP_ERR_ARG;   // packed buffers only hold the upper triangle
   hipLaunchKernelGGL(copy_window_kernel, grid2d(rows, cols, 256), dim3(256), 0, cap_stream(stream), src, src_packed, src_ld,
                      src_row0, src_col0, dst, dst_packed, dst_ld, dst_row0, dst_col0, rows, cols, tri_only, zero_lower);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+int cap_cyclic_import(const double* piece, int64_t ldp, double* dense, int64_t ldd, int64_t m, int64_t n, int64_t x, int64_t y,
+                      int64_t dx, int64_t dy, void* stream) {
+  if (!piece || !dense || dx <= 0 || dy <= 0 || x < 0 || y < 0 || x >= dx || y >= dy || m <= 0 || n <= 0) return CAP_ERR_ARG;
+  const int64_t rl = cap_ceil_div(m, dy), cl = cap_ceil_div(n, dx);
+  if (ldp < rl || ldd < m) return CAP_ERR_ARG;
+  hipLaunchKernelGGL(cyclic_piece_kernel, grid2d(rl, cl, 256), dim3(256), 0, cap_stream(stream), const_cast<double*>(piece), ldp, rl, cl,
+                     dense, ldd, m, n, x, y, dx, dy, 1);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+int cap_cyclic_export(const double* dense, int64_t ldd, double* piece, int64_t ldp, int64_t m, int64_t n, int64_t x, int64_t y,
+                      int64_t dx, int64_t dy, void* stream) {
+  if (!piece || !dense || dx <= 0 || dy <= 0 || x < 0 || y < 0 || x >= dx || y >= dy || m <= 0 || n <= 0) return CAP_ERR_ARG;
+  const int64_t rl = cap_ceil_div(m, dy), cl = cap_ceil_div(n, dx);
+  if (ldp < rl || ldd < m) return CAP_ERR_ARG;
+  hipLaunchKernelGGL(cyclic_piece_kernel, grid2d(rl, cl, 256), dim3(256), 0, cap_stream(stream), piece, ldp, rl, cl,
+                     const_cast<double*>(dense), ldd, m, n, x, y, dx, dy, 0);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }

@@ -106,3 +106,17 @@ def serialize(src, dst, src_window, dst_origin, tri_only=False, zero_lower=False
                                     dst_ld or 0, dst_origin[0], dst_origin[1], r1 - r0, c1 - c0, int(tri_only), int(zero_lower),
                                     cur_stream())
     _lib.check(st, "serialize")
+
+
+def cyclic_import(piece, dense, x, y, dx, dy):
+    """Scatter the element-cyclic piece (x, y) of a dx x dy grid (a `matrix` created with those grid dims) into `dense`
+    (a `matrix` on a 1 x 1 grid) - util::block_to_cyclic_* / cyclic_to_local of the reference, on the GPU."""
+    st = _lib.lib().cap_cyclic_import(piece.data_ptr(), piece.ld(), dense.data_ptr(), dense.ld(), dense.num_rows_global(),
+                                      dense.num_columns_global(), x, y, dx, dy, cur_stream())
+    _lib.check(st, "cyclic_import")
+
+
+def cyclic_export(dense, piece, x, y, dx, dy):
+    st = _lib.lib().cap_cyclic_export(dense.data_ptr(), dense.ld(), piece.data_ptr(), piece.ld(), dense.num_rows_global(),
+                                      dense.num_columns_global(), x, y, dx, dy, cur_stream())
+    _lib.check(st, "cyclic_export")

@@ -117,6 +117,15 @@ int cap_copy_window(const double* src, int src_packed, int64_t src_ld, int64_t s
                     double* dst, int dst_packed, int64_t dst_ld, int64_t dst_row0, int64_t dst_col0,
                     int64_t rows, int64_t cols, int tri_only, int zero_lower, void* stream);
 
+/* Element-cyclic layout of the reference (matrix.hpp:8-11; util::block_to_cyclic_* / cyclic_to_local,
+ * util.hpp:56-230): piece (x, y) of a dx x dy grid holds global rows y, y+dy, ... and columns x, x+dx, ...
+ * (ceil sizes, zero padded).  import scatters one piece into a dense m x n matrix, export extracts it - so a
+ * caller holding upstream-style cyclic pieces can assemble / split the dense operand of the GPU plans.      */
+int cap_cyclic_import(const double* piece, int64_t ldp, double* dense, int64_t ldd, int64_t m, int64_t n, int64_t x, int64_t y,
+                      int64_t dx, int64_t dy, void* stream);
+int cap_cyclic_export(const double* dense, int64_t ldd, double* piece, int64_t ldp, int64_t m, int64_t n, int64_t x, int64_t y,
+                      int64_t dx, int64_t dy, void* stream);
+
 /* util::remove_triangle - util.hpp:266-318: zero the entries of a local element-cyclic piece
  * that are globally strictly below (dir 'U') / above ('L') the diagonal.                   */
 int cap_remove_triangle(double* local, int64_t ld, int64_t rows_local, int64_t cols_local, int64_t x, int64_t y,

@@ -84,3 +84,44 @@ def test_remove_triangle(d):
             L, Lv = to_dev(loc)
             _lib.check(_lib.lib().cap_remove_triangle(L.data_ptr(), loc.shape[0], loc.shape[0], loc.shape[1], x, y, d, 1, cur_stream()))
             assert np.array_equal(to_host(Lv), orc.cyclic_local(np.triu(full), x, y, d, d))
+
+
+@pytest.mark.parametrize("m,n,dx,dy", [(64, 64, 2, 2), (101, 37, 3, 2), (50, 50, 1, 1), (129, 257, 4, 4)])
+def test_cyclic_import_export_roundtrip(m, n, dx, dy):
+    """Upstream-style element-cyclic pieces <-> the dense operand of the GPU plans (matrix.hpp:8-11, util.hpp:135-164)."""
+    from capital_amd.matrix import matrix, cyclic_import, cyclic_export
+    a = np.random.default_rng(m + n).standard_normal((m, n))
+    dense = matrix(n, m, 1, 1)
+    for x in range(dx):
+        for y in range(dy):
+            P = matrix(n, m, dx, dy).from_numpy(orc.cyclic_local(a, x, y, dx, dy))
+            cyclic_import(P, dense, x, y, dx, dy)
+    assert np.array_equal(dense.to_numpy(), a)
+    for x in range(dx):
+        for y in range(dy):
+            P = matrix(n, m, dx, dy)
+            P.view().fill_(7.0)
+            cyclic_export(dense, P, x, y, dx, dy)
+            assert np.array_equal(P.to_numpy(), orc.cyclic_local(a, x, y, dx, dy))     # incl. the zero padding
+
+
+def test_factor_from_cyclic_pieces_matches_reference_semantics():
+    """d = 2 upstream layout: assemble the 4 pieces of distribute_symmetric, factor, split R back into pieces."""
+    from capital_amd import cholinv
+    from capital_amd.matrix import matrix, cyclic_import, cyclic_export
+    n, d = 200, 2
+    dense = matrix(n, n, 1, 1)
+    for x in range(d):
+        for y in range(d):
+            P = matrix(n, n, d, d); P.distribute_symmetric(x, y, d, d, 0, True)
+            cyclic_import(P, dense, x, y, d, d)
+    a = orc.symmetric_global(n, True)
+    assert np.array_equal(dense.to_numpy(), a)
+    pack = cholinv.info(1, 1, -2, 'U'); cholinv.factor(dense, pack, None)
+    R = cholinv.construct_R(pack)
+    r_ref, _ = orc.cholinv(a, 1, 1, -2, 2, 2)
+    for x in range(d):
+        for y in range(d):
+            P = matrix(n, n, d, d); cyclic_export(R, P, x, y, d, d)
+            ref = orc.cyclic_local(r_ref, x, y, d, d)
+            assert np.linalg.norm(P.to_numpy() - ref) <= 1e-13 * np.linalg.norm(r_ref)
