@@ -36,7 +36,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=65536, help="matrix dimension (BASELINE metric: 65536)")
+    ap.add_argument("--n", "--size", dest="n", type=int, default=65536,
+                    help="matrix dimension (BASELINE metric: 65536); use --size under torch.distributed.run, whose own parser trips over --n")
     ap.add_argument("--nb", type=int, default=0, help="panel width override (0 = library default)")
     ap.add_argument("--outer", type=int, default=0, help="outer strip height NB override (0 = library default)")
     ap.add_argument("--tail", type=int, default=-1, help="trailing size below which strips are nb wide (-1 = default)")
@@ -107,12 +108,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    # CAPITAL_BENCH_EMULATE=1 (tests only): all ranks share cuda:0 and talk through gloo + the host-staged communicator,
+    # which exercises this file's N > 1 path on a 1-GPU box; the product path is RCCL, one GPU per rank.
+    emulate = os.environ.get("CAPITAL_BENCH_EMULATE") == "1"
+    torch.cuda.set_device(0 if emulate else local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if emulate:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from capital_amd import _lib
     L = _lib.lib()     # fails loudly if the HIP library is missing
@@ -141,7 +148,7 @@ def main():
         parallelism = "1 GPU"
     else:
         from capital_amd import dist_cholesky
-        ctx = dist_cholesky.setup(n, nb=args.nb or 0)
+        ctx = dist_cholesky.setup(n, nb=args.nb or 0, comm=dist_cholesky.HostStagedComm() if emulate else None)
         run = ctx.factor
         finish = ctx.last_info
         parallelism = "1x%d block-cyclic columns, RCCL over xGMI" % world
@@ -162,7 +169,7 @@ def main():
     dt = time.perf_counter() - t0
     info = finish()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if emulate else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     sec = dt / args.steps

@@ -80,3 +80,21 @@ def test_multirank_cacqr_on_one_gpu(nproc, m, n):
     r = _launch(nproc, "cacqr", m, n, 29641 + nproc)
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "CACQR-OK" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_code_path_emulated():
+    """bench.py --gpus 2 end to end (rank bootstrap, timing reduce, JSON) with both ranks on cuda:0 (gloo + host-staged
+    collectives instead of RCCL); the numbers are meaningless, the contract fields are checked."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29655", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--size", "4096",
+           "--no-cpu-baseline"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CAPITAL_BENCH_EMULATE="1", OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["unit"] == "TFLOP/s" and d["value"] > 0
+    assert d["config"]["info"] == 0 and d["dtype"] == "f64" and d["higher_is_better"] is True
