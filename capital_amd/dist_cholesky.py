@@ -96,13 +96,6 @@ class HostStagedComm:
             raise _lib.CapitalError("HostStagedComm needs torch.distributed initialised with the gloo backend")
         self.rank, self.size = dist.get_rank(), dist.get_world_size()
         self.calls = {"allgather": 0, "bcast": 0, "allreduce": 0}
-        hip = torch.cuda
-
-        def view(ptr, count):
-            # wrap a raw device pointer as a tensor without owning it
-            arr = (C.c_double * 0).from_address(0)  # placeholder to keep ctypes happy
-            del arr
-            return _DevView(ptr, count)
 
         def sync(stream):
             torch.cuda.synchronize()
