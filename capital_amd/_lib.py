@@ -43,6 +43,16 @@ SIGNATURES = {
     "cap_comm_create": (cint, [C.POINTER(ptr), ptr, cint, cint, ptr]),
     "cap_comm_create_self": (cint, [C.POINTER(ptr)]),
     "cap_comm_create_callbacks": (cint, [C.POINTER(ptr), cint, cint, ptr, ptr, ptr, ptr]),
+    "cap_comm_split": (cint, [ptr, cint, cint, C.POINTER(ptr)]),
+    "cap_comm_dup": (cint, [ptr, C.POINTER(ptr)]),
+    "cap_comm_backend": (cint, [ptr]),
+    "cap_comm_reduce_sum": (cint, [ptr, ptr, i64, cint, ptr]),
+    "cap_topo_coords": (cint, [cint, cint, cint, cint, C.POINTER(cint), C.POINTER(cint), C.POINTER(cint), C.POINTER(cint)]),
+    "cap_topo_create": (cint, [C.POINTER(ptr), cint, ptr, cint, cint, cint]),
+    "cap_topo_create_from": (cint, [C.POINTER(ptr), cint, ptr, cint, cint, cint, C.POINTER(ptr), cint]),
+    "cap_topo_destroy": (cint, [ptr]),
+    "cap_topo_comm": (ptr, [ptr, cint]),
+    "cap_topo_get": (cint, [ptr, cint]),
     "cap_comm_destroy": (cint, [ptr]),
     "cap_comm_rank": (cint, [ptr]),
     "cap_comm_size": (cint, [ptr]),
@@ -67,6 +77,10 @@ SIGNATURES = {
     "cap_dist_factor": (cint, [ptr, ptr, i64, ptr]),
     "cap_dist_R_ptr": (ptr, [ptr, C.POINTER(i64)]),
     "cap_dist_info": (cint, [ptr, ptr, C.POINTER(i64)]),
+    "cap_dist_get_R": (cint, [ptr, ptr, i64, ptr]),
+    "cap_dist_set_option": (cint, [ptr, C.c_char_p, i64]),
+    "cap_dist_get_option": (i64, [ptr, C.c_char_p]),
+    "cap_dist_profile": (cint, [ptr, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]),
     "cap_fill_symmetric_bc": (cint, [ptr, i64, i64, i64, cint, cint, cint, ptr]),
     "cap_bc_owner": (cint, [i64, cint]),
     "cap_bc_local_block": (i64, [i64, cint]),

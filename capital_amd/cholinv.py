@@ -21,6 +21,7 @@ class info:
         self.complete_inv, self.split, self.bc_mult_dim, self.dir = int(complete_inv), int(split), int(bc_mult_dim), dir
         self._plan = None
         self._n = None
+        self._comm = None
         self.options = {}
 
     def set_option(self, key, value):
@@ -34,16 +35,16 @@ class info:
             return self.options.get(key)
         return _lib.lib().cap_cholinv_get_option(self._plan, key.encode())
 
-    def _ensure(self, n):
-        if self._plan is not None and self._n == n:
+    def _ensure(self, n, comm=None):
+        if self._plan is not None and self._n == n and self._comm == comm:
             return
         self._release()
         L = _lib.lib()
         h = C.c_void_p()
         # args.R/_Rinv._register_: allocated once, later calls are no-ops (cholinv.hpp:11-12)
         _lib.check(L.cap_cholinv_plan_create(C.byref(h), n, self.complete_inv, self.split, self.bc_mult_dim,
-                                             self.dir.encode()[0:1], None), "cap_cholinv_plan_create")
-        self._plan, self._n = h, n
+                                             self.dir.encode()[0:1], comm), "cap_cholinv_plan_create")
+        self._plan, self._n, self._comm = h, n, comm
         for k, v in self.options.items():
             _lib.check(L.cap_cholinv_set_option(self._plan, k.encode(), v), "set_option")
 
@@ -72,8 +73,12 @@ def factor(A, args, CommInfo=None):
     if args.split <= 0:
         raise _lib.CapitalError("split must be > 0 (cholinv.hpp:9)")
     if CommInfo is not None and getattr(CommInfo, "size", 1) != 1:
-        raise _lib.CapitalError("cholinv on this build runs one GPU per factorization (P = 1); "
-                                "upstream supports only cubic grids P = 1, 8, 27 (SURVEY 3.3)")
+        # multi-GPU: A is a `block_cyclic_columns` piece (this rank's block columns, all n rows) and CommInfo.world the
+        # communicator; the 1 x P schedule of csrc/dist.hip runs behind the same plan handle (complete_inv = -1 only)
+        n = A.num_rows_global()
+        args._ensure(n, getattr(CommInfo, "world", None))
+        _lib.check(_lib.lib().cap_cholinv_factor(args._plan, A.data_ptr(), A.ld(), cur_stream()), "cholinv::factor")
+        return
     n = A.num_rows_global()
     if n != A.num_columns_global():
         raise _lib.CapitalError("cholinv needs a square matrix")
@@ -83,7 +88,11 @@ def factor(A, args, CommInfo=None):
 
 def _construct(args, which):
     n = args._n
-    out = matrix(n, n, 1, 1, rect)
+    if args._comm is not None and _lib.lib().cap_comm_size(args._comm) > 1:
+        lc = int(_lib.lib().cap_cholinv_get_option(args._plan, b"local_cols"))
+        out = matrix(max(lc, 1), n, 1, 1, rect)      # my block-cyclic columns (n x local_cols)
+    else:
+        out = matrix(n, n, 1, 1, rect)
     fn = _lib.lib().cap_cholinv_get_R if which == "R" else _lib.lib().cap_cholinv_get_Rinv
     _lib.check(fn(args._plan, out.data_ptr(), out.ld(), cur_stream()), "construct_" + which)
     return out

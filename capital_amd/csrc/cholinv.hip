@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -165,6 +166,8 @@ struct cap_cholinv_plan {
   // it is launched on, algorithmic flops m(m+1)k per launch
   int profile;
   std::vector<hipEvent_t>* prof_ev; std::vector<double>* prof_flops; int prof_used;
+  // multi-GPU plans (comm size > 1): the 1 x P block-cyclic schedule of dist.hip behind the same handle
+  cap_dist_plan* dist;
 };
 
 namespace {
@@ -385,12 +388,22 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   if (!plan || n <= 0 || split <= 0) return CAP_ERR_ARG;          // assert(args.split>0), cholinv.hpp:9
   if (dir != 'U') return CAP_ERR_UNSUPPORTED;                      // assert(args.dir == 'U'), cholinv.hpp:9
   if (complete_inv < -1 || complete_inv > 1) return CAP_ERR_ARG;
-  if (comm && cap_comm_size(comm) > 1) return CAP_ERR_UNSUPPORTED;  // distributed plans: cap_cholinv_plan_create_dist (dist.hip)
+  const bool multi = comm && cap_comm_size(comm) > 1;
+  // multi-GPU: only the blocked Cholesky (no explicit inverse) is distributed; R and R^-1 of upstream's
+  // d x d x c schedule stay single-GPU modes
+  if (multi && complete_inv != -1) return CAP_ERR_UNSUPPORTED;
   cap_cholinv_plan* p = new (std::nothrow) cap_cholinv_plan();
   if (!p) return CAP_ERR_ALLOC;
   memset(p, 0, sizeof(*p));
   p->n = n; p->complete_inv = complete_inv; p->split = split; p->bc_mult_dim = bc_mult_dim; p->dir = dir; p->comm = comm;
   p->nb = default_nb(n, bc_mult_dim); p->leaf = CAP_LEAF_MAX; p->lookahead = 1;
+  if (multi) {
+    // A is this rank's block-cyclic column set (cap_bc_num_local_cols columns, all n rows); see dist.hip
+    int st = cap_dist_plan_create(&p->dist, n, std::max<int64_t>(128, (p->nb / 128) * 128), comm);
+    if (st != CAP_OK) { delete p; return st; }
+    *plan = p;
+    return CAP_OK;
+  }
   // two-level blocking defaults (tools/sweep.sh on MI355X): K = 2 nb bulk updates while the trailing matrix is
   // large, nb-wide strips for the last n/8 columns where the strip chain could no longer hide
   p->outer = n >= 8192 ? 2 * p->nb : p->nb; p->tail = n >= 8192 ? n / 8 : 0; p->reserve = 0;
@@ -407,6 +420,7 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
 
 int cap_cholinv_plan_destroy(cap_cholinv_plan* p) {
   if (!p) return CAP_OK;
+  if (p->dist) (void)cap_dist_plan_destroy(p->dist);
   if (p->R) (void)hipFree(p->R);
   if (p->Rinv) (void)hipFree(p->Rinv);
   if (p->work) (void)hipFree(p->work);
@@ -425,6 +439,18 @@ int cap_cholinv_plan_destroy(cap_cholinv_plan* p) {
 int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) {
   if (!p || !key) return CAP_ERR_ARG;
   std::string k(key);
+  if (p->dist) {
+    if (k == "nb") {        // block width of the distribution: rebuild the inner plan
+      if (value < 128 || value % 128) return CAP_ERR_ARG;
+      if (value == cap_dist_get_option(p->dist, "nb")) return CAP_OK;
+      cap_dist_plan* nd = nullptr;
+      CAP_TRY(cap_dist_plan_create(&nd, p->n, value, p->comm));
+      (void)cap_dist_plan_destroy(p->dist);
+      p->dist = nd; p->nb = value;
+      return CAP_OK;
+    }
+    return cap_dist_set_option(p->dist, key, value);
+  }
   if (k == "nb") {
     if (p->complete_inv >= 0) { p->nb = value; return CAP_OK; }
     if (value < 64 || value % 64) return CAP_ERR_ARG;
@@ -462,6 +488,14 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
 int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
   if (!p || !key) return -1;
   std::string k(key);
+  if (p->dist) {
+    if (k == "complete_inv") return p->complete_inv;
+    if (k == "split") return p->split;
+    if (k == "bc_mult_dim") return p->bc_mult_dim;
+    if (k == "local_cols") return cap_dist_local_cols(p->dist);
+    return cap_dist_get_option(p->dist, key);
+  }
+  if (k == "local_cols") return p->n;
   if (k == "nb") return p->nb;
   if (k == "leaf") return p->leaf;
   if (k == "lookahead") return p->lookahead;
@@ -479,7 +513,9 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
 }
 
 int cap_cholinv_factor(cap_cholinv_plan* p, const double* A, int64_t lda, void* stream) {
-  if (!p || !A || lda < p->n) return CAP_ERR_ARG;
+  if (!p) return CAP_ERR_ARG;
+  if (p->dist) return cap_dist_factor(p->dist, A, lda, stream);
+  if (!A || lda < p->n) return CAP_ERR_ARG;
   hipStream_t s = cap_stream(stream);
   const int64_t n = p->n;
   CAP_HIP(hipMemsetAsync(p->info_dev, 0, sizeof(int), s));
@@ -498,6 +534,7 @@ int cap_cholinv_factor(cap_cholinv_plan* p, const double* A, int64_t lda, void* 
 }
 
 int cap_cholinv_get_R(cap_cholinv_plan* p, double* out, int64_t ld, void* stream) {
+  if (p && p->dist) return cap_dist_get_R(p->dist, out, ld, stream);   // my block-cyclic columns
   if (!p || !out || ld < p->n) return CAP_ERR_ARG;
   return cap_copy_window(p->R, 0, p->ldr, 0, 0, out, 0, ld, 0, 0, p->n, p->n, 1, 1, stream);
 }
@@ -508,7 +545,12 @@ int cap_cholinv_get_Rinv(cap_cholinv_plan* p, double* out, int64_t ld, void* str
   return cap_copy_window(p->Rinv, 0, p->ldi, 0, 0, out, 0, ld, 0, 0, p->n, p->n, 1, 1, stream);
 }
 
-double* cap_cholinv_R_ptr(cap_cholinv_plan* p, int64_t* ld) { if (!p) return nullptr; if (ld) *ld = p->ldr; return p->R; }
+double* cap_cholinv_R_ptr(cap_cholinv_plan* p, int64_t* ld) {
+  if (!p) return nullptr;
+  if (p->dist) return cap_dist_R_ptr(p->dist, ld);
+  if (ld) *ld = p->ldr;
+  return p->R;
+}
 double* cap_cholinv_Rinv_ptr(cap_cholinv_plan* p, int64_t* ld) {
   if (!p || p->complete_inv < 0) return nullptr;
   if (ld) *ld = p->ldi;
@@ -517,6 +559,7 @@ double* cap_cholinv_Rinv_ptr(cap_cholinv_plan* p, int64_t* ld) {
 
 int cap_cholinv_info(cap_cholinv_plan* p, void* stream, int64_t* info) {
   if (!p || !info) return CAP_ERR_ARG;
+  if (p->dist) return cap_dist_info(p->dist, stream, info);
   int h = 0;
   CAP_HIP(hipMemcpyAsync(&h, p->info_dev, sizeof(int), hipMemcpyDeviceToHost, cap_stream(stream)));
   CAP_HIP(hipStreamSynchronize(cap_stream(stream)));
@@ -528,6 +571,7 @@ int cap_cholinv_info(cap_cholinv_plan* p, void* stream, int64_t* info) {
 // duration (ms, HIP events on the launch stream) and summed algorithmic flops.  Synchronises.
 int cap_cholinv_profile(cap_cholinv_plan* p, int64_t* launches, double* ms_total, double* flops_total) {
   if (!p || !launches || !ms_total || !flops_total) return CAP_ERR_ARG;
+  if (p->dist) return cap_dist_profile(p->dist, launches, ms_total, flops_total);
   *launches = 0; *ms_total = 0; *flops_total = 0;
   if (!p->prof_ev) return CAP_OK;
   for (int i = 0; i + 1 < p->prof_used; i += 2) {
@@ -542,10 +586,24 @@ int cap_cholinv_profile(cap_cholinv_plan* p, int64_t* launches, double* ms_total
 // -------------------------------------------------------------------------------------------------
 // operator seam built from the same blocks (lapack::engine::_potrf/_trtri, blas::engine::_trmm, DTRSM)
 // -------------------------------------------------------------------------------------------------
+// schedule knobs of the LAPACK-shaped entry point: the same choices cap_cholinv_plan_create makes
+static void potrf_knobs(int64_t n, int64_t* nb, int64_t* outer, int64_t* tail, int* depth2) {
+  int64_t b = std::min<int64_t>(default_nb(n, 0), cap_round_up(std::max<int64_t>(n, 1), 64));
+  *nb = b; *outer = n >= 8192 ? 2 * b : b; *tail = n >= 8192 ? n / 8 : 0; *depth2 = n >= 24576;
+}
+
 int64_t cap_dpotrf_work_size(int64_t n) {
-  int64_t nb = default_nb(n, -100);
-  nb = std::min<int64_t>(nb, cap_round_up(std::max<int64_t>(n, 1), 64));
+  int64_t nb, outer, tail; int d2;
+  potrf_knobs(n, &nb, &outer, &tail, &d2);
   return nb * nb + rec_work_size(nb) + cap_round_up(nb * n, 2) + 8;
+}
+
+// helper stream + events of cap_dpotrf's look-ahead (process-wide, created once; the mutex serialises the
+// ENQUEUE of concurrent calls - the work itself is ordered by events on the callers' streams)
+namespace {
+struct PotrfCtx { cap_cholinv_plan plan; bool ready; };
+std::mutex g_potrf_mu;
+PotrfCtx g_potrf_ctx[8];     // one per device
 }
 
 int cap_dpotrf(int uplo, int64_t n, double* A, int64_t lda, int* info, double* work, void* stream) {
@@ -553,16 +611,20 @@ int cap_dpotrf(int uplo, int64_t n, double* A, int64_t lda, int* info, double* w
   if (uplo != CAP_UPPER) return CAP_ERR_UNSUPPORTED;    // upstream removed 'L' as well (cholinv.hpp:9)
   if (n == 0) return CAP_OK;
   hipStream_t s = cap_stream(stream);
-  // a throw-away single-stream plan view over caller memory
-  cap_cholinv_plan p;
-  memset(&p, 0, sizeof(p));
-  p.n = n; p.complete_inv = -1; p.leaf = CAP_LEAF_MAX; p.lookahead = 0;
-  p.nb = std::min<int64_t>(default_nb(n, -100), cap_round_up(n, 64));
-  p.outer = p.nb; p.tail = 0; p.fastdiag = 1;   // cap_dpotrf runs alone on its stream: the fused path wins
+  int dev = 0;
+  CAP_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_potrf_mu);
+  // a plan view over caller memory; streams/events are the only state that survives the call
+  PotrfCtx& ctx = g_potrf_ctx[dev & 7];
+  if (!ctx.ready) { memset(&ctx.plan, 0, sizeof(ctx.plan)); ctx.ready = true; }
+  cap_cholinv_plan& p = ctx.plan;
+  p.n = n; p.complete_inv = -1; p.leaf = CAP_LEAF_MAX; p.fastdiag = 1;
+  potrf_knobs(n, &p.nb, &p.outer, &p.tail, &p.depth2);
+  p.lookahead = n >= 4096;
   p.ldi = p.nb;
   p.Rinv = work;                                // nb x nb
   p.work = work + p.nb * p.nb;                  // rec scratch + panel scratch
-  p.info_dev = info;
+  p.info_dev = info;                            // may be NULL: the leaf kernels then drop the pivot report
   CAP_HIP(hipMemsetAsync(p.Rinv, 0, sizeof(double) * p.nb * p.nb, s));
   if (info) CAP_HIP(hipMemsetAsync(info, 0, sizeof(int), s));
   return right_looking(&p, A, lda, n, s);

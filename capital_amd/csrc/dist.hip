@@ -1,24 +1,34 @@
 // Multi-GPU blocked Cholesky (upper, A = R^T R), one process per GPU, RCCL over xGMI.
 //
 // Layout: 1 x P block-column-cyclic (the 2D block-cyclic descriptor with Pr = 1): global block
-// column J (nb wide) lives on rank J % P as local block J / P; every rank stores all n rows of its
-// columns (column-major, ld = n).  The reference distributes element-cyclically over a d x d x c grid
-// and moves operands with MPI_Bcast / MPI_Allreduce / MPI_Allgather (summa.hpp:163-253,
-// policy.h:160-305); here the same roles are played by
-//   * one small ncclBroadcast per step:  msg(k+1) = [ R(k,k+1) | Dinv(k+1) ]  (2 nb^2 doubles),
-//   * one ncclAllGather per step:        the solved block row k (nb x (n - (k+1) nb) in total).
+// column J (nb wide) lives on rank J % P as local block J / P; every rank stores all rows of its
+// columns (column-major).  N need not be a multiple of nb: the plan works on the matrix padded to
+// npad = ceil(N / nb) nb with an identity tail ([[A, 0], [0, I]] -> [[R, 0], [0, I]]), the way the
+// reference pads its base case (`span`, policy.h:196).  The reference distributes element-cyclically
+// over a d x d x c grid and moves operands with MPI_Bcast / MPI_Allreduce / MPI_Allgather
+// (summa.hpp:163-253, policy.h:160-305); here the same roles are played by
+//   * one small ncclBroadcast per block row k:  msg(k) = [ R(k-1,k) | Dinv(k) ]  (2 nb^2 doubles) on its
+//     own communicator + stream, so it never queues behind the big collective,
+//   * one ncclAllGather per STRIP (two block rows): the solved strip right of itself, 2nb x cols.
 //
-// Per step k on every rank, three HIP streams + events (no host synchronisation):
-//   panel stream (high priority)  solve my part of block row k with Dinv(k)           (1 GEMM)
-//                                 owner(k+1): update + factor + invert diag block k+1 (cholinv recursion)
-//                                 after msg(k+1): apply step k to my part of block row k+1 (look-ahead)
-//   comm stream                   all-gather block row k; broadcast msg(k+1)
-//   main stream                   rank-nb update of my columns, rows >= (k+2) nb, upper staircase only,
-//                                 A operand read straight out of the gathered pieces (no repacking)
-// so the bulk update of step k overlaps with the factorization / communication of step k+1.
+// Schedule = the single-GPU schedule of cholinv.hip (two-level blocking, look-ahead depth 2), per strip
+// t = block rows (a, b = a + 1), on four HIP streams tied together by events only (no host sync):
+//   panel stream (high priority)   owner(a): factor + invert D(a)            | msg(a) |
+//                                  all: S_a = Dinv(a)^T R[a, mine]           (1 GEMM)
+//                                  owner(b): D(b) -= S_a^T S_a, factor + invert | msg(b) = [R(a,b) | Dinv(b)] |
+//                                  all: R[b, mine] -= R(a,b)^T S_a;  S_b = Dinv(b)^T R[b, mine]
+//                                  after the strip's all-gather: HEAD = K = 2nb update of the rows of strip t+1
+//   msg stream / comm2             the small broadcasts
+//   comm stream / comm             all-gather of the solved strip (feeds HEAD and the bulk)
+//   main stream                    bulk K = 2nb update of my columns, rows below strip t+1, upper staircase only,
+//                                  A operand read straight out of the gathered pieces (no repacking); split into
+//                                  the rows of strip t+2 (signals the panel stream early: look-ahead depth 2) + rest
+// so the bulk update of strip t overlaps with factorization + communication of strips t+1 and t+2.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -28,47 +38,86 @@ int cap_rec_cholinv_full(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_
 int64_t cap_rec_work_size(int64_t n);
 
 struct cap_dist_plan {
-  int64_t n, nb, nblk;
+  int64_t n, npad, nb, nblk;
   int P, p;
-  cap_comm* comm;
-  int64_t nloc_blocks, lc;       // local blocks / columns
+  cap_comm* comm;                // all-gathers (not owned)
+  cap_comm* comm2;               // small broadcasts (owned duplicate)
+  int64_t nloc_blocks, lc;       // local blocks / padded local columns
+  int64_t lc_valid;              // local columns that exist in the n x n matrix
   int64_t nmax0;                 // widest gathered piece (columns)
-  double* R;                     // n x lc
-  double* S[2];                  // my solved block row (nb x cols, ld = nb)
-  double* G[2];                  // gathered block row: P pieces
-  double* msg[2];                // [R(k-1,k) | Dinv(k)], 2 nb^2
+  double* R; int64_t ld;         // npad x lc
+  double* S[2];                  // my solved strip (q nb x cols, ld = q nb)
+  double* G[2];                  // gathered strip: P pieces
+  double* msg[4];                // [R(k-1,k) | Dinv(k)], 2 nb^2 each, ring over block rows
   double* W; int64_t wcap;       // recursion scratch
   int* info_dev; double* info_red;
-  hipStream_t s_panel, s_comm;
-  std::vector<hipEvent_t> ev_msg, ev_solved, ev_gather, ev_update, ev_fact;
-  hipEvent_t ev_init, ev_join_p, ev_join_c;
+  hipStream_t s_panel, s_comm, s_msg;
+  std::vector<hipEvent_t> ev_fact, ev_msg, ev_rowdone;             // per block row
+  std::vector<hipEvent_t> ev_solved, ev_gather, ev_head2, ev_rest; // per strip
+  hipEvent_t ev_init, ev_join_p, ev_join_c, ev_join_m;
+  // schedule knobs
+  int strip;                     // block rows per strip (1 or 2)
+  int depth2;                    // split the bulk update (look-ahead depth 2)
+  // stress testing: random spin kernels in front of every launch group (exposes missing event edges)
+  uint64_t jitter_state; int jitter_max_us;
+  // live profile of the bulk update (HIP events on its stream)
+  int profile; std::vector<hipEvent_t> prof_ev; std::vector<double> prof_flops; int prof_used;
 };
 
 namespace {
 __host__ __device__ inline int64_t lbfirst(int64_t r, int64_t k, int64_t P) { return k >= r ? (k - r) / P + 1 : 0; }  // blocks J <= k owned by r
 __host__ __device__ inline int64_t nblocks_of(int64_t r, int64_t nblk, int64_t P) { return r < nblk ? (nblk - 1 - r) / P + 1 : 0; }
 
-__global__ void fill_symmetric_bc_kernel(double* out, int64_t ld, int64_t n, int64_t nb, int P, int p, int dom) {
+__global__ void fill_symmetric_bc_kernel(double* out, int64_t ld, int64_t n, int64_t nb, int P, int p, int dom, int64_t lc_valid) {
   // same closed form as fill_symmetric_kernel (aux.hip), local column -> global column through the block-cyclic map
   int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t lcol = blockIdx.y + (int64_t)blockIdx.z * 65535;
-  int64_t nblk = (n + nb - 1) / nb;
-  int64_t nl = nblocks_of(p, nblk, P);
-  if (row >= n || lcol >= nl * nb) return;
+  if (row >= n || lcol >= lc_valid) return;
   int64_t gcol = ((lcol / nb) * P + p) * nb + lcol % nb;
-  double v = 0.0;
-  if (gcol < n) {
-    int64_t hi = gcol > row ? gcol : row, lo = gcol > row ? row : gcol;
-    uint64_t seed = (uint64_t)(hi + n * lo);
-    uint64_t x0 = ((seed & 0xFFFFFFFFull) << 16) | 0x330Eull;
-    uint64_t x1 = (0x5DEECE66Dull * x0 + 0xBull) & ((1ull << 48) - 1);
-    v = (double)x1 * (1.0 / 281474976710656.0);
-    if (dom && gcol == row) v += (double)n;
-  }
+  int64_t hi = gcol > row ? gcol : row, lo = gcol > row ? row : gcol;
+  uint64_t seed = (uint64_t)(hi + n * lo);
+  uint64_t x0 = ((seed & 0xFFFFFFFFull) << 16) | 0x330Eull;
+  uint64_t x1 = (0x5DEECE66Dull * x0 + 0xBull) & ((1ull << 48) - 1);
+  double v = (double)x1 * (1.0 / 281474976710656.0);
+  if (dom && gcol == row) v += (double)n;
   out[row + lcol * ld] = v;
 }
 
+// identity tail of the padded matrix: entries with row >= n or global column >= n become (row == gcol)
+__global__ void pad_identity_kernel(double* R, int64_t ld, int64_t n, int64_t npad, int64_t nb, int P, int p, int64_t row0,
+                                    int64_t col0, int64_t rows, int64_t cols) {
+  int64_t row = row0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t lcol = col0 + blockIdx.y;
+  if (row >= row0 + rows || lcol >= col0 + cols) return;
+  int64_t gcol = ((lcol / nb) * P + p) * nb + lcol % nb;
+  if (row >= n || gcol >= n) R[row + lcol * ld] = (row == gcol) ? 1.0 : 0.0;
+}
+
+// construct_R for the block-cyclic layout: copy my valid columns, zero below the GLOBAL diagonal
+__global__ void export_upper_bc_kernel(const double* R, int64_t ld, double* out, int64_t ldo, int64_t n, int64_t nb, int P, int p,
+                                       int64_t lc_valid) {
+  int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t lcol = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (row >= n || lcol >= lc_valid) return;
+  int64_t gcol = ((lcol / nb) * P + p) * nb + lcol % nb;
+  out[row + lcol * ldo] = row <= gcol ? R[row + lcol * ld] : 0.0;
+}
+
 __global__ void info_to_double(const int* info, double* out) { *out = (double)*info; }
+
+// busy-wait for about `us` microseconds (wall_clock64 ticks at 100 MHz)
+__global__ void spin_kernel(int us) {
+  const uint64_t t0 = wall_clock64();
+  while (wall_clock64() - t0 < (uint64_t)us * 100ull) __builtin_amdgcn_s_sleep(32);
+}
+
+int jitter(cap_dist_plan* d, hipStream_t s) {
+  if (d->jitter_max_us <= 0) return CAP_OK;
+  d->jitter_state = d->jitter_state * 6364136223846793005ull + 1442695040888963407ull;
+  const int us = (int)((d->jitter_state >> 33) % (uint64_t)(d->jitter_max_us + 1));
+  if (us > 0) { hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, us); CAP_HIP(hipGetLastError()); }
+  return CAP_OK;
+}
 
 int ensure_events(cap_dist_plan* d) {
   if (!d->ev_msg.empty()) return CAP_OK;
@@ -78,15 +127,45 @@ int ensure_events(cap_dist_plan* d) {
     return CAP_OK;
   };
   size_t cnt = (size_t)d->nblk + 2;
-  CAP_TRY(mk(d->ev_msg, cnt)); CAP_TRY(mk(d->ev_solved, cnt)); CAP_TRY(mk(d->ev_gather, cnt));
-  CAP_TRY(mk(d->ev_update, cnt)); CAP_TRY(mk(d->ev_fact, cnt));
+  CAP_TRY(mk(d->ev_fact, cnt)); CAP_TRY(mk(d->ev_msg, cnt)); CAP_TRY(mk(d->ev_rowdone, cnt));
+  CAP_TRY(mk(d->ev_solved, cnt)); CAP_TRY(mk(d->ev_gather, cnt)); CAP_TRY(mk(d->ev_head2, cnt)); CAP_TRY(mk(d->ev_rest, cnt));
   CAP_HIP(hipEventCreateWithFlags(&d->ev_init, hipEventDisableTiming));
   CAP_HIP(hipEventCreateWithFlags(&d->ev_join_p, hipEventDisableTiming));
   CAP_HIP(hipEventCreateWithFlags(&d->ev_join_c, hipEventDisableTiming));
+  CAP_HIP(hipEventCreateWithFlags(&d->ev_join_m, hipEventDisableTiming));
   int lo = 0, hi = 0;
   CAP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
   CAP_HIP(hipStreamCreateWithPriority(&d->s_panel, hipStreamNonBlocking, hi));
   CAP_HIP(hipStreamCreateWithPriority(&d->s_comm, hipStreamNonBlocking, hi));
+  CAP_HIP(hipStreamCreateWithPriority(&d->s_msg, hipStreamNonBlocking, hi));
+  return CAP_OK;
+}
+
+// bulk / head update launch, optionally bracketed by profiling events
+int update(cap_dist_plan* d, int64_t m, int64_t nloc, int64_t K, const double* G, int64_t piece, const int* gstart, const double* B,
+           double* C, int64_t J0, int64_t lb0, hipStream_t s, bool prof) {
+  if (m <= 0 || nloc <= 0) return CAP_OK;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (prof && d->profile) {
+    if ((size_t)d->prof_used + 2 > d->prof_ev.size())
+      for (int i = 0; i < 64; i++) { hipEvent_t e; CAP_HIP(hipEventCreate(&e)); d->prof_ev.push_back(e); }
+    e0 = d->prof_ev[d->prof_used]; e1 = d->prof_ev[d->prof_used + 1];
+    CAP_HIP(hipEventRecord(e0, s));
+  }
+  CAP_TRY(cap_dist_update_launch(m, nloc, K, G, piece, gstart, B, C, d->ld, d->P, d->p, (int)d->nb, (int)J0, (int)lb0, s));
+  if (e0) {
+    CAP_HIP(hipEventRecord(e1, s));
+    d->prof_used += 2;
+    // algorithmic flops: 2K per element of my part of the upper staircase
+    double elems = 0;
+    for (int64_t lb = lb0; lb < d->nloc_blocks; lb++) {
+      const int64_t J = lb * d->P + d->p;
+      const int64_t rows_above = std::min<int64_t>(m, (J - J0) * d->nb);   // full rows above the diagonal block
+      elems += (double)rows_above * d->nb;
+      if ((J - J0) * d->nb < m) elems += 0.5 * (double)d->nb * (d->nb + 1);
+    }
+    d->prof_flops.push_back(2.0 * (double)K * elems);
+  }
   return CAP_OK;
 }
 }  // namespace
@@ -95,9 +174,15 @@ extern "C" {
 
 int cap_bc_owner(int64_t J, int P) { return (int)(J % P); }
 int64_t cap_bc_local_block(int64_t J, int P) { return J / P; }
+// columns of the n x n matrix stored on rank p (the last block may be partial)
 int64_t cap_bc_num_local_cols(int64_t n, int64_t nb, int P, int p) {
   int64_t nblk = (n + nb - 1) / nb;
-  return nblocks_of(p, nblk, P) * nb;
+  int64_t nl = nblocks_of(p, nblk, P);
+  if (nl == 0) return 0;
+  int64_t cols = nl * nb;
+  const int64_t last = nblk - 1;
+  if (last % P == p) cols -= nblk * nb - n;
+  return cols;
 }
 
 int cap_fill_symmetric_bc(double* local, int64_t ld, int64_t n, int64_t nb, int P, int p, int diagonally_dominant, void* stream) {
@@ -105,7 +190,7 @@ int cap_fill_symmetric_bc(double* local, int64_t ld, int64_t n, int64_t nb, int 
   int64_t lc = cap_bc_num_local_cols(n, nb, P, p);
   if (lc == 0) return CAP_OK;
   dim3 grid((unsigned)cap_ceil_div(n, 256), (unsigned)std::min<int64_t>(lc, 65535), (unsigned)cap_ceil_div(lc, 65535));
-  hipLaunchKernelGGL(fill_symmetric_bc_kernel, grid, dim3(256), 0, cap_stream(stream), local, ld, n, nb, P, p, diagonally_dominant);
+  hipLaunchKernelGGL(fill_symmetric_bc_kernel, grid, dim3(256), 0, cap_stream(stream), local, ld, n, nb, P, p, diagonally_dominant, lc);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
@@ -113,29 +198,41 @@ int cap_fill_symmetric_bc(double* local, int64_t ld, int64_t n, int64_t nb, int 
 int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* comm) {
   if (!plan || n <= 0) return CAP_ERR_ARG;
   if (nb <= 0) nb = 512;
-  if (nb % 128 || n % nb) return CAP_ERR_UNSUPPORTED;      // block width: multiple of the 128 MFMA tile, N divisible
+  if (nb % 128) return CAP_ERR_UNSUPPORTED;                // block width: multiple of the 128 MFMA tile
   cap_dist_plan* d = new (std::nothrow) cap_dist_plan();
   if (!d) return CAP_ERR_ALLOC;
-  d->n = n; d->nb = nb; d->nblk = n / nb; d->comm = comm;
+  d->n = n; d->nb = nb; d->nblk = cap_ceil_div(n, nb); d->npad = d->nblk * nb; d->comm = comm; d->comm2 = nullptr;
   d->P = cap_comm_size(comm); d->p = cap_comm_rank(comm);
-  if (d->P > 8) { delete d; return CAP_ERR_UNSUPPORTED; }
+  if (d->P > 8) { delete d; return CAP_ERR_UNSUPPORTED; }  // one xGMI node; the update kernel carries 8 piece offsets
   d->nloc_blocks = nblocks_of(d->p, d->nblk, d->P); d->lc = d->nloc_blocks * nb;
+  d->lc_valid = cap_bc_num_local_cols(n, nb, d->P, d->p);
   d->nmax0 = nblocks_of(0, d->nblk, d->P) * nb;            // rank 0 owns the most blocks
+  d->ld = d->npad;
   d->R = nullptr; d->W = nullptr; d->info_dev = nullptr; d->info_red = nullptr;
-  for (int i = 0; i < 2; i++) { d->S[i] = d->G[i] = d->msg[i] = nullptr; }
-  d->s_panel = d->s_comm = nullptr;
+  for (int i = 0; i < 2; i++) d->S[i] = d->G[i] = nullptr;
+  for (int i = 0; i < 4; i++) d->msg[i] = nullptr;
+  d->s_panel = d->s_comm = d->s_msg = nullptr;
+  d->strip = d->nblk >= 8 ? 2 : 1; d->depth2 = 1;
+  d->jitter_state = 0x9E3779B97F4A7C15ull * (uint64_t)(d->p + 1); d->jitter_max_us = 0;
+  d->profile = 0; d->prof_used = 0;
   d->wcap = cap_rec_work_size(nb);
-  hipError_t e = hipMalloc((void**)&d->R, sizeof(double) * std::max<int64_t>(n * d->lc, 2));
+  if (cap_comm_size(comm) > 1 || cap_comm_backend(comm) != 0) {
+    int st = cap_comm_dup(comm, &d->comm2);
+    if (st != CAP_OK) { delete d; return st; }
+  }
+  hipError_t e = hipMalloc((void**)&d->R, sizeof(double) * std::max<int64_t>(d->npad * d->lc, 2));
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
-    e = hipMalloc((void**)&d->S[i], sizeof(double) * nb * d->nmax0);
-    if (e == hipSuccess) e = hipMalloc((void**)&d->G[i], sizeof(double) * nb * d->nmax0 * d->P);
-    if (e == hipSuccess) e = hipMalloc((void**)&d->msg[i], sizeof(double) * 2 * nb * nb);
+    e = hipMalloc((void**)&d->S[i], sizeof(double) * 2 * nb * d->nmax0);
+    if (e == hipSuccess) e = hipMalloc((void**)&d->G[i], sizeof(double) * 2 * nb * d->nmax0 * d->P);
+    if (e == hipSuccess) e = hipMemset(d->S[i], 0, sizeof(double) * 2 * nb * d->nmax0);
+  }
+  for (int i = 0; i < 4 && e == hipSuccess; i++) {
+    e = hipMalloc((void**)&d->msg[i], sizeof(double) * 2 * nb * nb);
     if (e == hipSuccess) e = hipMemset(d->msg[i], 0, sizeof(double) * 2 * nb * nb);
-    if (e == hipSuccess) e = hipMemset(d->S[i], 0, sizeof(double) * nb * d->nmax0);
   }
   if (e == hipSuccess) e = hipMalloc((void**)&d->W, sizeof(double) * d->wcap);
   if (e == hipSuccess) e = hipMalloc((void**)&d->info_dev, sizeof(int));
-  if (e == hipSuccess) e = hipMalloc((void**)&d->info_red, sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&d->info_red, sizeof(double) * (d->P + 1));
   if (e != hipSuccess) { cap_dist_plan_destroy(d); return CAP_ERR_ALLOC; }
   *plan = d;
   return CAP_OK;
@@ -144,128 +241,231 @@ int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* 
 int cap_dist_plan_destroy(cap_dist_plan* d) {
   if (!d) return CAP_OK;
   if (d->R) (void)hipFree(d->R);
-  for (int i = 0; i < 2; i++) { if (d->S[i]) (void)hipFree(d->S[i]); if (d->G[i]) (void)hipFree(d->G[i]); if (d->msg[i]) (void)hipFree(d->msg[i]); }
+  for (int i = 0; i < 2; i++) { if (d->S[i]) (void)hipFree(d->S[i]); if (d->G[i]) (void)hipFree(d->G[i]); }
+  for (int i = 0; i < 4; i++) if (d->msg[i]) (void)hipFree(d->msg[i]);
   if (d->W) (void)hipFree(d->W);
   if (d->info_dev) (void)hipFree(d->info_dev);
   if (d->info_red) (void)hipFree(d->info_red);
   if (!d->ev_msg.empty()) {
-    for (auto* v : {&d->ev_msg, &d->ev_solved, &d->ev_gather, &d->ev_update, &d->ev_fact}) for (auto e : *v) (void)hipEventDestroy(e);
+    for (auto* v : {&d->ev_fact, &d->ev_msg, &d->ev_rowdone, &d->ev_solved, &d->ev_gather, &d->ev_head2, &d->ev_rest})
+      for (auto e : *v) (void)hipEventDestroy(e);
     (void)hipEventDestroy(d->ev_init); (void)hipEventDestroy(d->ev_join_p); (void)hipEventDestroy(d->ev_join_c);
-    (void)hipStreamDestroy(d->s_panel); (void)hipStreamDestroy(d->s_comm);
+    (void)hipEventDestroy(d->ev_join_m);
+    (void)hipStreamDestroy(d->s_panel); (void)hipStreamDestroy(d->s_comm); (void)hipStreamDestroy(d->s_msg);
   }
+  for (hipEvent_t e : d->prof_ev) (void)hipEventDestroy(e);
+  if (d->comm2) cap_comm_destroy(d->comm2);
   delete d;
   return CAP_OK;
 }
 
-int64_t cap_dist_local_cols(const cap_dist_plan* d) { return d ? d->lc : 0; }
-double* cap_dist_R_ptr(cap_dist_plan* d, int64_t* ld) { if (!d) return nullptr; if (ld) *ld = d->n; return d->R; }
+int cap_dist_set_option(cap_dist_plan* d, const char* key, int64_t value) {
+  if (!d || !key) return CAP_ERR_ARG;
+  std::string k(key);
+  if (k == "strip") { if (value < 1 || value > 2) return CAP_ERR_ARG; d->strip = (int)value; return CAP_OK; }
+  if (k == "depth2") { d->depth2 = value != 0; return CAP_OK; }
+  if (k == "jitter_us") { if (value < 0 || value > 100000) return CAP_ERR_ARG; d->jitter_max_us = (int)value; return CAP_OK; }
+  if (k == "jitter_seed") { d->jitter_state = 0x9E3779B97F4A7C15ull * (uint64_t)(value + 1) + (uint64_t)d->p; return CAP_OK; }
+  if (k == "profile") { d->profile = value != 0; return CAP_OK; }
+  return CAP_ERR_ARG;
+}
+
+int64_t cap_dist_get_option(const cap_dist_plan* d, const char* key) {
+  if (!d || !key) return -1;
+  std::string k(key);
+  if (k == "strip") return d->strip;
+  if (k == "depth2") return d->depth2;
+  if (k == "jitter_us") return d->jitter_max_us;
+  if (k == "nb") return d->nb;
+  if (k == "n") return d->n;
+  if (k == "npad") return d->npad;
+  if (k == "P") return d->P;
+  if (k == "p") return d->p;
+  return -1;
+}
+
+int64_t cap_dist_local_cols(const cap_dist_plan* d) { return d ? d->lc_valid : 0; }
+double* cap_dist_R_ptr(cap_dist_plan* d, int64_t* ld) { if (!d) return nullptr; if (ld) *ld = d->ld; return d->R; }
 
 int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* stream) {
-  if (!d || (d->lc > 0 && (!Aloc || lda < d->n))) return CAP_ERR_ARG;
+  if (!d || (d->lc_valid > 0 && (!Aloc || lda < d->n))) return CAP_ERR_ARG;
   CAP_TRY(ensure_events(d));
-  hipStream_t s0 = cap_stream(stream), s1 = d->s_panel, sc = d->s_comm;
-  const int64_t n = d->n, nb = d->nb, nblk = d->nblk, P = d->P, p = d->p, ld = n;
+  hipStream_t s0 = cap_stream(stream), s1 = d->s_panel, sc = d->s_comm, sm = d->s_msg;
+  const int64_t n = d->n, npad = d->npad, nb = d->nb, nblk = d->nblk, P = d->P, p = d->p, ld = d->ld;
   const int64_t nb2 = nb * nb;
+  d->prof_used = 0; d->prof_flops.clear();
   CAP_HIP(hipMemsetAsync(d->info_dev, 0, sizeof(int), s0));
-  if (d->lc > 0) CAP_TRY(cap_copy_rect(Aloc, lda, d->R, ld, n, d->lc, s0));
+  if (d->lc_valid > 0) CAP_TRY(cap_copy_rect(Aloc, lda, d->R, ld, n, d->lc_valid, s0));
+  if (npad != n && d->lc > 0) {
+    // rows [n, npad) of every local column, and the padding columns of the last block on its owner
+    hipLaunchKernelGGL(pad_identity_kernel, dim3((unsigned)cap_ceil_div(npad - n, 256), (unsigned)d->lc), dim3(256), 0, s0, d->R, ld, n,
+                       npad, nb, (int)P, (int)p, n, (int64_t)0, npad - n, d->lc);
+    if (d->lc > d->lc_valid)
+      hipLaunchKernelGGL(pad_identity_kernel, dim3((unsigned)cap_ceil_div(npad, 256), (unsigned)(d->lc - d->lc_valid)), dim3(256), 0, s0,
+                         d->R, ld, n, npad, nb, (int)P, (int)p, (int64_t)0, d->lc_valid, npad, d->lc - d->lc_valid);
+    CAP_HIP(hipGetLastError());
+  }
   CAP_HIP(hipEventRecord(d->ev_init, s0));
   CAP_HIP(hipStreamWaitEvent(s1, d->ev_init, 0));
   CAP_HIP(hipStreamWaitEvent(sc, d->ev_init, 0));
+  CAP_HIP(hipStreamWaitEvent(sm, d->ev_init, 0));
 
-  // diagonal block 0 on its owner, then msg(0) = [ - | Dinv(0) ]
-  if (p == 0) {
-    CAP_TRY(cap_rec_cholinv_full(d->R, ld, d->msg[0] + nb2, nb, nb, d->W, d->wcap, d->info_dev, s1, 0));
-    CAP_HIP(hipEventRecord(d->ev_fact[0], s1));
-    CAP_HIP(hipStreamWaitEvent(sc, d->ev_fact[0], 0));
-  }
-  CAP_TRY(cap_comm_bcast(d->comm, d->msg[0], 2 * nb2, 0, (void*)sc));
-  CAP_HIP(hipEventRecord(d->ev_msg[0], sc));
+  // strips: sb[t] = first block row, sq[t] = block rows (d->strip, the last one may be shorter)
+  std::vector<int64_t> sb, sq;
+  for (int64_t k = 0; k < nblk; k += d->strip) { sb.push_back(k); sq.push_back(std::min<int64_t>(d->strip, nblk - k)); }
+  const int64_t nstrips = (int64_t)sb.size();
 
-  for (int64_t k = 0; k < nblk; k++) {
-    const int par = (int)(k & 1);
-    const int64_t lb0 = lbfirst(p, k, P);                       // my first local block with J > k
-    const int64_t nloc_k = (d->nloc_blocks - lb0) * nb;          // my columns right of block column k
-    int64_t nmax_k = 0;
-    for (int64_t r = 0; r < P; r++) nmax_k = std::max(nmax_k, (nblocks_of(r, nblk, P) - lbfirst(r, k, P)) * nb);
-    const int64_t piece = nb * nmax_k;
-    double* Dinv = d->msg[par] + nb2;
+  for (int64_t t = 0; t < nstrips; t++) {
+    const int par = (int)(t & 1);
+    const int64_t a = sb[t], q = sq[t], b = a + q - 1, e = b + 1;
+    const int64_t ldS = q * nb;
+    const int64_t lbS = lbfirst(p, a, P);                        // my first local block with J > a: column origin of S[par]
+    double* S = d->S[par];
 
-    // ---- panel: solve my part of block row k:  S = Dinv(k)^T * R[k, mine]
-    CAP_HIP(hipStreamWaitEvent(s1, d->ev_msg[k], 0));
-    if (nloc_k > 0) {
-      if (k >= 2) CAP_HIP(hipStreamWaitEvent(s1, d->ev_gather[k - 2], 0));   // S[par] was the all-gather source of step k-2
-      double* Rrow = d->R + k * nb + lb0 * nb * ld;
-      CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, nloc_k, nb, 1.0, Dinv, nb, Rrow, ld, 0.0, d->S[par], nb, 0, s1, 2 | 16));
-      CAP_TRY(cap_copy_rect(d->S[par], nb, Rrow, ld, nb, nloc_k, s1));
-    }
-    CAP_HIP(hipEventRecord(d->ev_solved[k], s1));
-
-    // ---- comm: all-gather block row k (equal-sized padded pieces)
-    if (nmax_k > 0) {
-      CAP_HIP(hipStreamWaitEvent(sc, d->ev_solved[k], 0));
-      if (k >= 2) CAP_HIP(hipStreamWaitEvent(sc, d->ev_update[k - 2], 0));   // G[par] was read by the bulk update of step k-2
-      CAP_TRY(cap_comm_allgather(d->comm, d->S[par], d->G[par], piece, (void*)sc));
-    }
-    CAP_HIP(hipEventRecord(d->ev_gather[k], sc));
-
-    if (k + 1 < nblk) {
-      const int q = (int)((k + 1) % P);
-      double* msg1 = d->msg[par ^ 1];
-      // ---- panel, owner of block column k+1: bring its diagonal block up to date, factor + invert it
-      if (p == q) {
-        const int64_t lbq = (k + 1) / P;                           // == lb0 on this rank
-        double* D = d->R + (k + 1) * nb + lbq * nb * ld;
-        if (k >= 1) CAP_HIP(hipStreamWaitEvent(s1, d->ev_update[k - 1], 0));
-        CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, nb, nb, -1.0, d->S[par], nb, d->S[par], nb, 1.0, D, ld, 1, s1));
-        CAP_TRY(cap_rec_cholinv_full(D, ld, msg1 + nb2, nb, nb, d->W, d->wcap, d->info_dev, s1, (k + 1) * nb));
-        CAP_TRY(cap_copy_rect(d->S[par], nb, msg1, nb, nb, nb, s1));   // R(k,k+1) rides along
-        CAP_HIP(hipEventRecord(d->ev_fact[k + 1], s1));
-        CAP_HIP(hipStreamWaitEvent(sc, d->ev_fact[k + 1], 0));
+    for (int64_t r = 0; r < q; r++) {
+      const int64_t k = a + r;
+      const int owner = (int)(k % P);
+      double* mb = d->msg[k & 3];
+      double* Dinv = mb + nb2;
+      // ---- panel, owner of block column k: finish its diagonal block, factor + invert it
+      if (p == owner) {
+        double* D = d->R + k * nb + (k / P) * nb * ld;
+        CAP_TRY(jitter(d, s1));
+        if (r == 1) {
+          // in-strip: D(b) -= S_a(:, blk b)^T S_a(:, blk b); block b is my first column block of S
+          const double* Sab = S + (k / P - lbS) * nb * ldS;
+          CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, nb, nb, -1.0, Sab, ldS, Sab, ldS, 1.0, D, ld, 1, s1, 2));
+        }
+        CAP_TRY(cap_rec_cholinv_full(D, ld, Dinv, nb, nb, d->W, d->wcap, d->info_dev, s1, k * nb));
+        if (r == 1) CAP_TRY(cap_copy_rect(S + (k / P - lbS) * nb * ldS, ldS, mb, nb, nb, nb, s1));   // R(a,b) rides along
+        CAP_HIP(hipEventRecord(d->ev_fact[k], s1));
+        CAP_HIP(hipStreamWaitEvent(sm, d->ev_fact[k], 0));
+      } else if (k >= 4) {
+        CAP_HIP(hipStreamWaitEvent(sm, d->ev_rowdone[k - 4], 0));   // the broadcast overwrites the buffer block row k-4 read
       }
-      // ---- comm: msg(k+1) = [ R(k,k+1) | Dinv(k+1) ] from the owner
-      CAP_TRY(cap_comm_bcast(d->comm, msg1, 2 * nb2, q, (void*)sc));
-      CAP_HIP(hipEventRecord(d->ev_msg[k + 1], sc));
+      // ---- msg: msg(k) = [ R(k-1,k) | Dinv(k) ] from the owner, on the small-message communicator
+      CAP_TRY(jitter(d, sm));
+      CAP_TRY(cap_comm_bcast(d->comm2, mb, 2 * nb2, owner, (void*)sm));
+      CAP_HIP(hipEventRecord(d->ev_msg[k], sm));
 
-      // ---- panel: look-ahead - apply step k to my part of block row k+1 (columns J > k+1)
-      const int64_t lb1 = lbfirst(p, k + 1, P);
-      const int64_t nloc_1 = (d->nloc_blocks - lb1) * nb;
-      if (nloc_1 > 0) {
-        CAP_HIP(hipStreamWaitEvent(s1, d->ev_msg[k + 1], 0));
-        if (k >= 1) CAP_HIP(hipStreamWaitEvent(s1, d->ev_update[k - 1], 0));
-        CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, nloc_1, nb, -1.0, msg1, nb, d->S[par] + (lb1 - lb0) * nb2, nb, 1.0,
-                                d->R + (k + 1) * nb + lb1 * nb * ld, ld, 0, s1));
+      // ---- panel, every rank: block row k of my columns J > k
+      CAP_HIP(hipStreamWaitEvent(s1, d->ev_msg[k], 0));
+      if (r == 0 && t >= 2) CAP_HIP(hipStreamWaitEvent(s1, d->ev_gather[t - 2], 0));   // S[par] was the all-gather source of strip t-2
+      const int64_t lbk = lbfirst(p, k, P);
+      const int64_t ncols = (d->nloc_blocks - lbk) * nb;
+      if (ncols > 0) {
+        CAP_TRY(jitter(d, s1));
+        double* Rrow = d->R + k * nb + lbk * nb * ld;
+        double* Scol = S + (lbk - lbS) * nb * ldS;                // my columns J > k inside the strip buffer
+        if (r == 1)   // in-strip update: R[b, mine] -= R(a,b)^T S_a(:, mine)
+          CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, ncols, nb, -1.0, mb, nb, Scol, ldS, 1.0, Rrow, ld, 0, s1, 2));
+        // S_k = Dinv(k)^T R[k, mine]  (TRSM by the inverse, cholinv.hpp:118-121), then back into R
+        CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, ncols, nb, 1.0, Dinv, nb, Rrow, ld, 0.0, Scol + r * nb, ldS, 0, s1, 2 | 16));
+        CAP_TRY(cap_copy_rect(Scol + r * nb, ldS, Rrow, ld, nb, ncols, s1));
       }
-
-      // ---- main: bulk update of my columns J >= k+2, rows >= (k+2) nb, upper staircase
-      const int64_t m2 = n - (k + 2) * nb;
-      if (m2 > 0 && nloc_1 > 0) {
-        int gstart[8];
-        for (int64_t r = 0; r < 8; r++) gstart[r] = r < P ? (int)lbfirst(r, k, P) : 0;
-        CAP_HIP(hipStreamWaitEvent(s0, d->ev_gather[k], 0));
-        CAP_TRY(cap_dist_update_launch(m2, nloc_1, nb, d->G[par], piece, gstart, d->G[par] + p * piece + (lb1 - lb0) * nb2,
-                                       d->R + (k + 2) * nb + lb1 * nb * ld, ld, (int)P, (int)p, (int)nb, (int)(k + 2), (int)lb1, s0));
-      }
+      CAP_HIP(hipEventRecord(d->ev_rowdone[k], s1));
     }
-    CAP_HIP(hipEventRecord(d->ev_update[k], s0));
+    CAP_HIP(hipEventRecord(d->ev_solved[t], s1));
+    if (e >= nblk) continue;
+
+    // ---- comm: all-gather the strip's columns J > b (equal-sized padded pieces)
+    int gstart[8];
+    int64_t nmax = 0;
+    for (int64_t r = 0; r < 8; r++) gstart[r] = r < P ? (int)lbfirst(r, b, P) : 0;
+    for (int64_t r = 0; r < P; r++) nmax = std::max(nmax, (nblocks_of(r, nblk, P) - lbfirst(r, b, P)) * nb);
+    const int64_t piece = ldS * nmax;
+    const int64_t lbe = lbfirst(p, b, P);                        // my first local block with J >= e
+    double* G = d->G[par];
+    CAP_HIP(hipStreamWaitEvent(sc, d->ev_solved[t], 0));
+    if (t >= 2) CAP_HIP(hipStreamWaitEvent(sc, d->ev_rest[t - 2], 0));   // G[par] was read by the bulk update of strip t-2
+    CAP_TRY(jitter(d, sc));
+    CAP_TRY(cap_comm_allgather(d->comm, S + (lbe - lbS) * nb * ldS, G, piece, (void*)sc));
+    CAP_HIP(hipEventRecord(d->ev_gather[t], sc));
+
+    // ---- panel: HEAD - bring the rows of strip t+1 up to date with strip t (my columns J >= e)
+    const int64_t q1 = sq[t + 1], e2 = e + q1;
+    const int64_t ncols_e = (d->nloc_blocks - lbe) * nb;
+    CAP_HIP(hipStreamWaitEvent(s1, d->ev_gather[t], 0));
+    if (t >= 1) CAP_HIP(hipStreamWaitEvent(s1, d->ev_head2[t - 1], 0));   // strip t-1's bulk update has passed these rows
+    CAP_TRY(jitter(d, s1));
+    CAP_TRY(update(d, q1 * nb, ncols_e, ldS, G, piece, gstart, G + p * piece, d->R + e * nb + lbe * nb * ld, e, lbe, s1, false));
+
+    // ---- main: bulk update of the rows below strip t+1 (my columns J >= e2), upper staircase
+    CAP_HIP(hipStreamWaitEvent(s0, d->ev_gather[t], 0));
+    if (e2 < nblk) {
+      const int64_t lbe2 = lbfirst(p, e2 - 1, P);
+      const int64_t ncols_e2 = (d->nloc_blocks - lbe2) * nb;
+      const double* B2 = G + p * piece + (lbe2 - lbe) * nb * ldS;
+      const int64_t q2 = (t + 2 < nstrips) ? sq[t + 2] : 0, e3 = e2 + q2;
+      CAP_TRY(jitter(d, s0));
+      if (d->depth2 && q2 > 0 && e3 < nblk) {
+        // head of the bulk: the rows of strip t+2 first, then release the panel stream (look-ahead depth 2)
+        CAP_TRY(update(d, q2 * nb, ncols_e2, ldS, G, piece, gstart, B2, d->R + e2 * nb + lbe2 * nb * ld, e2, lbe2, s0, true));
+        CAP_HIP(hipEventRecord(d->ev_head2[t], s0));
+        const int64_t lbe3 = lbfirst(p, e3 - 1, P);
+        const int64_t ncols_e3 = (d->nloc_blocks - lbe3) * nb;
+        CAP_TRY(jitter(d, s0));
+        CAP_TRY(update(d, npad - e3 * nb, ncols_e3, ldS, G, piece, gstart, G + p * piece + (lbe3 - lbe) * nb * ldS,
+                       d->R + e3 * nb + lbe3 * nb * ld, e3, lbe3, s0, true));
+      } else {
+        CAP_TRY(update(d, npad - e2 * nb, ncols_e2, ldS, G, piece, gstart, B2, d->R + e2 * nb + lbe2 * nb * ld, e2, lbe2, s0, true));
+        CAP_HIP(hipEventRecord(d->ev_head2[t], s0));
+      }
+    } else {
+      CAP_HIP(hipEventRecord(d->ev_head2[t], s0));
+    }
+    CAP_HIP(hipEventRecord(d->ev_rest[t], s0));
   }
   // join the helper streams back into the caller's stream
   CAP_HIP(hipEventRecord(d->ev_join_p, s1));
   CAP_HIP(hipEventRecord(d->ev_join_c, sc));
+  CAP_HIP(hipEventRecord(d->ev_join_m, sm));
   CAP_HIP(hipStreamWaitEvent(s0, d->ev_join_p, 0));
   CAP_HIP(hipStreamWaitEvent(s0, d->ev_join_c, 0));
+  CAP_HIP(hipStreamWaitEvent(s0, d->ev_join_m, 0));
   return CAP_OK;
 }
 
+// construct_R (cholinv.hpp:30-37) for this layout: my columns of R (n x local_cols), zero below the global diagonal
+int cap_dist_get_R(cap_dist_plan* d, double* out, int64_t ldo, void* stream) {
+  if (!d || (d->lc_valid > 0 && (!out || ldo < d->n))) return CAP_ERR_ARG;
+  if (d->lc_valid == 0) return CAP_OK;
+  dim3 grid((unsigned)cap_ceil_div(d->n, 256), (unsigned)std::min<int64_t>(d->lc_valid, 65535), (unsigned)cap_ceil_div(d->lc_valid, 65535));
+  hipLaunchKernelGGL(export_upper_bc_kernel, grid, dim3(256), 0, cap_stream(stream), d->R, d->ld, out, ldo, d->n, d->nb, d->P, d->p,
+                     d->lc_valid);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+// Agreed on all ranks: 0, or the smallest 1-based failing pivot index any owner reported.  Collective on the
+// plan's communicator: call it on the stream cap_dist_factor was given (or after synchronising it).
 int cap_dist_info(cap_dist_plan* d, void* stream, int64_t* info) {
   if (!d || !info) return CAP_ERR_ARG;
   hipStream_t s = cap_stream(stream);
-  hipLaunchKernelGGL(info_to_double, dim3(1), dim3(1), 0, s, d->info_dev, d->info_red);
-  CAP_TRY(cap_comm_allreduce_sum(d->comm, d->info_red, 1, stream));   // only a diagonal block's owner sets info
-  double h = 0;
-  CAP_HIP(hipMemcpyAsync(&h, d->info_red, sizeof(double), hipMemcpyDeviceToHost, s));
+  double* mine = d->info_red + d->P;
+  hipLaunchKernelGGL(info_to_double, dim3(1), dim3(1), 0, s, d->info_dev, mine);
+  CAP_HIP(hipGetLastError());
+  CAP_TRY(cap_comm_allgather(d->comm, mine, d->info_red, 1, stream));
+  double h[8] = {0};
+  CAP_HIP(hipMemcpyAsync(h, d->info_red, sizeof(double) * d->P, hipMemcpyDeviceToHost, s));
   CAP_HIP(hipStreamSynchronize(s));
-  *info = (int64_t)h;
-  return h == 0 ? CAP_OK : CAP_ERR_NOT_SPD;
+  int64_t best = 0;
+  for (int r = 0; r < d->P; r++) { const int64_t v = (int64_t)h[r]; if (v > 0 && (best == 0 || v < best)) best = v; }
+  *info = best;
+  return best == 0 ? CAP_OK : CAP_ERR_NOT_SPD;
+}
+
+// live profile of the bulk updates of the LAST factor call (see cap_cholinv_profile)
+int cap_dist_profile(cap_dist_plan* d, int64_t* launches, double* ms_total, double* flops_total) {
+  if (!d || !launches || !ms_total || !flops_total) return CAP_ERR_ARG;
+  *launches = 0; *ms_total = 0; *flops_total = 0;
+  for (int i = 0; i + 1 < d->prof_used; i += 2) {
+    CAP_HIP(hipEventSynchronize(d->prof_ev[i + 1]));
+    float ms = 0;
+    CAP_HIP(hipEventElapsedTime(&ms, d->prof_ev[i], d->prof_ev[i + 1]));
+    *ms_total += ms; *flops_total += d->prof_flops[i / 2]; (*launches)++;
+  }
+  return CAP_OK;
 }
 
 }  // extern "C"

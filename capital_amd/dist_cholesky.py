@@ -57,24 +57,29 @@ def _dist():
 
 
 class RcclComm:
-    """cap_comm over RCCL: unique id from rank 0 shipped through torch.distributed (plumbing only)."""
+    """cap_comm over RCCL: unique id from rank 0 shipped through torch.distributed (plumbing only).
 
-    def __init__(self):
+    force_rccl=True builds a REAL RCCL communicator (ncclCommInitRank) even for one rank, so that every collective of
+    the schedules runs through ncclBroadcast / ncclAllGather / ncclAllReduce on a one-GPU box; the default for one
+    rank is the RCCL-free self communicator."""
+
+    def __init__(self, force_rccl=False):
         L = _lib.lib()
         dist = _dist()
         self.rank, self.size = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
         h = C.c_void_p()
-        if self.size == 1:
+        if self.size == 1 and not force_rccl:
             _lib.check(L.cap_comm_create_self(C.byref(h)), "cap_comm_create_self")
         else:
             idbuf = (C.c_ubyte * 128)()
             if self.rank == 0:
                 _lib.check(L.cap_comm_unique_id(idbuf), "cap_comm_unique_id")
-            t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8)
-            if dist.get_backend() == "nccl":
-                t = t.cuda()
-            dist.broadcast(t, src=0)
-            idbuf = (C.c_ubyte * 128).from_buffer_copy(bytes(t.cpu().tolist()))
+            if self.size > 1:
+                t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8)
+                if dist.get_backend() == "nccl":
+                    t = t.cuda()
+                dist.broadcast(t, src=0)
+                idbuf = (C.c_ubyte * 128).from_buffer_copy(bytes(t.cpu().tolist()))
             _lib.check(L.cap_comm_create(C.byref(h), idbuf, self.rank, self.size, None), "cap_comm_create")
         self.handle = h
 
@@ -85,27 +90,36 @@ class RcclComm:
 
 
 class HostStagedComm:
-    """cap_comm whose collectives are gloo calls on host copies (several ranks may share one GPU)."""
+    """cap_comm whose collectives are gloo calls on host copies (several ranks may share one GPU).
+
+    Each callback waits for the stream it is handed - and nothing else - before it reads the device buffer, exactly
+    the ordering an RCCL kernel enqueued on that stream would have; the other streams of the schedule keep running, so
+    a missing event edge between them shows up as a wrong result (tests add random per-stream delays on top).
+    group: a torch.distributed process group (sub-communicators of a grid bundle); ranks are group-local."""
     _AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
     _BC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
     _AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
-    def __init__(self):
+    def __init__(self, group=None):
         dist = _dist()
         if dist is None or dist.get_backend() != "gloo":
             raise _lib.CapitalError("HostStagedComm needs torch.distributed initialised with the gloo backend")
-        self.rank, self.size = dist.get_rank(), dist.get_world_size()
+        self.group = group
+        self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
         self.calls = {"allgather": 0, "bcast": 0, "allreduce": 0}
 
         def sync(stream):
-            torch.cuda.synchronize()
+            if stream:
+                torch.cuda.ExternalStream(int(stream)).synchronize()
+            else:
+                torch.cuda.default_stream().synchronize()
 
         def ag(ctx, send, recv, count, stream):
             try:
                 sync(stream)
                 mine = _DevView(send, count).to_host()
                 outs = [torch.empty(count, dtype=torch.float64) for _ in range(self.size)]
-                dist.all_gather(outs, mine)
+                dist.all_gather(outs, mine, group=self.group)
                 _DevView(recv, count * self.size).from_host(torch.cat(outs))
                 self.calls["allgather"] += 1
                 return 0
@@ -118,7 +132,7 @@ class HostStagedComm:
                 sync(stream)
                 v = _DevView(buf, count)
                 t = v.to_host()
-                dist.broadcast(t, src=root)
+                dist.broadcast(t, src=dist.get_global_rank(self.group, root) if self.group is not None else root, group=self.group)
                 if self.rank != root:
                     v.from_host(t)
                 self.calls["bcast"] += 1
@@ -132,7 +146,7 @@ class HostStagedComm:
                 sync(stream)
                 v = _DevView(buf, count)
                 t = v.to_host()
-                dist.all_reduce(t)
+                dist.all_reduce(t, group=self.group)
                 v.from_host(t)
                 self.calls["allreduce"] += 1
                 return 0
@@ -204,6 +218,9 @@ class Context:
         """a: numpy (n x local_cols)"""
         self.A[: self.local_cols].copy_(torch.from_numpy(np.ascontiguousarray(a.T)).to(self.device))
 
+    def set_option(self, key, value):
+        _lib.check(_lib.lib().cap_dist_set_option(self.plan, key.encode(), int(value)), "cap_dist_set_option")
+
     def factor(self):
         _lib.check(_lib.lib().cap_dist_factor(self.plan, self.A.data_ptr(), self.n, cur_stream()), "cap_dist_factor")
 
@@ -212,13 +229,18 @@ class Context:
         _lib.lib().cap_dist_info(self.plan, cur_stream(), C.byref(v))
         return v.value
 
+    def local_R_device(self):
+        """(local_cols, n) device buffer = this rank's columns of R (column-major n x local_cols), zero below the diagonal."""
+        out = torch.empty(max(self.local_cols, 1), self.n, dtype=torch.float64, device=self.device)
+        _lib.check(_lib.lib().cap_dist_get_R(self.plan, out.data_ptr(), self.n, cur_stream()), "cap_dist_get_R")
+        return out
+
     def local_R(self):
-        """numpy (n x local_cols) copy of this rank's columns of R (entries below the global diagonal are scratch)."""
-        ld = C.c_int64(0)
-        ptr = _lib.lib().cap_dist_R_ptr(self.plan, C.byref(ld))
+        """numpy (n x local_cols) copy of this rank's columns of R, zero below the global diagonal (construct_R)."""
+        out = torch.empty(max(self.local_cols, 1), self.n, dtype=torch.float64, device=self.device)
+        _lib.check(_lib.lib().cap_dist_get_R(self.plan, out.data_ptr(), self.n, cur_stream()), "cap_dist_get_R")
         torch.cuda.synchronize()
-        t = _DevView(ptr, self.n * self.local_cols).to_host()
-        return t.numpy().reshape(self.local_cols, self.n).T.copy()
+        return out[: self.local_cols].cpu().numpy().T.copy()
 
     def close(self):
         if self.plan:

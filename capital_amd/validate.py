@@ -25,6 +25,30 @@ class cholesky:
         return math.sqrt(e) / math.sqrt(c)
 
 
+    @staticmethod
+    def probe(A_cols, R_cols, gcols=None, nvec=8, allreduce=None, seed=7):
+        """Independent check - torch fp64 matmul (rocBLAS), none of this library's kernels:
+        ||(R^T R - A) X||_F / ||A X||_F for nvec fixed pseudo-random vectors X.
+
+        A_cols, R_cols: [n, lc] device views of this rank's columns of the symmetric A and of R (zero below the global
+        diagonal); gcols: their global column indices (None = all n columns, single rank); allreduce: sums a device
+        tensor over the ranks.  Uses (A X)[gcols] = A[:, gcols]^T X (symmetry), so every operand is local."""
+        n = A_cols.shape[0]
+        g = torch.Generator(device="cpu"); g.manual_seed(seed)
+        X = torch.rand(n, nvec, dtype=torch.float64, generator=g).to(A_cols.device) - 0.5
+        Xl = X if gcols is None else X[gcols]
+        y = R_cols @ Xl                       # y = R X, summed over the ranks' column sets
+        if allreduce is not None:
+            y = allreduce(y)
+        z = R_cols.t() @ y                    # (R^T R X)[gcols]
+        w = A_cols.t() @ X                    # (A X)[gcols]
+        v = torch.stack([((z - w) ** 2).sum(), (w ** 2).sum()])
+        if allreduce is not None:
+            v = allreduce(v)
+        e, c = v.tolist()
+        return math.sqrt(e) / math.sqrt(c)
+
+
 class qr:
     @staticmethod
     def _sumsq(t, ld, m, n, sub_identity=False):

@@ -144,29 +144,58 @@ int cap_sumsq(const double* X, int64_t ldx, int64_t m, int64_t n, int sub_identi
               double* out1, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * Communicator bundle (replaces topo::square / topo::rect, util/topology.h:16-143)
+ * Communicators (replaces the MPI_Comm handles of topo::square / topo::rect, util/topology.h:16-143)
  * RCCL over xGMI, one process per GPU.  The 128-byte unique id is produced on rank 0 by
  * cap_comm_unique_id and shipped to the other ranks by the host (torch.distributed / MPI).
+ * A communicator made by cap_comm_create issues RCCL calls for every collective, also when
+ * size == 1; cap_comm_create_self is the RCCL-free single-rank form.
  * ---------------------------------------------------------------------------------- */
 typedef struct cap_comm cap_comm;
 int cap_comm_unique_id(void* id128);
 int cap_comm_create(cap_comm** comm, const void* id128, int rank, int size, void* stream);
 int cap_comm_create_self(cap_comm** comm);           /* P = 1, no RCCL */
 /* Host-staged communicator: the three collectives are provided by the caller (device pointers in,
- * 0 = success).  Used by the tests to run the multi-rank schedule with several processes sharing one
- * GPU (gloo over host memory); the product uses cap_comm_create (RCCL).                         */
+ * 0 = success).  The callback must order itself behind `stream` (and only that stream) before it
+ * touches the buffers.  Used by the tests to run the multi-rank schedules with several processes
+ * sharing one GPU (gloo over host memory); the product uses cap_comm_create (RCCL).              */
 typedef int (*cap_allgather_fn)(void* ctx, const double* send, double* recv, int64_t count_per_rank, void* stream);
 typedef int (*cap_bcast_fn)(void* ctx, double* buf, int64_t count, int root, void* stream);
 typedef int (*cap_allreduce_fn)(void* ctx, double* buf, int64_t count, void* stream);
 int cap_comm_create_callbacks(cap_comm** comm, int rank, int size, cap_allgather_fn allgather, cap_bcast_fn bcast,
                               cap_allreduce_fn allreduce, void* ctx);
+/* MPI_Comm_split (topology.h:28-39,84-126) -> ncclCommSplit: collective over `comm`; color < 0 joins no
+ * group (*out = NULL).  MPI_Comm_dup (topology.h:54-59): an independent communicator over the same ranks. */
+int cap_comm_split(cap_comm* comm, int color, int key, cap_comm** out);
+int cap_comm_dup(cap_comm* comm, cap_comm** out);
 int cap_comm_destroy(cap_comm* comm);
 int cap_comm_rank(const cap_comm* comm);
 int cap_comm_size(const cap_comm* comm);
+int cap_comm_backend(const cap_comm* comm);          /* 0 self, 1 RCCL, 2 host-staged */
+/* MPI_Allreduce(IN_PLACE, SUM) summa.hpp:236 | MPI_Reduce(SUM) to root cacqr.hpp:98 | MPI_Bcast summa.hpp:185
+ * | MPI_Allgather policy.h:176 | MPI_Barrier bench/cholesky/cholinv.cpp:47 (drains the stream).          */
 int cap_comm_allreduce_sum(cap_comm* comm, double* buf, int64_t count, void* stream);
+int cap_comm_reduce_sum(cap_comm* comm, double* buf, int64_t count, int root, void* stream);
 int cap_comm_bcast(cap_comm* comm, double* buf, int64_t count, int root, void* stream);
 int cap_comm_allgather(cap_comm* comm, const double* send, double* recv, int64_t count_per_rank, void* stream);
 int cap_comm_barrier(cap_comm* comm, void* stream);
+
+/* Grid bundles: topo::square (kind 0, d x d x c, topology.h:67-143) and topo::rect (kind 1, c x d x c,
+ * topology.h:16-65) - the row / column / depth / slice (/ column_contig / column_alt / cube)
+ * sub-communicators split off `world` exactly as upstream's constructors do, plus the grid coordinates.
+ * Collective over `world` (which stays owned by the caller).  Square layouts 1-2 are rejected
+ * (numerically wrong upstream).  cap_topo_coords is the pure rank -> (d, x, y, z) map.               */
+typedef struct cap_topo cap_topo;
+int cap_topo_coords(int kind, int rank, int size, int c, int* d, int* x, int* y, int* z);
+int cap_topo_create(cap_topo** topo, int kind, cap_comm* world, int c, int layout, int num_chunks);
+/* bundle over caller-built sub-communicators: comms[7] = row, column, depth, slice, column_contig,
+ * column_alt, cube (NULL where the kind has none); not owned.                                        */
+int cap_topo_create_from(cap_topo** topo, int kind, cap_comm* world, int c, int layout, int num_chunks,
+                         cap_comm** comms, int ncomms);
+int cap_topo_destroy(cap_topo* topo);
+/* which: 0 world, 1 row, 2 column, 3 depth, 4 slice, 5 column_contig, 6 column_alt, 7 cube */
+cap_comm* cap_topo_comm(cap_topo* topo, int which);
+/* field: 0 rank, 1 size, 2 c, 3 d, 4 x, 5 y, 6 z, 7 layout, 8 num_chunks, 9 kind */
+int cap_topo_get(const cap_topo* topo, int field);
 
 /* ------------------------------------------------------------------------------------
  * Algorithm seam (replaces src/alg/cholesky/cholinv, src/alg/qr/cacqr)
@@ -181,8 +210,10 @@ int cap_comm_barrier(cap_comm* comm, void* stream);
  *   split:        root partition is n >> split (cholinv.hpp:107);
  *   bc_mult_dim:  base-case size knob (cholinv.hpp:15-18) -> panel width of the GPU schedule;
  *   dir:          'U' only, as upstream (cholinv.hpp:9).
- * Single-GPU plans take comm = NULL or a self comm.  Multi-GPU plans (1 x P block-cyclic
- * column distribution) are created with cap_cholinv_plan_create_dist.                      */
+ * comm = NULL or a size-1 communicator: single-GPU plan, A is the whole n x n matrix.
+ * comm of size P > 1 (complete_inv = -1 only): the multi-GPU schedule of cap_dist_* behind the same
+ * handle - A, get_R and R_ptr then refer to THIS RANK's block-cyclic columns (global block column J,
+ * width nb, on rank J % P; cap_bc_num_local_cols columns, all n rows; option "nb" sets the width). */
 typedef struct cap_cholinv_plan cap_cholinv_plan;
 int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv, int64_t split,
                             int64_t bc_mult_dim, char dir, cap_comm* comm);
@@ -217,12 +248,23 @@ int cap_cholinv_profile(cap_cholinv_plan* plan, int64_t* launches, double* ms_to
  * Replaces the MPI_Bcast / MPI_Allgather schedule of summa.hpp:163-253 + policy.h:160-305 with RCCL
  * over xGMI; one process per GPU.  Inputs/outputs are the LOCAL column blocks (n rows, ld >= n).     */
 typedef struct cap_dist_plan cap_dist_plan;
+/* nb: block width (multiple of 128; 0 = 512).  Any n: the plan pads to a multiple of nb with an identity tail. */
 int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* comm);
 int cap_dist_plan_destroy(cap_dist_plan* plan);
 int64_t cap_dist_local_cols(const cap_dist_plan* plan);                 /* columns stored on this rank   */
 int cap_dist_factor(cap_dist_plan* plan, const double* Alocal, int64_t lda, void* stream);
-double* cap_dist_R_ptr(cap_dist_plan* plan, int64_t* ld);               /* local columns of R (n x lc)   */
-int cap_dist_info(cap_dist_plan* plan, void* stream, int64_t* info);    /* agreed on all ranks           */
+double* cap_dist_R_ptr(cap_dist_plan* plan, int64_t* ld);               /* local columns of R, ld = padded n; entries
+                                                                           below the global diagonal are scratch */
+int cap_dist_get_R(cap_dist_plan* plan, double* out, int64_t ld, void* stream);   /* construct_R: n x local_cols, zero below
+                                                                                      the global diagonal              */
+/* 0, or the smallest failing pivot (1-based) reported by any rank.  Collective; call it on the stream
+ * cap_dist_factor ran on.                                                                              */
+int cap_dist_info(cap_dist_plan* plan, void* stream, int64_t* info);
+/* knobs: "strip" (block rows per bulk update, 1|2), "depth2" (split bulk updates), "profile",
+ * "jitter_us" / "jitter_seed" (stress testing: random spin kernels in front of every launch group).    */
+int cap_dist_set_option(cap_dist_plan* plan, const char* key, int64_t value);
+int64_t cap_dist_get_option(const cap_dist_plan* plan, const char* key);
+int cap_dist_profile(cap_dist_plan* plan, int64_t* launches, double* ms_total, double* flops_total);
 /* distribute_symmetric (structure.hpp:68-103) for this layout: fills the local block columns.            */
 int cap_fill_symmetric_bc(double* local, int64_t ld, int64_t n, int64_t nb, int P, int p, int diagonally_dominant,
                           void* stream);

@@ -20,6 +20,10 @@ def main():
     ap.add_argument("--mode", default="index")
     ap.add_argument("--size", dest="n", type=int, default=1024)
     ap.add_argument("--nb", type=int, default=128)
+    ap.add_argument("--strip", type=int, default=0, help="block rows per strip (0 = library default)")
+    ap.add_argument("--depth2", type=int, default=-1)
+    ap.add_argument("--jitter", type=int, default=0, help="max random delay (us) in front of every launch group")
+    ap.add_argument("--seam", type=int, default=0, help="1: drive the run through cholinv.factor(A, pack, topo)")
     args = ap.parse_args()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
@@ -87,22 +91,49 @@ def main():
         torch.cuda.set_device(0)
         from capital_amd import dist_cholesky as dc
         comm = dc.HostStagedComm()
-        ctx = dc.Context(n, nb, comm)
-        ctx.fill_symmetric(True)
         a = orc.symmetric_global(n, True)
         cols = dc.global_cols_of_rank(n, nb, size, rank)
-        torch.cuda.synchronize()
-        assert np.array_equal(ctx.A[: ctx.local_cols].cpu().numpy().T, a[:, cols]), "block-cyclic generator mismatch"
-        for rep in range(2):                       # plan reuse
-            ctx.factor()
-        info = ctx.last_info()
-        rl = ctx.local_R()
+        if args.seam:
+            # the algorithm seam: cholinv::factor(A, pack, topo) with a multi-rank topo -> same schedule behind the plan handle
+            from capital_amd import cholinv
+            from capital_amd.matrix import matrix
+
+            class Topo:
+                pass
+            topo = Topo(); topo.rank, topo.size, topo.world = rank, size, comm.handle
+            A = matrix(max(cols.size, 1), n, 1, 1)
+            if cols.size:
+                A.view()[:, : cols.size].copy_(torch.from_numpy(np.ascontiguousarray(a[:, cols])).cuda())
+            pack = cholinv.info(-1, 1, -2, 'U')
+            pack.set_option("nb", nb)
+            cholinv.factor(A, pack, topo)
+            info = pack.last_info()
+            rl = cholinv.construct_R(pack, topo).to_numpy()[:, : cols.size]
+            close = lambda: pack._release()
+        else:
+            ctx = dc.Context(n, nb, comm)
+            ctx.fill_symmetric(True)
+            torch.cuda.synchronize()
+            assert np.array_equal(ctx.A[: ctx.local_cols].cpu().numpy().T, a[:, cols]), "block-cyclic generator mismatch"
+            if args.strip:
+                ctx.set_option("strip", args.strip)
+            if args.depth2 >= 0:
+                ctx.set_option("depth2", args.depth2)
+            if args.jitter:
+                ctx.set_option("jitter_us", args.jitter)
+                ctx.set_option("jitter_seed", 1234 + rank)
+            for rep in range(2):                       # plan reuse
+                ctx.factor()
+            info = ctx.last_info()
+            rl = ctx.local_R()
+            close = ctx.close
         lc_max = max(dc.global_cols_of_rank(n, nb, size, r).size for r in range(size))
         pad = torch.zeros(n, lc_max, dtype=torch.float64); pad[:, : cols.size] = torch.from_numpy(rl)
         outs = [torch.empty_like(pad) for _ in range(size)]
         dist.all_gather(outs, pad)
         if rank == 0:
-            R = np.triu(dc.assemble_global([o.numpy() for o in outs], n, nb, size))
+            R = dc.assemble_global([o.numpy() for o in outs], n, nb, size)
+            assert np.array_equal(np.tril(R, -1), np.zeros_like(R)), "construct_R must zero the part below the global diagonal"
             ref = np.linalg.cholesky(a).T
             err = np.linalg.norm(R - ref) / np.linalg.norm(ref)
             res = orc.cholesky_residual(a, R)
@@ -110,7 +141,7 @@ def main():
             assert err < 1e-13, err
             assert res < 1e-14, res
             print("DIST-OK world=%d n=%d nb=%d err=%.2e residual=%.2e collectives=%s" % (size, n, nb, err, res, comm.calls), flush=True)
-        ctx.close(); comm.close()
+        close(); comm.close()
     dist.barrier()
     dist.destroy_process_group()
 

@@ -13,10 +13,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(nproc, mode, n, nb, port):
+def _launch(nproc, mode, n, nb, port, extra=()):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "--mode", mode, "--size", str(n),
-           "--nb", str(nb)]
+           "--nb", str(nb)] + [str(x) for x in extra]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     return subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
 
@@ -28,6 +28,28 @@ def test_block_cyclic_index_logic_gloo(nproc, n, nb):
     assert "INDEX-OK" in r.stdout
 
 
+def test_topo_coords_match_reference_formulas():
+    """cap_topo_coords (pure, no GPU) against the rank -> (x, y, z) maps of topology.h:44-50,75-83."""
+    so = os.path.join(ROOT, "capital_amd", "lib", "libcapital_amd.so")
+    if not os.path.exists(so):
+        pytest.skip("library not built")
+    import ctypes as C
+    from capital_amd import _lib
+    L = _lib.lib()
+    for kind, size, c in [(0, 8, 2), (0, 1, 1), (0, 4, 1), (0, 27, 3), (0, 16, 1), (1, 8, 1), (1, 8, 2), (1, 16, 2), (1, 4, 1)]:
+        for rank in range(size):
+            d, x, y, z = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            assert L.cap_topo_coords(kind, rank, size, c, C.byref(d), C.byref(x), C.byref(y), C.byref(z)) == 0
+            if kind == 0:
+                dd = int(round((size / c) ** 0.5)); top = dd * c
+                want = (dd, (rank % top) // c, rank // top, rank % c)
+            else:
+                want = (size // (c * c), (rank % (c * c)) // c, rank // (c * c), rank % c)
+            assert (d.value, x.value, y.value, z.value) == want
+    d = C.c_int()
+    assert L.cap_topo_coords(0, 0, 6, 1, C.byref(d), C.byref(d), C.byref(d), C.byref(d)) != 0      # 6 is no d*d*c grid
+
+
 def test_index_helpers_match_library_when_built():
     """The pure-Python maps agree with the C helpers the schedule uses (cap_bc_*); skipped if the .so is absent."""
     so = os.path.join(ROOT, "capital_amd", "lib", "libcapital_amd.so")
@@ -35,11 +57,11 @@ def test_index_helpers_match_library_when_built():
         pytest.skip("library not built")
     from capital_amd import _lib, dist_cholesky as dc
     L = _lib.lib()
-    for (n, nb, P) in [(4096, 512, 8), (1024, 128, 3), (65536, 512, 8), (2048, 256, 1)]:
+    for (n, nb, P) in [(4096, 512, 8), (1024, 128, 3), (65536, 512, 8), (2048, 256, 1), (1000, 128, 3), (2049, 256, 4)]:
         nblk = (n + nb - 1) // nb
         tot = 0
         for p in range(P):
-            assert L.cap_bc_num_local_cols(n, nb, P, p) == dc.num_local_blocks(nblk, P, p) * nb
+            assert L.cap_bc_num_local_cols(n, nb, P, p) == dc.global_cols_of_rank(n, nb, P, p).size
             tot += dc.global_cols_of_rank(n, nb, P, p).size
         assert tot == n
         for J in range(0, nblk, 3):
@@ -56,6 +78,86 @@ def test_multirank_schedule_on_one_gpu(nproc, n, nb):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc,n,nb,extra", [
+    (3, 1000, 128, ()),                                   # ragged N: identity-padded last block (policy.h:196 `span`)
+    (2, 2047, 256, ()), (4, 2049, 128, ()),               # the reference's own odd sizes (matrix.hpp:8-11)
+    (2, 2048, 128, ("--strip", 1, "--depth2", 0)),        # schedule knobs change the association order only
+    (4, 4096, 128, ("--strip", 2, "--depth2", 1)),
+    (2, 2048, 256, ("--seam", 1)),                        # through cholinv::factor(A, pack, topo)
+])
+def test_multirank_schedule_variants(nproc, n, nb, extra):
+    r = _launch(nproc, "gpu", n, nb, 29671 + nproc, extra)
+    assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    assert "DIST-OK" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,n,nb,jitter", [(2, 4096, 128, 300), (4, 4096, 128, 200), (3, 3072, 256, 500)])
+def test_multirank_schedule_under_random_stream_delays(nproc, n, nb, jitter):
+    """Event-edge stress: every launch group of the four streams is preceded by a spin kernel of random length (different
+    per rank), and the host-staged collectives only wait for their own stream - a missing dependency between the panel /
+    msg / comm / main streams changes R."""
+    r = _launch(nproc, "gpu", n, nb, 29681 + nproc, ("--jitter", jitter))
+    assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    assert "DIST-OK" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_real_rccl_communicator_size1_runs_every_collective():
+    """A REAL RCCL communicator (ncclCommInitRank, size 1) on this box's GPU: the distributed Cholesky schedule and
+    CholeskyQR2 run their broadcast / all-gather / all-reduce through ncclBroadcast / ncclAllGather / ncclAllReduce, plus
+    ncclCommSplit sub-communicators of the grid bundle."""
+    import ctypes as C
+    import torch
+    from capital_amd import _lib, cacqr, cholinv, validate, dist_cholesky as dc
+    from capital_amd.matrix import matrix
+    L = _lib.lib()
+    comm = dc.RcclComm(force_rccl=True)
+    assert L.cap_comm_backend(comm.handle) == 1 and L.cap_comm_size(comm.handle) == 1
+    # raw collectives
+    x = torch.arange(1000, dtype=torch.float64, device="cuda")
+    y = torch.zeros(1000, dtype=torch.float64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.cap_comm_allreduce_sum(comm.handle, x.data_ptr(), 1000, s))
+    _lib.check(L.cap_comm_bcast(comm.handle, x.data_ptr(), 1000, 0, s))
+    _lib.check(L.cap_comm_allgather(comm.handle, x.data_ptr(), y.data_ptr(), 1000, s))
+    _lib.check(L.cap_comm_reduce_sum(comm.handle, x.data_ptr(), 1000, 0, s))
+    _lib.check(L.cap_comm_barrier(comm.handle, s))
+    assert torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float64)) and torch.equal(x, y)
+    # sub-communicators + grid bundle through ncclCommSplit
+    t = C.c_void_p()
+    _lib.check(L.cap_topo_create(C.byref(t), 0, comm.handle, 1, 0, 0), "cap_topo_create")
+    for which in (1, 2, 3, 4):
+        sub = L.cap_topo_comm(t, which)
+        assert sub and L.cap_comm_size(sub) == 1 and L.cap_comm_backend(sub) == 1
+        _lib.check(L.cap_comm_allreduce_sum(sub, x.data_ptr(), 1000, s))
+    torch.cuda.synchronize()
+    assert [L.cap_topo_get(t, f) for f in range(7)] == [0, 1, 1, 1, 0, 0, 0]
+    L.cap_topo_destroy(t)
+    # the distributed Cholesky schedule over it (also ragged N)
+    for n, nb in ((4096, 512), (3000, 256)):
+        ctx = dc.Context(n, nb, comm)
+        ctx.fill_symmetric(True)
+        ctx.factor()
+        assert ctx.last_info() == 0
+        R1 = ctx.local_R()
+        A = matrix(n, n, 1, 1); A.distribute_symmetric(0, 0, 1, 1, 0, True)
+        pack = cholinv.info(-1, 1, -3, 'U'); cholinv.factor(A, pack, None)
+        R2 = cholinv.construct_R(pack).to_numpy()
+        assert np.linalg.norm(R1 - R2) / np.linalg.norm(R2) < 1e-14
+        ctx.close()
+    # CholeskyQR2 with the Gram all-reduce on RCCL
+    class Topo:
+        pass
+    topo = Topo(); topo.c, topo.d, topo.x, topo.y, topo.z, topo.rank, topo.size, topo.world = 1, 1, 0, 0, 0, 0, 1, comm.handle
+    Q = matrix(64, 8192, 1, 1); Q.distribute_random(0, 0, 1, 1, 0)
+    qp = cacqr.info(2, cholinv.info(1, 1, 0, 'U'))
+    cacqr.factor(Q, qp, topo)
+    assert validate.qr.residual(Q, qp, topo) < 1e-13 and validate.qr.orthogonality(Q, qp, topo) < 1e-15
+    comm.close()
+
+
+@pytest.mark.gpu
 def test_single_rank_dist_path_matches_single_gpu_plan():
     """P = 1 through the RCCL-less self communicator: same R as the single-GPU plan, at a larger size."""
     import torch
@@ -65,7 +167,7 @@ def test_single_rank_dist_path_matches_single_gpu_plan():
     ctx = dc.setup(n, nb)
     ctx.factor()
     assert ctx.last_info() == 0
-    R1 = np.triu(ctx.local_R())
+    R1 = ctx.local_R()
     A = matrix(n, n, 1, 1); A.distribute_symmetric(0, 0, 1, 1, 0, True)
     pack = cholinv.info(-1, 1, -3, 'U'); cholinv.factor(A, pack, None)
     R2 = cholinv.construct_R(pack).to_numpy()
