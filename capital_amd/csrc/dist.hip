@@ -222,9 +222,11 @@ int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* 
   }
   hipError_t e = hipMalloc((void**)&d->R, sizeof(double) * std::max<int64_t>(d->npad * d->lc, 2));
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
-    e = hipMalloc((void**)&d->S[i], sizeof(double) * 2 * nb * d->nmax0);
+    // S: one extra block column - a rank that owns the strip's last block sends from one block further in, and the
+    // equal-sized padded pieces are as wide as the widest rank's remainder
+    e = hipMalloc((void**)&d->S[i], sizeof(double) * 2 * nb * (d->nmax0 + nb));
     if (e == hipSuccess) e = hipMalloc((void**)&d->G[i], sizeof(double) * 2 * nb * d->nmax0 * d->P);
-    if (e == hipSuccess) e = hipMemset(d->S[i], 0, sizeof(double) * 2 * nb * d->nmax0);
+    if (e == hipSuccess) e = hipMemset(d->S[i], 0, sizeof(double) * 2 * nb * (d->nmax0 + nb));
   }
   for (int i = 0; i < 4 && e == hipSuccess; i++) {
     e = hipMalloc((void**)&d->msg[i], sizeof(double) * 2 * nb * nb);

@@ -69,12 +69,32 @@ __device__ __forceinline__ const double* a_tile_base(const GemmArgs& g, int ti) 
   return g.A + (int64_t)r * g.gpiece + ((int64_t)(lb * g.snbT + ti % g.snbT) * 128) * g.lda;
 }
 
+// staircase enumeration (etri == 3): supertile column sj holds this many supertiles with at least one valid tile
+__host__ __device__ __forceinline__ int stair_gtj_hd(int sp, int sP, int slb0, int snbT, int sJ0, int tj) {
+  const int J = sp + sP * (slb0 + tj / snbT);
+  return (J - sJ0) * snbT + tj % snbT;
+}
+__host__ __device__ __forceinline__ int stair_cnt(int sj, int st, int tn, int nsm, int sp, int sP, int slb0, int snbT, int sJ0) {
+  int tjm = sj * st + st - 1;
+  if (tjm > tn - 1) tjm = tn - 1;
+  const int c = stair_gtj_hd(sp, sP, slb0, snbT, sJ0, tjm) / st + 1;
+  return c < nsm ? c : nsm;
+}
+
 // logical slot -> tile coordinates (returns false when the slot is empty)
 __device__ __forceinline__ bool slot_to_tile(const GemmArgs& g, int L, int& ti, int& tj) {
   const int ST = g.st;
   int S = L / (ST * ST), w = L % (ST * ST);
   int si, sj;
-  if (g.etri == 1) {  // upper triangle of supertiles, column-major: S = sj(sj+1)/2 + si
+  if (g.etri == 3) {  // staircase: walk the supertile columns, only supertiles that hold valid tiles are numbered
+    sj = 0;
+    for (; sj < g.nsn; sj++) {
+      const int c = stair_cnt(sj, ST, g.tn, g.nsm, g.sp, g.sP, g.slb0, g.snbT, g.sJ0);
+      if (S < c) break;
+      S -= c;
+    }
+    si = S;
+  } else if (g.etri == 1) {  // upper triangle of supertiles, column-major: S = sj(sj+1)/2 + si
     sj = (int)((__builtin_sqrtf(8.0f * (float)S + 1.0f) - 1.0f) * 0.5f);
     while ((sj + 1) * (sj + 2) / 2 <= S) sj++;
     while (sj * (sj + 1) / 2 > S) sj--;
@@ -807,7 +827,11 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   g.hiprio = 0; g.ctr = nullptr; g.bupper = 0; g.aupt = 0; g.aupn = 0;
   g.stair = 1; g.gather = 1; g.sP = P; g.sp = p; g.snbT = nb / 128; g.sJ0 = J0; g.slb0 = lb0; g.gpiece = piece;
   for (int i = 0; i < 8; i++) g.gstart[i] = i < P ? gstart[i] : 0;
-  int64_t slots = (int64_t)g.nsm * g.nsn * ST * ST;
+  // only supertiles under the staircase are enumerated, so the 8 XCD ranges carry equal work
+  g.etri = 3;
+  int64_t nsuper = 0;
+  for (int sj = 0; sj < g.nsn; sj++) nsuper += stair_cnt(sj, ST, g.tn, g.nsm, p, P, lb0, nb / 128, J0);
+  int64_t slots = nsuper * ST * ST;
   g.chunk = (int)cap_ceil_div(slots, 8);
   return launch_tn_dma<1>(g, g.chunk * 8, stream, persist_wgs);
 }
