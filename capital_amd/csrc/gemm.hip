@@ -55,6 +55,12 @@ struct GemmArgs {
   int hiprio;       // panel-stream launches: raise the waves' issue priority (they share CUs with the bulk update)
   int stair, gather, sP, sp, snbT, sJ0, slb0;
   int64_t gpiece; int gstart[8];
+  // epilogue of the beta == 1 update form as fire-and-forget fp64 atomic adds executed in L2 (global_atomic_add_f64):
+  // no C read-back into registers, no load latency on the tile's critical path.  Every C element has exactly one
+  // writer (no split-K on this path), so the result is the same single rounding fl(C + alpha*acc) as the load/add/store
+  // form and stays run-to-run deterministic.
+  int atomic_c;
+  int usebuf;       // operand rows of a tile fit a 31-bit byte offset: LDS-DMA through buffer descriptors (scalar offsets)
 };
 
 // global tile index (relative to the row origin) of local column tile tj under the staircase view
@@ -308,6 +314,39 @@ __device__ __forceinline__ void dma_tile(const double* __restrict__ P, int64_t l
   }
 }
 
+// The same tile move through a buffer descriptor (buffer_load_dwordx4 ... lds): the per-lane part of the address is ONE
+// loop-invariant 32-bit VGPR offset (two: even / odd row groups differ in the swizzle), everything that changes from
+// piece to piece and from K tile to K tile (row group, k) is a scalar offset.  No 64-bit VALU address arithmetic in
+// the main loop - measured: the LDS-DMA issue sequence was the only thing keeping the MFMA pipe below 97 % busy.
+// `rowbytes` = ld * 8;  base = first row of the tile at k = 0;  requires 128 * rowbytes + K * 8 < 2^31.
+struct DmaBuf {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff_even, voff_odd;   // per-lane byte offsets of a piece with even / odd q
+  int rowgrp;                // byte stride between row groups of 8 rows
+};
+__device__ __forceinline__ DmaBuf dma_buf_make(const double* base, int64_t ld) {
+  DmaBuf d;
+  d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+  const int lane = threadIdx.x & 63;
+  const int rsub = lane >> 3, p = lane & 7;
+  const int rowbytes = (int)(ld * 8);
+  // row = r0 + rsub with r0 a multiple of 8: (row >> 1) & 7 = ((rsub >> 1) + (r0 >> 1)) & 7, r0 >> 1 is 0 or 4 mod 8 (q even / odd)
+  d.voff_even = rsub * rowbytes + ((p ^ (rsub >> 1)) << 4);
+  d.voff_odd = rsub * rowbytes + ((p ^ ((rsub >> 1) ^ 4)) << 4);
+  d.rowgrp = 8 * rowbytes;
+  return d;
+}
+// pieces [q0, q1) of the wave's four row groups; wid must be wave-uniform (readfirstlane'd by the caller)
+template <int Q0, int Q1>
+__device__ __forceinline__ void dma_tile_buf(const DmaBuf& d, int wid, int kbytes, double* lds_tile) {
+#pragma unroll
+  for (int q = Q0; q < Q1; q++) {
+    const int g8 = wid * 4 + q;                         // row group of 8 rows
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rsrc, (__attribute__((address_space(3))) void*)(lds_tile + g8 * 8 * BK), 16,
+                                             (q & 1) ? d.voff_odd : d.voff_even, g8 * d.rowgrp + kbytes, 0, 0);
+  }
+}
+
 // M-contiguous A operand (op(A) = A, column-major m x k): a K tile is 16 rows (k) of 128 consecutive doubles.
 // One wave-instruction moves one k row (1 KiB); the LDS image is [k][128], with the two 128-byte halves of a
 // row swapped when (k >> 1) is odd (source-side XOR) so that the four k rows a fragment read touches
@@ -324,7 +363,9 @@ __device__ __forceinline__ void dma_tile_mc(const double* __restrict__ P, int64_
   }
 }
 
-template <bool A_MC>
+// DIAG (timing experiments only, results are wrong): 1 = no DMA inside the loop, 2 = no DMA and no barrier,
+// 3 = no DMA, no barrier, no fragment reads (pure MFMA stream with the kernel's register pattern)
+template <bool A_MC, int DIAG, bool BUF>
 __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, const int tj, const int kz, double* smem) {
   const int64_t i0 = (int64_t)ti * BM, j0 = (int64_t)tj * BN;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -391,16 +432,31 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
   // The barrier at the top of iteration kt proves: all reads of tile kt are done (buffer kt&1 may be
   // refilled) and tile kt+1 has landed (each wave drained its own DMA share with vmcnt(0) before it).
   const double* Abase = a_tile_base(g, ti);   // rows of this tile start at Abase (row offset 0 below)
-  auto dma_a = [&](int64_t k0, double* dst) { if (A_MC) dma_tile_mc(g.A, g.lda, i0, k0, dst); else dma_tile(Abase, g.lda, 0, k0, dst); };
+  // buffer-addressed DMA (scalar offsets) whenever the tile's rows fit a 31-bit byte offset; else 64-bit global addresses
+  constexpr bool ubuf = BUF;
+  const int wid_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  DmaBuf dA, dB;
+  if (BUF && !A_MC) dA = dma_buf_make(Abase + kbeg, g.lda);
+  if (BUF) dB = dma_buf_make(g.B + j0 * g.ldb + kbeg, g.ldb);
+  // half = 0: first part of the K tile's pieces (issued in phase A), 1: second part (phase B), 2: everything
+  auto dma_a = [&](int kt_, double* dst, int half) {
+    if (A_MC) { if (half != 1) dma_tile_mc(g.A, g.lda, i0, kbeg + (int64_t)kt_ * BK, dst); }
+    else if (ubuf) { if (half != 1) dma_tile_buf<0, 4>(dA, wid_s, kt_ * BK * 8, dst); }
+    else { if (half != 1) dma_tile(Abase, g.lda, 0, kbeg + (int64_t)kt_ * BK, dst); }
+  };
+  auto dma_b = [&](int kt_, double* dst, int half) {
+    if (ubuf) { if (half != 0) dma_tile_buf<0, 4>(dB, wid_s, kt_ * BK * 8, dst); }
+    else { if (half != 0) dma_tile(g.B, g.ldb, j0, kbeg + (int64_t)kt_ * BK, dst); }
+  };
   if (nk > 0) {
-    dma_a(kbeg, sA(0));
-    dma_tile(g.B, g.ldb, j0, kbeg, sB(0));
+    dma_a(0, sA(0), 2);
+    dma_b(0, sB(0), 2);
     __syncthreads();
     read_frags(sA(0), sB(0), a_off0, b_off0, fa0, fb0);
     {
-      const int64_t k1 = kbeg + (int64_t)(nk > 1 ? 1 : 0) * BK;
-      dma_a(k1, sA(1));
-      dma_tile(g.B, g.ldb, j0, k1, sB(1));
+      const int k1 = nk > 1 ? 1 : 0;
+      dma_a(k1, sA(1), 2);
+      dma_b(k1, sB(1), 2);
     }
     read_frags(sA(0), sB(0), a_off1, b_off1, fa1, fb1);
     __builtin_amdgcn_sched_barrier(0);
@@ -409,31 +465,30 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
     for (int kt = 0; kt + 1 < nk; kt++) {
       const int nxt = (kt + 1) & 1;
       __builtin_amdgcn_s_waitcnt(0xc07f);                // F1 (issued during the previous MFMA block) is complete
-      __syncthreads();
+      if (DIAG < 2) __syncthreads();
       // ---- phase A: refill the buffer tile kt just vacated, fetch F0 of tile kt+1, contract 2nd half of tile kt.
       // The DMA pieces and LDS reads are interleaved INTO the MFMA stream (one of each per 4 MFMAs) so that
       // a single wave keeps the matrix pipe busy while it issues them (sched_group_barrier pipeline).
-      {
-        const int kn = (kt + 2 < nk) ? kt + 2 : nk - 1;  // clamp: the last refill is redundant but branch-free
-        dma_a(kbeg + (int64_t)kn * BK, sA(nxt ^ 1));
-        dma_tile(g.B, g.ldb, j0, kbeg + (int64_t)kn * BK, sB(nxt ^ 1));
-      }
-      read_frags(sA(nxt), sB(nxt), a_off0, b_off0, fa0, fb0);
+      const int kn = (kt + 2 < nk) ? kt + 2 : nk - 1;    // clamp: the last refill is redundant but branch-free
+      if (DIAG == 0) dma_a(kn, sA(nxt ^ 1), 0);          // A operand's pieces ride in phase A, B's in phase B
+      if (DIAG < 3) read_frags(sA(nxt), sB(nxt), a_off0, b_off0, fa0, fb0);
       mma32(fa1, fb1);
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // 1 VMEM (LDS-DMA piece)
+        if (q & 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // 1 VMEM (LDS-DMA piece) per 8 MFMAs
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase B: fetch F1 of tile kt+1, contract its first half
       __builtin_amdgcn_s_waitcnt(0xc07f);                // F0 has landed (last read issued >= 4 MFMAs ago)
-      read_frags(sA(nxt), sB(nxt), a_off1, b_off1, fa1, fb1);
+      if (DIAG == 0) { dma_a(kn, sA(nxt ^ 1), 1); dma_b(kn, sB(nxt ^ 1), 2); }
+      if (DIAG < 3) read_frags(sA(nxt), sB(nxt), a_off1, b_off1, fa1, fb1);
       mma32(fa0, fb0);
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        if (q & 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -476,68 +531,56 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
         }
     }
   };
+  auto epilogue_atomic = [&](auto masked) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int64_t row = i0 + wi + 16 * i + lr;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int64_t col = j0 + wj + 16 * j + kg + 4 * r;
+          bool ok = !masked.value || (g.tri == 1 ? (row - i0) <= (col - j0) : (row - i0) >= (col - j0));
+          if (ok) __builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double*)(g.C + row + col * g.ldc), alpha * acc[i][j][r]);
+        }
+    }
+  };
   using T = std::true_type; using F = std::false_type;
   if (g.ksplit > 1) { if (diag_tile) epilogue(T{}, F{}, T{}); else epilogue(F{}, F{}, T{}); }
+  else if (g.atomic_c) { if (diag_tile) epilogue_atomic(T{}); else epilogue_atomic(F{}); }
   else if (beta != 0.0) { if (diag_tile) epilogue(T{}, T{}, F{}); else epilogue(F{}, T{}, F{}); }
   else { if (diag_tile) epilogue(T{}, F{}, F{}); else epilogue(F{}, F{}, F{}); }
 }
 
-// One tile per workgroup (PERSIST = false), or a persistent workgroup that pulls tiles from its XCD's slot
-// range through an atomic counter and steals from the other XCDs when its own range is drained (PERSIST =
-// true).  The persistent form is launched with FEWER workgroups than the chip has slots (2 per CU): the
-// slots left free are what the latency-bound panel chain on the other stream runs in, instead of waiting
-// for (and time-slicing against) one of 512 resident bulk workgroups.
-template <int TAG, bool PERSIST, bool A_MC = false>
+// One C tile per workgroup.  (A persistent variant that pulled tiles from per-XCD atomic queues was measured in round 1:
+// +2.4 % on the bulk kernel alone, -10 % end to end because the latency-bound panel chain starves behind workgroups
+// that never retire; it also needed > 256 VGPRs.  It was removed.)
+template <int TAG, bool A_MC = false, int DIAG = 0, bool BUF = false>
 __global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  if (!PERSIST) {
-    const int b = (int)((blockIdx.x + blockIdx.y) % gridDim.x);   // split-K: rotate tiles over the XCDs (see dgemm_kernel)
-    const int L = (b & 7) * g.chunk + (b >> 3);
-    int ti, tj;
-    if ((b >> 3) >= g.chunk || !slot_to_tile(g, L, ti, tj)) return;
-    if (g.hiprio) __builtin_amdgcn_s_setprio(3);
-    tn_dma_tile<A_MC>(g, ti, tj, (int)blockIdx.y, smem);
-    return;
-  }
-  int* slot_word = reinterpret_cast<int*>(smem + 4 * DMA_TILE);
-  const int xcd = blockIdx.x & 7;          // block b is placed on XCD b % 8 (speed only; correctness does not depend on it)
-  for (int pass = 0; pass < 8; pass++) {
-    const int q = (xcd + pass) & 7;
-    for (;;) {
-      if (threadIdx.x == 0) *slot_word = atomicAdd(&g.ctr[q], 1);
-      __syncthreads();
-      const int r = *slot_word;
-      __syncthreads();                     // also fences the previous tile's LDS reads against the next tile's DMA
-      if (r >= g.chunk) break;
-      int ti, tj;
-      if (slot_to_tile(g, q * g.chunk + r, ti, tj)) tn_dma_tile<A_MC>(g, ti, tj, 0, smem);
-    }
-  }
+  const int b = (int)((blockIdx.x + blockIdx.y) % gridDim.x);   // split-K: rotate tiles over the XCDs (see dgemm_kernel)
+  const int L = (b & 7) * g.chunk + (b >> 3);
+  int ti, tj;
+  if ((b >> 3) >= g.chunk || !slot_to_tile(g, L, ti, tj)) return;
+  if (g.hiprio) __builtin_amdgcn_s_setprio(3);
+  tn_dma_tile<A_MC, DIAG, BUF>(g, ti, tj, (int)blockIdx.y, smem);
 }
 
 int launch_nn_dma(const GemmArgs& g, int grid, hipStream_t stream) {
   size_t lds = 4 * DMA_TILE * sizeof(double);
-  hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, false, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+  hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
 
-// ring of per-launch counter sets for persistent launches
-int* g_ctr_ring = nullptr;
-int g_ctr_next = 0;
-constexpr int CTR_RING = 256;
-
 template <int TAG>
 int launch_tn_dma(GemmArgs g, int grid, hipStream_t stream, int persist_wgs = 0) {
+  (void)persist_wgs;
   size_t lds = 4 * DMA_TILE * sizeof(double);
-  if (persist_wgs > 0 && g.ksplit == 1 && grid > persist_wgs) {
-    if (!g_ctr_ring) CAP_HIP(hipMalloc((void**)&g_ctr_ring, sizeof(int) * 8 * CTR_RING));
-    g.ctr = g_ctr_ring + 8 * (g_ctr_next++ % CTR_RING);
-    CAP_HIP(hipMemsetAsync(g.ctr, 0, sizeof(int) * 8, stream));
-    hipLaunchKernelGGL((dgemm_tn_dma_kernel<TAG, true>), dim3((persist_wgs / 8) * 8), dim3(NTHREADS), lds + 16, stream, g);
-  } else {
-    hipLaunchKernelGGL((dgemm_tn_dma_kernel<TAG, false>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
-  }
+  static const int diag_env = getenv("CAP_DIAG") ? atoi(getenv("CAP_DIAG")) : 0;    // timing experiments only
+  if (diag_env == 1 && TAG == 0) hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, false, 1, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+  else if (g.usebuf) hipLaunchKernelGGL((dgemm_tn_dma_kernel<TAG, false, 0, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+  else hipLaunchKernelGGL((dgemm_tn_dma_kernel<TAG, false, 0, false>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
@@ -746,6 +789,7 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   g.hiprio = (tag & 2) ? 1 : 0; g.bupper = (tag & 8) ? 1 : 0;
   g.aupt = ((tag & 16) && transa == CAP_TRANS) ? 1 : 0; g.aupn = ((tag & 32) && transa != CAP_TRANS) ? 1 : 0;
   tag &= 1; g.ctr = nullptr;
+  g.atomic_c = 0; g.usebuf = 0;
   g.stair = 0; g.gather = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0;
   for (int i = 0; i < 8; i++) g.gstart[i] = 0;
   g.tm = (int)cap_ceil_div(m, BM); g.tn = (int)cap_ceil_div(n, BN);
@@ -778,6 +822,12 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
     }
   }
 
+  {
+    static const int atomic_env = getenv("CAP_ATOMIC_C") ? atoi(getenv("CAP_ATOMIC_C")) : 1;
+    g.atomic_c = (atomic_env && beta == 1.0 && g.ksplit == 1) ? 1 : 0;
+    static const int buf_env = getenv("CAP_DMA_BUF") ? atoi(getenv("CAP_DMA_BUF")) : 1;
+    g.usebuf = (buf_env && 128 * lda * 8 + k * 8 < 0x7fffffffLL && 128 * ldb * 8 + k * 8 < 0x7fffffffLL) ? 1 : 0;
+  }
   const bool a_kc = (transa == CAP_TRANS);   // op(A)=A^T: k contiguous
   const bool b_kc = (transb != CAP_TRANS);   // op(B)=B:   k contiguous
   auto aligned16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
@@ -825,6 +875,11 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   g.nsm = (int)cap_ceil_div(g.tm, ST); g.nsn = (int)cap_ceil_div(g.tn, ST);
   g.ksplit = 1; g.kchunk = k; g.P = nullptr; g.slab = 0;
   g.hiprio = 0; g.ctr = nullptr; g.bupper = 0; g.aupt = 0; g.aupn = 0;
+  {
+    static const int atomic_env = getenv("CAP_ATOMIC_C") ? atoi(getenv("CAP_ATOMIC_C")) : 1;
+    g.atomic_c = atomic_env ? 1 : 0;
+    g.usebuf = (128 * k * 8 + k * 8 < 0x7fffffffLL) ? 1 : 0;
+  }
   g.stair = 1; g.gather = 1; g.sP = P; g.sp = p; g.snbT = nb / 128; g.sJ0 = J0; g.slb0 = lb0; g.gpiece = piece;
   for (int i = 0; i < 8; i++) g.gstart[i] = i < P ? gstart[i] : 0;
   // only supertiles under the staircase are enumerated, so the 8 XCD ranges carry equal work
