@@ -28,21 +28,21 @@ struct cap_cacqr_plan {
 };
 
 namespace {
-int sweep(cap_cacqr_plan* p, hipStream_t s) {
+// one CholeskyQR sweep: Qout = Qin * chol(Qin^T Qin)^-1.  The first sweep reads the caller's A in place (no A -> Q copy:
+// serialize<rect,rect>(A -> Q) of cacqr.hpp:226 only exists upstream because its TRMM is in place)
+int sweep(cap_cacqr_plan* p, const double* Qin, int64_t ldin, double* Qout, hipStream_t s) {
   const int64_t m = p->m, n = p->n;
-  double* Qin = p->Q[p->cur]; double* Qout = p->Q[p->cur ^ 1];
   // Gram: upper triangle of Q^T Q (cacqr.hpp:15), full square zero-initialised so the all-reduce moves
   // a dense n x n block like NoSerialize::compute_gram (policy.h:22)
   CAP_TRY(cap_zero_rect(p->G, n, n, n, s));
-  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n, n, m, 1.0, Qin, p->ldq, Qin, p->ldq, 0.0, p->G, n, 1, s));
+  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n, n, m, 1.0, Qin, ldin, Qin, ldin, 0.0, p->G, n, 1, s));
   CAP_TRY(cap_comm_allreduce_sum(p->comm, p->G, n * n, (void*)s));
   // R = chol(G) in place (upper), Gi = R^-1
   CAP_TRY(cap_zero_rect(p->Gi, n, n, n, s));
   CAP_TRY(cap_rec_cholinv_full(p->G, n, p->Gi, n, n, p->W, p->wcap, p->info_dev, s));
   // Q <- Q * R^-1 (cacqr.hpp:24-25)
   // tag 8: R^-1 is upper triangular -> a column tile only contracts the rows above its diagonal block
-  CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, m, n, n, 1.0, Qin, p->ldq, p->Gi, n, 0.0, Qout, p->ldq, 0, s, 8));
-  p->cur ^= 1;
+  CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, m, n, n, 1.0, Qin, ldin, p->Gi, n, 0.0, Qout, p->ldq, 0, s, 8));
   return CAP_OK;
 }
 }  // namespace
@@ -83,12 +83,12 @@ int cap_cacqr_factor(cap_cacqr_plan* p, const double* A, int64_t lda, void* stre
   hipStream_t s = cap_stream(stream);
   const int64_t n = p->n;
   CAP_HIP(hipMemsetAsync(p->info_dev, 0, sizeof(int), s));
+  CAP_TRY(sweep(p, A, lda, p->Q[0], s));
   p->cur = 0;
-  CAP_TRY(cap_copy_rect(A, lda, p->Q[0], p->ldq, p->m, n, s));    // serialize<rect,rect>(A -> Q), cacqr.hpp:226
-  CAP_TRY(sweep(p, s));
   if (p->num_iter > 1) {
     CAP_TRY(cap_copy_rect(p->G, n, p->R1, n, n, n, s));            // save_R_1d, policy.h:27-30
-    CAP_TRY(sweep(p, s));
+    CAP_TRY(sweep(p, p->Q[0], p->ldq, p->Q[1], s));
+    p->cur = 1;
     // R = R2 * R1 (dtrmm Right/Upper/NoTrans, cacqr.hpp:182-187); both are upper with zero lower parts
     CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, n, n, n, 1.0, p->G, n, p->R1, n, 0.0, p->R, n, 0, s));
   } else {

@@ -60,7 +60,8 @@ struct GemmArgs {
   // writer (no split-K on this path), so the result is the same single rounding fl(C + alpha*acc) as the load/add/store
   // form and stays run-to-run deterministic.
   int atomic_c;
-  int usebuf;       // operand rows of a tile fit a 31-bit byte offset: LDS-DMA through buffer descriptors (scalar offsets)
+  int usebuf;       // operand rows of a tile fit a 32-bit byte offset: LDS-DMA through buffer descriptors (scalar offsets)
+  int skip;         // launch the block-skipping instantiation (triangular operands, few-tile SYRK)
 };
 
 // global tile index (relative to the row origin) of local column tile tj under the staircase view
@@ -318,18 +319,18 @@ __device__ __forceinline__ void dma_tile(const double* __restrict__ P, int64_t l
 // loop-invariant 32-bit VGPR offset (two: even / odd row groups differ in the swizzle), everything that changes from
 // piece to piece and from K tile to K tile (row group, k) is a scalar offset.  No 64-bit VALU address arithmetic in
 // the main loop - measured: the LDS-DMA issue sequence was the only thing keeping the MFMA pipe below 97 % busy.
-// `rowbytes` = ld * 8;  base = first row of the tile at k = 0;  requires 128 * rowbytes + K * 8 < 2^31.
+// `rowbytes` = ld * 8;  base = first row of the tile at k = 0;  requires 128 * rowbytes + K * 8 < 2^32.
 struct DmaBuf {
   __amdgpu_buffer_rsrc_t rsrc;
-  int voff_even, voff_odd;   // per-lane byte offsets of a piece with even / odd q
-  int rowgrp;                // byte stride between row groups of 8 rows
+  uint32_t voff_even, voff_odd;   // per-lane byte offsets of a piece with even / odd q
+  uint32_t rowgrp;                // byte stride between row groups of 8 rows
 };
 __device__ __forceinline__ DmaBuf dma_buf_make(const double* base, int64_t ld) {
   DmaBuf d;
-  d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+  d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0xffffffffu, 0x00020000);   // offsets are unsigned 32-bit
   const int lane = threadIdx.x & 63;
   const int rsub = lane >> 3, p = lane & 7;
-  const int rowbytes = (int)(ld * 8);
+  const uint32_t rowbytes = (uint32_t)(ld * 8);
   // row = r0 + rsub with r0 a multiple of 8: (row >> 1) & 7 = ((rsub >> 1) + (r0 >> 1)) & 7, r0 >> 1 is 0 or 4 mod 8 (q even / odd)
   d.voff_even = rsub * rowbytes + ((p ^ (rsub >> 1)) << 4);
   d.voff_odd = rsub * rowbytes + ((p ^ ((rsub >> 1) ^ 4)) << 4);
@@ -338,12 +339,12 @@ __device__ __forceinline__ DmaBuf dma_buf_make(const double* base, int64_t ld) {
 }
 // pieces [q0, q1) of the wave's four row groups; wid must be wave-uniform (readfirstlane'd by the caller)
 template <int Q0, int Q1>
-__device__ __forceinline__ void dma_tile_buf(const DmaBuf& d, int wid, int kbytes, double* lds_tile) {
+__device__ __forceinline__ void dma_tile_buf(const DmaBuf& d, int wid, uint32_t kbytes, double* lds_tile) {
 #pragma unroll
   for (int q = Q0; q < Q1; q++) {
-    const int g8 = wid * 4 + q;                         // row group of 8 rows
+    const uint32_t g8 = (uint32_t)(wid * 4 + q);        // row group of 8 rows
     __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rsrc, (__attribute__((address_space(3))) void*)(lds_tile + g8 * 8 * BK), 16,
-                                             (q & 1) ? d.voff_odd : d.voff_even, g8 * d.rowgrp + kbytes, 0, 0);
+                                             (int)((q & 1) ? d.voff_odd : d.voff_even), (int)(g8 * d.rowgrp + kbytes), 0, 0);
   }
 }
 
@@ -365,7 +366,10 @@ __device__ __forceinline__ void dma_tile_mc(const double* __restrict__ P, int64_
 
 // DIAG (timing experiments only, results are wrong): 1 = no DMA inside the loop, 2 = no DMA and no barrier,
 // 3 = no DMA, no barrier, no fragment reads (pure MFMA stream with the kernel's register pattern)
-template <bool A_MC, int DIAG, bool BUF>
+// SKIP: operands / results with triangular structure - the 16 x 16 blocks of a wave that only see zeros (or lie below
+// the diagonal of a SYRK tile) are left out of the MFMA stream with wave-uniform branches.  Separate instantiation:
+// the branches would break the single-basic-block software pipeline of the bulk update.
+template <bool A_MC, int DIAG, bool BUF, bool SKIP>
 __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, const int tj, const int kz, double* smem) {
   const int64_t i0 = (int64_t)ti * BM, j0 = (int64_t)tj * BN;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -412,15 +416,37 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
 #pragma unroll
     for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const d2*>(tB + boff + j * 16 * BK);
   };
-  auto mma32 = [&](const d2 (&fa)[4], const d2 (&fb)[4]) {
+  // SKIP bookkeeping (wave-uniform): origin of the wave's blocks relative to the tile and the structure flags
+  const int wid_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wi_u = (wid_u & 1) * 64, wj_u = (wid_u >> 1) * 64;
+  const bool dtri = SKIP && g.tri == 1 && !g.stair && ti == tj;        // diagonal tile of an upper SYRK: blocks below the diagonal are dead
+  auto mma32 = [&](const d2 (&fa)[4], const d2 (&fb)[4], int64_t kb) {    // kb: first k of this 8-deep half tile
+    if (!SKIP) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+      for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+      for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
+    } else {
+      // block column j holds columns c0 = j0 + wj + 16 j ...; block row i holds rows r0 = i0 + wi + 16 i ...
+      int jlo = 0, ilo = 0, ihi = 3;
+      if (g.bupper) { const int64_t d = kb - j0 - wj_u; jlo = d > 0 ? (int)(d >> 4) : 0; }          // op(B)[k][c] = 0 for k > c
+      if (g.aupt) { const int64_t d = kb - i0 - wi_u; ilo = d > 0 ? (int)(d >> 4) : 0; }            // op(A)[r][k] = 0 for k > r
+      if (g.aupn) { const int64_t d = kb + 7 - i0 - wi_u; ihi = d < 0 ? -1 : (d >> 4) > 3 ? 3 : (int)(d >> 4); }   // op(A)[r][k] = 0 for k < r
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const bool on = j >= jlo && i >= ilo && i <= ihi && !(dtri && wi_u + 16 * i > wj_u + 16 * j);
+          if (on) {
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
+          }
+        }
+    }
   };
 
   // Software pipeline, rotated so that every fragment set is consumed in the basic block that issued
@@ -441,11 +467,11 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
   // half = 0: first part of the K tile's pieces (issued in phase A), 1: second part (phase B), 2: everything
   auto dma_a = [&](int kt_, double* dst, int half) {
     if (A_MC) { if (half != 1) dma_tile_mc(g.A, g.lda, i0, kbeg + (int64_t)kt_ * BK, dst); }
-    else if (ubuf) { if (half != 1) dma_tile_buf<0, 4>(dA, wid_s, kt_ * BK * 8, dst); }
+    else if (ubuf) { if (half != 1) dma_tile_buf<0, 4>(dA, wid_s, (uint32_t)kt_ * BK * 8, dst); }
     else { if (half != 1) dma_tile(Abase, g.lda, 0, kbeg + (int64_t)kt_ * BK, dst); }
   };
   auto dma_b = [&](int kt_, double* dst, int half) {
-    if (ubuf) { if (half != 0) dma_tile_buf<0, 4>(dB, wid_s, kt_ * BK * 8, dst); }
+    if (ubuf) { if (half != 0) dma_tile_buf<0, 4>(dB, wid_s, (uint32_t)kt_ * BK * 8, dst); }
     else { if (half != 0) dma_tile(g.B, g.ldb, j0, kbeg + (int64_t)kt_ * BK, dst); }
   };
   if (nk > 0) {
@@ -460,7 +486,7 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
     }
     read_frags(sA(0), sB(0), a_off1, b_off1, fa1, fb1);
     __builtin_amdgcn_sched_barrier(0);
-    mma32(fa0, fb0);
+    mma32(fa0, fb0, kbeg);
     __builtin_amdgcn_sched_barrier(0);
     for (int kt = 0; kt + 1 < nk; kt++) {
       const int nxt = (kt + 1) & 1;
@@ -472,7 +498,7 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
       const int kn = (kt + 2 < nk) ? kt + 2 : nk - 1;    // clamp: the last refill is redundant but branch-free
       if (DIAG == 0) dma_a(kn, sA(nxt ^ 1), 0);          // A operand's pieces ride in phase A, B's in phase B
       if (DIAG < 3) read_frags(sA(nxt), sB(nxt), a_off0, b_off0, fa0, fb0);
-      mma32(fa1, fb1);
+      mma32(fa1, fb1, kbeg + (int64_t)kt * BK + 8);
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA
@@ -484,7 +510,7 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
       __builtin_amdgcn_s_waitcnt(0xc07f);                // F0 has landed (last read issued >= 4 MFMAs ago)
       if (DIAG == 0) { dma_a(kn, sA(nxt ^ 1), 1); dma_b(kn, sB(nxt ^ 1), 2); }
       if (DIAG < 3) read_frags(sA(nxt), sB(nxt), a_off1, b_off1, fa1, fb1);
-      mma32(fa0, fb0);
+      mma32(fa0, fb0, kbeg + (int64_t)(kt + 1) * BK);
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
@@ -493,7 +519,7 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    mma32(fa1, fb1);
+    mma32(fa1, fb1, kbeg + (int64_t)(nk - 1) * BK + 8);
   }
 
   // epilogue: lane holds C[i0+wi+16i+lr][j0+wj+16j+kg+4r]; all branches are block-uniform
@@ -555,7 +581,7 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
 // One C tile per workgroup.  (A persistent variant that pulled tiles from per-XCD atomic queues was measured in round 1:
 // +2.4 % on the bulk kernel alone, -10 % end to end because the latency-bound panel chain starves behind workgroups
 // that never retire; it also needed > 256 VGPRs.  It was removed.)
-template <int TAG, bool A_MC = false, int DIAG = 0, bool BUF = false>
+template <int TAG, bool A_MC = false, int DIAG = 0, bool BUF = false, bool SKIP = false>
 __global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = (int)((blockIdx.x + blockIdx.y) % gridDim.x);   // split-K: rotate tiles over the XCDs (see dgemm_kernel)
@@ -563,12 +589,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) dgemm_tn_dma_kernel(const GemmArg
   int ti, tj;
   if ((b >> 3) >= g.chunk || !slot_to_tile(g, L, ti, tj)) return;
   if (g.hiprio) __builtin_amdgcn_s_setprio(3);
-  tn_dma_tile<A_MC, DIAG, BUF>(g, ti, tj, (int)blockIdx.y, smem);
+  tn_dma_tile<A_MC, DIAG, BUF, SKIP>(g, ti, tj, (int)blockIdx.y, smem);
 }
 
 int launch_nn_dma(const GemmArgs& g, int grid, hipStream_t stream) {
   size_t lds = 4 * DMA_TILE * sizeof(double);
-  hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+  if (g.skip) hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, true, 0, false, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+  else hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
@@ -579,6 +606,8 @@ int launch_tn_dma(GemmArgs g, int grid, hipStream_t stream, int persist_wgs = 0)
   size_t lds = 4 * DMA_TILE * sizeof(double);
   static const int diag_env = getenv("CAP_DIAG") ? atoi(getenv("CAP_DIAG")) : 0;    // timing experiments only
   if (diag_env == 1 && TAG == 0) hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, false, 1, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+  else if (g.skip && g.usebuf) hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, false, 0, true, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+  else if (g.skip) hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, false, 0, false, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
   else if (g.usebuf) hipLaunchKernelGGL((dgemm_tn_dma_kernel<TAG, false, 0, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
   else hipLaunchKernelGGL((dgemm_tn_dma_kernel<TAG, false, 0, false>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
   CAP_HIP(hipGetLastError());
@@ -789,7 +818,7 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   g.hiprio = (tag & 2) ? 1 : 0; g.bupper = (tag & 8) ? 1 : 0;
   g.aupt = ((tag & 16) && transa == CAP_TRANS) ? 1 : 0; g.aupn = ((tag & 32) && transa != CAP_TRANS) ? 1 : 0;
   tag &= 1; g.ctr = nullptr;
-  g.atomic_c = 0; g.usebuf = 0;
+  g.atomic_c = 0; g.usebuf = 0; g.skip = 0;
   g.stair = 0; g.gather = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0;
   for (int i = 0; i < 8; i++) g.gstart[i] = 0;
   g.tm = (int)cap_ceil_div(m, BM); g.tn = (int)cap_ceil_div(n, BN);
@@ -825,8 +854,10 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   {
     static const int atomic_env = getenv("CAP_ATOMIC_C") ? atoi(getenv("CAP_ATOMIC_C")) : 1;
     g.atomic_c = (atomic_env && beta == 1.0 && g.ksplit == 1) ? 1 : 0;
+    static const int skip_env = getenv("CAP_SKIP") ? atoi(getenv("CAP_SKIP")) : 1;
+    g.skip = (skip_env && tag != 1 && (g.bupper || g.aupt || g.aupn || (tri == 1 && g.tm <= 8))) ? 1 : 0;
     static const int buf_env = getenv("CAP_DMA_BUF") ? atoi(getenv("CAP_DMA_BUF")) : 1;
-    g.usebuf = (buf_env && 128 * lda * 8 + k * 8 < 0x7fffffffLL && 128 * ldb * 8 + k * 8 < 0x7fffffffLL) ? 1 : 0;
+    g.usebuf = (buf_env && 128 * lda * 8 + k * 8 < 0xfffffff0LL && 128 * ldb * 8 + k * 8 < 0xfffffff0LL) ? 1 : 0;
   }
   const bool a_kc = (transa == CAP_TRANS);   // op(A)=A^T: k contiguous
   const bool b_kc = (transb != CAP_TRANS);   // op(B)=B:   k contiguous
@@ -878,7 +909,7 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   {
     static const int atomic_env = getenv("CAP_ATOMIC_C") ? atoi(getenv("CAP_ATOMIC_C")) : 1;
     g.atomic_c = atomic_env ? 1 : 0;
-    g.usebuf = (128 * k * 8 + k * 8 < 0x7fffffffLL) ? 1 : 0;
+    g.usebuf = (128 * k * 8 + k * 8 < 0x7fffffffLL) ? 1 : 0; g.skip = 0;
   }
   g.stair = 1; g.gather = 1; g.sP = P; g.sp = p; g.snbT = nb / 128; g.sJ0 = J0; g.slb0 = lb0; g.gpiece = piece;
   for (int i = 0; i < 8; i++) g.gstart[i] = i < P ? gstart[i] : 0;

@@ -3,7 +3,7 @@
 N=$1; shift
 for cfg in $@; do
   IFS=: read nb outer tail rsv bw d2 <<< "$cfg"; [ -z "$rsv" ] && rsv=-1; [ -z "$bw" ] && bw=-1; [ -z "$d2" ] && d2=-1
-  r=$(python bench.py --n $N --nb $nb --outer $outer --tail $tail --reserve $rsv --bulk-wgs $bw --depth2 $d2 --steps 2 --no-cpu-baseline --check 2>/dev/null | python -c "
+  r=$(python bench.py --n $N --nb $nb --outer $outer --tail $tail --reserve $rsv --bulk-wgs $bw --depth2 $d2 --steps 3 --no-cpu-baseline --no-extra 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
