@@ -85,7 +85,14 @@ SIGNATURES = {
     "cap_bc_owner": (cint, [i64, cint]),
     "cap_bc_local_block": (i64, [i64, cint]),
     "cap_bc_num_local_cols": (i64, [i64, i64, cint, cint]),
+    "cap_summa_plan_create": (cint, [C.POINTER(ptr), ptr, i64, i64, i64, cint]),
+    "cap_summa_plan_destroy": (cint, [ptr]),
+    "cap_summa_local_dims": (None, [ptr, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "cap_summa_dgemm": (cint, [ptr, dbl, ptr, i64, ptr, i64, dbl, ptr, i64, ptr]),
     "cap_cacqr_plan_create": (cint, [C.POINTER(ptr), i64, i64, cint, ptr]),
+    "cap_cacqr_plan_create_grid": (cint, [C.POINTER(ptr), i64, i64, cint, ptr]),
+    "cap_cacqr_local_cols": (i64, [ptr]),
+    "cap_cacqr_R_piece": (cint, [ptr, ptr, i64, ptr]),
     "cap_cacqr_plan_destroy": (cint, [ptr]),
     "cap_cacqr_factor": (cint, [ptr, ptr, i64, ptr]),
     "cap_cacqr_Q_ptr": (ptr, [ptr, C.POINTER(i64)]),

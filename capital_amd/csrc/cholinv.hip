@@ -644,10 +644,12 @@ int cap_dtrtri(int uplo, int64_t n, double* A, int64_t lda, double* work, void* 
   return cap_copy_window(T, 0, n, 0, 0, A, 0, lda, 0, 0, n, n, 1, 0, stream);
 }
 
-// B = alpha op(T) B  or  alpha B op(T): copy triangle to a zero-filled square, GEMM out of place, copy back.
-// work layout: [tdim*tdim triangle copy][m*n result]
-static int trmm_like(int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha, const double* T,
-                     int64_t ldt, double* B, int64_t ldb, double* work, hipStream_t s, bool solve) {
+// B = alpha op(T) B  or  alpha B op(T)  (blas::engine::_trmm, blas/interface.hpp:61-79): the upper triangle is copied
+// into a zero-filled square (BLAS does not reference the other triangle, the MFMA kernel reads full tiles), then ONE
+// out-of-place GEMM whose K ranges stop at the triangle (tags 8 / 16 / 32: half the flops of a full product).
+// work layout: [td*td triangle copy][m*n result]
+static int trmm_impl(int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha, const double* T,
+                     int64_t ldt, double* B, int64_t ldb, double* work, hipStream_t s) {
   if (m < 0 || n < 0) return CAP_ERR_ARG;
   if (m == 0 || n == 0) return CAP_OK;
   if (!T || !B || !work || ldb < m) return CAP_ERR_ARG;
@@ -656,14 +658,10 @@ static int trmm_like(int side, int uplo, int trans, int diag, int64_t m, int64_t
   if (ldt < td) return CAP_ERR_ARG;
   double* Tc = work; double* Out = work + cap_round_up(td * td, 2);
   CAP_TRY(cap_copy_window(T, 0, ldt, 0, 0, Tc, 0, td, 0, 0, td, td, 1, 1, (void*)s));
-  if (solve) {
-    double* W = Out + cap_round_up(m * n, 2);
-    CAP_TRY(rec_trtri(Tc, td, td, W, rec_work_size(td), CAP_LEAF_MAX, s));
-  }
   if (side == CAP_LEFT)
-    CAP_TRY(cap_gemm_launch(trans, CAP_NOTRANS, m, n, m, alpha, Tc, td, B, ldb, 0.0, Out, m, 0, s));
+    CAP_TRY(cap_gemm_launch(trans, CAP_NOTRANS, m, n, m, alpha, Tc, td, B, ldb, 0.0, Out, m, 0, s, trans == CAP_TRANS ? 16 : 32));
   else
-    CAP_TRY(cap_gemm_launch(CAP_NOTRANS, trans, m, n, n, alpha, B, ldb, Tc, td, 0.0, Out, m, 0, s));
+    CAP_TRY(cap_gemm_launch(CAP_NOTRANS, trans, m, n, n, alpha, B, ldb, Tc, td, 0.0, Out, m, 0, s, trans == CAP_TRANS ? 0 : 8));
   return cap_copy_rect(Out, m, B, ldb, m, n, s);
 }
 
@@ -674,18 +672,75 @@ int64_t cap_dtrmm_work_size(int side, int64_t m, int64_t n) {
 
 int cap_dtrmm(int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha, const double* T, int64_t ldt,
               double* B, int64_t ldb, double* work, void* stream) {
-  return trmm_like(side, uplo, trans, diag, m, n, alpha, T, ldt, B, ldb, work, cap_stream(stream), false);
+  return trmm_impl(side, uplo, trans, diag, m, n, alpha, T, ldt, B, ldb, work, cap_stream(stream));
 }
 
+// ---- DTRSM: blocked substitution.  Only the diagonal blocks (width tb <= 512) are inverted (recursive TRTRI on zero-lower
+// copies, all blocks independent); every block step is one GEMM with the block inverse plus one GEMM update of the
+// remaining right-hand sides - td^2 n flops like a substitution, no td^3 inverse of the whole triangle.
+//   LEFT  NOTRANS  T X = aB    blocks bottom-up:  X_i = Tii^-1 B_i ;           B_0..i-1   -= T(0..i-1, i) X_i
+//   LEFT  TRANS    T^T X = aB  blocks top-down:   X_i = Tii^-T B_i ;           B_i+1..    -= T(i, i+1..)^T X_i
+//   RIGHT NOTRANS  X T = aB    block columns left-right: X_j = B_j Tjj^-1 ;    B_j+1..    -= X_j T(j, j+1..)
+//   RIGHT TRANS    X T^T = aB  right-left:        X_j = B_j Tjj^-T ;           B_0..j-1   -= X_j T(0..j-1, j)^T
+// work layout: [nblk * tb * tb block inverses][tb * max(m, n) block temp][rec_trtri scratch]
+static int64_t trsm_block(int64_t td) { return td >= 2048 ? 512 : (td >= 512 ? 256 : 128); }
+
 int64_t cap_dtrsm_work_size(int side, int64_t m, int64_t n) {
-  const int64_t td = side == CAP_LEFT ? m : n;
-  return cap_round_up(td * td, 2) + cap_round_up(m * n, 2) + rec_work_size(td);
+  const int64_t td = side == CAP_LEFT ? m : n, tb = std::min(trsm_block(td), cap_round_up(std::max<int64_t>(td, 1), 2));
+  const int64_t nblk = cap_ceil_div(td, tb), other = side == CAP_LEFT ? n : m;
+  return nblk * tb * tb + cap_round_up(tb * other, 2) + rec_work_size(tb) + 8;
 }
 
 int cap_dtrsm(int side, int uplo, int trans, int64_t m, int64_t n, double alpha, const double* T, int64_t ldt, double* B,
               int64_t ldb, double* work, void* stream) {
-  // op(T) X = alpha B  <=>  X = alpha op(T^-1) B: invert the (small) triangle once, then one GEMM on MFMA
-  return trmm_like(side, uplo, trans, CAP_NONUNIT, m, n, alpha, T, ldt, B, ldb, work, cap_stream(stream), true);
+  if (m < 0 || n < 0) return CAP_ERR_ARG;
+  if (m == 0 || n == 0) return CAP_OK;
+  if (!T || !B || !work || ldb < m) return CAP_ERR_ARG;
+  if (uplo != CAP_UPPER) return CAP_ERR_UNSUPPORTED;
+  hipStream_t s = cap_stream(stream);
+  const bool left = side == CAP_LEFT, tr = trans == CAP_TRANS;
+  const int64_t td = left ? m : n, other = left ? n : m;
+  if (ldt < td) return CAP_ERR_ARG;
+  const int64_t tb = std::min(trsm_block(td), cap_round_up(td, 2));
+  const int64_t nblk = cap_ceil_div(td, tb);
+  double* Inv = work; double* X = work + nblk * tb * tb; double* W = X + cap_round_up(tb * other, 2);
+  // block inverses (zero-lower copies, so they can be GEMM operands as full squares)
+  for (int64_t i = 0; i < nblk; i++) {
+    const int64_t o = i * tb, w = std::min(tb, td - o);
+    double* Ii = Inv + i * tb * tb;
+    CAP_TRY(cap_copy_window(T, 0, ldt, o, o, Ii, 0, tb, 0, 0, w, w, 1, 1, stream));
+    CAP_TRY(rec_trtri(Ii, tb, w, W, rec_work_size(tb), CAP_LEAF_MAX, s));
+  }
+  // alpha once, up front (B <- alpha B through the GEMM launcher's scaling path); the sweep then solves op(T) X = B
+  if (alpha != 1.0) CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, m, n, 0, 0.0, B, ldb, B, ldb, alpha, B, ldb, 0, s));
+  const bool forward = left ? tr : !tr;      // order of the block sweep
+  for (int64_t step = 0; step < nblk; step++) {
+    const int64_t i = forward ? step : nblk - 1 - step;
+    const int64_t o = i * tb, w = std::min(tb, td - o);
+    const double* Ii = Inv + i * tb * tb;
+    if (left) {
+      // X_i = op(Tii^-1) * B_i   (w x n)
+      CAP_TRY(cap_gemm_launch(trans, CAP_NOTRANS, w, n, w, 1.0, Ii, tb, B + o, ldb, 0.0, X, w, 0, s, tr ? 16 : 32));
+      CAP_TRY(cap_copy_rect(X, w, B + o, ldb, w, n, s));
+      if (tr) {          // rows below: B_r -= T(i, r)^T X_i
+        const int64_t r0 = o + w, rows = td - r0;
+        if (rows > 0) CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows, n, w, -1.0, T + o + r0 * ldt, ldt, X, w, 1.0, B + r0, ldb, 0, s));
+      } else {           // rows above: B_r -= T(r, i) X_i
+        if (o > 0) CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, o, n, w, -1.0, T + o * ldt, ldt, X, w, 1.0, B, ldb, 0, s));
+      }
+    } else {
+      // X_j = B_j * op(Tjj^-1)   (m x w)
+      CAP_TRY(cap_gemm_launch(CAP_NOTRANS, trans, m, w, w, 1.0, B + o * ldb, ldb, Ii, tb, 0.0, X, m, 0, s, tr ? 0 : 8));
+      CAP_TRY(cap_copy_rect(X, m, B + o * ldb, ldb, m, w, s));
+      if (!tr) {         // columns to the right: B_c -= X_j T(j, c)
+        const int64_t c0 = o + w, cols = td - c0;
+        if (cols > 0) CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, m, cols, w, -1.0, X, m, T + o + c0 * ldt, ldt, 1.0, B + c0 * ldb, ldb, 0, s));
+      } else {           // columns to the left: B_c -= X_j T(c, j)^T
+        if (o > 0) CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_TRANS, m, o, w, -1.0, X, m, T + o * ldt, ldt, 1.0, B, ldb, 0, s));
+      }
+    }
+  }
+  return CAP_OK;
 }
 
 }  // extern "C"

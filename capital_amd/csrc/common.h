@@ -46,7 +46,7 @@ int cap_leaf_trtri(const double* R, int64_t ldr, double* Rinv, int64_t ldi, int 
 // aux.hip
 int cap_copy_rect(const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s);
 int cap_zero_rect(double* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s);
-double* cap_scratch(int64_t elems);  // gemm.hip: library-owned device scratch (split-K partials)
+double* cap_scratch(int64_t elems, hipStream_t stream);  // gemm.hip: per-stream device scratch (split-K partials)
 
 // gemm.hip: distributed (1 x P block-column-cyclic) trailing update with staircase mask + gathered A operand
 int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, int64_t piece, const int* gstart,

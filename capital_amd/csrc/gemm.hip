@@ -18,7 +18,10 @@
 //   Blocks are remapped XCD-aware: block b runs on XCD b%8; each XCD walks a contiguous
 //   range of 8x8-tile supertiles so its private L2 sees compact A/B panels.
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -775,18 +778,26 @@ __global__ void splitk_reduce_kernel(double* C, int64_t ldc, const double* P, in
   }
 }
 
-// library-owned scratch for split-K partials (grown on demand; first use synchronises)
-double* g_scratch = nullptr;
-int64_t g_scratch_elems = 0;
+// library-owned scratch for split-K partials: ONE buffer per (device, stream), because two split-K products in
+// flight on different streams must not share slabs.  Growth uses the stream-ordered allocator (no device-wide sync);
+// the map itself is guarded by a mutex (the operator seam may be called from several host threads).
+struct ScratchBuf { double* p; int64_t elems; };
+std::mutex g_scratch_mu;
+std::map<std::pair<int, hipStream_t>, ScratchBuf> g_scratch;
 
 }  // namespace
 
-double* cap_scratch(int64_t elems) {
-  if (elems <= g_scratch_elems) return g_scratch;
-  if (g_scratch) { (void)hipDeviceSynchronize(); (void)hipFree(g_scratch); g_scratch = nullptr; g_scratch_elems = 0; }
-  if (hipMalloc((void**)&g_scratch, sizeof(double) * elems) != hipSuccess) return nullptr;
-  g_scratch_elems = elems;
-  return g_scratch;
+double* cap_scratch(int64_t elems, hipStream_t stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  ScratchBuf& b = g_scratch[std::make_pair(dev, stream)];
+  if (elems <= b.elems) return b.p;
+  if (b.p) { (void)hipFreeAsync(b.p, stream); b.p = nullptr; b.elems = 0; }   // ordered behind the stream's earlier readers
+  double* np_ = nullptr;
+  if (hipMallocAsync((void**)&np_, sizeof(double) * elems, stream) != hipSuccess) return nullptr;
+  b.p = np_; b.elems = elems;
+  return b.p;
 }
 
 int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
@@ -839,13 +850,15 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   {
     int64_t tiles = (tri == 0) ? (int64_t)g.tm * g.tn : ((int64_t)g.tm * (g.tm + 1)) / 2;
     if (tiles < 128 && k >= 4096 && n <= 65535) {
-      int64_t want = cap_ceil_div(768, tiles);
+      // whole rounds of the chip's 512 workgroup slots, at least three of them: the tiles of a small SYRK are unequal
+      // (diagonal tiles skip their dead blocks) and a half-empty last round costs as much as a full one
+      int64_t want = cap_ceil_div(1536, tiles);
       int64_t maxs = k / 1024;
       int64_t ks = want < maxs ? want : maxs;
       if (ks > 1) {
         int64_t kc = cap_round_up(cap_ceil_div(k, ks), BK);
         ks = cap_ceil_div(k, kc);
-        double* P = cap_scratch(ks * m * n);
+        double* P = cap_scratch(ks * m * n, stream);
         if (P && ks > 1) { g.ksplit = (int)ks; g.kchunk = kc; g.P = P; g.slab = m * n; }
       }
     }

@@ -57,8 +57,39 @@ class qr:
         return out
 
     @staticmethod
+    def _grid_terms(A, args, T):
+        """c > 1 grids: (Q R)_local by the same layer-wise product the factorization uses, and the Gram blocks of Q.
+        Local arithmetic is torch fp64 (validator = test infrastructure); collectives go through the C ABI."""
+        L = _lib.lib()
+        s = cur_stream()
+        Q = _cacqr.construct_Q(args, T); Rd = _cacqr.dense_R(args)
+        ml, nl = Q.num_rows_local(), Q.num_columns_local()
+        Qz = torch.empty_like(Q.data())
+        if T.x == T.z:
+            Qz.copy_(Q.data())
+        _lib.check(L.cap_comm_bcast(T.row, Qz.data_ptr(), Qz.numel(), T.z, s), "bcast")
+        Qzv = Qz[:, :ml].t()
+        # (Q R)[rows y, cols x] = sum_z Q[:, cols z] R[z::c, x::c]
+        QR = torch.zeros_like(Q.data())
+        QR[:, :ml].copy_((Qzv @ Rd.view()[T.z::T.c, T.x::T.c]).t())
+        _lib.check(L.cap_comm_allreduce_sum(T.depth, QR.data_ptr(), QR.numel(), s), "allreduce")
+        # Gram block G[z::c, x::c] summed over the process rows
+        G = (Qzv.t() @ Q.view()).t().contiguous()          # stored column-major nl x nl
+        _lib.check(L.cap_comm_allreduce_sum(T.column_contig, G.data_ptr(), G.numel(), s), "allreduce")
+        _lib.check(L.cap_comm_allreduce_sum(T.column_alt, G.data_ptr(), G.numel(), s), "allreduce")
+        return Q, QR, G
+
+    @staticmethod
     def residual(A, args, CommInfo=None):
         """||QR - A||_F / ||A||_F (test/qr/validate.hpp:37-52); partial sums all-reduced over ranks."""
+        if args._grid:
+            T = CommInfo
+            Q, QR, _ = qr._grid_terms(A, args, T)
+            ml = Q.num_rows_local()
+            v = torch.stack([((QR[:, :ml] - A.data()[:, :ml]) ** 2).sum(), (A.data()[:, :ml] ** 2).sum()])
+            _lib.check(_lib.lib().cap_comm_allreduce_sum(T.slice, v.data_ptr(), 2, cur_stream()), "allreduce")   # one layer: every piece once
+            e, c = v.tolist()
+            return math.sqrt(e) / math.sqrt(c)
         Q = _cacqr.construct_Q(args, CommInfo); R = _cacqr.construct_R(args, CommInfo)
         m, n = A.num_rows_local(), A.num_columns_local()
         E = torch.empty_like(A.data()); E.copy_(A.data())
@@ -76,6 +107,19 @@ class qr:
     @staticmethod
     def orthogonality(A, args, CommInfo=None):
         """||Q^T Q - I||_F / sqrt(n*n): upstream normalises by control = 1 per entry (validate.hpp:24-31)."""
+        if args._grid:
+            T = CommInfo
+            Q, _, G = qr._grid_terms(A, args, T)
+            nl = Q.num_columns_local()
+            Gv = G.t()                                      # [row a, col b] of block (z, x): global (z + c a, x + c b)
+            if T.x == T.z:
+                Gv = Gv - torch.eye(nl, dtype=torch.float64, device=Gv.device)
+            v = (Gv ** 2).sum().reshape(1)
+            L = _lib.lib()
+            _lib.check(L.cap_comm_allreduce_sum(T.row, v.data_ptr(), 1, cur_stream()), "allreduce")      # blocks (z, x'), every x'
+            _lib.check(L.cap_comm_allreduce_sum(T.depth, v.data_ptr(), 1, cur_stream()), "allreduce")    # every z'
+            n = Q.num_columns_global()
+            return math.sqrt(v.item()) / math.sqrt(n * n)
         Q = _cacqr.construct_Q(args, CommInfo)
         m, n = Q.num_rows_local(), Q.num_columns_local()
         G = torch.zeros(n, n, dtype=torch.float64, device=Q.device)

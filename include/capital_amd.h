@@ -273,11 +273,33 @@ int cap_bc_owner(int64_t J, int P);
 int64_t cap_bc_local_block(int64_t J, int P);
 int64_t cap_bc_num_local_cols(int64_t n, int64_t nb, int P, int p);
 
+/* matmult::summa::invoke, GEMM overload (summa.hpp:6-44, distribute :163-221, collect :223-253; driver
+ * bench/matmult/summa_gemm.cpp:7-55): C = alpha A B + beta C on the d x d x c grid of a topo::square bundle, operands
+ * are the element-cyclic local pieces (ceil(M/d) x ceil(K/d) etc., zero padded).  Layer z walks the inner process
+ * indices z, z + c, ... (c == d: upstream's single step; c == 1: 2D SUMMA); row / column broadcasts run on their own
+ * streams and communicators, B moves in `num_chunks` column chunks overlapped with the local MFMA GEMMs
+ * (upstream's Ibcast pipelining, summa.hpp:195-215); partial products are summed over `depth` when c > 1.          */
+typedef struct cap_summa_plan cap_summa_plan;
+int cap_summa_plan_create(cap_summa_plan** plan, cap_topo* topo, int64_t m, int64_t n, int64_t k, int num_chunks);
+int cap_summa_plan_destroy(cap_summa_plan* plan);
+void cap_summa_local_dims(const cap_summa_plan* plan, int64_t* ml, int64_t* nl, int64_t* kl);
+int cap_summa_dgemm(cap_summa_plan* plan, double alpha, const double* A_local, int64_t lda, const double* B_local,
+                    int64_t ldb, double beta, double* C_local, int64_t ldc, void* stream);
+
 /* qr::cacqr<...>::info + factor, 1D path - cacqr.h:18-49, cacqr.hpp:5-29,172-193,217-248.
  * A is the local row-cyclic piece (m_local x n, column-major); R (n x n) is replicated;
  * num_iter = 1 (CholeskyQR) or 2 (CholeskyQR2).  comm == NULL -> single rank.              */
 typedef struct cap_cacqr_plan cap_cacqr_plan;
 int cap_cacqr_plan_create(cap_cacqr_plan** plan, int64_t m_local, int64_t n, int num_iter, cap_comm* comm);
+/* The 3D / tunable-grid path (cacqr.hpp:44-170: sweep_3d, sweep_tune, solve; invoke_3d :195-215) on a topo::rect
+ * bundle (c x d x c; c == d is the 3D cube): A_local = ceil(M/d) x (N/c) element-cyclic piece (rows y mod d, columns
+ * x mod c, replicated over the layers).  Row broadcast + Gram block + all-reduces over the process column, dense
+ * Gram assembled on every rank, Cholesky factor and inverse computed redundantly per GPU, Q R^-1 as one term per
+ * layer summed over `depth`.  Q_ptr is the local piece of Q, R_ptr the dense replicated R, cap_cacqr_R_piece the
+ * c x c cyclic piece upstream keeps.                                                                              */
+int cap_cacqr_plan_create_grid(cap_cacqr_plan** plan, int64_t m_global, int64_t n_global, int num_iter, cap_topo* topo);
+int64_t cap_cacqr_local_cols(const cap_cacqr_plan* plan);
+int cap_cacqr_R_piece(cap_cacqr_plan* plan, double* out, int64_t ld, void* stream);
 int cap_cacqr_plan_destroy(cap_cacqr_plan* plan);
 int cap_cacqr_factor(cap_cacqr_plan* plan, const double* A, int64_t lda, void* stream);
 double* cap_cacqr_Q_ptr(cap_cacqr_plan* plan, int64_t* ld);

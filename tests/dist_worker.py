@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--depth2", type=int, default=-1)
     ap.add_argument("--jitter", type=int, default=0, help="max random delay (us) in front of every launch group")
     ap.add_argument("--seam", type=int, default=0, help="1: drive the run through cholinv.factor(A, pack, topo)")
+    ap.add_argument("--c", type=int, default=1, help="grid depth c (summa: d x d x c, cacqr3d: c x d x c)")
+    ap.add_argument("--k", type=int, default=0, help="summa: inner dimension")
+    ap.add_argument("--chunks", type=int, default=0, help="summa: num_chunks")
     args = ap.parse_args()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
@@ -58,6 +61,81 @@ def main():
         assert int(t.item()) == n
         if rank == 0:
             print("INDEX-OK world=%d n=%d nb=%d" % (size, n, nb), flush=True)
+    elif args.mode == "summa":
+        # matmult::summa::invoke on the d x d x c grid (bench/matmult/summa_gemm.cpp:32-38): element-cyclic pieces on every rank
+        torch.cuda.set_device(0)
+        from capital_amd import blas, summa, topo as tp
+        from capital_amd.matrix import matrix
+        T = tp.square(args.c, 0, args.chunks)
+        M, N, K, d = args.n, args.nb, args.k, T.d           # --size = M, --nb = N, --k = K
+        A = matrix(K, M, d, d); B = matrix(N, K, d, d); Cm = matrix(N, M, d, d)
+        A.distribute_random(T.x, T.y, d, d, rank // T.c); B.distribute_random(T.x, T.y, d, d, 100 + rank // T.c)
+        Cm.distribute_random(T.x, T.y, d, d, 200 + rank // T.c)
+        a, b, c0 = A.to_numpy(), B.to_numpy(), Cm.to_numpy()
+        alpha, beta = 1.5, -0.5
+        for rep in range(2):                                 # plan reuse; the second call starts from the first result
+            summa.invoke(A, B, Cm, T, blas.ArgPack_gemm(blas.Order.AblasColumnMajor, blas.Transpose.AblasNoTrans, blas.Transpose.AblasNoTrans, alpha, beta))
+        c2 = Cm.to_numpy()
+        pieces = [None] * size
+        dist.all_gather_object(pieces, (T.x, T.y, T.z, a, b, c0, c2))
+        if rank == 0:
+            ag = np.zeros((M, K)); bg = np.zeros((K, N)); cg = np.zeros((M, N)); og = np.zeros((M, N))
+            for (x, y, z, pa, pb, pc, po) in pieces:
+                if z != 0:
+                    continue
+                ag[y::d, x::d] = pa[: len(range(y, M, d)), : len(range(x, K, d))]
+                bg[y::d, x::d] = pb[: len(range(y, K, d)), : len(range(x, N, d))]
+                cg[y::d, x::d] = pc[: len(range(y, M, d)), : len(range(x, N, d))]
+                og[y::d, x::d] = po[: len(range(y, M, d)), : len(range(x, N, d))]
+            ref = cg
+            for rep in range(2):
+                ref = alpha * (ag @ bg) + beta * ref
+            err = np.linalg.norm(og - ref) / np.linalg.norm(ref)
+            # every layer holds the same result
+            for (x, y, z, pa, pb, pc, po) in pieces:
+                assert np.array_equal(po[: len(range(y, M, d)), : len(range(x, N, d))], og[y::d, x::d])
+            assert err < 1e-13, err
+            print("SUMMA-OK world=%d d=%d c=%d M=%d N=%d K=%d chunks=%d err=%.2e" % (size, d, T.c, M, N, K, args.chunks, err), flush=True)
+        summa.release(T); T.close()
+    elif args.mode == "cacqr3d":
+        # qr::cacqr on the c x d x c grid (bench/qr/cacqr.cpp:28-41): rows cyclic over d, columns over c, replicated over the layers
+        torch.cuda.set_device(0)
+        from capital_amd import cacqr, cholinv, validate, topo as tp
+        from capital_amd.matrix import matrix
+        T = tp.rect(args.c, 0, 0)
+        m, ncol, c, d = args.n, args.nb, T.c, T.d
+        A = matrix(ncol, m, c, d)
+        A.distribute_random(T.x, T.y, c, d, rank // c)      # key = rank / c (bench/qr/cacqr.cpp:34)
+        a_loc = A.to_numpy()
+        pack = cacqr.info(2, cholinv.info(1, 1, 0, 'U'))
+        for rep in range(2):
+            cacqr.factor(A, pack, T)
+        assert pack.last_info() == 0
+        res = validate.qr.residual(A, pack, T); orth = validate.qr.orthogonality(A, pack, T)
+        q_loc = cacqr.construct_Q(pack, T).to_numpy(); r_piece = cacqr.construct_R(pack, T).to_numpy()
+        r_dense = cacqr.dense_R(pack).to_numpy()
+        pieces = [None] * size
+        dist.all_gather_object(pieces, (T.x, T.y, T.z, a_loc, q_loc, r_piece))
+        if rank == 0:
+            ag = np.zeros((m, ncol)); qg = np.zeros((m, ncol)); rg = np.zeros((ncol, ncol))
+            for (x, y, z, pa, pq, pr) in pieces:
+                rows, cols = len(range(y, m, d)), len(range(x, ncol, c))
+                if z == 0:
+                    ag[y::d, x::c] = pa[:rows, :cols]; qg[y::d, x::c] = pq[:rows, :cols]
+                if z == 0 and y < c:
+                    rg[y::c, x::c] = pr
+            # layers are replicas
+            for (x, y, z, pa, pq, pr) in pieces:
+                rows, cols = len(range(y, m, d)), len(range(x, ncol, c))
+                assert np.array_equal(pq[:rows, :cols], qg[y::d, x::c])
+            q_ref, r_ref = orc.cacqr_1d([ag], 2)
+            assert np.array_equal(np.triu(rg), rg) and np.allclose(rg, r_dense, rtol=0, atol=0)
+            assert np.linalg.norm(rg - r_ref) / np.linalg.norm(r_ref) < 1e-11
+            assert np.linalg.norm(qg - q_ref[0]) / np.linalg.norm(q_ref[0]) < 1e-10
+            assert np.linalg.norm(qg @ rg - ag) / np.linalg.norm(ag) < 1e-13
+            assert res < 1e-13 and orth < 1e-15, (res, orth)
+            print("CACQR3D-OK world=%d c=%d d=%d m=%d n=%d residual=%.2e orth=%.2e" % (size, c, d, m, ncol, res, orth), flush=True)
+        T.close()
     elif args.mode == "cacqr":
         # CholeskyQR2 on the 1D grid (c = 1, d = world): rows cyclic over ranks, Gram all-reduce through the communicator
         torch.cuda.set_device(0)

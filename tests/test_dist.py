@@ -134,6 +134,15 @@ def test_real_rccl_communicator_size1_runs_every_collective():
     torch.cuda.synchronize()
     assert [L.cap_topo_get(t, f) for f in range(7)] == [0, 1, 1, 1, 0, 0, 0]
     L.cap_topo_destroy(t)
+    # SUMMA and the grid CholeskyQR path over size-1 RCCL sub-communicators (ncclCommSplit)
+    from capital_amd import blas, summa, topo as tp
+    Tq = tp.square(1, 0, 2, force_rccl=True)
+    assert L.cap_comm_backend(Tq.row) == 1 and L.cap_comm_backend(Tq.depth) == 1
+    Am = matrix(384, 512, 1, 1); Bm = matrix(256, 384, 1, 1); Cm = matrix(256, 512, 1, 1)
+    Am.distribute_random(0, 0, 1, 1, 1); Bm.distribute_random(0, 0, 1, 1, 2)
+    summa.invoke(Am, Bm, Cm, Tq, blas.ArgPack_gemm(blas.Order.AblasColumnMajor, blas.Transpose.AblasNoTrans, blas.Transpose.AblasNoTrans, 1.0, 0.0))
+    assert np.linalg.norm(Cm.to_numpy() - Am.to_numpy() @ Bm.to_numpy()) / np.linalg.norm(Cm.to_numpy()) < 1e-14
+    summa.release(Tq); Tq.close()
     # the distributed Cholesky schedule over it (also ragged N)
     for n, nb in ((4096, 512), (3000, 256)):
         ctx = dc.Context(n, nb, comm)
@@ -200,3 +209,24 @@ def test_bench_multi_gpu_code_path_emulated():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["unit"] == "TFLOP/s" and d["value"] > 0
     assert d["config"]["info"] == 0 and d["dtype"] == "f64" and d["higher_is_better"] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,c,M,N,K,chunks", [(4, 1, 512, 384, 640, 0), (4, 1, 300, 200, 250, 3), (8, 2, 512, 512, 512, 2),
+                                                   (1, 1, 256, 256, 256, 2), (9, 1, 300, 300, 300, 2)])
+def test_summa_gemm_on_process_grids(nproc, c, M, N, K, chunks):
+    """matmult::summa GEMM on d x d x c grids sharing one GPU (host-staged row / column / depth communicators): 2 x 2 x 1
+    (2D SUMMA, 2 steps), 2 x 2 x 2 (the reference's own 3D cube, one step per layer + depth all-reduce), 3 x 3 x 1, ragged
+    cyclic pieces, chunked B broadcasts overlapped with the local GEMMs."""
+    r = _launch(nproc, "summa", M, N, 29701 + nproc + c, ("--c", c, "--k", K, "--chunks", chunks))
+    assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    assert "SUMMA-OK" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,c,m,n", [(8, 2, 4096, 64), (4, 1, 3000, 48), (16, 2, 6000, 96), (8, 2, 1001, 32)])
+def test_cacqr_3d_and_tunable_grid(nproc, c, m, n):
+    """CholeskyQR2 on c x d x c grids: 2 x 2 x 2 (sweep_3d), 1 x 4 x 1 (degenerates to 1D), 2 x 4 x 2 (sweep_tune), ragged rows."""
+    r = _launch(nproc, "cacqr3d", m, n, 29721 + nproc + c, ("--c", c))
+    assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    assert "CACQR3D-OK" in r.stdout, r.stdout[-2000:]

@@ -145,3 +145,22 @@ def test_large_sizes_by_properties(n, ci):
         _, pack2 = _factor(n, 1 if ci < 0 else -1, 1, -2)
         d2 = torch.diagonal(cholinv.construct_R(pack2).view())
         assert abs(float(torch.log(d).sum() - torch.log(d2).sum())) < 1e-9 * n
+
+
+@pytest.mark.parametrize("n,ci", [(8192, -1), (8192, 1), (16384, -1)])
+def test_large_result_against_independent_arithmetic(n, ci):
+    """Third opinion above the sizes the NumPy oracle reaches: ||(R^T R - A) X|| / ||A X|| for 8 random vectors with torch's
+    fp64 matmul (rocBLAS) - none of this library's kernels is involved in the check (validate.cholesky.residual uses the
+    library's own GEMM)."""
+    from capital_amd import cholinv, validate
+    A, pack = _factor(n, ci, 1, -4)
+    assert pack.last_info() == 0
+    R = cholinv.construct_R(pack)
+    assert validate.cholesky.probe(A.view(), R.view()) < 1e-13
+    if ci == 1:
+        # R^-1 too: ||R (R^-1 X) - X|| / ||X||
+        Ri = cholinv.construct_Rinv(pack)
+        g = torch.Generator(device="cpu"); g.manual_seed(3)
+        X = torch.rand(n, 8, dtype=torch.float64, generator=g).cuda()
+        Y = R.view() @ (Ri.view() @ X)
+        assert float((Y - X).norm() / X.norm()) < 1e-13

@@ -123,3 +123,68 @@ def test_trmm_and_trsm(side, trans, alpha, m, n):
     B2, B2v = to_dev(b)
     blas.engine._trsm(T, B2, m, n, td, m, pack)
     assert relerr(to_host(B2v), orc.trsm(t, b, side == 0, True, bool(trans), alpha)) < 1e-12
+
+
+@pytest.mark.parametrize("side,trans", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("td,other,alpha", [(700, 300, 1.0), (1536, 520, -0.5), (2304, 130, 2.0)])
+def test_trsm_blocked_substitution_all_forms(side, trans, td, other, alpha):
+    """cap_dtrsm = blocked substitution (diagonal-block inverses + GEMM updates): all four side/trans forms on
+    several-block triangles with ragged last blocks, against scipy.linalg.solve_triangular."""
+    import scipy.linalg as sla
+    blas, _ = _mods()
+    rng = np.random.default_rng(td + other + 2 * side + trans)
+    t = np.triu(rng.standard_normal((td, td))) / np.sqrt(td) + 2.0 * np.eye(td)
+    tj = t.copy(); tj[np.tril_indices(td, -1)] = -7.0            # the other triangle is not referenced
+    m, n = (td, other) if side == 0 else (other, td)
+    b = rng.standard_normal((m, n))
+    if side == 0:
+        ref = sla.solve_triangular(t, alpha * b, trans=trans, lower=False)
+    else:     # X op(T) = alpha B  <=>  op(T)^T X^T = alpha B^T
+        ref = sla.solve_triangular(t, alpha * b.T, trans=1 - trans, lower=False).T
+    T, _ = to_dev(tj); B, Bv = to_dev(b)
+    pack = blas.ArgPack_trmm(blas.Order.AblasColumnMajor, blas.Side(side), blas.UpLo.AblasUpper, blas.Transpose(trans), blas.Diag.AblasNonUnit, alpha)
+    blas.engine._trsm(T, B, m, n, td, m, pack)
+    x = to_host(Bv)
+    assert relerr(x, ref) < 1e-12
+    # backward error of the solve itself
+    r = (t.T if trans else t) @ x - alpha * b if side == 0 else x @ (t.T if trans else t) - alpha * b
+    assert np.linalg.norm(r) / (np.linalg.norm(t) * np.linalg.norm(x)) < 1e-14
+
+
+@pytest.mark.parametrize("kappa", [1e4, 1e8])
+def test_trsm_ill_conditioned_triangle(kappa):
+    """kappa(T) ~ 1e4 / 1e8 (graded singular values): the blocked substitution must stay backward stable - the
+    residual ||T x - b|| / (||T|| ||x||) at the 1e-14 level and the forward error within kappa * eps of scipy's."""
+    import scipy.linalg as sla
+    blas, _ = _mods()
+    n, nrhs = 1024, 64
+    rng = np.random.default_rng(int(np.log10(kappa)))
+    q1, _ = np.linalg.qr(rng.standard_normal((n, n))); q2, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    a = q1 @ np.diag(np.logspace(0, -np.log10(kappa), n)) @ q2
+    t = np.triu(np.linalg.qr(a)[1])
+    t = t * np.sign(np.diag(t))[:, None]
+    assert 0.1 * kappa < np.linalg.cond(t) < 10 * kappa
+    b = rng.standard_normal((n, nrhs))
+    for trans in (0, 1):
+        ref = sla.solve_triangular(t, b, trans=trans, lower=False)
+        T, _ = to_dev(t); B, Bv = to_dev(b)
+        pack = blas.ArgPack_trmm(blas.Order.AblasColumnMajor, blas.Side(0), blas.UpLo.AblasUpper, blas.Transpose(trans), blas.Diag.AblasNonUnit, 1.0)
+        blas.engine._trsm(T, B, n, nrhs, n, n, pack)
+        x = to_host(Bv)
+        op = t.T if trans else t
+        assert np.linalg.norm(op @ x - b) / (np.linalg.norm(t) * np.linalg.norm(x)) < 5e-14
+        assert relerr(x, ref) < 50 * kappa * np.finfo(float).eps
+
+
+def test_trmm_hinted_paths_large():
+    """public _trmm on operands big enough for the MFMA tile kernel with the triangular K-range hints (tags 8/16/32)."""
+    blas, _ = _mods()
+    rng = np.random.default_rng(5)
+    for side, trans, m, n in ((0, 0, 1024, 640), (0, 1, 1152, 512), (1, 0, 768, 1280)):
+        td = m if side == 0 else n
+        t = rng.standard_normal((td, td)); t[np.tril_indices(td, -1)] = 3.0
+        b = rng.standard_normal((m, n))
+        T, _ = to_dev(t); B, Bv = to_dev(b)
+        pack = blas.ArgPack_trmm(blas.Order.AblasColumnMajor, blas.Side(side), blas.UpLo.AblasUpper, blas.Transpose(trans), blas.Diag.AblasNonUnit, 1.5)
+        blas.engine._trmm(T, B, m, n, td, m, pack)
+        assert relerr(to_host(Bv), orc.trmm(t, b, side == 0, True, bool(trans), 1.5)) < 1e-14
