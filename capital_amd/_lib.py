@@ -31,6 +31,13 @@ SIGNATURES = {
     "cap_dpotrf_work_size": (i64, [i64]),
     "cap_dtrtri": (cint, [cint, i64, ptr, i64, ptr, ptr]),
     "cap_dtrtri_work_size": (i64, [i64]),
+    "cap_desc_create": (cint, [C.POINTER(ptr), i64, i64, i64, i64]),
+    "cap_desc_create_view": (cint, [C.POINTER(ptr), i64, i64, i64, i64, ptr, i64]),
+    "cap_desc_destroy": (cint, [ptr]),
+    "cap_desc_data": (ptr, [ptr]),
+    "cap_desc_get": (i64, [ptr, cint]),
+    "cap_desc_import_host": (cint, [ptr, ptr, i64, ptr]),
+    "cap_desc_export_host": (cint, [ptr, ptr, i64, ptr]),
     "cap_fill_symmetric": (cint, [ptr, i64, i64, i64, i64, i64, cint, ptr]),
     "cap_fill_random": (cint, [ptr, i64, i64, i64, i64, i64, i64, i64, i64, ptr]),
     "cap_copy_window": (cint, [ptr, cint, i64, i64, i64, ptr, cint, i64, i64, i64, i64, i64, cint, cint, ptr]),

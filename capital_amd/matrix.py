@@ -84,15 +84,37 @@ class matrix:
                                         localPgridX, localPgridY, globalPgridX, globalPgridY, key, cur_stream())
         _lib.check(st, "distribute_random")
 
-    # --- host transfer (tests / drivers; pinned staging is the caller's business) ---
+    # --- host transfer through the C descriptor's pinned double-buffered staging (cap_desc_import/export_host) ---
+    def _desc(self):
+        if getattr(self, "_cdesc", None) is None:
+            import ctypes as C
+            h = C.c_void_p()
+            _lib.check(_lib.lib().cap_desc_create_view(C.byref(h), self._globalDimensionX, self._globalDimensionY, self._pgridX,
+                                                       self._pgridY, self._buf.data_ptr(), self._ld), "cap_desc_create_view")
+            self._cdesc = h
+        return self._cdesc
+
     def to_numpy(self):
-        return self.view().cpu().numpy().copy()
+        """column-major export, returned as a [row, col] C-ordered array"""
+        out = np.empty((self._dimensionX, self._dimensionY), dtype=np.float64)       # [col][row] = column-major, ld = rows
+        _lib.check(_lib.lib().cap_desc_export_host(self._desc(), out.ctypes.data, self._dimensionY, cur_stream()), "export_host")
+        return np.ascontiguousarray(out.T)
 
     def from_numpy(self, a):
         a = np.asarray(a, dtype=np.float64)
         assert a.shape == (self._dimensionY, self._dimensionX), (a.shape, self._dimensionY, self._dimensionX)
-        self.view().copy_(torch.from_numpy(np.ascontiguousarray(a)).to(self.device))
+        colmajor = np.ascontiguousarray(a.T)                                          # [col][row]
+        _lib.check(_lib.lib().cap_desc_import_host(self._desc(), colmajor.ctypes.data, self._dimensionY, cur_stream()), "import_host")
+        torch.cuda.current_stream().synchronize()                                     # `colmajor` may be released
         return self
+
+    def __del__(self):
+        try:
+            if getattr(self, "_cdesc", None) is not None:
+                _lib.lib().cap_desc_destroy(self._cdesc)
+                self._cdesc = None
+        except Exception:
+            pass
 
 
 def serialize(src, dst, src_window, dst_origin, tri_only=False, zero_lower=False, src_packed=False, dst_packed=False,

@@ -97,6 +97,25 @@ int64_t cap_dtrtri_work_size(int64_t n);
  * Matrix descriptor helpers (replaces src/matrix/: generators, serialize, structure)
  * ---------------------------------------------------------------------------------- */
 
+/* matrix<T,U,Structure> descriptor - matrix.h:9-97: global dims (X = columns, Y = rows, upstream's naming), process
+ * grid, local element-cyclic dims ceil(global / grid) (matrix.hpp:8-11), one column-major HBM buffer and its ownership:
+ * cap_desc_create allocates (zero-filled; matrix.hpp:5-50,141-155), cap_desc_create_view is the injection constructor
+ * (matrix.hpp:52-74: the caller keeps ownership of `device_data`), destroy frees only what the descriptor owns
+ * (matrix.hpp:157-169).  import / export move the local piece between HOST memory (column-major, ld_host) and HBM
+ * through two pinned 64 MiB chunk buffers, overlapping the host-side copy of one chunk with the PCIe transfer of the
+ * other; a host pointer that is already pinned is copied directly.  import is ordered on `stream`; export blocks
+ * until the host buffer is complete.  cap_desc_get: 0 global cols, 1 global rows, 2 local cols, 3 local rows, 4 ld,
+ * 5 owns, 6 grid x, 7 grid y, 8 local element count.                                                                  */
+typedef struct cap_desc cap_desc;
+int cap_desc_create(cap_desc** desc, int64_t global_cols, int64_t global_rows, int64_t grid_x, int64_t grid_y);
+int cap_desc_create_view(cap_desc** desc, int64_t global_cols, int64_t global_rows, int64_t grid_x, int64_t grid_y,
+                         double* device_data, int64_t ld);
+int cap_desc_destroy(cap_desc* desc);
+double* cap_desc_data(cap_desc* desc);
+int64_t cap_desc_get(const cap_desc* desc, int field);
+int cap_desc_import_host(cap_desc* desc, const double* host, int64_t ld_host, void* stream);
+int cap_desc_export_host(cap_desc* desc, double* host, int64_t ld_host, void* stream);
+
 /* rect::_distribute_symmetric - structure.hpp:68-103.  Fills the local element-cyclic piece
  * (grid position x,y of a d x d grid) of the N x N SPD test matrix directly on the GPU:
  * A[gy,gx] = u(max + N*min) (+N on the diagonal), u = srand48/drand48 closed form.

@@ -125,3 +125,43 @@ def test_factor_from_cyclic_pieces_matches_reference_semantics():
             P = matrix(n, n, d, d); cyclic_export(R, P, x, y, d, d)
             ref = orc.cyclic_local(r_ref, x, y, d, d)
             assert np.linalg.norm(P.to_numpy() - ref) <= 1e-13 * np.linalg.norm(r_ref)
+
+
+def test_descriptor_ownership_and_pinned_staging_round_trip():
+    """cap_desc_*: the allocating and the injection constructor (matrix.hpp:5-74), and host <-> HBM through the
+    double-buffered pinned chunks: several chunks, ragged sizes, strided host images, pinned host memory (direct path)."""
+    import ctypes as C
+    from capital_amd import _lib
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(0)
+    for (gx, gy, px, py) in [(300, 200, 1, 1), (1000, 9001, 2, 3), (2, 9_000_000, 1, 1), (4097, 4099, 1, 1)]:
+        d = C.c_void_p()
+        _lib.check(L.cap_desc_create(C.byref(d), gx, gy, px, py))
+        lx, ly, ld = L.cap_desc_get(d, 2), L.cap_desc_get(d, 3), L.cap_desc_get(d, 4)
+        assert (lx, ly) == (-(-gx // px), -(-gy // py)) and ld >= ly and L.cap_desc_get(d, 5) == 1
+        ldh = ly + 3                                            # strided host image
+        host = rng.standard_normal((lx, ldh))
+        _lib.check(L.cap_desc_import_host(d, host.ctypes.data, ldh, s))
+        back = np.full((lx, ldh), np.nan)
+        _lib.check(L.cap_desc_export_host(d, back.ctypes.data, ldh, s))
+        assert np.array_equal(back[:, :ly], host[:, :ly]) and np.isnan(back[:, ly:]).all()
+        # the same device buffer seen through a view descriptor (injection constructor): not owned, same content
+        v = C.c_void_p()
+        _lib.check(L.cap_desc_create_view(C.byref(v), gx, gy, px, py, L.cap_desc_data(d), ld))
+        assert L.cap_desc_get(v, 5) == 0 and L.cap_desc_data(v) == L.cap_desc_data(d)
+        pinned = torch.empty(lx, ly, dtype=torch.float64).pin_memory()
+        _lib.check(L.cap_desc_export_host(v, pinned.data_ptr(), ly, s))        # pinned host memory: direct engine copy
+        assert np.array_equal(pinned.numpy(), host[:, :ly])
+        L.cap_desc_destroy(v)                                    # must not free d's buffer
+        _lib.check(L.cap_desc_export_host(d, back.ctypes.data, ldh, s))
+        assert np.array_equal(back[:, :ly], host[:, :ly])
+        L.cap_desc_destroy(d)
+
+
+def test_matrix_numpy_round_trip_uses_the_descriptor():
+    from capital_amd.matrix import matrix
+    a = np.random.default_rng(1).standard_normal((777, 333))
+    A = matrix(333, 777, 1, 1).from_numpy(a)
+    assert np.array_equal(A.to_numpy(), a)
+    assert np.array_equal(A.view().cpu().numpy(), a)
