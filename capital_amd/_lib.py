@@ -96,6 +96,12 @@ SIGNATURES = {
     "cap_summa_plan_destroy": (cint, [ptr]),
     "cap_summa_local_dims": (None, [ptr, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
     "cap_summa_dgemm": (cint, [ptr, dbl, ptr, i64, ptr, i64, dbl, ptr, i64, ptr]),
+    "cap_mpchol_plan_create": (cint, [C.POINTER(ptr), i64, i64]),
+    "cap_mpchol_plan_destroy": (cint, [ptr]),
+    "cap_mpchol_factor": (cint, [ptr, ptr, i64, ptr]),
+    "cap_mpchol_info": (cint, [ptr, ptr, C.POINTER(i64)]),
+    "cap_mpchol_solve": (cint, [ptr, ptr, i64, ptr, i64, ptr, i64, i64, cint, dbl, C.POINTER(cint), C.POINTER(dbl), ptr]),
+    "cap_mpchol_R32_ptr": (ptr, [ptr, C.POINTER(i64)]),
     "cap_cacqr_plan_create": (cint, [C.POINTER(ptr), i64, i64, cint, ptr]),
     "cap_cacqr_plan_create_grid": (cint, [C.POINTER(ptr), i64, i64, cint, ptr]),
     "cap_cacqr_local_cols": (i64, [ptr]),

@@ -698,21 +698,42 @@ int cap_dtrsm(int side, int uplo, int trans, int64_t m, int64_t n, double alpha,
   if (!T || !B || !work || ldb < m) return CAP_ERR_ARG;
   if (uplo != CAP_UPPER) return CAP_ERR_UNSUPPORTED;
   hipStream_t s = cap_stream(stream);
-  const bool left = side == CAP_LEFT, tr = trans == CAP_TRANS;
+  const bool left = side == CAP_LEFT;
   const int64_t td = left ? m : n, other = left ? n : m;
   if (ldt < td) return CAP_ERR_ARG;
   const int64_t tb = std::min(trsm_block(td), cap_round_up(td, 2));
   const int64_t nblk = cap_ceil_div(td, tb);
   double* Inv = work; double* X = work + nblk * tb * tb; double* W = X + cap_round_up(tb * other, 2);
-  // block inverses (zero-lower copies, so they can be GEMM operands as full squares)
+  CAP_TRY(cap_trsm_prepare(T, ldt, td, tb, Inv, W, s));
+  // alpha once, up front (B <- alpha B through the GEMM launcher's scaling path); the sweep then solves op(T) X = B
+  if (alpha != 1.0) CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, m, n, 0, 0.0, B, ldb, B, ldb, alpha, B, ldb, 0, s));
+  return cap_trsm_apply(side, trans, m, n, T, ldt, Inv, tb, B, ldb, X, s);
+}
+
+}  // extern "C"
+
+// ---- the two halves of cap_dtrsm, also used by the mixed-precision solver (which keeps the block inverses between
+// refinement sweeps).  Inv: nblk * tb * tb doubles, W: rec_work_size(tb) scratch, X: tb * max(m, n) block temp.
+int64_t cap_trsm_block(int64_t td) { return std::min(trsm_block(td), cap_round_up(std::max<int64_t>(td, 1), 2)); }
+int64_t cap_trsm_prepare_work(int64_t tb) { return rec_work_size(tb); }
+
+int cap_trsm_prepare(const double* T, int64_t ldt, int64_t td, int64_t tb, double* Inv, double* W, hipStream_t s) {
+  const int64_t nblk = cap_ceil_div(td, tb);
   for (int64_t i = 0; i < nblk; i++) {
     const int64_t o = i * tb, w = std::min(tb, td - o);
     double* Ii = Inv + i * tb * tb;
-    CAP_TRY(cap_copy_window(T, 0, ldt, o, o, Ii, 0, tb, 0, 0, w, w, 1, 1, stream));
+    // zero-lower copy, so the inverse can be a GEMM operand as a full square
+    CAP_TRY(cap_copy_window(T, 0, ldt, o, o, Ii, 0, tb, 0, 0, w, w, 1, 1, (void*)s));
     CAP_TRY(rec_trtri(Ii, tb, w, W, rec_work_size(tb), CAP_LEAF_MAX, s));
   }
-  // alpha once, up front (B <- alpha B through the GEMM launcher's scaling path); the sweep then solves op(T) X = B
-  if (alpha != 1.0) CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, m, n, 0, 0.0, B, ldb, B, ldb, alpha, B, ldb, 0, s));
+  return CAP_OK;
+}
+
+int cap_trsm_apply(int side, int trans, int64_t m, int64_t n, const double* T, int64_t ldt, const double* Inv, int64_t tb, double* B,
+                   int64_t ldb, double* X, hipStream_t s) {
+  const bool left = side == CAP_LEFT, tr = trans == CAP_TRANS;
+  const int64_t td = left ? m : n;
+  const int64_t nblk = cap_ceil_div(td, tb);
   const bool forward = left ? tr : !tr;      // order of the block sweep
   for (int64_t step = 0; step < nblk; step++) {
     const int64_t i = forward ? step : nblk - 1 - step;
@@ -742,8 +763,6 @@ int cap_dtrsm(int side, int uplo, int trans, int64_t m, int64_t n, double alpha,
   }
   return CAP_OK;
 }
-
-}  // extern "C"
 
 // used by cacqr.hip: full cholinv (R in place, Ri = R^-1) of an n x n block on one stream
 int cap_rec_cholinv_full(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, double* W, int64_t wcap, int* info,

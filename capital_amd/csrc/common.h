@@ -60,3 +60,13 @@ int cap_panel64_solve_update(double* R, int64_t ldr, const double* Dinv, int64_t
 int cap_gemm_small_batched(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
                            int64_t sa, const double* B, int64_t ldb, int64_t sb, double beta, double* C, int64_t ldc, int64_t sc,
                            int nbatch, hipStream_t stream);
+
+// cholinv.hip: the two halves of cap_dtrsm (diagonal-block inverses once, block substitution per right-hand side set)
+int64_t cap_trsm_block(int64_t td);
+int64_t cap_trsm_prepare_work(int64_t tb);
+int cap_trsm_prepare(const double* T, int64_t ldt, int64_t td, int64_t tb, double* Inv, double* W, hipStream_t s);
+int cap_trsm_apply(int side, int trans, int64_t m, int64_t n, const double* T, int64_t ldt, const double* Inv, int64_t tb, double* B,
+                   int64_t ldb, double* X, hipStream_t s);
+int cap_rec_cholinv_full(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, double* W, int64_t wcap, int* info,
+                         hipStream_t s, int64_t info_base);
+int64_t cap_rec_work_size(int64_t n);

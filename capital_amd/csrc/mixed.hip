@@ -1,0 +1,332 @@
+// Mixed-precision Cholesky solve: bf16 MFMA factorization + fp64 iterative refinement (BASELINE config 5).
+//
+// Not in the reference: its only solve path is the stub trsm/diaginvert (diaginvert.hpp:7-10, static_assert) and its
+// factorization is fp64 only.  The fp64 path of this library (cholinv.hip + cap_dtrsm) is the oracle of this one.
+//
+//   factor   R32 (fp32 storage, upper) from A (fp64): blocked right-looking, panel width nb = 1024
+//              diagonal block   -> fp64, the existing in-LDS / MFMA fp64 cholinv chain (R_kk and its inverse), back to fp32
+//              block row        -> fp64, S = Dinv^T * row  (fp64 MFMA GEMM), stored as fp32 (the factor) and bf16 (the panel)
+//              trailing update  -> C32 -= P16^T P16 on v_mfma_f32_32x32x16_bf16, fp32 accumulate, upper tiles only
+//            i.e. ALL O(N^3) flops run at bf16 MFMA rate; the O(nb N^2) panel work stays fp64.
+//   solve    x = R^-1 R^-T b with the fp64-promoted factor and the blocked TRSM (diagonal-block inverses cached in the
+//            plan), then classical iterative refinement in fp64:  r = b - A x (fp64 MFMA GEMM), d = R^-1 R^-T r, x += d,
+//            until ||r||_F / ||b||_F <= tol.  Converges when kappa(A) * eps_bf16-factor < 1.
+//
+// bf16 tile kernel (same shape as the fp64 one, gemm.hip): 128 x 128 C tile per 256-thread workgroup, 4 waves x (2 x 2
+// blocks of 32 x 32), K tile = 64 bf16 = 128 bytes per row, so the LDS image, its XOR swizzle and the buffer-addressed
+// LDS-DMA are byte-for-byte those of the fp64 kernel (tile_dma.h); fragments by ds_read_b128 (8 bf16 = one MFMA operand);
+// operands swapped so a lane owns 32 consecutive rows of a column -> the fp32 atomic-add epilogue touches whole lines.
+// Roofline of the update: C traffic 8 B per 2K flop -> K/4 flop/B; K = 1024: 1.5 PFLOP/s at 6 TB/s - HBM-bound below the
+// 2.5 PFLOP/s MFMA peak, and this 128-wide tile additionally pulls 32 KiB of operands per 16 MFMAs through L2.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.h"
+#include "tile_dma.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int TB = 128;            // C tile edge
+constexpr int KB = 64;             // K tile (bf16 elements) = 128 bytes per row
+constexpr int TILE_D = 128 * 16;   // doubles per operand tile image (16 KiB)
+
+struct BfArgs {
+  const __bf16* A; const __bf16* B; float* C;
+  int64_t lda, ldb, ldc;           // elements
+  int64_t M, N, K;
+  float alpha;
+  int tri;                         // 1: only tiles / elements with row <= col (square problems)
+  int tm, tn, chunk;
+};
+
+// C[M x N] += alpha * A^T B,  A: K x M, B: K x N (both K-contiguous bf16), C fp32 column-major.  M, N % 128 == 0, K % 64 == 0.
+__global__ void __launch_bounds__(256, 2) bf16_tn_kernel(const BfArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  // block -> tile: XCD b % 8 walks a contiguous range of the tile list (column-major; upper triangle for tri)
+  const int b = (int)blockIdx.x;
+  const int L = (b & 7) * g.chunk + (b >> 3);
+  int ti, tj;
+  if ((b >> 3) >= g.chunk) return;
+  if (g.tri) {
+    tj = (int)((__builtin_sqrtf(8.0f * (float)L + 1.0f) - 1.0f) * 0.5f);
+    while ((tj + 1) * (tj + 2) / 2 <= L) tj++;
+    while (tj * (tj + 1) / 2 > L) tj--;
+    ti = L - tj * (tj + 1) / 2;
+    if (tj >= g.tn) return;
+  } else {
+    ti = L % g.tm; tj = L / g.tm;
+    if (tj >= g.tn) return;
+  }
+  const int64_t i0 = (int64_t)ti * TB, j0 = (int64_t)tj * TB;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wi = (wid & 1) * 64, wj = (wid >> 1) * 64;
+  const int r32 = lane & 31, kg = lane >> 5;
+  auto sA = [&](int buf) -> double* { return smem + buf * 2 * TILE_D; };
+  auto sB = [&](int buf) -> double* { return smem + buf * 2 * TILE_D + TILE_D; };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+  const int nk = (int)(g.K / KB);
+  // the bf16 panels are addressed as "double" matrices of K / 4 doubles per row: same 128-byte rows, same swizzle
+  DmaBuf dA = dma_buf_make(reinterpret_cast<const double*>(g.A + i0 * g.lda), g.lda / 4);
+  DmaBuf dB = dma_buf_make(reinterpret_cast<const double*>(g.B + j0 * g.ldb), g.ldb / 4);
+  // fragment byte offsets: row (block origin + r32), chunk (2 s + kg) ^ ((row >> 1) & 7) = (2 s) ^ t
+  const int t = kg ^ ((r32 >> 1) & 7);
+  const int a_row = (wi + r32) * 128, b_row = (wj + r32) * 128;
+  bf16x8 fa[2][2][2], fb[2][2][2];          // [half][step in half][block]
+  auto read_half = [&](const double* tA, const double* tB, int h, bf16x8 (&xa)[2][2], bf16x8 (&xb)[2][2]) {
+    const char* pa = reinterpret_cast<const char*>(tA); const char* pb = reinterpret_cast<const char*>(tB);
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const int off = (((2 * (2 * h + s)) ^ t) << 4);
+#pragma unroll
+      for (int blk = 0; blk < 2; blk++) {
+        xa[s][blk] = *reinterpret_cast<const bf16x8*>(pa + a_row + blk * 32 * 128 + off);
+        xb[s][blk] = *reinterpret_cast<const bf16x8*>(pb + b_row + blk * 32 * 128 + off);
+      }
+    }
+  };
+  auto mma_half = [&](const bf16x8 (&xa)[2][2], const bf16x8 (&xb)[2][2]) {
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[s][j], xa[s][i], acc[i][j], 0, 0, 0);   // swapped: lane = C row
+  };
+
+  if (nk > 0) {
+    dma_tile_buf<0, 4>(dA, wid, 0u, sA(0)); dma_tile_buf<0, 4>(dB, wid, 0u, sB(0));
+    __syncthreads();
+    read_half(sA(0), sB(0), 0, fa[0], fb[0]);
+    { const uint32_t k1 = (nk > 1 ? 1u : 0u) * 128u; dma_tile_buf<0, 4>(dA, wid, k1, sA(1)); dma_tile_buf<0, 4>(dB, wid, k1, sB(1)); }
+    read_half(sA(0), sB(0), 1, fa[1], fb[1]);
+    mma_half(fa[0], fb[0]);
+    for (int kt = 0; kt + 1 < nk; kt++) {
+      const int nxt = (kt + 1) & 1;
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __syncthreads();                                   // tile kt+1 has landed, tile kt's buffer is free
+      const uint32_t kn = (uint32_t)((kt + 2 < nk) ? kt + 2 : nk - 1) * 128u;
+      dma_tile_buf<0, 4>(dA, wid, kn, sA(nxt ^ 1));
+      read_half(sA(nxt), sB(nxt), 0, fa[0], fb[0]);
+      mma_half(fa[1], fb[1]);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      dma_tile_buf<0, 4>(dB, wid, kn, sB(nxt ^ 1));
+      read_half(sA(nxt), sB(nxt), 1, fa[1], fb[1]);
+      mma_half(fa[0], fb[0]);
+    }
+    mma_half(fa[1], fb[1]);
+  }
+
+  // epilogue: lane holds C[i0 + wi + 32 i + r32][j0 + wj + 32 j + (e & 3) + 8 (e >> 2) + 4 kg]: 32 consecutive rows per half wave
+  const bool diag = g.tri && ti == tj;
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int64_t row = i0 + wi + 32 * i + r32;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int64_t col = j0 + wj + 32 * j + (e & 3) + 8 * (e >> 2) + 4 * kg;
+        if (!diag || row <= col)
+          __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)(g.C + row + col * g.ldc), g.alpha * acc[i][j][e]);
+      }
+  }
+}
+
+int launch_bf16_tn(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A, int64_t lda, const __bf16* B, int64_t ldb, float* C,
+                   int64_t ldc, int tri, hipStream_t s) {
+  if (m <= 0 || n <= 0 || k <= 0) return CAP_OK;
+  if ((m % TB) || (n % TB) || (k % KB) || (lda % 8) || (ldb % 8) || (tri && m != n)) return CAP_ERR_UNSUPPORTED;
+  if (128 * lda * 2 + k * 2 >= 0xfffffff0LL || 128 * ldb * 2 + k * 2 >= 0xfffffff0LL) return CAP_ERR_UNSUPPORTED;
+  BfArgs g;
+  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.tri = tri;
+  g.tm = (int)(m / TB); g.tn = (int)(n / TB);
+  const int64_t tiles = tri ? (int64_t)g.tn * (g.tn + 1) / 2 : (int64_t)g.tm * g.tn;
+  g.chunk = (int)cap_ceil_div(tiles, 8);
+  hipLaunchKernelGGL(bf16_tn_kernel, dim3((unsigned)(g.chunk * 8)), dim3(256), 4 * TILE_D * sizeof(double), s, g);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+// ---- precision conversions (HBM-bound element kernels) ------------------------------------------------------------
+__global__ void f64_to_f32_upper_kernel(const double* A, int64_t lda, float* R, int64_t ldr, int64_t n) {
+  const int64_t col = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (col >= n) return;
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x)
+    R[row + col * ldr] = row <= col ? (float)A[row + col * lda] : 0.0f;
+}
+__global__ void f32_to_f64_kernel(const float* S, int64_t lds_, double* D, int64_t ldd, int64_t rows, int64_t cols, int upper_only) {
+  const int64_t col = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (col >= cols) return;
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < rows; row += (int64_t)gridDim.x * blockDim.x)
+    D[row + col * ldd] = (!upper_only || row <= col) ? (double)S[row + col * lds_] : 0.0;
+}
+// the solved block row: fp64 -> fp32 (into the factor) and bf16 (into the K-contiguous panel of the trailing update)
+__global__ void f64_to_f32_bf16_kernel(const double* S, int64_t lds_, float* R, int64_t ldr, __bf16* P, int64_t ldp, int64_t rows, int64_t cols,
+                                       int upper_only) {
+  const int64_t col = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (col >= cols) return;
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < rows; row += (int64_t)gridDim.x * blockDim.x) {
+    const double v = (!upper_only || row <= col) ? S[row + col * lds_] : 0.0;
+    R[row + col * ldr] = (float)v;
+    if (P) P[row + col * ldp] = (__bf16)(float)v;
+  }
+}
+__global__ void axpy_cols_kernel(double* X, int64_t ldx, const double* D, int64_t ldd, int64_t rows, int64_t cols) {
+  const int64_t col = blockIdx.y;
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < rows; row += (int64_t)gridDim.x * blockDim.x)
+    X[row + col * ldx] += D[row + col * ldd];
+}
+
+dim3 grid2(int64_t rows, int64_t cols) {
+  return dim3((unsigned)std::min<int64_t>(cap_ceil_div(rows, 256), 4096), (unsigned)std::min<int64_t>(cols, 65535), (unsigned)cap_ceil_div(cols, 65535));
+}
+}  // namespace
+
+struct cap_mpchol_plan {
+  int64_t n, nb, nrhs_cap;          // nrhs_cap: internal right-hand-side width (multiple of 128)
+  float* R32; double* R64; __bf16* P16;
+  double* D64; double* Dinv; double* T64; double* S64; double* W; int64_t wcap;
+  double* Inv; int64_t tb; double* Xt; double* Wt;          // blocked TRSM state
+  double* Xw; double* Rw; double* Bw; double* norms;
+  int* info_dev; bool have_r64;
+};
+
+extern "C" {
+
+int cap_mpchol_plan_create(cap_mpchol_plan** plan, int64_t n, int64_t nrhs_max) {
+  if (!plan || n <= 0 || nrhs_max <= 0) return CAP_ERR_ARG;
+  if (n % 128) return CAP_ERR_UNSUPPORTED;                     // the bf16 tile kernel works on whole 128 x 128 tiles
+  cap_mpchol_plan* p = new (std::nothrow) cap_mpchol_plan();
+  if (!p) return CAP_ERR_ALLOC;
+  memset(p, 0, sizeof(*p));
+  p->n = n; p->nb = std::min<int64_t>(1024, n); p->nrhs_cap = cap_round_up(nrhs_max, 128);
+  while (p->nb > 128 && ((p->nb & (p->nb - 1)) || p->nb > n)) p->nb /= 2;   // power of two <= n: the fused diagonal-block chain
+  p->wcap = cap_rec_work_size(p->nb);
+  p->tb = cap_trsm_block(n);
+  const int64_t nb = p->nb, w = p->nrhs_cap, nblk = cap_ceil_div(n, p->tb);
+  hipError_t e = hipMalloc((void**)&p->R32, sizeof(float) * n * n);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->R64, sizeof(double) * n * n);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->P16, sizeof(__bf16) * nb * n);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->D64, sizeof(double) * (2 * nb * nb + 2 * nb * n + p->wcap));
+  if (e == hipSuccess) e = hipMalloc((void**)&p->Inv, sizeof(double) * (nblk * p->tb * p->tb + p->tb * w + cap_trsm_prepare_work(p->tb)));
+  if (e == hipSuccess) e = hipMalloc((void**)&p->Xw, sizeof(double) * (3 * n * w + 8));
+  if (e == hipSuccess) e = hipMalloc((void**)&p->info_dev, sizeof(int));
+  if (e != hipSuccess) { cap_mpchol_plan_destroy(p); return CAP_ERR_ALLOC; }
+  p->Dinv = p->D64 + nb * nb; p->T64 = p->Dinv + nb * nb; p->S64 = p->T64 + nb * n; p->W = p->S64 + nb * n;
+  p->Xt = p->Inv + nblk * p->tb * p->tb; p->Wt = p->Xt + p->tb * w;
+  p->Rw = p->Xw + n * w; p->Bw = p->Rw + n * w; p->norms = p->Bw + n * w;
+  *plan = p;
+  return CAP_OK;
+}
+
+int cap_mpchol_plan_destroy(cap_mpchol_plan* p) {
+  if (!p) return CAP_OK;
+  for (void* q : {(void*)p->R32, (void*)p->R64, (void*)p->P16, (void*)p->D64, (void*)p->Inv, (void*)p->Xw, (void*)p->info_dev}) if (q) (void)hipFree(q);
+  delete p;
+  return CAP_OK;
+}
+
+// A: n x n fp64, upper triangle consumed.  Leaves the fp32 factor, its fp64 promotion and the TRSM block inverses in the plan.
+int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* stream) {
+  if (!p || !A || lda < p->n) return CAP_ERR_ARG;
+  hipStream_t s = cap_stream(stream);
+  const int64_t n = p->n, nb = p->nb;
+  CAP_HIP(hipMemsetAsync(p->info_dev, 0, sizeof(int), s));
+  hipLaunchKernelGGL(f64_to_f32_upper_kernel, grid2(n, n), dim3(256), 0, s, A, lda, p->R32, n, n);
+  CAP_HIP(hipGetLastError());
+  for (int64_t j0 = 0; j0 < n; j0 += nb) {
+    const int64_t jb = std::min(nb, n - j0), j1 = j0 + jb, m = n - j1;
+    float* D32 = p->R32 + j0 + j0 * n;
+    // diagonal block in fp64: R_kk and its inverse (the existing chain), R_kk back into the fp32 factor
+    hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, jb), dim3(256), 0, s, D32, n, p->D64, jb, jb, jb, 1);
+    CAP_HIP(hipMemsetAsync(p->Dinv, 0, sizeof(double) * jb * jb, s));
+    CAP_TRY(cap_rec_cholinv_full(p->D64, jb, p->Dinv, jb, jb, p->W, p->wcap, p->info_dev, s, j0));
+    hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(jb, jb), dim3(256), 0, s, p->D64, jb, D32, n, (__bf16*)nullptr, (int64_t)0, jb, jb, 1);
+    CAP_HIP(hipGetLastError());
+    if (m <= 0) break;
+    // block row in fp64: S = Dinv^T * R[j0:j1, j1:n]; fp32 into the factor, bf16 into the panel
+    float* Row32 = p->R32 + j0 + j1 * n;
+    hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, m), dim3(256), 0, s, Row32, n, p->T64, jb, jb, m, 0);
+    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, m, jb, 1.0, p->Dinv, jb, p->T64, jb, 0.0, p->S64, jb, 0, s, 16));
+    hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(jb, m), dim3(256), 0, s, p->S64, jb, Row32, n, p->P16, jb, jb, m, 0);
+    CAP_HIP(hipGetLastError());
+    // trailing update on bf16 MFMA: R32[j1:, j1:] -= P^T P, upper tiles
+    CAP_TRY(launch_bf16_tn(m, m, jb, -1.0f, p->P16, jb, p->P16, jb, p->R32 + j1 + j1 * n, n, 1, s));
+  }
+  // fp64 promotion of the factor + the diagonal-block inverses of the blocked TRSM (reused by every refinement sweep)
+  hipLaunchKernelGGL(f32_to_f64_kernel, grid2(n, n), dim3(256), 0, s, p->R32, n, p->R64, n, n, n, 1);
+  CAP_HIP(hipGetLastError());
+  CAP_TRY(cap_trsm_prepare(p->R64, n, n, p->tb, p->Inv, p->Wt, s));
+  p->have_r64 = true;
+  return CAP_OK;
+}
+
+float* cap_mpchol_R32_ptr(cap_mpchol_plan* p, int64_t* ld) { if (!p) return nullptr; if (ld) *ld = p->n; return p->R32; }
+
+int cap_mpchol_info(cap_mpchol_plan* p, void* stream, int64_t* info) {
+  if (!p || !info) return CAP_ERR_ARG;
+  int h = 0;
+  CAP_HIP(hipMemcpyAsync(&h, p->info_dev, sizeof(int), hipMemcpyDeviceToHost, cap_stream(stream)));
+  CAP_HIP(hipStreamSynchronize(cap_stream(stream)));
+  *info = h;
+  return h == 0 ? CAP_OK : CAP_ERR_NOT_SPD;
+}
+
+// Solve A X = B (nrhs columns) to fp64 accuracy.  A must be the FULL symmetric matrix (the residual is a plain GEMM).
+// Returns the sweeps used and the final ||B - A X||_F / ||B||_F; CAP_OK also when max_iter was reached (check relres).
+// Synchronises the stream once per sweep (the convergence test is a host decision).
+int cap_mpchol_solve(cap_mpchol_plan* p, const double* A, int64_t lda, const double* B, int64_t ldb, double* X, int64_t ldx, int64_t nrhs,
+                     int max_iter, double tol, int* iters, double* relres, void* stream) {
+  if (!p || !A || !B || !X || lda < p->n || ldb < p->n || ldx < p->n || nrhs <= 0 || nrhs > p->nrhs_cap || !p->have_r64) return CAP_ERR_ARG;
+  hipStream_t s = cap_stream(stream);
+  const int64_t n = p->n, w = cap_round_up(nrhs, 128);
+  auto apply_Ainv = [&](double* V) -> int {      // V <- R^-1 R^-T V  (n x w)
+    CAP_TRY(cap_trsm_apply(CAP_LEFT, CAP_TRANS, n, w, p->R64, n, p->Inv, p->tb, V, n, p->Xt, s));
+    return cap_trsm_apply(CAP_LEFT, CAP_NOTRANS, n, w, p->R64, n, p->Inv, p->tb, V, n, p->Xt, s);
+  };
+  // zero-padded working copies: B, X (= first solve), residual
+  CAP_HIP(hipMemsetAsync(p->Bw, 0, sizeof(double) * n * w, s));
+  CAP_TRY(cap_copy_rect(B, ldb, p->Bw, n, n, nrhs, s));
+  CAP_HIP(hipMemcpyAsync(p->Xw, p->Bw, sizeof(double) * n * w, hipMemcpyDeviceToDevice, s));
+  CAP_TRY(apply_Ainv(p->Xw));
+  CAP_TRY(cap_sumsq(p->Bw, n, n, w, 0, 0, p->norms, stream));
+  double h[2] = {0, 0};
+  int it = 0; double rr = 0;
+  for (;;) {
+    // r = b - A x  (A symmetric: A^T form = the fast K-contiguous kernel)
+    CAP_HIP(hipMemcpyAsync(p->Rw, p->Bw, sizeof(double) * n * w, hipMemcpyDeviceToDevice, s));
+    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n, w, n, -1.0, A, lda, p->Xw, n, 1.0, p->Rw, n, 0, s));
+    CAP_TRY(cap_sumsq(p->Rw, n, n, w, 0, 0, p->norms + 1, stream));
+    CAP_HIP(hipMemcpyAsync(h, p->norms, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
+    CAP_HIP(hipStreamSynchronize(s));
+    rr = h[0] > 0 ? std::sqrt(h[1] / h[0]) : 0.0;
+    if (rr <= tol || it >= max_iter || !(rr == rr)) break;
+    CAP_TRY(apply_Ainv(p->Rw));                  // correction
+    hipLaunchKernelGGL(axpy_cols_kernel, dim3((unsigned)std::min<int64_t>(cap_ceil_div(n, 256), 4096), (unsigned)w), dim3(256), 0, s, p->Xw, n,
+                       p->Rw, n, n, w);
+    CAP_HIP(hipGetLastError());
+    it++;
+  }
+  CAP_TRY(cap_copy_rect(p->Xw, n, X, ldx, n, nrhs, s));
+  if (iters) *iters = it;
+  if (relres) *relres = rr;
+  return CAP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+"""Mixed-precision Cholesky solve (BASELINE config 5): bf16 MFMA factorization + fp64 iterative refinement.
+
+    plan = mixed.plan(n, nrhs_max)
+    plan.factor(A)                       # A: `matrix` (n x n fp64, full symmetric, resident in HBM)
+    X, iters, relres = plan.solve(A, B)  # B: `matrix` (n x nrhs); X to fp64 accuracy
+
+Not in the reference (its solve path is a stub, trsm/diaginvert/diaginvert.hpp:7-10); the fp64 path of this package
+(cholinv + blas::engine::_trsm) is its oracle.  Everything runs behind the C ABI (csrc/mixed.hip)."""
+import ctypes as C
+
+from . import _lib
+from ._util import cur_stream
+from .matrix import matrix
+
+
+class plan:
+    def __init__(self, n, nrhs_max=128):
+        self.n, self.nrhs_max = int(n), int(nrhs_max)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().cap_mpchol_plan_create(C.byref(h), self.n, self.nrhs_max), "cap_mpchol_plan_create")
+        self._h = h
+
+    def factor(self, A):
+        _lib.check(_lib.lib().cap_mpchol_factor(self._h, A.data_ptr(), A.ld(), cur_stream()), "mpchol::factor")
+
+    def last_info(self):
+        v = C.c_int64(0)
+        _lib.lib().cap_mpchol_info(self._h, cur_stream(), C.byref(v))
+        return v.value
+
+    def solve(self, A, B, max_iter=30, tol=1e-15):
+        nrhs = B.num_columns_global()
+        X = matrix(nrhs, self.n, 1, 1)
+        it, rr = C.c_int(0), C.c_double(0)
+        _lib.check(_lib.lib().cap_mpchol_solve(self._h, A.data_ptr(), A.ld(), B.data_ptr(), B.ld(), X.data_ptr(), X.ld(), nrhs, int(max_iter),
+                                               float(tol), C.byref(it), C.byref(rr), cur_stream()), "mpchol::solve")
+        return X, it.value, rr.value
+
+    def R32(self):
+        """[row, col] torch view of the fp32 factor (upper)."""
+        import torch
+        ld = C.c_int64(0)
+        p = _lib.lib().cap_mpchol_R32_ptr(self._h, C.byref(ld))
+        out = torch.empty(self.n, self.n, dtype=torch.float32, device="cuda")
+        rt = C.CDLL("libamdhip64.so")
+        rt.hipMemcpy(C.c_void_p(out.data_ptr()), C.c_void_p(p), C.c_size_t(self.n * self.n * 4), C.c_int(3))
+        return out.t()
+
+    def close(self):
+        if self._h:
+            _lib.lib().cap_mpchol_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -325,6 +325,25 @@ double* cap_cacqr_Q_ptr(cap_cacqr_plan* plan, int64_t* ld);
 double* cap_cacqr_R_ptr(cap_cacqr_plan* plan, int64_t* ld);
 int cap_cacqr_info(cap_cacqr_plan* plan, void* stream, int64_t* info);
 
+/* ------------------------------------------------------------------------------------
+ * Mixed-precision Cholesky solve (BASELINE config 5; not in the reference, whose solve path is the
+ * stub trsm/diaginvert/diaginvert.hpp:7-10): factor in low precision - every O(n^3) flop on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation and fp32 storage, the O(nb n^2) panel work in fp64 -
+ * then solve A X = B to fp64 accuracy by iterative refinement (fp64 residual GEMM + blocked fp64
+ * TRSMs with the promoted factor).  n must be a multiple of 128.  `A` is the same fp64 matrix in both
+ * calls; solve needs it FULL symmetric.  The fp64 path (cap_cholinv_* + cap_dtrsm) is its oracle.
+ * ---------------------------------------------------------------------------------- */
+typedef struct cap_mpchol_plan cap_mpchol_plan;
+int cap_mpchol_plan_create(cap_mpchol_plan** plan, int64_t n, int64_t nrhs_max);
+int cap_mpchol_plan_destroy(cap_mpchol_plan* plan);
+int cap_mpchol_factor(cap_mpchol_plan* plan, const double* A, int64_t lda, void* stream);
+int cap_mpchol_info(cap_mpchol_plan* plan, void* stream, int64_t* info);
+/* up to max_iter refinement sweeps until ||B - A X||_F / ||B||_F <= tol; *iters sweeps used, *relres the final value.
+ * Synchronises the stream once per sweep.                                                                          */
+int cap_mpchol_solve(cap_mpchol_plan* plan, const double* A, int64_t lda, const double* B, int64_t ldb, double* X,
+                     int64_t ldx, int64_t nrhs, int max_iter, double tol, int* iters, double* relres, void* stream);
+float* cap_mpchol_R32_ptr(cap_mpchol_plan* plan, int64_t* ld);          /* the fp32 factor (upper, n x n) */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,80 @@
+"""-m gpu: mixed-precision Cholesky solve (bf16 MFMA factor + fp64 refinement) against the fp64 path / NumPy."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import capital_oracle as orc  # noqa: E402
+from tests.gpu_util import relerr  # noqa: E402
+
+
+def _spd(n, kind, seed=0):
+    if kind == "reference":                      # upstream's distribute_symmetric(diagonallyDominant): kappa ~ 1
+        return orc.symmetric_global(n, True)
+    rng = np.random.default_rng(seed)
+    b = rng.standard_normal((n, n))
+    return b @ b.T / n + (0.5 if kind == "gram" else 0.02) * np.eye(n)      # kappa ~ 10 / ~ 200
+
+
+@pytest.mark.parametrize("n,kind,nrhs", [(128, "reference", 1), (1024, "reference", 3), (2048, "gram", 130), (1152, "gram", 7), (4096, "reference", 16)])
+def test_solve_reaches_fp64_accuracy(n, kind, nrhs):
+    from capital_amd import mixed
+    from capital_amd.matrix import matrix
+    a = _spd(n, kind)
+    rng = np.random.default_rng(n + nrhs)
+    b = rng.standard_normal((n, nrhs))
+    A = matrix(n, n, 1, 1).from_numpy(a); B = matrix(nrhs, n, 1, 1).from_numpy(b)
+    p = mixed.plan(n, nrhs)
+    p.factor(A)
+    assert p.last_info() == 0
+    # the low-precision factor: bf16 products, fp32 accumulation -> a few 1e-3 of the fp64 factor, upper triangular
+    r32 = p.R32().cpu().numpy().astype(np.float64)
+    ref = np.linalg.cholesky(a).T
+    assert np.array_equal(np.tril(r32, -1), np.zeros_like(r32))
+    assert 1e-9 < relerr(r32, ref) < 2e-2
+    X, iters, rr = p.solve(A, B, max_iter=30, tol=1e-15)
+    x = X.to_numpy(); xref = np.linalg.solve(a, b)
+    assert rr <= 5e-15 and 1 <= iters <= 25, (rr, iters)
+    assert np.linalg.norm(a @ x - b) / np.linalg.norm(b) < 1e-14
+    assert relerr(x, xref) < 1e-12 * np.linalg.cond(a)
+    # plan reuse: same factor, new right-hand side
+    b2 = rng.standard_normal((n, nrhs)); B2 = matrix(nrhs, n, 1, 1).from_numpy(b2)
+    X2, _, rr2 = p.solve(A, B2)
+    assert rr2 <= 5e-15 and relerr(X2.to_numpy(), np.linalg.solve(a, b2)) < 1e-12 * np.linalg.cond(a)
+    p.close()
+
+
+def test_matches_the_fp64_path_and_reports_failures():
+    from capital_amd import blas, cholinv, mixed
+    from capital_amd.matrix import matrix
+    from tests.gpu_util import to_dev, to_host
+    n, nrhs = 2048, 8
+    a = _spd(n, "reference"); b = np.random.default_rng(1).standard_normal((n, nrhs))
+    A = matrix(n, n, 1, 1).from_numpy(a); B = matrix(nrhs, n, 1, 1).from_numpy(b)
+    # oracle: the fp64 factorization + two blocked TRSMs of this library
+    pack = cholinv.info(-1, 1, -2, 'U'); cholinv.factor(A, pack, None)
+    R = cholinv.construct_R(pack)
+    Bd, Bv = to_dev(b)
+    for trans in (1, 0):
+        blas.engine._trsm(R.data(), Bd, n, nrhs, R.ld(), n, blas.ArgPack_trmm(blas.Order.AblasColumnMajor, blas.Side.AblasLeft, blas.UpLo.AblasUpper,
+                                                                              blas.Transpose(trans), blas.Diag.AblasNonUnit, 1.0))
+    x64 = to_host(Bv)
+    p = mixed.plan(n, nrhs); p.factor(A)
+    X, iters, rr = p.solve(A, B)
+    assert relerr(X.to_numpy(), x64) < 1e-13 and rr < 5e-15
+    # not positive definite: info reports the pivot like the fp64 path
+    bad = a.copy(); bad[700, 700] = -1.0
+    Ab = matrix(n, n, 1, 1).from_numpy(bad)
+    p.factor(Ab)
+    assert 0 < p.last_info() <= n
+    # too ill-conditioned for a bf16 factor: refinement stalls and says so (relres stays large, no exception, no NaN claim of success)
+    rng = np.random.default_rng(2)
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    hard = (q * np.logspace(0, -6, n)) @ q.T; hard = (hard + hard.T) / 2
+    Ah = matrix(n, n, 1, 1).from_numpy(hard)
+    p.factor(Ah)
+    if p.last_info() == 0:
+        _, it, rr = p.solve(Ah, B, max_iter=5)
+        assert it == 5 and not (rr <= 1e-14)
+    p.close()
