@@ -290,6 +290,7 @@ int cap_mpchol_info(cap_mpchol_plan* p, void* stream, int64_t* info) {
 
 // Solve A X = B (nrhs columns) to fp64 accuracy.  A must be the FULL symmetric matrix (the residual is a plain GEMM).
 // Returns the sweeps used and the final ||B - A X||_F / ||B||_F; CAP_OK also when max_iter was reached (check relres).
+// Stops early when the residual stagnates below 1e-10 (the attainable level is ~ n eps ||A|| ||X|| / ||B||).
 // Synchronises the stream once per sweep (the convergence test is a host decision).
 int cap_mpchol_solve(cap_mpchol_plan* p, const double* A, int64_t lda, const double* B, int64_t ldb, double* X, int64_t ldx, int64_t nrhs,
                      int max_iter, double tol, int* iters, double* relres, void* stream) {
@@ -307,7 +308,7 @@ int cap_mpchol_solve(cap_mpchol_plan* p, const double* A, int64_t lda, const dou
   CAP_TRY(apply_Ainv(p->Xw));
   CAP_TRY(cap_sumsq(p->Bw, n, n, w, 0, 0, p->norms, stream));
   double h[2] = {0, 0};
-  int it = 0; double rr = 0;
+  int it = 0; double rr = 0, prev = 1e300;
   for (;;) {
     // r = b - A x  (A symmetric: A^T form = the fast K-contiguous kernel)
     CAP_HIP(hipMemcpyAsync(p->Rw, p->Bw, sizeof(double) * n * w, hipMemcpyDeviceToDevice, s));
@@ -316,7 +317,9 @@ int cap_mpchol_solve(cap_mpchol_plan* p, const double* A, int64_t lda, const dou
     CAP_HIP(hipMemcpyAsync(h, p->norms, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
     CAP_HIP(hipStreamSynchronize(s));
     rr = h[0] > 0 ? std::sqrt(h[1] / h[0]) : 0.0;
-    if (rr <= tol || it >= max_iter || !(rr == rr)) break;
+    // converged, out of sweeps, broken (NaN), or stagnating at the attainable accuracy (less than 2x progress per sweep)
+    if (rr <= tol || it >= max_iter || !(rr == rr) || (it >= 2 && rr > 0.5 * prev && rr < 1e-10)) break;
+    prev = rr;
     CAP_TRY(apply_Ainv(p->Rw));                  // correction
     hipLaunchKernelGGL(axpy_cols_kernel, dim3((unsigned)std::min<int64_t>(cap_ceil_div(n, 256), 4096), (unsigned)w), dim3(256), 0, s, p->Xw, n,
                        p->Rw, n, n, w);
