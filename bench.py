@@ -5,6 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
            --master-port 29501 bench.py --gpus 8 --steps 3 --warmup 1
     python bench.py --workload cacqr                          # CholeskyQR2 2^21 x 256 per GPU (BASELINE config 4 shape)
+    python bench.py --workload mixed                          # bf16 MFMA factor + fp64 refinement, 1 GPU (BASELINE config 5's method)
 
 A "step" = one warm `factor` call on a resident synthetic matrix (the reference's own generators,
 structure.hpp:68-129, computed on the GPU), timed like bench/cholesky/cholinv.cpp:44-60:
@@ -44,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cholesky", choices=["cholesky", "cacqr"])
+    ap.add_argument("--workload", default="cholesky", choices=["cholesky", "cacqr", "mixed"])
     ap.add_argument("--n", "--size", dest="n", type=int, default=65536,
                     help="matrix dimension (BASELINE metric: 65536); use --size under torch.distributed.run, whose own parser trips over --n")
     ap.add_argument("--nb", type=int, default=0, help="panel width override (0 = library default)")
@@ -207,6 +208,8 @@ def main():
 
     if args.workload == "cacqr":
         out, ok = bench_cacqr(args, torch, L, C, rank, world, dist, emulate, timed, allreduce_sum)
+    elif args.workload == "mixed":
+        out, ok = bench_mixed(args, torch, L, C, rank, world, timed)
     else:
         out, ok = bench_cholesky(args, torch, L, C, rank, world, dist, emulate, timed, allreduce_sum)
     if rank == 0:
@@ -332,6 +335,46 @@ def bench_cholesky(args, torch, L, C, rank, world, dist, emulate, timed, allredu
     if not ok:
         out["value"] = None
         out["error"] = "factorization failed its parity gate (info != 0 or residual above %g)" % RES_TOL
+    return out, ok
+
+
+def bench_mixed(args, torch, L, C, rank, world, timed):
+    """Mixed-precision Cholesky solve on ONE GPU: a step = bf16-MFMA factorization + fp64 iterative refinement of 8 right-hand
+    sides to fp64 accuracy; value = fp64-equivalent TFLOP/s (N^3/3 per second of factor + solve)."""
+    if world != 1:
+        raise SystemExit("--workload mixed runs on one GPU (the multi-GPU form of config 5 is not built)")
+    from capital_amd import mixed, cholinv
+    from capital_amd.matrix import matrix
+    n, nrhs = args.n, 8
+    A = matrix(n, n, 1, 1); A.distribute_symmetric(0, 0, 1, 1, 0, True)
+    B = matrix(nrhs, n, 1, 1); B.distribute_random(0, 0, 1, 1, 7)
+    p = mixed.plan(n, nrhs)
+    res = {}
+
+    def step():
+        p.factor(A)
+        res["x"] = p.solve(A, B, max_iter=30, tol=1e-15)
+    sec = timed(step, args.steps, args.warmup)
+    X, sweeps, relres = res["x"]
+    info = p.last_info()
+    tf_only = timed(lambda: p.factor(A), 2, 0)
+    tflops = n ** 3 / 3.0 / sec / 1e12
+    # independent check of the solution: ||A X - B||_F / ||B||_F with torch fp64 matmul
+    r = A.view() @ X.view() - B.view()
+    indep = float(r.norm() / B.view().norm())
+    ok = int(info) == 0 and relres == relres and relres <= 1e-14 and indep <= 1e-13
+    out = {"metric": "fp64-equivalent Cholesky-solve TFLOP/s (N^3/3 per wall-second of bf16-MFMA factor + fp64 refinement), N=%d" % n,
+           "value": tflops if ok else None, "unit": "TFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16 MFMA (fp32 accumulate) factor, f64 refinement",
+           "data": "synthetic",
+           "config": {"workload": "N=%d mixed-precision Cholesky solve, %d right-hand sides, upstream distribute_symmetric input resident in HBM" % (n, nrhs),
+                      "parallelism": "1 GPU", "info": int(info), "refinement_sweeps": int(sweeps), "residual": relres,
+                      "residual_kind": "||B - A X||_F/||B||_F (fp64, library kernels)", "independent_residual": indep,
+                      "factor_ms": tf_only * 1e3, "factor_fp64_equiv_tflops": n ** 3 / 3.0 / tf_only / 1e12},
+           "roofline": {"bound": "hbm", "kernel": "bf16_tn_kernel (trailing update, fp32 C read-modify-write: K/4 flop per byte at K = 1024)",
+                        "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}}
+    if not ok:
+        out["error"] = "mixed-precision solve failed its parity gate"
     return out, ok
 
 

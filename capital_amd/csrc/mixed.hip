@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256, 2) bf16_tn_kernel(const BfArgs g) {
   const int L = (b & 7) * g.chunk + (b >> 3);
   int ti, tj;
   if ((b >> 3) >= g.chunk) return;
-  if (g.tri) {
+  if (g.tri && g.tm == g.tn) {
     tj = (int)((__builtin_sqrtf(8.0f * (float)L + 1.0f) - 1.0f) * 0.5f);
     while ((tj + 1) * (tj + 2) / 2 <= L) tj++;
     while (tj * (tj + 1) / 2 > L) tj--;
@@ -62,6 +62,7 @@ __global__ void __launch_bounds__(256, 2) bf16_tn_kernel(const BfArgs g) {
   } else {
     ti = L % g.tm; tj = L / g.tm;
     if (tj >= g.tn) return;
+    if (g.tri && ti > tj) return;                        // strip of a triangular update: only tiles on / above the diagonal
   }
   const int64_t i0 = (int64_t)ti * TB, j0 = (int64_t)tj * TB;
   const int lane = threadIdx.x & 63;
@@ -151,12 +152,12 @@ __global__ void __launch_bounds__(256, 2) bf16_tn_kernel(const BfArgs g) {
 int launch_bf16_tn(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A, int64_t lda, const __bf16* B, int64_t ldb, float* C,
                    int64_t ldc, int tri, hipStream_t s) {
   if (m <= 0 || n <= 0 || k <= 0) return CAP_OK;
-  if ((m % TB) || (n % TB) || (k % KB) || (lda % 8) || (ldb % 8) || (tri && m != n)) return CAP_ERR_UNSUPPORTED;
+  if ((m % TB) || (n % TB) || (k % KB) || (lda % 8) || (ldb % 8) || (tri && m > n)) return CAP_ERR_UNSUPPORTED;
   if (128 * lda * 2 + k * 2 >= 0xfffffff0LL || 128 * ldb * 2 + k * 2 >= 0xfffffff0LL) return CAP_ERR_UNSUPPORTED;
   BfArgs g;
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.tri = tri;
   g.tm = (int)(m / TB); g.tn = (int)(n / TB);
-  const int64_t tiles = tri ? (int64_t)g.tn * (g.tn + 1) / 2 : (int64_t)g.tm * g.tn;
+  const int64_t tiles = (tri && m == n) ? (int64_t)g.tn * (g.tn + 1) / 2 : (int64_t)g.tm * g.tn;
   g.chunk = (int)cap_ceil_div(tiles, 8);
   hipLaunchKernelGGL(bf16_tn_kernel, dim3((unsigned)(g.chunk * 8)), dim3(256), 4 * TILE_D * sizeof(double), s, g);
   CAP_HIP(hipGetLastError());
@@ -200,7 +201,8 @@ dim3 grid2(int64_t rows, int64_t cols) {
 
 struct cap_mpchol_plan {
   int64_t n, nb, nrhs_cap;          // nrhs_cap: internal right-hand-side width (multiple of 128)
-  float* R32; double* R64; __bf16* P16;
+  float* R32; double* R64; __bf16* P16[2];
+  hipStream_t s_panel; hipEvent_t ev_rest[2], ev_panel[2], ev_fork, ev_join; bool streams_ready;
   double* D64; double* Dinv; double* T64; double* S64; double* W; int64_t wcap;
   double* Inv; int64_t tb; double* Xt; double* Wt;          // blocked TRSM state
   double* Xw; double* Rw; double* Bw; double* norms;
@@ -218,18 +220,18 @@ int cap_mpchol_plan_create(cap_mpchol_plan** plan, int64_t n, int64_t nrhs_max) 
   p->n = n; p->nb = std::min<int64_t>(1024, n); p->nrhs_cap = cap_round_up(nrhs_max, 128);
   while (p->nb > 128 && ((p->nb & (p->nb - 1)) || p->nb > n)) p->nb /= 2;   // power of two <= n: the fused diagonal-block chain
   p->wcap = cap_rec_work_size(p->nb);
-  p->tb = cap_trsm_block(n);
+  p->tb = p->nb;                      // the TRSM blocks ARE the panels: their inverses fall out of the factorization
   const int64_t nb = p->nb, w = p->nrhs_cap, nblk = cap_ceil_div(n, p->tb);
   hipError_t e = hipMalloc((void**)&p->R32, sizeof(float) * n * n);
   if (e == hipSuccess) e = hipMalloc((void**)&p->R64, sizeof(double) * n * n);
-  if (e == hipSuccess) e = hipMalloc((void**)&p->P16, sizeof(__bf16) * nb * n);
+  for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void**)&p->P16[i], sizeof(__bf16) * nb * n);
   if (e == hipSuccess) e = hipMalloc((void**)&p->D64, sizeof(double) * (2 * nb * nb + 2 * nb * n + p->wcap));
-  if (e == hipSuccess) e = hipMalloc((void**)&p->Inv, sizeof(double) * (nblk * p->tb * p->tb + p->tb * w + cap_trsm_prepare_work(p->tb)));
+  if (e == hipSuccess) e = hipMalloc((void**)&p->Inv, sizeof(double) * (nblk * p->tb * p->tb + p->tb * w));
   if (e == hipSuccess) e = hipMalloc((void**)&p->Xw, sizeof(double) * (3 * n * w + 8));
   if (e == hipSuccess) e = hipMalloc((void**)&p->info_dev, sizeof(int));
   if (e != hipSuccess) { cap_mpchol_plan_destroy(p); return CAP_ERR_ALLOC; }
   p->Dinv = p->D64 + nb * nb; p->T64 = p->Dinv + nb * nb; p->S64 = p->T64 + nb * n; p->W = p->S64 + nb * n;
-  p->Xt = p->Inv + nblk * p->tb * p->tb; p->Wt = p->Xt + p->tb * w;
+  p->Xt = p->Inv + nblk * p->tb * p->tb; p->Wt = nullptr;
   p->Rw = p->Xw + n * w; p->Bw = p->Rw + n * w; p->norms = p->Bw + n * w;
   *plan = p;
   return CAP_OK;
@@ -237,42 +239,90 @@ int cap_mpchol_plan_create(cap_mpchol_plan** plan, int64_t n, int64_t nrhs_max) 
 
 int cap_mpchol_plan_destroy(cap_mpchol_plan* p) {
   if (!p) return CAP_OK;
-  for (void* q : {(void*)p->R32, (void*)p->R64, (void*)p->P16, (void*)p->D64, (void*)p->Inv, (void*)p->Xw, (void*)p->info_dev}) if (q) (void)hipFree(q);
+  for (void* q : {(void*)p->R32, (void*)p->R64, (void*)p->P16[0], (void*)p->P16[1], (void*)p->D64, (void*)p->Inv, (void*)p->Xw, (void*)p->info_dev})
+    if (q) (void)hipFree(q);
+  if (p->streams_ready) {
+    (void)hipStreamDestroy(p->s_panel);
+    for (int i = 0; i < 2; i++) { (void)hipEventDestroy(p->ev_rest[i]); (void)hipEventDestroy(p->ev_panel[i]); }
+    (void)hipEventDestroy(p->ev_fork); (void)hipEventDestroy(p->ev_join);
+  }
   delete p;
   return CAP_OK;
 }
 
 // A: n x n fp64, upper triangle consumed.  Leaves the fp32 factor, its fp64 promotion and the TRSM block inverses in the plan.
+// Two streams: the caller's carries the bf16 trailing updates, a high-priority one the fp64 panel work of the NEXT panel
+// (it only needs the head of the previous update: the rows of that panel), so the latency-bound diagonal-block chain
+// and the fp64 row solve hide behind the bf16 MFMA update once that is the longer of the two.
 int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* stream) {
   if (!p || !A || lda < p->n) return CAP_ERR_ARG;
-  hipStream_t s = cap_stream(stream);
+  hipStream_t s0 = cap_stream(stream);
   const int64_t n = p->n, nb = p->nb;
-  CAP_HIP(hipMemsetAsync(p->info_dev, 0, sizeof(int), s));
-  hipLaunchKernelGGL(f64_to_f32_upper_kernel, grid2(n, n), dim3(256), 0, s, A, lda, p->R32, n, n);
+  if (!p->streams_ready) {
+    int lo = 0, hi = 0;
+    CAP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    CAP_HIP(hipStreamCreateWithPriority(&p->s_panel, hipStreamNonBlocking, hi));
+    for (int i = 0; i < 2; i++) {
+      CAP_HIP(hipEventCreateWithFlags(&p->ev_rest[i], hipEventDisableTiming));
+      CAP_HIP(hipEventCreateWithFlags(&p->ev_panel[i], hipEventDisableTiming));
+    }
+    CAP_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    CAP_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    p->streams_ready = true;
+  }
+  hipStream_t s1 = p->s_panel;
+  CAP_HIP(hipMemsetAsync(p->info_dev, 0, sizeof(int), s0));
+  hipLaunchKernelGGL(f64_to_f32_upper_kernel, grid2(n, n), dim3(256), 0, s0, A, lda, p->R32, n, n);
   CAP_HIP(hipGetLastError());
-  for (int64_t j0 = 0; j0 < n; j0 += nb) {
-    const int64_t jb = std::min(nb, n - j0), j1 = j0 + jb, m = n - j1;
+  CAP_HIP(hipEventRecord(p->ev_fork, s0));
+  CAP_HIP(hipStreamWaitEvent(s1, p->ev_fork, 0));
+
+  // fp64 panel work of panel k on stream s: diagonal block (R_kk, inverse), block row solve; writes P16[k & 1]
+  auto panel = [&](int64_t k, hipStream_t s) -> int {
+    const int64_t j0 = k * nb, jb = std::min(nb, n - j0), j1 = j0 + jb, m = n - j1;
     float* D32 = p->R32 + j0 + j0 * n;
-    // diagonal block in fp64: R_kk and its inverse (the existing chain), R_kk back into the fp32 factor
+    double* Dinv = p->Inv + k * nb * nb;                  // kept: the diagonal-block inverse of the blocked TRSM
     hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, jb), dim3(256), 0, s, D32, n, p->D64, jb, jb, jb, 1);
-    CAP_HIP(hipMemsetAsync(p->Dinv, 0, sizeof(double) * jb * jb, s));
-    CAP_TRY(cap_rec_cholinv_full(p->D64, jb, p->Dinv, jb, jb, p->W, p->wcap, p->info_dev, s, j0));
+    CAP_HIP(hipMemsetAsync(Dinv, 0, sizeof(double) * nb * nb, s));
+    CAP_TRY(cap_rec_cholinv_full(p->D64, jb, Dinv, nb, jb, p->W, p->wcap, p->info_dev, s, j0));
     hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(jb, jb), dim3(256), 0, s, p->D64, jb, D32, n, (__bf16*)nullptr, (int64_t)0, jb, jb, 1);
     CAP_HIP(hipGetLastError());
+    if (m > 0) {
+      float* Row32 = p->R32 + j0 + j1 * n;
+      hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, m), dim3(256), 0, s, Row32, n, p->T64, jb, jb, m, 0);
+      CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, m, jb, 1.0, Dinv, nb, p->T64, jb, 0.0, p->S64, jb, 0, s, 2 | 16));
+      hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(jb, m), dim3(256), 0, s, p->S64, jb, Row32, n, p->P16[k & 1], jb, jb, m, 0);
+      CAP_HIP(hipGetLastError());
+    }
+    return CAP_OK;
+  };
+
+  // update(k): R32[j1:, j1:] -= Pk^T Pk (upper), split into HEAD (the rows of panel k+1, panel stream) and REST (rows
+  // below, caller's stream).  panel(k+1) needs head(k) (same stream) and rest(k-1) (it touched those rows too; waiting for
+  // it before head(k) also keeps the order of the atomic adds - hence the bits - fixed) and frees P16[(k+1) & 1].
+  const int64_t npan = cap_ceil_div(n, nb);
+  CAP_TRY(panel(0, s1));
+  CAP_HIP(hipEventRecord(p->ev_panel[0], s1));
+  for (int64_t k = 0; k < npan; k++) {
+    const int64_t j0 = k * nb, jb = std::min(nb, n - j0), j1 = j0 + jb, m = n - j1;
     if (m <= 0) break;
-    // block row in fp64: S = Dinv^T * R[j0:j1, j1:n]; fp32 into the factor, bf16 into the panel
-    float* Row32 = p->R32 + j0 + j1 * n;
-    hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, m), dim3(256), 0, s, Row32, n, p->T64, jb, jb, m, 0);
-    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, m, jb, 1.0, p->Dinv, jb, p->T64, jb, 0.0, p->S64, jb, 0, s, 16));
-    hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(jb, m), dim3(256), 0, s, p->S64, jb, Row32, n, p->P16, jb, jb, m, 0);
-    CAP_HIP(hipGetLastError());
-    // trailing update on bf16 MFMA: R32[j1:, j1:] -= P^T P, upper tiles
-    CAP_TRY(launch_bf16_tn(m, m, jb, -1.0f, p->P16, jb, p->P16, jb, p->R32 + j1 + j1 * n, n, 1, s));
+    const __bf16* P = p->P16[k & 1];
+    const int64_t hb = std::min(nb, m);                   // rows of the next panel
+    if (k > 0) CAP_HIP(hipStreamWaitEvent(s1, p->ev_rest[(k - 1) & 1], 0));
+    CAP_TRY(launch_bf16_tn(hb, m, jb, -1.0f, P, jb, P, jb, p->R32 + j1 + j1 * n, n, 1, s1));
+    CAP_HIP(hipStreamWaitEvent(s0, p->ev_panel[k & 1], 0));
+    if (m > hb) CAP_TRY(launch_bf16_tn(m - hb, m - hb, jb, -1.0f, P + hb * jb, jb, P + hb * jb, jb, p->R32 + (j1 + hb) * (n + 1), n, 1, s0));
+    CAP_HIP(hipEventRecord(p->ev_rest[k & 1], s0));
+    if (k + 1 < npan) {
+      CAP_TRY(panel(k + 1, s1));
+      CAP_HIP(hipEventRecord(p->ev_panel[(k + 1) & 1], s1));
+    }
   }
-  // fp64 promotion of the factor + the diagonal-block inverses of the blocked TRSM (reused by every refinement sweep)
-  hipLaunchKernelGGL(f32_to_f64_kernel, grid2(n, n), dim3(256), 0, s, p->R32, n, p->R64, n, n, n, 1);
+  CAP_HIP(hipEventRecord(p->ev_join, s1));
+  CAP_HIP(hipStreamWaitEvent(s0, p->ev_join, 0));
+  // fp64 promotion of the factor for the refinement sweeps (the TRSM block inverses were stored panel by panel)
+  hipLaunchKernelGGL(f32_to_f64_kernel, grid2(n, n), dim3(256), 0, s0, p->R32, n, p->R64, n, n, n, 1);
   CAP_HIP(hipGetLastError());
-  CAP_TRY(cap_trsm_prepare(p->R64, n, n, p->tb, p->Inv, p->Wt, s));
   p->have_r64 = true;
   return CAP_OK;
 }
