@@ -148,6 +148,7 @@ struct cap_cholinv_plan {
   int64_t nb, leaf; int lookahead;
   int64_t outer;   // outer strip height NB (multiple of nb): K of the big trailing SYRK
   int64_t tail;    // trailing sizes <= tail fall back to nb-wide strips
+  int64_t serial_m; // remaining rows below which the chain is no longer overlapped with the bulk update (see right_looking)
   int fastdiag;     // diagonal blocks by the 64-blocked fused path (default) instead of the recursion
   int depth2;       // split each bulk update into head (next-next strip's rows) + rest: look-ahead depth 2
   int64_t bulk_wgs; // > 0: bulk updates run as a persistent grid of this many workgroups (512 slots on the chip)
@@ -339,9 +340,30 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
   if (p->bulk_ready) { s0 = p->s_bulk; CAP_HIP(hipStreamWaitEvent(s0, p->ev_fork, 0)); }
   CAP_TRY(factor_strip(p, R, ldr, n, 0, bnd[1], s1));
   CAP_HIP(hipEventRecord(p->ev_panel[0], s1));
+  // Optional (serial_m > 0, default off): from strip ksw on the chain and the bulk update are NOT overlapped any more.
+  // Measured (tools/contend.cpp): the chain's kernels run 8-15x slower next to the bulk kernel - a co-resident wave issuing
+  // 64-cycle fp64 MFMAs back to back leaves the chain's dependent VALU / MFMA instructions one issue slot per MFMA, and
+  // every launch first waits for a slot of a retiring bulk workgroup (stream priorities change nothing).  Letting the
+  // chain run alone in the tail was measured too (tools/sweep_serial.sh): N = 32768: 209.0 ms overlapped vs 212.3 ms with
+  // serial_m = 16384, N = 16384: 49.2 vs 50.7 - the overlapped schedule already costs about the serial sum, no gain.
+  int64_t ksw = nstrip;
+  for (int64_t k = 1; k < nstrip; k++) if (n - bnd[k + 1] <= p->serial_m) { ksw = k; break; }
   for (int64_t k = 0; k < nstrip; k++) {
     const int64_t J0 = bnd[k], rows = bnd[k + 1] - J0, m = n - bnd[k + 1];
     if (m <= 0) break;
+    if (k >= ksw) {
+      // serial phase: strip k is factored (panel stream, ev_panel[k & 1]); everything from here on runs on the bulk stream
+      CAP_HIP(hipStreamWaitEvent(s0, p->ev_panel[k & 1], 0));
+      for (int64_t q = k; q < nstrip; q++) {
+        const int64_t Jq = bnd[q], rq = bnd[q + 1] - Jq, mq = n - bnd[q + 1];
+        if (q > k) CAP_TRY(factor_strip(p, R, ldr, n, Jq, rq, s0));
+        if (mq > 0) {
+          double* Sq = R + Jq + bnd[q + 1] * ldr;
+          CAP_TRY(trailing_update(p, mq, mq, rq, Sq, Sq, R + bnd[q + 1] + bnd[q + 1] * ldr, ldr, s0));
+        }
+      }
+      break;
+    }
     const int64_t J1 = bnd[k + 1], rows1 = bnd[k + 2] - J1, m2 = m - rows1;
     double* S = R + J0 + J1 * ldr;                 // strip k right of its diagonal block: rows x m
     // (a) panel stream: bring strip k+1 up to date (K = rows, upper part), then factor it.
@@ -411,6 +433,7 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   // 20.8 -> 15.5 ms).  Its workgroups use 84 KiB of LDS so that they fit into ONE slot vacated by a bulk
   // workgroup - a first 135 KiB version needed a fully idle CU and lost 4 % under a concurrent bulk update.
   p->fastdiag = getenv("CAP_FASTDIAG") ? atoi(getenv("CAP_FASTDIAG")) : 1;
+  p->serial_m = 0;
   p->depth2 = n >= 24576;     // look-ahead depth 2 pays once a bulk update is long enough to split (+2 % at N = 32768)
   int st = plan_alloc(p);
   if (st != CAP_OK) { cap_cholinv_plan_destroy(p); return st; }
@@ -469,6 +492,7 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
   if (k == "lookahead") { p->lookahead = value != 0; return CAP_OK; }
   if (k == "outer") { if (value < 64) return CAP_ERR_ARG; p->outer = value; return CAP_OK; }
   if (k == "tail") { if (value < 0) return CAP_ERR_ARG; p->tail = value; return CAP_OK; }
+  if (k == "serial_m") { if (value < 0) return CAP_ERR_ARG; p->serial_m = value; return CAP_OK; }
   if (k == "bulk_wgs") { if (value < 0 || value > 2048) return CAP_ERR_ARG; p->bulk_wgs = value; return CAP_OK; }
   if (k == "depth2") { p->depth2 = value != 0; return CAP_OK; }
   if (k == "fastdiag") { p->fastdiag = value != 0; return CAP_OK; }
@@ -501,6 +525,7 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
   if (k == "lookahead") return p->lookahead;
   if (k == "outer") return p->outer;
   if (k == "tail") return p->tail;
+  if (k == "serial_m") return p->serial_m;
   if (k == "bulk_wgs") return p->bulk_wgs;
   if (k == "depth2") return p->depth2;
   if (k == "fastdiag") return p->fastdiag;
@@ -620,6 +645,7 @@ int cap_dpotrf(int uplo, int64_t n, double* A, int64_t lda, int* info, double* w
   cap_cholinv_plan& p = ctx.plan;
   p.n = n; p.complete_inv = -1; p.leaf = CAP_LEAF_MAX; p.fastdiag = 1;
   potrf_knobs(n, &p.nb, &p.outer, &p.tail, &p.depth2);
+  p.serial_m = 0;
   p.lookahead = n >= 4096;
   p.ldi = p.nb;
   p.Rinv = work;                                // nb x nb
