@@ -24,6 +24,7 @@
 //   Q_new[=y, =x] = sum_z Qz * Rinv[=z, =x]: layer z contributes its term, ncclAllReduce over `depth`
 //                                                                          (summa TRMM + depth all-reduce, :107-111)
 // which is `A2 - Q1 R12` done right for every block at once (upstream's solve() has the sign flipped).
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -33,12 +34,17 @@
 int cap_rec_cholinv_full(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, double* W, int64_t wcap, int* info,
                          hipStream_t s, int64_t info_base = 0);
 int64_t cap_rec_work_size(int64_t n);
+// cqr_kernels.hip: the n = 256 streaming kernels (whole-Gram workgroups; persistent row-streaming Q R^-1)
+int64_t cap_gram256_work(int64_t m);
+int cap_gram256_launch(const double* Q, int64_t ld, int64_t m, double* G, int64_t ldg, double* work, hipStream_t s);
+int cap_qrapply256_launch(const double* Qin, int64_t ldin, const double* Ri, double* Qout, int64_t ldout, int64_t m, hipStream_t s);
 
 struct cap_cacqr_plan {
   int64_t m, n; int num_iter; cap_comm* comm;
   double* Q[2]; int cur; int64_t ldq;
   double* G; double* Gi; double* R1; double* R; double* W; int64_t wcap;
   int* info_dev;
+  double* gram_work;      // n == 256: one partial-Gram slab per workgroup of gram256
   // grid path: m, n above are the GLOBAL column count / local row count of the dense n x n work; nl = n / c local columns
   cap_topo* topo; int c, d, x, y, z; int64_t nl;
   double* Qz; double* Gblk; double* Gall; double* Rip; double* Rpiece;
@@ -52,14 +58,18 @@ int sweep(cap_cacqr_plan* p, const double* Qin, int64_t ldin, double* Qout, hipS
   // Gram: upper triangle of Q^T Q (cacqr.hpp:15), full square zero-initialised so the all-reduce moves
   // a dense n x n block like NoSerialize::compute_gram (policy.h:22)
   CAP_TRY(cap_zero_rect(p->G, n, n, n, s));
-  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n, n, m, 1.0, Qin, ldin, Qin, ldin, 0.0, p->G, n, 1, s));
+  static const bool k256_env = getenv("CAP_CQR256") ? atoi(getenv("CAP_CQR256")) != 0 : true;
+  const bool k256 = k256_env && p->gram_work && n == 256 && m % 128 == 0 && !(ldin & 1) && 128 * ldin * 8 < 0xfffffff0LL && !((uintptr_t)Qin & 15);
+  if (k256) CAP_TRY(cap_gram256_launch(Qin, ldin, m, p->G, n, p->gram_work, s));
+  else CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n, n, m, 1.0, Qin, ldin, Qin, ldin, 0.0, p->G, n, 1, s));
   CAP_TRY(cap_comm_allreduce_sum(p->comm, p->G, n * n, (void*)s));
   // R = chol(G) in place (upper), Gi = R^-1
   CAP_TRY(cap_zero_rect(p->Gi, n, n, n, s));
   CAP_TRY(cap_rec_cholinv_full(p->G, n, p->Gi, n, n, p->W, p->wcap, p->info_dev, s));
   // Q <- Q * R^-1 (cacqr.hpp:24-25)
   // tag 8: R^-1 is upper triangular -> a column tile only contracts the rows above its diagonal block
-  CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, m, n, n, 1.0, Qin, ldin, p->Gi, n, 0.0, Qout, p->ldq, 0, s, 8));
+  if (k256) CAP_TRY(cap_qrapply256_launch(Qin, ldin, p->Gi, Qout, p->ldq, m, s));
+  else CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, m, n, n, 1.0, Qin, ldin, p->Gi, n, 0.0, Qout, p->ldq, 0, s, 8));
   return CAP_OK;
 }
 // gathered[z'][x'] blocks (nl x nl each, block (z', x') = G[rows = z' mod c, cols = x' mod c]) -> dense n x n
@@ -147,6 +157,7 @@ int cap_cacqr_plan_create(cap_cacqr_plan** plan, int64_t m_local, int64_t n, int
   if (e == hipSuccess) e = hipMalloc((void**)&p->G, sizeof(double) * n * n * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&p->W, sizeof(double) * p->wcap);
   if (e == hipSuccess) e = hipMalloc((void**)&p->info_dev, sizeof(int));
+  if (e == hipSuccess && n == 256 && m_local % 128 == 0) e = hipMalloc((void**)&p->gram_work, sizeof(double) * cap_gram256_work(m_local));
   if (e != hipSuccess) { cap_cacqr_plan_destroy(p); return CAP_ERR_ALLOC; }
   p->Gi = p->G + n * n; p->R1 = p->G + 2 * n * n; p->R = p->G + 3 * n * n;
   *plan = p;
@@ -159,6 +170,7 @@ int cap_cacqr_plan_destroy(cap_cacqr_plan* p) {
   if (p->G) (void)hipFree(p->G);
   if (p->W) (void)hipFree(p->W);
   if (p->info_dev) (void)hipFree(p->info_dev);
+  if (p->gram_work) (void)hipFree(p->gram_work);
   if (p->Qz) (void)hipFree(p->Qz);
   if (p->Gblk) (void)hipFree(p->Gblk);
   delete p;
