@@ -109,11 +109,12 @@ __global__ void gram256_reduce_kernel(const double* P, int nslab, double* G, int
 constexpr int TA = 128 * BK, TB = GN * BK;       // A tile [16 k][128 m] (16 KiB), B tile [256 cols][16 k] (32 KiB)
 constexpr int A_NST = 4, B_NST = 3;              // 4 x 16 KiB + 3 x 32 KiB = 160 KiB: the whole LDS of the CU
 // A (the streamed panel, straight from HBM) is requested 3 steps ahead, B (Rinv, L2-resident) 2 steps ahead.  Per step a wave
-// issues [4 pieces of B(u+2), 2 pieces of A(u+3)]; vmcnt retires in order, so "B(u) and A(u) have landed" = at most the 8
-// younger pieces A(u+1), B(u+1), A(u+2) outstanding.
+// issues [4 pieces of B, 2 pieces of A]; vmcnt retires in order, so "tile t has landed" = at most the 8 younger pieces
+// A(t+1), B(t+1), A(t+2) outstanding.
 
 struct ApplyArgs { const double* Qin; int64_t ldin; const double* Ri; double* Qout; int64_t ldout; int ntiles; };
 
+template <int DIAG, bool PIPE>
 __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
@@ -156,57 +157,98 @@ __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (d4){0, 0, 0, 0};
   const int amc_flip = (kg & 1) << 4;
-  issue_a(0); issue_b(0); issue_a(1); issue_b(1); issue_a(2);
-  for (int u = 0; u < U; u++) {
-    const int kt = u & 15;
-    // after a row tile's store burst loads and stores share the counter: drain it (once per 16 steps)
-    if (kt == 0 && u > 0) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8));
-    else __builtin_amdgcn_s_waitcnt(8 | (7 << 4) | (0 << 8));
-    __builtin_amdgcn_s_barrier();
-    issue_b(u + 2);                                            // B stage of step u-1, A stage of step u-1: both consumed before this barrier
-    issue_a(u + 3);
+  auto frags = [&](int u, int h, d2 (&fa)[4], d2 (&fb)[4]) {
     const double* tA = sAbase + (u & (A_NST - 1)) * TA;
     const double* tB = sBbase + (u % B_NST) * TB;
-    // block column cb = wn + 4 j is active at K tile kt iff cb >= kt
-    const int jlo = kt > wn ? (kt - wn + 3) >> 2 : 0;
-    if (jlo < 4) {
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        d2 fa[4], fb[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int mm = (wi + 16 * i + lr) ^ amc_flip;
-          fa[i] = (d2){tA[(8 * h + 2 * kg) * 128 + mm], tA[(8 * h + 2 * kg + 1) * 128 + mm]};
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const d2*>(tB + (16 * (wn + 4 * j) + lr) * BK + (((h * 4 + kg) ^ sw) << 1));
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (j >= jlo) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
-          }
-      }
+    for (int i = 0; i < 4; i++) {
+      const int mm = (wi + 16 * i + lr) ^ amc_flip;
+      fa[i] = (d2){tA[(8 * h + 2 * kg) * 128 + mm], tA[(8 * h + 2 * kg + 1) * 128 + mm]};
     }
-    if (kt == 15) {
-      // row tile complete: lane holds Qout[i0 + wi + 16 i + lr][16 (wn + 4 j) + kg + 4 r]
-      const int64_t i0 = (int64_t)(b + (u >> 4) * G) * 128;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int64_t row = i0 + wi + 16 * i + lr;
+    for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const d2*>(tB + (16 * (wn + 4 * j) + lr) * BK + (((h * 4 + kg) ^ sw) << 1));
+  };
+  // (MMA / STORE_COL are macros, not lambdas: with acc captured by reference the compiler kept three quarters of it in scratch)
+#define CQR_MMA(fa, fb, jlo)                                                                                                   \
+  if (!(DIAG & 2)) {                                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; j++)                                                                              \
+      if (j >= (jlo)) {                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; i++)                                                                          \
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);                              \
+        _Pragma("unroll") for (int i = 0; i < 4; i++)                                                                          \
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);                              \
+      }                                                                                                                        \
+  }
+  // vmcnt retires loads and stores in issue order (the compiler itself counts past younger stores on gfx950), so "tile t has
+  // landed" = at most the younger pieces outstanding: 8 DMA pieces (A(t+1), B(t+1), A(t+2)) plus the 16 stores of the two steps
+  // before the wait, if this wave finished a block column there (it does every 4th step: kt % 4 == wn)
+  auto wait_tile = [&](int ulast) {        // ulast = the last step whose stores were issued before this wait
+    const bool st_young = !(DIAG & 1) && ((ulast >= 0 && (ulast & 3) == wn) || (ulast >= 1 && ((ulast - 1) & 3) == wn));
+    if (st_young) __builtin_amdgcn_s_waitcnt((24 & 15) | (7 << 4) | (0 << 8) | ((24 >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt(8 | (7 << 4) | (0 << 8));
+    __builtin_amdgcn_s_barrier();
+  };
+  // Block column kt = wn + 4 j is complete after K tile kt (K tiles beyond it only meet zeros of Rinv): store it right away, so
+  // the writes trickle out over the row tile instead of draining as one 256 KiB burst.  Lane holds
+  // Qout[i0 + wi + 16 i + lr][16 kt + kg + 4 r].  In place (Qout == Qin) is fine: these columns of this row tile were consumed
+  // as K tile kt, later K tiles lie to the right.
+#define CQR_STORE_COL(u)                                                                                                       \
+  if ((((u) & 15) & 3) == wn && (!(DIAG & 1) || g.ntiles < 0)) {                                                               \
+    const int kt_ = (u) & 15;                                                                                                  \
+    const int64_t i0_ = (int64_t)(b + ((u) >> 4) * G) * 128;                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; j++)                                                                              \
+      if (j == (kt_ >> 2)) {                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                                        \
+          const int64_t row = i0_ + wi + 16 * i + lr;                                                                          \
+          _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                                      \
+            g.Qout[row + (int64_t)(16 * kt_ + kg + 4 * r) * g.ldout] = acc[i][j][r];                                           \
+            acc[i][j][r] = 0.0;                                                                                                \
+          }                                                                                                                    \
+        }                                                                                                                      \
+      }                                                                                                                        \
+  }
+  issue_a(0); issue_b(0); issue_a(1); issue_b(1); issue_a(2);
+  if (PIPE) {
+    // The tile hand-over (wait + barrier + refill + first fragment reads of the NEXT tile) sits in the middle of a step, between
+    // the two k-halves of the current tile, so every wave has half a step of MFMAs queued behind its LDS reads.
+    d2 fa0[4], fb0[4], fa1[4], fb1[4];
+    wait_tile(-1);
+    issue_b(2); issue_a(3);
+    frags(0, 0, fa0, fb0);
+    for (int u = 0; u < U; u++) {
+      const int kt = u & 15;
+      const int jlo = kt > wn ? (kt - wn + 3) >> 2 : 0;          // block column cb = wn + 4 j is active at K tile kt iff cb >= kt
+      frags(u, 1, fa1, fb1);
+      CQR_MMA(fa0, fb0, jlo)
+      __builtin_amdgcn_s_waitcnt(63 | (7 << 4) | (0 << 8) | (3 << 14));   // lgkmcnt(0): my reads of tile u are done -> its stages may be refilled
+      wait_tile(u - 1);
+      issue_b(u + 3);
+      issue_a(u + 4);
+      frags(u + 1, 0, fa0, fb0);
+      CQR_MMA(fa1, fb1, jlo)
+      CQR_STORE_COL(u)
+    }
+  } else {
+    for (int u = 0; u < U; u++) {
+      const int kt = u & 15;
+      const int jlo = kt > wn ? (kt - wn + 3) >> 2 : 0;
+      wait_tile(u - 1);
+      issue_b(u + 2);                                          // into the stages of step u-1: consumed before this barrier
+      issue_a(u + 3);
+      if (jlo < 4) {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            g.Qout[row + (int64_t)(16 * (wn + 4 * j) + kg + 4 * r) * g.ldout] = acc[i][j][r];
-            acc[i][j][r] = 0.0;
-          }
+        for (int h = 0; h < 2; h++) {
+          d2 fa[4], fb[4];
+          frags(u, h, fa, fb);
+          CQR_MMA(fa, fb, jlo)
+        }
       }
+      CQR_STORE_COL(u)
     }
   }
   __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+#undef CQR_MMA
+#undef CQR_STORE_COL
 }
 
 }  // namespace
@@ -239,7 +281,16 @@ int cap_qrapply256_launch(const double* Qin, int64_t ldin, const double* Ri, dou
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   ApplyArgs g{Qin, ldin, Ri, Qout, ldout, (int)(m / 128)};
   const int grid = (int)std::min<int64_t>(cus, g.ntiles);
-  hipLaunchKernelGGL(qrapply256_kernel, dim3((unsigned)grid), dim3(512), (A_NST * TA + B_NST * TB) * sizeof(double), s, g);
+  // CAP_CQR_DIAG is timing surgery only (1 = no stores, 2 = no MFMA: results are wrong); CAP_CQR_PIPE picks the loop form
+  static const int diag = getenv("CAP_CQR_DIAG") ? atoi(getenv("CAP_CQR_DIAG")) : 0;
+  static const int pipe = getenv("CAP_CQR_PIPE") ? atoi(getenv("CAP_CQR_PIPE")) : 1;
+  const size_t lds = (A_NST * TA + B_NST * TB) * sizeof(double);
+  const dim3 gr((unsigned)grid), bl(512);
+  if (diag == 1) hipLaunchKernelGGL((qrapply256_kernel<1, false>), gr, bl, lds, s, g);
+  else if (diag == 2) hipLaunchKernelGGL((qrapply256_kernel<2, false>), gr, bl, lds, s, g);
+  else if (diag == 3) hipLaunchKernelGGL((qrapply256_kernel<3, false>), gr, bl, lds, s, g);
+  else if (pipe) hipLaunchKernelGGL((qrapply256_kernel<0, true>), gr, bl, lds, s, g);
+  else hipLaunchKernelGGL((qrapply256_kernel<0, false>), gr, bl, lds, s, g);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
