@@ -6,6 +6,7 @@ hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with gpu
 """
 import glob
 import os
+import re
 import subprocess
 import sys
 
@@ -15,7 +16,11 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcapital_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-I" + os.path.join(os.path.dirname(HERE), "include")]
+         "-Rpass-analysis=kernel-resource-usage", "-I" + os.path.join(os.path.dirname(HERE), "include")]
+# Kernels of the hot path that must live in registers: a silent scratch allocation (seen once: accumulators captured by a
+# lambda) costs 5-7x and nothing else reports it.  Checked after every build against the compiler's own resource remarks.
+NO_SCRATCH = ("dgemm_tn_dma_kernel", "gram256_kernel", "qrapply256_kernel", "bf16_tn_kernel", "leaf_cholinv_kernel",
+              "panel64_solve_update_kernel")
 
 
 def sources():
@@ -48,16 +53,48 @@ def build(force=False, verbose=True):
         cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd)))
-    for src, p in procs:
-        if p.wait() != 0:
+        procs.append((src, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+    for src, obj, p in procs:
+        _, err = p.communicate()
+        remarks = [l for l in err.splitlines() if "kernel-resource-usage" in l]
+        other = [l for l in err.splitlines() if "kernel-resource-usage" not in l and not re.match(r"^\s*\d*\s*\|", l)
+                 and "remarks generated" not in l]   # (drop the source excerpt clang prints under every remark)
+        if other:
+            print("\n".join(other), file=sys.stderr, flush=True)
+        if p.returncode != 0:
             raise RuntimeError("hipcc failed on " + src)
+        with open(obj + ".resources.txt", "w") as f:
+            f.write("\n".join(remarks) + "\n")
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl",
                                                                                       "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    check_no_scratch()
     return LIB
+
+
+def kernel_resources():
+    """{kernel symbol: {"VGPRs": n, "ScratchSize": bytes per lane, "VGPRs Spill": n, ...}} from the last compile of every source."""
+    out, cur = {}, None
+    for f in sorted(glob.glob(os.path.join(LIBDIR, "obj", "*.resources.txt"))):
+        for line in open(f):
+            body = line.split("remark:", 1)[-1].split("[-Rpass")[0].strip()
+            if body.startswith("Function Name:"):
+                cur = out.setdefault(body.split(":", 1)[1].strip(), {})
+            elif cur is not None and ":" in body:
+                k, v = body.rsplit(":", 1)
+                cur[k.split("[")[0].strip()] = v.strip()
+    return out
+
+
+def check_no_scratch():
+    res = kernel_resources()
+    bad = [(k, v) for k, v in res.items() if any(n in k for n in NO_SCRATCH)
+           and (int(v.get("ScratchSize", 0)) != 0 or int(v.get("VGPRs Spill", 0)) != 0)]
+    if bad:
+        raise RuntimeError("hot kernels use scratch memory: " + ", ".join("%s (%s B/lane)" % (k, v.get("ScratchSize")) for k, v in bad))
+    return res
 
 
 if __name__ == "__main__":

@@ -48,6 +48,18 @@ def test_status_strings_and_pure_helpers(built):
     assert L.cap_bc_owner(11, 8) == 3 and L.cap_bc_local_block(11, 8) == 1
 
 
+def test_hot_kernels_use_no_scratch(built):
+    """The compiler's own resource remarks, saved by the build: hot kernels must keep their accumulators in registers."""
+    from capital_amd import build as b
+    if not b.kernel_resources():
+        b.build(force=True, verbose=False)
+    res = b.check_no_scratch()
+    hot = [k for k in res if any(n in k for n in b.NO_SCRATCH)]
+    assert len(hot) >= 6
+    for k in hot:
+        assert int(res[k]["ScratchSize"]) == 0 and int(res[k]["VGPRs Spill"]) == 0, k
+
+
 def test_no_cpu_fallback():
     """CPU tensors are rejected before any native call; there is no host path to fall back to."""
     import torch
