@@ -138,15 +138,15 @@ def cpu_baseline_cacqr(m, n):
 
 def traffic_from_profile(n, args):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
-    (profiles/r02_traffic_bench_n65536.json, produced by tools/prof_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate
+    (profiles/r02_traffic_bench_n65536.json, produced by tools/prof_round.sh + tools/make_traffic_json.py: FETCH_SIZE and WRITE_SIZE in separate
     runs, FETCH_SIZE doubled per the gfx950 correction).  Counters cannot be collected inside the timed run; the
     number is only reported for the exact configuration AND library build it was measured on, else null."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic_bench_n65536.json")))
         if d["config"]["n"] == n and d["config"]["complete_inv"] == args.complete_inv and not (args.nb or args.outer or args.tail >= 0):
             import hashlib
-            h = hashlib.sha256(open(os.path.join(ROOT, "capital_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
-            if d.get("gemm_hip_sha16") == h:
+            src = b"".join(open(os.path.join(ROOT, "capital_amd", "csrc", f), "rb").read() for f in ("gemm.hip", "tile_dma.h"))
+            if d.get("kernel_src_sha16") == hashlib.sha256(src).hexdigest()[:16]:
                 return d["traffic_bytes_per_launch"]
     except Exception:
         pass

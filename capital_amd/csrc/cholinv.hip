@@ -162,6 +162,9 @@ struct cap_cholinv_plan {
   // panel stream, so the latency-bound diagonal-block chain is not time-sliced against 512 resident bulk
   // workgroups (hipExtStreamCreateWithCUMask: bit i -> XCD i % 8, tools/cumask_probe.hip)
   hipStream_t s_bulk; hipEvent_t ev_join_b; int64_t reserve; bool bulk_ready;
+  // ... and the diagonal-block chain itself (leaf / fused-step / assembly kernels: a handful of workgroups each) runs on a stream
+  // masked to exactly those reserved CUs, so none of its waves ever shares a SIMD with fp64-MFMA bulk waves
+  hipStream_t s_chain; hipEvent_t ev_chain[2];
   bool streams_ready;
   // optional live profile of the dominant kernel (trailing-update SYRK): HIP events on the stream
   // it is launched on, algorithmic flops m(m+1)k per launch
@@ -235,6 +238,9 @@ int ensure_bulk_stream(cap_cholinv_plan* p) {
   for (int i = 0; i < 8; i++) mask[i] = 0xffffffffu;
   for (int64_t b = 0; b < p->reserve && b < 128; b++) mask[b / 32] &= ~(1u << (b % 32));
   CAP_HIP(hipExtStreamCreateWithCUMask(&p->s_bulk, 8, mask));
+  for (int i = 0; i < 8; i++) mask[i] = ~mask[i];
+  CAP_HIP(hipExtStreamCreateWithCUMask(&p->s_chain, 8, mask));
+  for (int i = 0; i < 2; i++) CAP_HIP(hipEventCreateWithFlags(&p->ev_chain[i], hipEventDisableTiming));
   p->bulk_ready = true;
   return CAP_OK;
 }
@@ -245,7 +251,17 @@ int panel_factor(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t
   double* Wrec = p->work;                       // rec scratch
   double* Wpan = p->work + rec_work_size(p->nb);  // jb x m panel scratch
   if (p->fastdiag && jb % 64 == 0 && jb >= 128 && jb <= 1024 && (jb & (jb - 1)) == 0 && p->leaf == CAP_LEAF_MAX) {
-    CAP_TRY(blocked_cholinv(R + j0 + j0 * ldr, ldr, Dinv, p->ldi, jb, Wrec, rec_work_size(p->nb), p->info_dev, j0, s));
+    hipStream_t sc = s;
+    if (p->bulk_ready && s != p->s_bulk) {          // (s == s_bulk: the non-overlapped tail, nothing to hide from)
+      sc = p->s_chain;
+      CAP_HIP(hipEventRecord(p->ev_chain[0], s));
+      CAP_HIP(hipStreamWaitEvent(sc, p->ev_chain[0], 0));
+    }
+    CAP_TRY(blocked_cholinv(R + j0 + j0 * ldr, ldr, Dinv, p->ldi, jb, Wrec, rec_work_size(p->nb), p->info_dev, j0, sc));
+    if (sc != s) {
+      CAP_HIP(hipEventRecord(p->ev_chain[1], sc));
+      CAP_HIP(hipStreamWaitEvent(s, p->ev_chain[1], 0));
+    }
   } else {
     RecCtx c{R + j0 + j0 * ldr, ldr, Dinv, p->ldi, Wrec, rec_work_size(p->nb), p->info_dev, p->leaf, 1, 1, s};
     CAP_TRY(rec_cholinv(c, 0, jb, false, j0));
@@ -453,7 +469,10 @@ int cap_cholinv_plan_destroy(cap_cholinv_plan* p) {
     for (int i = 0; i < 2; i++) { (void)hipEventDestroy(p->ev_panel[i]); (void)hipEventDestroy(p->ev_update[i]); }
     (void)hipEventDestroy(p->ev_fork); (void)hipEventDestroy(p->ev_join); (void)hipEventDestroy(p->ev_join_b);
   }
-  if (p->bulk_ready) (void)hipStreamDestroy(p->s_bulk);
+  if (p->bulk_ready) {
+    (void)hipStreamDestroy(p->s_bulk); (void)hipStreamDestroy(p->s_chain);
+    for (int i = 0; i < 2; i++) (void)hipEventDestroy(p->ev_chain[i]);
+  }
   if (p->prof_ev) { for (hipEvent_t e : *p->prof_ev) (void)hipEventDestroy(e); delete p->prof_ev; delete p->prof_flops; }
   delete p;
   return CAP_OK;
@@ -498,7 +517,12 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
   if (k == "fastdiag") { p->fastdiag = value != 0; return CAP_OK; }
   if (k == "reserve") {   // CUs kept free for the panel chain (multiple of 8 keeps the XCDs balanced); 0 = off
     if (value < 0 || value > 64) return CAP_ERR_ARG;
-    if (p->bulk_ready) { (void)hipStreamSynchronize(p->s_bulk); (void)hipStreamDestroy(p->s_bulk); p->bulk_ready = false; }
+    if (p->bulk_ready) {
+      (void)hipStreamSynchronize(p->s_bulk); (void)hipStreamDestroy(p->s_bulk);
+      (void)hipStreamSynchronize(p->s_chain); (void)hipStreamDestroy(p->s_chain);
+      for (int i = 0; i < 2; i++) (void)hipEventDestroy(p->ev_chain[i]);
+      p->bulk_ready = false;
+    }
     p->reserve = value; return CAP_OK;
   }
   if (k == "profile") {

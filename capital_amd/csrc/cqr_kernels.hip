@@ -96,13 +96,24 @@ __global__ void __launch_bounds__(512, 2) gram256_kernel(const GramArgs g) {
   }
 }
 
-// G(upper) = sum over the slabs, fixed order
-__global__ void gram256_reduce_kernel(const double* P, int nslab, double* G, int64_t ldg) {
-  const int col = blockIdx.x, row = threadIdx.x;
-  if (row > col) return;
-  double s = 0.0;
-  for (int z = 0; z < nslab; z++) s += P[(int64_t)z * GN * GN + row + (int64_t)col * GN];
-  G[row + (int64_t)col * ldg] = s;
+// G(upper) = sum over the slabs in a fixed association order (deterministic): 4 slab groups per element, 4 independent partial
+// sums per thread so that 16 loads per element are in flight, groups combined through LDS
+__global__ void __launch_bounds__(1024) gram256_reduce_kernel(const double* P, int nslab, double* G, int64_t ldg) {
+  __shared__ double part[4][GN];
+  const int col = blockIdx.x, row = threadIdx.x & (GN - 1), grp = threadIdx.x >> 8;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (row <= col) {
+    const double* p = P + row + (int64_t)col * GN;
+    int z = grp;
+    for (; z + 12 < nslab; z += 16) {
+      s0 += p[(int64_t)z * GN * GN]; s1 += p[(int64_t)(z + 4) * GN * GN];
+      s2 += p[(int64_t)(z + 8) * GN * GN]; s3 += p[(int64_t)(z + 12) * GN * GN];
+    }
+    for (; z < nslab; z += 4) s0 += p[(int64_t)z * GN * GN];
+  }
+  part[grp][row] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && row <= col) G[row + (int64_t)col * ldg] = (part[0][row] + part[1][row]) + (part[2][row] + part[3][row]);
 }
 
 // ================================================================================================ qrapply256
@@ -114,7 +125,7 @@ constexpr int A_NST = 4, B_NST = 3;              // 4 x 16 KiB + 3 x 32 KiB = 16
 
 struct ApplyArgs { const double* Qin; int64_t ldin; const double* Ri; double* Qout; int64_t ldout; int ntiles; };
 
-template <int DIAG, bool PIPE>
+template <int DIAG, int PIPE>
 __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
@@ -208,7 +219,7 @@ __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {
       }                                                                                                                        \
   }
   issue_a(0); issue_b(0); issue_a(1); issue_b(1); issue_a(2);
-  if (PIPE) {
+  if (PIPE == 1) {
     // The tile hand-over (wait + barrier + refill + first fragment reads of the NEXT tile) sits in the middle of a step, between
     // the two k-halves of the current tile, so every wave has half a step of MFMAs queued behind its LDS reads.
     d2 fa0[4], fb0[4], fa1[4], fb1[4];
@@ -267,7 +278,7 @@ int cap_gram256_launch(const double* Q, int64_t ld, int64_t m, double* G, int64_
   const int64_t nslab = cap_gram256_slabs(m);
   GramArgs g{Q, ld, m, cap_round_up(cap_ceil_div(m, nslab), BK), work};
   hipLaunchKernelGGL(gram256_kernel, dim3((unsigned)nslab), dim3(512), G_STAGES * G_TILE * sizeof(double), s, g);
-  hipLaunchKernelGGL(gram256_reduce_kernel, dim3(GN), dim3(GN), 0, s, work, (int)nslab, G, ldg);
+  hipLaunchKernelGGL(gram256_reduce_kernel, dim3(GN), dim3(4 * GN), 0, s, work, (int)nslab, G, ldg);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
@@ -286,11 +297,11 @@ int cap_qrapply256_launch(const double* Qin, int64_t ldin, const double* Ri, dou
   static const int pipe = getenv("CAP_CQR_PIPE") ? atoi(getenv("CAP_CQR_PIPE")) : 1;
   const size_t lds = (A_NST * TA + B_NST * TB) * sizeof(double);
   const dim3 gr((unsigned)grid), bl(512);
-  if (diag == 1) hipLaunchKernelGGL((qrapply256_kernel<1, false>), gr, bl, lds, s, g);
-  else if (diag == 2) hipLaunchKernelGGL((qrapply256_kernel<2, false>), gr, bl, lds, s, g);
-  else if (diag == 3) hipLaunchKernelGGL((qrapply256_kernel<3, false>), gr, bl, lds, s, g);
-  else if (pipe) hipLaunchKernelGGL((qrapply256_kernel<0, true>), gr, bl, lds, s, g);
-  else hipLaunchKernelGGL((qrapply256_kernel<0, false>), gr, bl, lds, s, g);
+  if (diag == 1) hipLaunchKernelGGL((qrapply256_kernel<1, 0>), gr, bl, lds, s, g);
+  else if (diag == 2) hipLaunchKernelGGL((qrapply256_kernel<2, 0>), gr, bl, lds, s, g);
+  else if (diag == 3) hipLaunchKernelGGL((qrapply256_kernel<3, 0>), gr, bl, lds, s, g);
+  else if (pipe == 1) hipLaunchKernelGGL((qrapply256_kernel<0, 1>), gr, bl, lds, s, g);
+  else hipLaunchKernelGGL((qrapply256_kernel<0, 0>), gr, bl, lds, s, g);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }

@@ -30,7 +30,12 @@ static void run(hipStream_t s, const char* tag) {
   printf("%s: CUs seen per XCC:", tag);
   int tot = 0;
   for (auto& kv : cus) { printf(" x%u=%zu", kv.first, kv.second.size()); tot += kv.second.size(); }
-  printf("  total=%d\n", tot);
+  printf("  total=%d", tot);
+  // is block b still dispatched to XCD b % 8 (what the XCD-aware tile maps assume)?
+  int agree = 0; unsigned first[8];
+  for (int r = 0; r < 8; r++) first[r] = h[2 * r] & 0xf;
+  for (int i = 0; i < nb; i++) agree += ((h[2 * i] & 0xf) == first[i & 7]);
+  printf("  blocks on XCD of (b %% 8): %d / %d\n", agree, nb);
   CK(hipFree(d));
 }
 int main() {

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <cstdint>
 #include "../include/capital_amd.h"
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n",hipGetErrorString(e),__LINE__); exit(1);} }while(0)
 __global__ void fill(double* p, size_t n, unsigned seed) {
@@ -21,16 +22,23 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&A, sizeof(double) * k * m)); CK(hipMalloc(&B, sizeof(double) * k * n)); CK(hipMalloc(&C, sizeof(double) * m * n));
   fill<<<2048, 256>>>(A, (size_t)k * m, 1); fill<<<2048, 256>>>(B, (size_t)k * n, 2); fill<<<2048, 256>>>(C, (size_t)m * n, 3);
   CK(hipDeviceSynchronize());
+  // MASK_OFF=n: run on a stream whose CU mask has its first n bits (CU i of XCD i % 8) cleared
+  hipStream_t st_ = nullptr;
+  if (getenv("MASK_OFF")) {
+    uint32_t mk[8]; for (int i = 0; i < 8; i++) mk[i] = 0xffffffffu;
+    for (int b = 0; b < atoi(getenv("MASK_OFF")); b++) mk[b / 32] &= ~(1u << (b % 32));
+    CK(hipExtStreamCreateWithCUMask(&st_, 8, mk));
+  }
   auto run = [&]() {
-    int st = syrk ? cap_dsyrk(CAP_UPPER, CAP_TRANS, n, k, -1.0, A, k, 1.0, C, m, nullptr)
-                  : cap_dgemm(CAP_TRANS, CAP_NOTRANS, m, n, k, -1.0, A, k, B, k, 1.0, C, m, nullptr);
+    int st = syrk ? cap_dsyrk(CAP_UPPER, CAP_TRANS, n, k, -1.0, A, k, 1.0, C, m, st_)
+                  : cap_dgemm(CAP_TRANS, CAP_NOTRANS, m, n, k, -1.0, A, k, B, k, 1.0, C, m, st_);
     if (st) { printf("status %d\n", st); exit(1); }
   };
   run(); CK(hipDeviceSynchronize());
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  CK(hipEventRecord(e0));
+  CK(hipEventRecord(e0, st_));
   for (int i = 0; i < reps; i++) run();
-  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  CK(hipEventRecord(e1, st_)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
   double fl = syrk ? (double)n * (n + 1) * k : 2.0 * m * n * k;
   printf("%s m=%ld n=%ld k=%ld: %.3f ms %.2f TFLOP/s\n", syrk ? "syrk" : "gemm", m, n, k, ms, fl / ms * 1e-9);

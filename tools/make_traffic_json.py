@@ -12,6 +12,7 @@ out = {"command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-include-rege
        "FETCH_SIZE_KB_per_launch_reported": f, "WRITE_SIZE_KB_per_launch": w,
        "fetch_correction": "x2 (gfx950 rocprofv3 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE is used as reported (it matches the algorithmic C-tile bytes 1:1)",
        "traffic_bytes_per_launch": (2 * f + w) * 1024.0, "algorithmic_bytes_per_launch": 5.42e9,
-       "gemm_hip_sha16": hashlib.sha256(open(os.path.join(ROOT, "capital_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]}
+       "kernel_src_sha16": hashlib.sha256(b"".join(open(os.path.join(ROOT, "capital_amd", "csrc", f), "rb").read()
+                                                    for f in ("gemm.hip", "tile_dma.h"))).hexdigest()[:16]}
 json.dump(out, open(os.path.join(ROOT, "profiles", "r02_traffic_bench_n65536.json"), "w"), indent=1)
 print(out["traffic_bytes_per_launch"] / 1e9, "GB per launch,", out["traffic_bytes_per_launch"] / out["algorithmic_bytes_per_launch"], "x algorithmic")
