@@ -123,7 +123,7 @@ constexpr int A_NST = 4, B_NST = 3;              // 4 x 16 KiB + 3 x 32 KiB = 16
 // issues [4 pieces of B, 2 pieces of A]; vmcnt retires in order, so "tile t has landed" = at most the 8 younger pieces
 // A(t+1), B(t+1), A(t+2) outstanding.
 
-struct ApplyArgs { const double* Qin; int64_t ldin; const double* Ri; double* Qout; int64_t ldout; int ntiles; };
+struct ApplyArgs { const double* Qin; int64_t ldin; const double* Ri; double* Qout; int64_t ldout; int ntiles; int contig; };
 
 template <int DIAG, int PIPE>
 __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {
@@ -131,7 +131,12 @@ __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int G = (int)gridDim.x, b = (int)blockIdx.x;
-  const int nmine = b < g.ntiles ? (g.ntiles - 1 - b) / G + 1 : 0;
+  // contig: workgroup b owns `per` consecutive row tiles, so per column it streams one contiguous range and its address
+  // translations (256 columns in, 256 out, 16 MiB apart at m = 2^21) stay the same for the whole launch; otherwise tiles are
+  // dealt round-robin (b, b + G, ...)
+  const int per = (g.ntiles + G - 1) / G;
+  const int t0 = g.contig ? b * per : b, tstride = g.contig ? 1 : G;
+  const int nmine = g.contig ? max(0, min(per, g.ntiles - t0)) : (b < g.ntiles ? (g.ntiles - 1 - b) / G + 1 : 0);
   const int U = nmine * 16;                                    // pipeline steps: (my row tile, K tile)
   if (U == 0) return;
   // column wave wn owns the block columns wn, wn + 4, wn + 8, wn + 12 (cyclic: at K tile kt only block columns >= kt are
@@ -146,7 +151,7 @@ __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {
   auto issue_a = [&](int u) {
     const int uc = u < U ? u : U - 1;
     const int kt = uc & 15;
-    const int64_t i0 = (int64_t)(b + (uc >> 4) * G) * 128;
+    const int64_t i0 = (int64_t)(t0 + (uc >> 4) * tstride) * 128;
     double* st = sAbase + (u & (A_NST - 1)) * TA;
     // rows of the stage = k, 128 consecutive doubles of Q each; one wave-instruction per k row, halves swapped when (k >> 1) is odd
 #pragma unroll
@@ -206,7 +211,7 @@ __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {
 #define CQR_STORE_COL(u)                                                                                                       \
   if ((((u) & 15) & 3) == wn && (!(DIAG & 1) || g.ntiles < 0)) {                                                               \
     const int kt_ = (u) & 15;                                                                                                  \
-    const int64_t i0_ = (int64_t)(b + ((u) >> 4) * G) * 128;                                                                   \
+    const int64_t i0_ = (int64_t)(t0 + ((u) >> 4) * tstride) * 128;                                                                  \
     _Pragma("unroll") for (int j = 0; j < 4; j++)                                                                              \
       if (j == (kt_ >> 2)) {                                                                                                   \
         _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                                        \
@@ -290,7 +295,8 @@ int cap_qrapply256_launch(const double* Qin, int64_t ldin, const double* Ri, dou
   int dev = 0, cus = 256;
   CAP_HIP(hipGetDevice(&dev));
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  ApplyArgs g{Qin, ldin, Ri, Qout, ldout, (int)(m / 128)};
+  static const int contig = getenv("CAP_CQR_CONTIG") ? atoi(getenv("CAP_CQR_CONTIG")) : 1;
+  ApplyArgs g{Qin, ldin, Ri, Qout, ldout, (int)(m / 128), contig};
   const int grid = (int)std::min<int64_t>(cus, g.ntiles);
   // CAP_CQR_DIAG is timing surgery only (1 = no stores, 2 = no MFMA: results are wrong); CAP_CQR_PIPE picks the loop form
   static const int diag = getenv("CAP_CQR_DIAG") ? atoi(getenv("CAP_CQR_DIAG")) : 0;
