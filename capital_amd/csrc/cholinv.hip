@@ -82,7 +82,7 @@ int rec_cholinv(const RecCtx& c, int64_t off, int64_t n, bool is_root, int64_t i
   return CAP_OK;
 }
 
-int64_t rec_work_size(int64_t n) { return cap_round_up(std::max<int64_t>((n / 2 + 1) * (n / 2 + 1), 64 * n), 2); }
+int64_t rec_work_size(int64_t n) { return cap_round_up(std::max<int64_t>((n / 2 + 1) * (n / 2 + 1), 128 * n), 2); }
 
 // Diagonal-block fast path (n = 64 * nblk <= 1024): 64-blocked right-looking potrf with ONE fused launch per step
 // (cap_panel64_solve_update) + the inverse assembled level by level with batched products - 3 nblk - 1 + 2 log2(nblk)
@@ -91,7 +91,23 @@ int64_t rec_work_size(int64_t n) { return cap_round_up(std::max<int64_t>((n / 2 
 int blocked_cholinv(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, double* W, int64_t wcap, int* info,
                     int64_t info_base, hipStream_t s) {
   const int nblk = (int)(n / 64);
-  if (64 * n > wcap) return CAP_ERR_ALLOC;
+  if (128 * n > wcap) return CAP_ERR_ALLOC;
+  static const bool fold = getenv("CAP_FOLD_LEAF") ? atoi(getenv("CAP_FOLD_LEAF")) != 0 : true;
+  if (fold) {
+    // one launch per step: the fused solve + update of step i also runs the leaf of step i + 1 (leaf.hip).  The solved block
+    // row of step i sits in half (i & 1) of W until the launch of step i + 1 moves it into R (the other workgroups of step i
+    // still read the unsolved blocks), the last step - a single workgroup - writes its piece in place.
+    CAP_TRY(cap_leaf_cholinv(R, ldr, Ri, ldi, 64, 1, info, (int)info_base, s));
+    for (int i = 0; i + 1 < nblk; i++) {
+      double* Dii = Ri + (int64_t)i * 64 * (ldi + 1);
+      double* Xw = W + (int64_t)(i & 1) * 64 * n;
+      const double* cj_src = i ? W + (int64_t)((i - 1) & 1) * 64 * n : nullptr;
+      double* cj_dst = i ? R + (int64_t)(i - 1) * 64 + (int64_t)i * 64 * ldr : nullptr;
+      CAP_TRY(cap_panel64_solve_update(R, ldr, Dii, ldi, i, nblk, Xw, s, Ri + (int64_t)(i + 1) * 64 * (ldi + 1), ldi, info,
+                                       (int)(info_base + (i + 1) * 64), cj_src, cj_dst, ldr, i ? (nblk - i) * 64 : 0,
+                                       nblk - 1 - i == 1));
+    }
+  } else {
   double* Xs = W;      // block row solved by the fused step, moved into R by the NEXT leaf launch (W is free until the inverse phase)
   for (int i = 0; i < nblk; i++) {
     double* Rii = R + (int64_t)i * 64 * (ldr + 1);
@@ -100,6 +116,7 @@ int blocked_cholinv(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, 
     else CAP_TRY(cap_leaf_cholinv(Rii, ldr, Dii, ldi, 64, 1, info, (int)(info_base + i * 64), s, Xs,
                                   R + (int64_t)(i - 1) * 64 + (int64_t)i * 64 * ldr, ldr, (nblk - i) * 64));
     CAP_TRY(cap_panel64_solve_update(R, ldr, Dii, ldi, i, nblk, Xs, s));
+  }
   }
   for (int64_t h = 64; h < n; h *= 2) {
     const int npairs = (int)(n / (2 * h));

@@ -54,8 +54,12 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
                            hipStream_t stream, int persist_wgs = 0);
 
 // leaf.hip: fused block-row solve + rank-64 trailing update of the 64-blocked diagonal-block factorization
+// (Dnext != nullptr: the workgroup of block (i + 1, i + 1) also runs the leaf of step i + 1 and writes R_{i+1,i+1}, Dinv_{i+1};
+//  cj_*: move the previous step's solved block row from scratch into R; direct: single-workgroup launch writes its piece in place)
 int cap_panel64_solve_update(double* R, int64_t ldr, const double* Dinv, int64_t ldi, int i, int nblk, double* Xs,
-                             hipStream_t stream);
+                             hipStream_t stream, double* Dnext = nullptr, int64_t ldn = 0, int* info = nullptr, int info_base = 0,
+                             const double* cj_src = nullptr, double* cj_dst = nullptr, int64_t cj_ld = 0, int cj_cols = 0,
+                             int direct = 0);
 // gemm.hip: batched 64x64-tile products (batch = blockIdx.z, affine strides)
 int cap_gemm_small_batched(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
                            int64_t sa, const double* B, int64_t ldb, int64_t sb, double beta, double* C, int64_t ldc, int64_t sc,

@@ -101,7 +101,7 @@ __device__ __forceinline__ void potrf16_wave(double* S, double* dinv, double* ro
 // Right-looking blocked Cholesky of the np x np (np = 16, 32 or 64) block in S, 16-wide panels:
 //   potrf16 (wave 0, registers) | row panel by forward substitution (one lane per column, R11 broadcast from LDS)
 //   | rank-16 update of the trailing blocks on MFMA.
-__device__ void potrf_lds(double* S, double* dinv, double* rowbuf, int np, int* bad) {
+__device__ __forceinline__ void potrf_lds(double* S, double* dinv, double* rowbuf, int np, int* bad) {
   const int t = threadIdx.x;
   for (int off = 0; off < np; off += 16) {
     if (t < 64) potrf16_wave(S, dinv, rowbuf, off, bad);
@@ -131,7 +131,7 @@ __device__ void potrf_lds(double* S, double* dinv, double* rowbuf, int np, int* 
 // T = R^-1 for the np x np upper-triangular block in S (T zero on entry): the 16 x 16 diagonal blocks by back
 // substitution (all blocks in parallel, reciprocals from dinv), then Ri12 = -Ri11 R12 Ri22 level by level on MFMA;
 // S's strictly-lower blocks serve as scratch.
-__device__ void trtri_lds(double* S, double* T, const double* dinv, int np) {
+__device__ __forceinline__ void trtri_lds(double* S, double* T, const double* dinv, int np) {
   const int t = threadIdx.x;
   const int nblk = np / 16;
   if (t < 16 * nblk) {
@@ -256,13 +256,28 @@ __global__ void __launch_bounds__(LTHREADS) leaf_trtri_kernel(const double* R, i
 // LDS budget: Dinv_i packed upper (16.6 KB) + two 64 x 64 panels (33.8 KB each) = 84 KB, so the workgroup fits
 // into ONE slot vacated by a bulk-update workgroup (96 KB); a 4-buffer version (135 KB) needed a whole idle CU
 // and lost 4 % end to end under a concurrent bulk update.  Products stay in registers between phases.
+//
+// fold (f.Dnext != nullptr): the workgroup of the NEXT diagonal block (a = b = i + 1) goes straight on to factor and invert
+// the block it has just updated (the leaf of step i + 1: same LDS, the two panels become S and T), so a step is ONE launch
+// instead of two - under a concurrent bulk update every launch of the chain waits for a workgroup slot to come free.
+// The solved block row of the previous step (f.cj_*) is moved into R by the last workgroup of the launch, the solved
+// pieces of this step go to the other half of the scratch (f.direct: a single-workgroup launch writes its piece in place).
+struct Panel64Fold {
+  double* Dnext; int64_t ldn;            // Dinv_{i+1} (strictly lower part zero-filled)
+  int* info; int info_base;              // first non-positive pivot -> info_base + 1-based index
+  const double* cj_src; double* cj_dst; int64_t cj_ld; int cj_cols;
+  int direct;
+};
+
 __global__ void __launch_bounds__(LTHREADS) panel64_solve_update_kernel(double* R, int64_t ldr, const double* Dinv, int64_t ldi,
-                                                                       int i, int nblk, double* Xs) {
+                                                                       int i, int nblk, double* Xs, const Panel64Fold f) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* B0 = lds;                       // A_ia -> X_a
   double* B1 = lds + LMAX * LLD;          // A_ib -> X_b
   double* Dp = lds + 2 * LMAX * LLD;      // Dinv_i, packed upper: (k, p), k <= p, at p(p+1)/2 + k
   __builtin_amdgcn_s_setprio(3);
+  if (blockIdx.x == gridDim.x - 1)
+    for (int e = threadIdx.x; e < 64 * f.cj_cols; e += LTHREADS) f.cj_dst[(e & 63) + (int64_t)(e >> 6) * f.cj_ld] = f.cj_src[e];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int lr = lane & 15, kg = lane >> 4;
   int q = blockIdx.x, bjt = 0;            // triangular decode -> (a, b), i < a <= b < nblk
@@ -324,12 +339,22 @@ __global__ void __launch_bounds__(LTHREADS) panel64_solve_update_kernel(double* 
   if (diag) {
     // the solved block R_ia goes to scratch (other workgroups of this launch still read the unsolved A_ia from R);
     // the next leaf launch moves the whole block row into place
-    double* dst = Xs + (int64_t)(a - i - 1) * 64 * 64;
-    for (int e = t; e < 64 * 64; e += LTHREADS) dst[e] = SM(B0, e & 63, e >> 6);
+    if (f.direct) {
+      double* dst = R + (int64_t)i * 64 + (int64_t)a * 64 * ldr;
+      for (int e = t; e < 64 * 64; e += LTHREADS) dst[(e & 63) + (int64_t)(e >> 6) * ldr] = SM(B0, e & 63, e >> 6);
+    } else {
+      double* dst = Xs + (int64_t)(a - i - 1) * 64 * 64;
+      for (int e = t; e < 64 * 64; e += LTHREADS) dst[e] = SM(B0, e & 63, e >> 6);
+    }
   }
   // C_ab -= X_a^T X_b, computed transposed (MFMA rows <- columns of C) so that a lane owns 16 consecutive ROWS of C
   const double* XB = diag ? B0 : B1;
   double* C = R + (int64_t)a * 64 + (int64_t)b * 64 * ldr;
+  const bool fold = f.Dnext != nullptr && blockIdx.x == 0;       // blockIdx.x == 0 <=> a == b == i + 1
+  if (fold) {                                                     // B1 is idle in a diagonal workgroup: it becomes S
+    for (int e = t; e < 64 * LLD; e += LTHREADS) B1[e] = 0.0;
+    __syncthreads();
+  }
 #pragma unroll
   for (int sblk = 0; sblk < 4; sblk++) {
     const int id = wid + 4 * sblk, bi = id & 3, bj = id >> 2;     // bi: row block of C (from X_a), bj: column block (from X_b)
@@ -344,19 +369,47 @@ __global__ void __launch_bounds__(LTHREADS) panel64_solve_update_kernel(double* 
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = bi * 16 + lr, col = bj * 16 + kg + 4 * r;
-      if (!diag || row <= col) C[row + (int64_t)col * ldr] -= c[r];
+      if (!diag || row <= col) {
+        if (fold) SM(B1, row, col) = C[row + (int64_t)col * ldr] - c[r];
+        else C[row + (int64_t)col * ldr] -= c[r];
+      }
     }
   }
+  if (!fold) return;
+  // ---- leaf of step i + 1 on the block just updated: S = B1, T = B0 (cf. leaf_cholinv_kernel)
+  __syncthreads();                                               // every read of B0 (X_a) is done, S is complete
+  double* S = B1; double* T = B0;
+  int& bad = *reinterpret_cast<int*>(Dp);                        // Dinv_i's packed copy is dead after the solve
+  double* dinv = Dp + 2; double* rowbuf = dinv + LMAX;
+  for (int e = t; e < 64 * LLD; e += LTHREADS) T[e] = 0.0;
+  if (t == 0) bad = 0;
+  __syncthreads();
+  potrf_lds(S, dinv, rowbuf, 64, &bad);
+  for (int e = t; e < 64 * 64; e += LTHREADS) {
+    const int ii = e & 63, jj = e >> 6;
+    if (ii <= jj) C[ii + (int64_t)jj * ldr] = SM(S, ii, jj);
+  }
+  trtri_lds(S, T, dinv, 64);
+  __syncthreads();
+  for (int e = t; e < 64 * 64; e += LTHREADS) {
+    const int ii = e & 63, jj = e >> 6;
+    f.Dnext[ii + (int64_t)jj * f.ldn] = (ii <= jj) ? SM(T, ii, jj) : 0.0;
+  }
+  if (t == 0 && bad != 0 && f.info) atomicCAS(f.info, 0, f.info_base + bad);
 }
 
 }  // namespace
 
 int cap_panel64_solve_update(double* R, int64_t ldr, const double* Dinv, int64_t ldi, int i, int nblk, double* Xs,
-                             hipStream_t stream) {
+                             hipStream_t stream, double* Dnext, int64_t ldn, int* info, int info_base, const double* cj_src,
+                             double* cj_dst, int64_t cj_ld, int cj_cols, int direct) {
   const int r = nblk - 1 - i;
   if (r <= 0) return CAP_OK;
   const size_t lds_bytes = (2 * LMAX * LLD + LMAX * (LMAX + 1) / 2) * sizeof(double);
-  hipLaunchKernelGGL(panel64_solve_update_kernel, dim3(r * (r + 1) / 2), dim3(LTHREADS), lds_bytes, stream, R, ldr, Dinv, ldi, i, nblk, Xs);
+  static_assert(LMAX * (LMAX + 1) / 2 >= 2 + LMAX + 32, "the folded leaf keeps bad / dinv / rowbuf in the packed-Dinv region");
+  const Panel64Fold f{Dnext, ldn, info, info_base, cj_src, cj_dst, cj_ld, cj_cols, direct};
+  hipLaunchKernelGGL(panel64_solve_update_kernel, dim3(r * (r + 1) / 2), dim3(LTHREADS), lds_bytes, stream, R, ldr, Dinv, ldi, i, nblk,
+                     Xs, f);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
