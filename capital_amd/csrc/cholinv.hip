@@ -182,6 +182,13 @@ struct cap_cholinv_plan {
   // ... and the diagonal-block chain itself (leaf / fused-step / assembly kernels: a handful of workgroups each) runs on a stream
   // masked to exactly those reserved CUs, so none of its waves ever shares a SIMD with fp64-MFMA bulk waves
   hipStream_t s_chain; hipEvent_t ev_chain[2];
+  // column-split look-ahead (right_looking_split): the panel stream only touches the columns the NEXT chain needs; the wide
+  // remainder of every block-row solve / in-strip update runs on s_rest
+  int inner_la; bool split_ready;
+  int64_t occ1_m;       // bulk updates of trailing matrices this wide or narrower run with one workgroup per CU
+  hipStream_t s_rest; hipEvent_t ev_crit[2], ev_near[2], ev_pchain[2][8], ev_psolve[2][8], ev_join_r;
+  double* Dring;        // 2 x 8 diagonal-block inverses (nb x nb each, strictly-lower parts stay zero)
+  double* Wpan2;        // s_rest's nb x n solve scratch
   bool streams_ready;
   // optional live profile of the dominant kernel (trailing-update SYRK): HIP events on the stream
   // it is launched on, algorithmic flops m(m+1)k per launch
@@ -262,11 +269,9 @@ int ensure_bulk_stream(cap_cholinv_plan* p) {
   return CAP_OK;
 }
 
-// factor the nb-wide panel starting at j0: diagonal block (R, Dinv), then the block row solve
-int panel_factor(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t j0, int64_t jb, hipStream_t s) {
-  double* Dinv = p->Rinv;                       // jb x jb, ld = nb, strictly-lower part stays zero
+// diagonal block of the nb-wide panel starting at j0: R_jj and Dinv = R_jj^-1 (jb x jb, ld = nb, strictly-lower part stays zero)
+int panel_chain(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t j0, int64_t jb, double* Dinv, hipStream_t s) {
   double* Wrec = p->work;                       // rec scratch
-  double* Wpan = p->work + rec_work_size(p->nb);  // jb x m panel scratch
   if (p->fastdiag && jb % 64 == 0 && jb >= 128 && jb <= 1024 && (jb & (jb - 1)) == 0 && p->leaf == CAP_LEAF_MAX) {
     hipStream_t sc = s;
     if (p->bulk_ready && s != p->s_bulk) {          // (s == s_bulk: the non-overlapped tail, nothing to hide from)
@@ -283,13 +288,26 @@ int panel_factor(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t
     RecCtx c{R + j0 + j0 * ldr, ldr, Dinv, p->ldi, Wrec, rec_work_size(p->nb), p->info_dev, p->leaf, 1, 1, s};
     CAP_TRY(rec_cholinv(c, 0, jb, false, j0));
   }
-  const int64_t m = n - j0 - jb;
-  if (m > 0) {
-    double* Rpan = R + j0 + (j0 + jb) * ldr;
-    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, m, jb, 1.0, Dinv, p->ldi, Rpan, ldr, 0.0, Wpan, jb, 0, s, 2 | 16));
-    CAP_TRY(cap_copy_rect(Wpan, jb, Rpan, ldr, jb, m, s));
-  }
   return CAP_OK;
+}
+
+// block-row solve of panel j0 on the columns [c0, c1): R[j0:j0+jb, c0:c1] <- Dinv^T R[j0:j0+jb, c0:c1]  (Wp: jb x n scratch,
+// addressed by global column so that concurrent solves of disjoint column ranges can share it)
+int panel_solve(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t j0, int64_t jb, const double* Dinv, int64_t c0, int64_t c1,
+                double* Wp, hipStream_t s) {
+  const int64_t m = c1 - c0;
+  if (m <= 0) return CAP_OK;
+  double* Rpan = R + j0 + c0 * ldr;
+  double* W = Wp + c0 * jb;
+  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, m, jb, 1.0, Dinv, p->ldi, Rpan, ldr, 0.0, W, jb, 0, s, 2 | 16));
+  CAP_TRY(cap_copy_rect(W, jb, Rpan, ldr, jb, m, s));
+  return CAP_OK;
+}
+
+// factor the nb-wide panel starting at j0: diagonal block (R, Dinv), then the block row solve
+int panel_factor(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t j0, int64_t jb, hipStream_t s) {
+  CAP_TRY(panel_chain(p, R, ldr, j0, jb, p->Rinv, s));
+  return panel_solve(p, R, ldr, j0, jb, p->Rinv, j0 + jb, n, p->work + rec_work_size(p->nb), s);
 }
 
 // trailing update C[M x N] -= A^T B on upper tiles (the dominant kernel), optionally bracketed by events.
@@ -305,7 +323,9 @@ int trailing_update(cap_cholinv_plan* p, int64_t M, int64_t N, int64_t k, const 
     e0 = (*p->prof_ev)[p->prof_used]; e1 = (*p->prof_ev)[p->prof_used + 1];
     CAP_HIP(hipEventRecord(e0, s));
   }
-  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, M, N, k, -1.0, A, ldr, B, ldr, 1.0, C, ldr, 1, s, 1, (int)p->bulk_wgs));
+  // chain-bound tail (N columns left <= occ1_m): one bulk workgroup per CU instead of two, see launch_tn_dma
+  const int occ = (p->occ1_m > 0 && N <= p->occ1_m) ? -1 : (int)p->bulk_wgs;
+  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, M, N, k, -1.0, A, ldr, B, ldr, 1.0, C, ldr, 1, s, 1, occ));
   if (e0) {
     CAP_HIP(hipEventRecord(e1, s));
     p->prof_used += 2;
@@ -330,6 +350,147 @@ int factor_strip(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t
                               R + j1 + j1 * ldr, ldr, 1, s));
     }
   }
+  return CAP_OK;
+}
+
+void release_split(cap_cholinv_plan* p) {
+  if (!p->split_ready) return;
+  (void)hipStreamSynchronize(p->s_rest); (void)hipStreamDestroy(p->s_rest);
+  for (int i = 0; i < 2; i++) {
+    (void)hipEventDestroy(p->ev_crit[i]); (void)hipEventDestroy(p->ev_near[i]);
+    for (int q = 0; q < 8; q++) { (void)hipEventDestroy(p->ev_pchain[i][q]); (void)hipEventDestroy(p->ev_psolve[i][q]); }
+  }
+  (void)hipEventDestroy(p->ev_join_r);
+  (void)hipFree(p->Dring); (void)hipFree(p->Wpan2);
+  p->Dring = nullptr; p->Wpan2 = nullptr; p->split_ready = false;
+}
+
+int ensure_split(cap_cholinv_plan* p) {
+  if (p->split_ready) return CAP_OK;
+  int lo = 0, hi = 0;
+  CAP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  CAP_HIP(hipStreamCreateWithPriority(&p->s_rest, hipStreamNonBlocking, hi));
+  for (int i = 0; i < 2; i++) {
+    CAP_HIP(hipEventCreateWithFlags(&p->ev_crit[i], hipEventDisableTiming));
+    CAP_HIP(hipEventCreateWithFlags(&p->ev_near[i], hipEventDisableTiming));
+    for (int q = 0; q < 8; q++) {
+      CAP_HIP(hipEventCreateWithFlags(&p->ev_pchain[i][q], hipEventDisableTiming));
+      CAP_HIP(hipEventCreateWithFlags(&p->ev_psolve[i][q], hipEventDisableTiming));
+    }
+  }
+  CAP_HIP(hipEventCreateWithFlags(&p->ev_join_r, hipEventDisableTiming));
+  CAP_HIP(hipMalloc((void**)&p->Dring, sizeof(double) * 16 * p->nb * p->nb));
+  CAP_HIP(hipMemset(p->Dring, 0, sizeof(double) * 16 * p->nb * p->nb));
+  CAP_HIP(hipMalloc((void**)&p->Wpan2, sizeof(double) * cap_round_up(p->nb * p->n, 2)));
+  p->split_ready = true;
+  return CAP_OK;
+}
+
+// R[r0:r1, c0:c1] -= R[k0:k0+kb, r0:r1]^T R[k0:k0+kb, c0:c1]; upper mask when the block starts on the diagonal (c0 == r0),
+// blocks right of it (c0 >= r1) are full
+int strip_update(double* R, int64_t ldr, int64_t r0, int64_t r1, int64_t c0, int64_t c1, int64_t k0, int64_t kb, hipStream_t s) {
+  if (r1 <= r0 || c1 <= c0) return CAP_OK;
+  return cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, r1 - r0, c1 - c0, kb, -1.0, R + k0 + r0 * ldr, ldr, R + k0 + c0 * ldr, ldr, 1.0,
+                         R + r0 + c0 * ldr, ldr, c0 == r0 ? 1 : 0, s);
+}
+
+// Column-split look-ahead.  Measured at N = 32768 (profiles/r02_bench_n32768_kernel_stats.csv): the panel stream's serial
+// time (diagonal-block chains + block-row solves + in-strip updates, all slowed by the co-resident bulk update) equals the
+// whole factorization - the bulk stream hides beneath it.  But the chain of the next panel only needs the columns of the
+// next diagonal blocks.  So while strip k+1 = [J1, J2) is factored (outer step k):
+//   panel stream s1 : everything restricted to the columns [J1, Jc), Jc = end of strip k+2 ("crit": what the chains of this
+//                     and of the next outer step read)
+//   s_rest          : the same solves / updates on [Jc, Jn) ("near" = strip k+3's columns, which s1 reads one step later;
+//                     its last piece is recorded as ev_near) and on [Jn, n) ("far", only the bulk update reads it)
+//   main stream     : bulk update of step k (unchanged), waits for both halves of strip k.
+// Diagonal-block inverses live in a ring (2 parities x 8 panels): s_rest of step k still reads them while s1 runs step k+1.
+int right_looking_split(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStream_t s0, const std::vector<int64_t>& bnd) {
+  const int64_t nb = p->nb;
+  const int64_t nstrip = (int64_t)bnd.size() - 1;
+  auto B = [&](int64_t i) { return bnd[(size_t)std::min<int64_t>(i, nstrip)]; };
+  CAP_TRY(ensure_streams(p));
+  CAP_TRY(ensure_split(p));
+  hipStream_t s1 = p->s_panel, sr = p->s_rest;
+  double* Wpan = p->work + rec_work_size(nb);
+  CAP_HIP(hipEventRecord(p->ev_fork, s0));
+  CAP_HIP(hipStreamWaitEvent(s1, p->ev_fork, 0));
+  CAP_HIP(hipStreamWaitEvent(sr, p->ev_fork, 0));
+  // strip 0: nothing to overlap with yet - whole width on the panel stream
+  CAP_TRY(factor_strip(p, R, ldr, n, 0, bnd[1], s1));
+  CAP_HIP(hipEventRecord(p->ev_crit[0], s1));
+  CAP_HIP(hipEventRecord(p->ev_panel[0], s1));
+  CAP_HIP(hipEventRecord(p->ev_near[1], s1));            // "step -1": parity (k - 1) & 1 of k = 0
+  for (int64_t k = 0; k + 1 < nstrip; k++) {
+    const int64_t J0 = bnd[k], J1 = bnd[k + 1], J2 = bnd[k + 2], rows = J1 - J0, m = n - J1;
+    const int64_t Jc = B(k + 3), Jn = B(k + 4);
+    const int par = (int)(k & 1);
+    // ---- (a) panel stream: strip k+1 on the columns [J1, Jc)
+    if (k > 0) CAP_HIP(hipStreamWaitEvent(s1, p->ev_update[(k - 1) & 1], 0));     // head of the bulk update of step k-1
+    CAP_HIP(hipStreamWaitEvent(s1, p->ev_near[(k - 1) & 1], 0));                  // strip k's rows on [J2, Jc), from s_rest
+    CAP_TRY(strip_update(R, ldr, J1, J2, J1, Jc, J0, rows, s1));
+    int q = 0;
+    for (int64_t j0 = J1; j0 < J2; j0 += nb, q++) {
+      const int64_t jb = std::min(nb, J2 - j0), j1 = j0 + jb;
+      double* D = p->Dring + (int64_t)(par * 8 + q) * nb * nb;
+      CAP_TRY(panel_chain(p, R, ldr, j0, jb, D, s1));
+      CAP_HIP(hipEventRecord(p->ev_pchain[par][q], s1));
+      CAP_TRY(panel_solve(p, R, ldr, j0, jb, D, j1, Jc, Wpan, s1));
+      CAP_HIP(hipEventRecord(p->ev_psolve[par][q], s1));
+      CAP_TRY(strip_update(R, ldr, j1, J2, j1, Jc, j0, jb, s1));
+    }
+    CAP_HIP(hipEventRecord(p->ev_crit[(k + 1) & 1], s1));
+    // ---- (b) s_rest: the same on [Jc, Jn) and [Jn, n)
+    if (Jc < n) {
+      if (k > 0) CAP_HIP(hipStreamWaitEvent(sr, p->ev_update[(k - 1) & 1], 0));
+      CAP_HIP(hipStreamWaitEvent(sr, p->ev_crit[par], 0));     // strip k's rows on [J1, J2): the A operand of the strip update
+      CAP_TRY(strip_update(R, ldr, J1, J2, Jc, Jn, J0, rows, sr));
+      CAP_TRY(strip_update(R, ldr, J1, J2, Jn, n, J0, rows, sr));
+      q = 0;
+      for (int64_t j0 = J1; j0 < J2; j0 += nb, q++) {
+        const int64_t jb = std::min(nb, J2 - j0), j1 = j0 + jb;
+        const double* D = p->Dring + (int64_t)(par * 8 + q) * nb * nb;
+        const bool last = j1 >= J2;
+        CAP_HIP(hipStreamWaitEvent(sr, p->ev_pchain[par][q], 0));
+        CAP_TRY(panel_solve(p, R, ldr, j0, jb, D, Jc, Jn, p->Wpan2, sr));
+        if (last) CAP_HIP(hipEventRecord(p->ev_near[par], sr));
+        CAP_TRY(panel_solve(p, R, ldr, j0, jb, D, Jn, n, p->Wpan2, sr));
+        if (!last) {
+          CAP_HIP(hipStreamWaitEvent(sr, p->ev_psolve[par][q], 0));    // X[:, j1:J2) (crit columns) is the A operand
+          CAP_TRY(strip_update(R, ldr, j1, J2, Jc, Jn, j0, jb, sr));
+          CAP_TRY(strip_update(R, ldr, j1, J2, Jn, n, j0, jb, sr));
+        }
+      }
+    } else {
+      CAP_HIP(hipStreamWaitEvent(sr, p->ev_crit[(k + 1) & 1], 0));
+      CAP_HIP(hipEventRecord(p->ev_near[par], sr));
+    }
+    CAP_HIP(hipEventRecord(p->ev_panel[(k + 1) & 1], sr));
+    // ---- (c) main stream: bulk of the trailing update of step k (rows below strip k+1)
+    CAP_HIP(hipStreamWaitEvent(s0, p->ev_crit[par], 0));
+    CAP_HIP(hipStreamWaitEvent(s0, p->ev_panel[par], 0));
+    const int64_t rows1 = J2 - J1, m2 = m - rows1;
+    double* S = R + J0 + J1 * ldr;
+    if (m2 > 0) {
+      double* S2 = S + rows1 * ldr;
+      const int64_t rows2 = (k + 3 <= nstrip) ? bnd[k + 3] - bnd[k + 2] : m2;   // height of strip k+2
+      if (p->depth2 && rows2 < m2) {
+        CAP_TRY(trailing_update(p, rows2, m2, rows, S2, S2, R + J2 + J2 * ldr, ldr, s0));
+        CAP_HIP(hipEventRecord(p->ev_update[par], s0));
+        const int64_t m3 = m2 - rows2;
+        double* S3 = S2 + rows2 * ldr;
+        CAP_TRY(trailing_update(p, m3, m3, rows, S3, S3, R + (J2 + rows2) + (J2 + rows2) * ldr, ldr, s0));
+      } else {
+        CAP_TRY(trailing_update(p, m2, m2, rows, S2, S2, R + J2 + J2 * ldr, ldr, s0));
+        CAP_HIP(hipEventRecord(p->ev_update[par], s0));
+      }
+    } else {
+      CAP_HIP(hipEventRecord(p->ev_update[par], s0));
+    }
+  }
+  CAP_HIP(hipEventRecord(p->ev_join, s1));
+  CAP_HIP(hipStreamWaitEvent(s0, p->ev_join, 0));
+  CAP_HIP(hipEventRecord(p->ev_join_r, sr));
+  CAP_HIP(hipStreamWaitEvent(s0, p->ev_join_r, 0));
   return CAP_OK;
 }
 
@@ -363,6 +524,7 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
     }
     return CAP_OK;
   }
+  if (p->inner_la && p->serial_m == 0 && p->reserve == 0 && NB / nb <= 8) return right_looking_split(p, R, ldr, n, s0, bnd);
   CAP_TRY(ensure_streams(p));
   CAP_TRY(ensure_bulk_stream(p));
   hipStream_t s1 = p->s_panel;
@@ -467,6 +629,10 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   // workgroup - a first 135 KiB version needed a fully idle CU and lost 4 % under a concurrent bulk update.
   p->fastdiag = getenv("CAP_FASTDIAG") ? atoi(getenv("CAP_FASTDIAG")) : 1;
   p->serial_m = 0;
+  p->inner_la = getenv("CAP_INNER_LA") ? atoi(getenv("CAP_INNER_LA")) : 0;
+  // below ~16K remaining columns a step's chain (2 x 512 diagonal blocks, ~4 ms next to the bulk update) outlasts its bulk
+  // update (m^2 x 1024 flops): from there on the bulk runs one workgroup per CU (N = 32768: 59.3 -> 61.2 TF, 16384: 34.4 -> 37.1)
+  p->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
   p->depth2 = n >= 24576;     // look-ahead depth 2 pays once a bulk update is long enough to split (+2 % at N = 32768)
   int st = plan_alloc(p);
   if (st != CAP_OK) { cap_cholinv_plan_destroy(p); return st; }
@@ -490,6 +656,7 @@ int cap_cholinv_plan_destroy(cap_cholinv_plan* p) {
     (void)hipStreamDestroy(p->s_bulk); (void)hipStreamDestroy(p->s_chain);
     for (int i = 0; i < 2; i++) (void)hipEventDestroy(p->ev_chain[i]);
   }
+  release_split(p);
   if (p->prof_ev) { for (hipEvent_t e : *p->prof_ev) (void)hipEventDestroy(e); delete p->prof_ev; delete p->prof_flops; }
   delete p;
   return CAP_OK;
@@ -515,6 +682,7 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
     if (value < 64 || value % 64) return CAP_ERR_ARG;
     if (value == p->nb) return CAP_OK;
     // workspace depends on nb: reallocate
+    release_split(p);
     (void)hipFree(p->Rinv); (void)hipFree(p->work);
     p->Rinv = nullptr; p->work = nullptr;
     p->nb = value; p->ldi = value;
@@ -531,6 +699,8 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
   if (k == "serial_m") { if (value < 0) return CAP_ERR_ARG; p->serial_m = value; return CAP_OK; }
   if (k == "bulk_wgs") { if (value < 0 || value > 2048) return CAP_ERR_ARG; p->bulk_wgs = value; return CAP_OK; }
   if (k == "depth2") { p->depth2 = value != 0; return CAP_OK; }
+  if (k == "inner_la") { p->inner_la = value != 0; return CAP_OK; }
+  if (k == "occ1_m") { if (value < 0) return CAP_ERR_ARG; p->occ1_m = value; return CAP_OK; }
   if (k == "fastdiag") { p->fastdiag = value != 0; return CAP_OK; }
   if (k == "reserve") {   // CUs kept free for the panel chain (multiple of 8 keeps the XCDs balanced); 0 = off
     if (value < 0 || value > 64) return CAP_ERR_ARG;
@@ -571,6 +741,8 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
   if (k == "depth2") return p->depth2;
   if (k == "fastdiag") return p->fastdiag;
   if (k == "reserve") return p->reserve;
+  if (k == "inner_la") return p->inner_la;
+  if (k == "occ1_m") return p->occ1_m;
   if (k == "n") return p->n;
   if (k == "complete_inv") return p->complete_inv;
   if (k == "split") return p->split;

@@ -573,8 +573,10 @@ int launch_nn_dma(const GemmArgs& g, int grid, hipStream_t stream) {
 
 template <int TAG>
 int launch_tn_dma(GemmArgs g, int grid, hipStream_t stream, int persist_wgs = 0) {
-  (void)persist_wgs;
-  size_t lds = 4 * DMA_TILE * sizeof(double);
+  // persist_wgs == -1 (the only value still honoured): ask for 96 KiB of LDS so that only ONE workgroup of this launch fits a
+  // CU.  Used for the bulk updates of the chain-bound tail (cholinv.hip, option occ1_m): the bulk update has slack there,
+  // and a CU that runs one bulk workgroup always has room (LDS, VGPRs) for a workgroup of the diagonal-block chain.
+  size_t lds = (persist_wgs == -1 ? 6 : 4) * DMA_TILE * sizeof(double);
   static const int diag_env = getenv("CAP_DIAG") ? atoi(getenv("CAP_DIAG")) : 0;    // timing experiments only
   if (diag_env == 1 && TAG == 0) hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, false, 1, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
   else if (g.skip && g.usebuf) hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, false, 0, true, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);

@@ -79,7 +79,13 @@ def test_matches_oracle(n, ci, split, bc):
 @pytest.mark.parametrize("opts", [{"lookahead": 0}, {"lookahead": 1, "nb": 128}, {"nb": 256}, {"nb": 512, "leaf": 32}, {"leaf": 16},
                                   {"nb": 128, "outer": 512, "tail": 256}, {"nb": 128, "outer": 256, "depth2": 1},
                                   {"nb": 128, "outer": 256, "tail": 512, "depth2": 1, "bulk_wgs": 64}, {"nb": 256, "reserve": 8}, {"nb": 512, "fastdiag": 1}, {"nb": 256, "fastdiag": 1, "lookahead": 0},
-                                  {"nb": 128, "fastdiag": 1, "outer": 256}])
+                                  {"nb": 128, "fastdiag": 1, "outer": 256},
+                                  # column-split look-ahead (panel stream on the next chains' columns only, the rest on s_rest)
+                                  {"nb": 128, "outer": 256, "inner_la": 1}, {"nb": 128, "outer": 512, "tail": 512, "depth2": 1, "inner_la": 1},
+                                  {"nb": 256, "outer": 256, "inner_la": 1}, {"nb": 128, "outer": 1024, "inner_la": 1},
+                                  # one bulk workgroup per CU below / above the threshold
+                                  {"nb": 128, "outer": 256, "occ1_m": 0}, {"nb": 128, "outer": 256, "occ1_m": 1024},
+                                  {"nb": 128, "outer": 256, "occ1_m": 4096, "inner_la": 1}])
 def test_schedule_knobs_do_not_change_the_answer(opts):
     from capital_amd import cholinv
     n = 1536
