@@ -58,6 +58,7 @@ struct cap_dist_plan {
   // schedule knobs
   int strip;                     // block rows per strip (1 or 2)
   int depth2;                    // split the bulk update (look-ahead depth 2)
+  int64_t occ1_m;                // bulk updates with rows x local columns <= occ1_m^2 run one workgroup per CU (cholinv.hip, occ1_m)
   // stress testing: random spin kernels in front of every launch group (exposes missing event edges)
   uint64_t jitter_state; int jitter_max_us;
   // live profile of the bulk update (HIP events on its stream)
@@ -152,7 +153,10 @@ int update(cap_dist_plan* d, int64_t m, int64_t nloc, int64_t K, const double* G
     e0 = d->prof_ev[d->prof_used]; e1 = d->prof_ev[d->prof_used + 1];
     CAP_HIP(hipEventRecord(e0, s));
   }
-  CAP_TRY(cap_dist_update_launch(m, nloc, K, G, piece, gstart, B, C, d->ld, d->P, d->p, (int)d->nb, (int)J0, (int)lb0, s));
+  // chain-bound steps (my share of the update is short: on P ranks that is most of them): one bulk workgroup per CU, so the
+  // diagonal-block chain of the owner always finds a free slot and shares its SIMDs with one fp64-MFMA wave instead of two
+  const int occ = (prof && d->occ1_m > 0 && (double)m * (double)nloc <= (double)d->occ1_m * (double)d->occ1_m) ? -1 : 0;
+  CAP_TRY(cap_dist_update_launch(m, nloc, K, G, piece, gstart, B, C, d->ld, d->P, d->p, (int)d->nb, (int)J0, (int)lb0, s, occ));
   if (e0) {
     CAP_HIP(hipEventRecord(e1, s));
     d->prof_used += 2;
@@ -214,6 +218,7 @@ int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* 
   d->s_panel = d->s_comm = d->s_msg = nullptr;
   d->strip = d->nblk >= 8 ? 2 : 1; d->depth2 = 1;
   d->jitter_state = 0x9E3779B97F4A7C15ull * (uint64_t)(d->p + 1); d->jitter_max_us = 0;
+  d->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
   d->profile = 0; d->prof_used = 0;
   d->wcap = cap_rec_work_size(nb);
   if (cap_comm_size(comm) > 1 || cap_comm_backend(comm) != 0) {
@@ -266,6 +271,7 @@ int cap_dist_set_option(cap_dist_plan* d, const char* key, int64_t value) {
   std::string k(key);
   if (k == "strip") { if (value < 1 || value > 2) return CAP_ERR_ARG; d->strip = (int)value; return CAP_OK; }
   if (k == "depth2") { d->depth2 = value != 0; return CAP_OK; }
+  if (k == "occ1_m") { if (value < 0) return CAP_ERR_ARG; d->occ1_m = value; return CAP_OK; }
   if (k == "jitter_us") { if (value < 0 || value > 100000) return CAP_ERR_ARG; d->jitter_max_us = (int)value; return CAP_OK; }
   if (k == "jitter_seed") { d->jitter_state = 0x9E3779B97F4A7C15ull * (uint64_t)(value + 1) + (uint64_t)d->p; return CAP_OK; }
   if (k == "profile") { d->profile = value != 0; return CAP_OK; }
@@ -277,6 +283,7 @@ int64_t cap_dist_get_option(const cap_dist_plan* d, const char* key) {
   std::string k(key);
   if (k == "strip") return d->strip;
   if (k == "depth2") return d->depth2;
+  if (k == "occ1_m") return d->occ1_m;
   if (k == "jitter_us") return d->jitter_max_us;
   if (k == "nb") return d->nb;
   if (k == "n") return d->n;
