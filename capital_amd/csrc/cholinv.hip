@@ -121,7 +121,10 @@ int blocked_cholinv(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, 
   for (int64_t h = 64; h < n; h *= 2) {
     const int npairs = (int)(n / (2 * h));
     if (h * h * npairs > wcap) return CAP_ERR_ALLOC;
-    if (h <= 256) {
+    static const bool merge1 = getenv("CAP_TRINV_MERGE") ? atoi(getenv("CAP_TRINV_MERGE")) != 0 : true;
+    if (merge1 && h <= 256) {
+      CAP_TRY(cap_trinv_merge(R, ldr, Ri, ldi, h, npairs, s));     // both products of the level in one launch (leaf.hip)
+    } else if (h <= 256) {
       // W_z = R12_z * Ri22_z ;  Ri12_z = -Ri11_z * W_z   for every aligned pair z at once
       CAP_TRY(cap_gemm_small_batched(CAP_NOTRANS, CAP_NOTRANS, h, h, h, 1.0, R + h * ldr, ldr, 2 * h * (ldr + 1),
                                      Ri + h + h * ldi, ldi, 2 * h * (ldi + 1), 0.0, W, h, h * h, npairs, s));

@@ -60,6 +60,8 @@ int cap_panel64_solve_update(double* R, int64_t ldr, const double* Dinv, int64_t
                              hipStream_t stream, double* Dnext = nullptr, int64_t ldn = 0, int* info = nullptr, int info_base = 0,
                              const double* cj_src = nullptr, double* cj_dst = nullptr, int64_t cj_ld = 0, int cj_cols = 0,
                              int direct = 0);
+// leaf.hip: one level of the triangular-inverse assembly, Ri12 = -Ri11 (R12 Ri22) for npairs aligned pairs (h = 64 / 128 / 256)
+int cap_trinv_merge(const double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t h, int npairs, hipStream_t stream);
 // gemm.hip: batched 64x64-tile products (batch = blockIdx.z, affine strides)
 int cap_gemm_small_batched(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
                            int64_t sa, const double* B, int64_t ldb, int64_t sb, double beta, double* C, int64_t ldc, int64_t sc,

@@ -398,7 +398,86 @@ __global__ void __launch_bounds__(LTHREADS) panel64_solve_update_kernel(double* 
   if (t == 0 && bad != 0 && f.info) atomicCAS(f.info, 0, f.info_base + bad);
 }
 
+// ---------------------------------------------------------------------------------------------
+// One launch per level of the triangular-inverse assembly (blocked_cholinv, cholinv.hip): for every aligned pair z of
+// h x h diagonal blocks (h = 64 RBW)      Ri12_z = -Ri11_z (R12_z Ri22_z).
+// Workgroup (s, z) owns the 16 columns s of the pair's off-diagonal block: W = R12 Ri22[:, s] (h x 16) stays in LDS between
+// the two products, so a level is one dependent launch instead of two.  Operands come straight from L2 (they were written
+// by the previous launches of the chain); the triangular structure cuts both K ranges (Ri22 upper: k < 16 (s + 1) rows,
+// Ri11 upper: k >= 16 rb for row block rb).  Wave w owns the row blocks w, w + 4, ...; the k loop is outermost so the
+// B operand of a k step is loaded once for all of them and 8 k steps of loads are in flight.
+template <int RBW>
+__global__ void __launch_bounds__(LTHREADS) trinv_merge_kernel(const double* R, int64_t ldr, double* Ri, int64_t ldi) {
+  constexpr int H = 64 * RBW, LDW = H + 1;
+  extern __shared__ __attribute__((aligned(16))) double Wl[];     // W, column-major [16][LDW]
+  __builtin_amdgcn_s_setprio(3);
+  const int sidx = blockIdx.x;
+  const int64_t o = (int64_t)blockIdx.y * 2 * H;
+  const double* R12 = R + o + (o + H) * ldr;
+  const double* Ri22 = Ri + (o + H) + (o + H + 16 * sidx) * ldi;   // the strip's 16 columns
+  const double* Ri11 = Ri + o + o * ldi;
+  double* Out = Ri + o + (o + H + 16 * sidx) * ldi;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lr = lane & 15, kg = lane >> 4;
+  d4 acc[RBW];
+#pragma unroll
+  for (int q = 0; q < RBW; q++) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int kmax = 16 * (sidx + 1);
+  for (int kb = 0; kb < kmax; kb += 16) {          // 16 k values per trip: all loads first, then the MFMAs
+    double b[4], a[4][RBW];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      b[u] = Ri22[(kb + 4 * u + kg) + (int64_t)lr * ldi];
+#pragma unroll
+      for (int q = 0; q < RBW; q++) a[u][q] = R12[(16 * (wid + 4 * q) + lr) + (int64_t)(kb + 4 * u + kg) * ldr];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int q = 0; q < RBW; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][q], b[u], acc[q], 0, 0, 0);   // rows kg + 4r, column lr
+  }
+#pragma unroll
+  for (int q = 0; q < RBW; q++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) Wl[16 * (wid + 4 * q) + kg + 4 * r + lr * LDW] = acc[q][r];
+    acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
+  }
+  __syncthreads();
+  // row block rb only meets k >= 16 rb; all of a wave's row blocks start at the smallest of them (the extra k steps of the
+  // lower ones multiply stored zeros of Ri11's lower triangle)
+  for (int kb = 16 * wid; kb < H; kb += 16) {
+    double b[4], a[4][RBW];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      b[u] = Wl[kb + 4 * u + kg + lr * LDW];
+#pragma unroll
+      for (int q = 0; q < RBW; q++) a[u][q] = Ri11[(16 * (wid + 4 * q) + lr) + (int64_t)(kb + 4 * u + kg) * ldi];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int q = 0; q < RBW; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][q], b[u], acc[q], 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < RBW; q++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) Out[16 * (wid + 4 * q) + kg + 4 * r + (int64_t)lr * ldi] = -acc[q][r];
+}
+
 }  // namespace
+
+// Ri12 = -Ri11 (R12 Ri22) for npairs aligned pairs of h x h diagonal blocks (h = 64, 128 or 256), one launch
+int cap_trinv_merge(const double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t h, int npairs, hipStream_t stream) {
+  if (npairs <= 0) return CAP_OK;
+  const dim3 grid((unsigned)(h / 16), (unsigned)npairs);
+  const size_t lds_bytes = (size_t)16 * (h + 1) * sizeof(double);
+  if (h == 64) hipLaunchKernelGGL(trinv_merge_kernel<1>, grid, dim3(LTHREADS), lds_bytes, stream, R, ldr, Ri, ldi);
+  else if (h == 128) hipLaunchKernelGGL(trinv_merge_kernel<2>, grid, dim3(LTHREADS), lds_bytes, stream, R, ldr, Ri, ldi);
+  else if (h == 256) hipLaunchKernelGGL(trinv_merge_kernel<4>, grid, dim3(LTHREADS), lds_bytes, stream, R, ldr, Ri, ldi);
+  else return CAP_ERR_UNSUPPORTED;
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
 
 int cap_panel64_solve_update(double* R, int64_t ldr, const double* Dinv, int64_t ldi, int i, int nblk, double* Xs,
                              hipStream_t stream, double* Dnext, int64_t ldn, int* info, int info_base, const double* cj_src,
