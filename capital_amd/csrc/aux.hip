@@ -72,6 +72,23 @@ __global__ void copy_window_kernel(const double* src, int sp, int64_t sld, int64
   dst[addr(dp, dld, dr0 + r, dc0 + c)] = src[addr(sp, sld, sr0 + r, sc0 + c)];
 }
 
+// plain rectangle copy, 16 bytes per access: a workgroup moves 8 columns x 4096 rows (the block-row solve's 512 x m result goes back into
+// R with 1/16 of the workgroups of the element-per-thread form - it runs on the panel stream, next to the bulk update)
+__global__ void __launch_bounds__(256) copy_rect_v2_kernel(const double* src, int64_t sld, double* dst, int64_t dld, int64_t rows,
+                                                           int64_t cols) {
+  const int64_t c0 = (int64_t)blockIdx.x * 8;
+  const int64_t r2n = rows >> 1;
+  const int64_t rb = (int64_t)blockIdx.y * 2048, re = rb + 2048 < r2n ? rb + 2048 : r2n;   // 4096 rows per workgroup
+#pragma unroll
+  for (int cc = 0; cc < 8; cc++) {
+    const int64_t c = c0 + cc;
+    if (c >= cols) break;
+    const d2* sp = reinterpret_cast<const d2*>(src + c * sld);
+    d2* dp = reinterpret_cast<d2*>(dst + c * dld);
+    for (int64_t r2 = rb + threadIdx.x; r2 < re; r2 += 256) dp[r2] = sp[r2];
+  }
+}
+
 __global__ void zero_rect_kernel(double* dst, int64_t ld, int64_t rows, int64_t cols) {
   int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t c = blockIdx.y + (int64_t)blockIdx.z * 65535;
@@ -132,6 +149,13 @@ inline dim3 grid2d(int64_t rows, int64_t cols, int bx) {
 
 int cap_copy_rect(const double* src, int64_t sld, double* dst, int64_t dld, int64_t rows, int64_t cols, hipStream_t s) {
   if (rows <= 0 || cols <= 0) return CAP_OK;
+  if (!(rows & 1) && !(sld & 1) && !(dld & 1) && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15) && rows * cols >= (1 << 16) && rows <= 2048 &&
+      cols / 8 < 0x7fffffff) {      // (block rows of a panel; tall copies keep the element-per-thread form)
+    hipLaunchKernelGGL(copy_rect_v2_kernel, dim3((unsigned)cap_ceil_div(cols, 8), (unsigned)cap_ceil_div(rows, 4096)), dim3(256), 0, s,
+                       src, sld, dst, dld, rows, cols);
+    CAP_HIP(hipGetLastError());
+    return CAP_OK;
+  }
   hipLaunchKernelGGL(copy_window_kernel, grid2d(rows, cols, 256), dim3(256), 0, s, src, 0, sld, (int64_t)0, (int64_t)0, dst,
                      0, dld, (int64_t)0, (int64_t)0, rows, cols, 0, 0);
   CAP_HIP(hipGetLastError());
