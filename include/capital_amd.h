@@ -250,7 +250,11 @@ double* cap_cholinv_Rinv_ptr(cap_cholinv_plan* plan, int64_t* ld);
 /* host-readable status of the last factor: 0, or 1-based index of the failing pivot.
  * Synchronises the stream.                                                                 */
 int cap_cholinv_info(cap_cholinv_plan* plan, void* stream, int64_t* info);
-/* tuning knobs of the GPU schedule (panel width nb, leaf size, look-ahead on/off).         */
+/* tuning knobs of the GPU schedule: "nb" (panel width), "leaf", "lookahead", "outer" (strip height = K of
+ * the bulk updates), "tail" (columns left below which strips are nb wide), "depth2" (look-ahead depth 2),
+ * "occ1_m" (columns left below which bulk updates run one workgroup per CU so the diagonal-block chain
+ * always finds a slot; 0 = never), "inner_la" (column-split look-ahead, off), "reserve" (CU-masked chain
+ * stream, off), "serial_m", "fastdiag", "profile".  Multi-GPU plans forward to cap_dist_set_option.        */
 int cap_cholinv_set_option(cap_cholinv_plan* plan, const char* key, int64_t value);
 int64_t cap_cholinv_get_option(cap_cholinv_plan* plan, const char* key);
 /* Live measurement of the dominant kernel (trailing-update DSYRK) of the LAST factor call, enabled
@@ -279,7 +283,8 @@ int cap_dist_get_R(cap_dist_plan* plan, double* out, int64_t ld, void* stream); 
 /* 0, or the smallest failing pivot (1-based) reported by any rank.  Collective; call it on the stream
  * cap_dist_factor ran on.                                                                              */
 int cap_dist_info(cap_dist_plan* plan, void* stream, int64_t* info);
-/* knobs: "strip" (block rows per bulk update, 1|2), "depth2" (split bulk updates), "profile",
+/* knobs: "strip" (block rows per bulk update, 1|2), "depth2" (split bulk updates), "occ1_m" (bulk updates of at most
+ * occ1_m^2 rows x local columns run one workgroup per CU), "profile",
  * "jitter_us" / "jitter_seed" (stress testing: random spin kernels in front of every launch group).    */
 int cap_dist_set_option(cap_dist_plan* plan, const char* key, int64_t value);
 int64_t cap_dist_get_option(const cap_dist_plan* plan, const char* key);
