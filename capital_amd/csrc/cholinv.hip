@@ -171,7 +171,7 @@ struct cap_cholinv_plan {
   int64_t serial_m; // remaining rows below which the chain is no longer overlapped with the bulk update (see right_looking)
   int fastdiag;     // diagonal blocks by the 64-blocked fused path (default) instead of the recursion
   int depth2;       // split each bulk update into head (next-next strip's rows) + rest: look-ahead depth 2
-  int64_t bulk_wgs; // > 0: bulk updates run as a persistent grid of this many workgroups (512 slots on the chip)
+  int64_t bulk_wgs; // accepted, no effect: the persistent bulk grid it sized was removed; kept so option files still load
   // device state
   double* R; int64_t ldr;
   double* Rinv; int64_t ldi;      // n x n (complete_inv >= 0) or nb x nb diagonal-block inverse
@@ -327,7 +327,7 @@ int trailing_update(cap_cholinv_plan* p, int64_t M, int64_t N, int64_t k, const 
     CAP_HIP(hipEventRecord(e0, s));
   }
   // chain-bound tail (N columns left <= occ1_m): one bulk workgroup per CU instead of two, see launch_tn_dma
-  const int occ = (p->occ1_m > 0 && N <= p->occ1_m) ? -1 : (int)p->bulk_wgs;
+  const int occ = (p->occ1_m > 0 && N <= p->occ1_m) ? -1 : 0;
   CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, M, N, k, -1.0, A, ldr, B, ldr, 1.0, C, ldr, 1, s, 1, occ));
   if (e0) {
     CAP_HIP(hipEventRecord(e1, s));
