@@ -43,7 +43,7 @@ RES_TOL = 1e-14               # ||A - R^T R||_F / ||A||_F (BASELINE.md section 4
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 3 factorizations; 20 for the 10 ms CholeskyQR2 step)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cholesky", choices=["cholesky", "cacqr", "mixed"])
     ap.add_argument("--n", "--size", dest="n", type=int, default=65536,
@@ -67,7 +67,10 @@ def parse():
     ap.add_argument("--no-check", action="store_true", help="skip the residual checks (profiling runs)")
     ap.add_argument("--cpu-n", type=int, default=16384, help="bounded CPU-baseline sample size")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the residual is always computed)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps <= 0:
+        args.steps = 20 if args.workload == "cacqr" else 3      # a CholeskyQR2 step is 10 ms: average over more of them
+    return args
 
 
 def cpu_baseline(cpu_n):
