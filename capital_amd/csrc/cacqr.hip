@@ -45,6 +45,7 @@ struct cap_cacqr_plan {
   double* G; double* Gi; double* R1; double* R; double* W; int64_t wcap;
   int* info_dev;
   double* gram_work;      // n == 256: one partial-Gram slab per workgroup of gram256
+  bool gi_clean;          // Gi's never-written blocks are known to be zero (see sweep)
   // grid path: m, n above are the GLOBAL column count / local row count of the dense n x n work; nl = n / c local columns
   cap_topo* topo; int c, d, x, y, z; int64_t nl;
   double* Qz; double* Gblk; double* Gall; double* Rip; double* Rpiece;
@@ -57,14 +58,19 @@ int sweep(cap_cacqr_plan* p, const double* Qin, int64_t ldin, double* Qout, hipS
   const int64_t m = p->m, n = p->n;
   // Gram: upper triangle of Q^T Q (cacqr.hpp:15), full square zero-initialised so the all-reduce moves
   // a dense n x n block like NoSerialize::compute_gram (policy.h:22)
-  CAP_TRY(cap_zero_rect(p->G, n, n, n, s));
   static const bool k256_env = getenv("CAP_CQR256") ? atoi(getenv("CAP_CQR256")) != 0 : true;
   const bool k256 = k256_env && p->gram_work && n == 256 && m % 128 == 0 && !(ldin & 1) && 128 * ldin * 8 < 0xfffffff0LL && !((uintptr_t)Qin & 15);
-  if (k256) CAP_TRY(cap_gram256_launch(Qin, ldin, m, p->G, n, p->gram_work, s));
-  else CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n, n, m, 1.0, Qin, ldin, Qin, ldin, 0.0, p->G, n, 1, s));
+  if (k256) {
+    CAP_TRY(cap_gram256_launch(Qin, ldin, m, p->G, n, p->gram_work, s));     // its slab sum also zero-fills below the diagonal
+  } else {
+    CAP_TRY(cap_zero_rect(p->G, n, n, n, s));
+    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n, n, m, 1.0, Qin, ldin, Qin, ldin, 0.0, p->G, n, 1, s));
+  }
   CAP_TRY(cap_comm_allreduce_sum(p->comm, p->G, n * n, (void*)s));
-  // R = chol(G) in place (upper), Gi = R^-1
-  CAP_TRY(cap_zero_rect(p->Gi, n, n, n, s));
+  // R = chol(G) in place (upper), Gi = R^-1.  The 64-blocked path (n = 256) rewrites every entry of Gi it ever wrote (diagonal
+  // blocks with their zero lower parts, the off-diagonal blocks above them) and never touches the blocks below: one zero-fill
+  // per plan is enough there
+  if (!(k256 && p->gi_clean)) { CAP_TRY(cap_zero_rect(p->Gi, n, n, n, s)); p->gi_clean = k256; }
   CAP_TRY(cap_rec_cholinv_full(p->G, n, p->Gi, n, n, p->W, p->wcap, p->info_dev, s));
   // Q <- Q * R^-1 (cacqr.hpp:24-25)
   // tag 8: R^-1 is upper triangular -> a column tile only contracts the rows above its diagonal block

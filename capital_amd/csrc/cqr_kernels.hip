@@ -113,7 +113,8 @@ __global__ void __launch_bounds__(1024) gram256_reduce_kernel(const double* P, i
   }
   part[grp][row] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (grp == 0 && row <= col) G[row + (int64_t)col * ldg] = (part[0][row] + part[1][row]) + (part[2][row] + part[3][row]);
+  // the strictly-lower part is written too (zeros): the callers move / multiply G as a dense square
+  if (grp == 0) G[row + (int64_t)col * ldg] = row <= col ? (part[0][row] + part[1][row]) + (part[2][row] + part[3][row]) : 0.0;
 }
 
 // ================================================================================================ qrapply256
