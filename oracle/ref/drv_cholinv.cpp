@@ -8,7 +8,10 @@
 //   policy 0 Serialize+NoReplication (bench default; NaN for d>1)
 //          1 Serialize+ReplicateCommComp   2 Serialize+ReplicateComp
 //          3 NoSerialize+NoReplication
-// dumpfile (1 rank only, "-" = none): A, R, Rinv as col-major N*N doubles each.
+// dumpfile ("-" = none): 1 rank: A, R, Rinv as col-major N*N doubles each.  More ranks: every rank writes
+//   <dumpfile>.<rank> = 8 int64 (rank, x, y, z, d, c, local rows, local columns) followed by its local pieces of
+//   A, R, Rinv (col-major, local rows x local columns; element-cyclic: piece (x, y) holds global rows y, y+d, ...
+//   and columns x, x+d, ..., matrix.hpp:8-11) - tests/golden/make_golden.py reassembles the global matrices.
 // stdout (rank 0): one line `ranks=.. c=.. d=.. n=.. ci=.. split=.. bc=.. pol=.. time=<median s> residual=..`
 #include "ref/src/alg/cholesky/cholinv/cholinv.h"
 #include "ref/test/cholesky/validate.h"
@@ -52,6 +55,16 @@ int main(int argc, char** argv) {
         auto R = CT::construct_R(pack, topo); auto Ri = CT::construct_Rinv(pack, topo);
         FILE* f = fopen(dump, "wb");
         fwrite(A.data(), 8, n * n, f); fwrite(R.data(), 8, n * n, f); fwrite(Ri.data(), 8, n * n, f);
+        fclose(f);
+      } else if (dump) {
+        auto R = CT::construct_R(pack, topo); auto Ri = CT::construct_Rinv(pack, topo);
+        char name[4096]; snprintf(name, sizeof(name), "%s.%d", dump, rank);
+        FILE* f = fopen(name, "wb");
+        int64_t hdr[8] = {rank, (int64_t)topo.x, (int64_t)topo.y, (int64_t)topo.z, (int64_t)topo.d, (int64_t)topo.c,
+                          (int64_t)A.num_rows_local(), (int64_t)A.num_columns_local()};
+        fwrite(hdr, 8, 8, f);
+        const size_t nl = (size_t)A.num_rows_local() * (size_t)A.num_columns_local();
+        fwrite(A.data(), 8, nl, f); fwrite(R.data(), 8, nl, f); fwrite(Ri.data(), 8, nl, f);
         fclose(f);
       }
     };

@@ -41,8 +41,39 @@ def cholinv_case(name, n, ci, split, bc, pol=0):
     print(name, out.strip())
 
 
+def cholinv_multirank_dump_case(name, n, ci, split, bc, pol=1, ranks=8):
+    """8-rank (2 x 2 x 2 grid) run of the real reference; every rank dumps its element-cyclic pieces (oracle/ref/drv_cholinv.cpp),
+    the layer z = 0 is reassembled into the global A, R, Rinv (the other layer is checked to hold the same pieces)."""
+    with tempfile.TemporaryDirectory() as td:
+        dump = os.path.join(td, "d.bin")
+        out = subprocess.check_output([MPIEXEC, "-n", str(ranks), os.path.join(REFDIR, "cholinv_ref"), str(n), str(ci),
+                                       str(split), str(bc), "0", "0", str(pol), dump, "1"], env=ENV).decode()
+        kv = _kv(out)
+        mats = [np.zeros((n, n)) for _ in range(3)]
+        layers = {}
+        for r in range(ranks):
+            raw = open("%s.%d" % (dump, r), "rb").read()
+            rank, x, y, z, d, c, rl, cl = (int(v) for v in np.frombuffer(raw[:64], dtype=np.int64))
+            body = np.frombuffer(raw[64:], dtype=np.float64).reshape(3, cl, rl)      # column-major local pieces
+            pieces = [body[k].T for k in range(3)]
+            layers.setdefault((x, y), []).append(pieces)
+            if z == 0:
+                nr, nc = len(range(y, n, d)), len(range(x, n, d))                     # ragged N: the padded tail is dropped
+                for k in range(3):
+                    mats[k][y::d, x::d] = pieces[k][:nr, :nc]
+        for (x, y), ps in layers.items():                                             # replicated layers agree (A, R exactly)
+            for other in ps[1:]:
+                assert np.array_equal(ps[0][0], other[0])
+                assert np.allclose(ps[0][1], other[1], rtol=0, atol=1e-13)
+    a, r, ri = mats
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), A=a, R=r, Rinv=ri, n=n, complete_inv=ci, split=split,
+                        bc_mult_dim=bc, policy=pol, ranks=ranks, c=c, d=d, ref_residual=float(kv["residual"]),
+                        ref_stdout=out.strip())
+    print(name, out.strip())
+
+
 def cholinv_multirank_case(name, cases):
-    """8-rank (2x2x2) runs: only the validator's residual can be recorded (no dump upstream)."""
+    """8-rank (2x2x2) runs, residual only (the dumps of the runs above pin R and Rinv themselves)."""
     rows = []
     for (n, ci, split, bc, pol) in cases:
         out = subprocess.check_output([MPIEXEC, "-n", "8", os.path.join(REFDIR, "cholinv_ref"), str(n), str(ci),
@@ -77,5 +108,9 @@ if __name__ == "__main__":
     cholinv_case("cholinv_n100_ci0_s2_bc-4", 100, 0, 2, -4)
     cholinv_multirank_case("cholinv_p8_residuals", [(256, 0, 1, -2, 1), (250, 1, 1, -2, 1), (512, 0, 1, -3, 2),
                                                     (257, 0, 1, -2, 3)])
+    # the real reference on its own 2 x 2 x 2 grid, R / Rinv gathered from the ranks' element-cyclic pieces
+    cholinv_multirank_dump_case("cholinv_p8_n128_ci1_s1_bc-2", 128, 1, 1, -2, 1)
+    cholinv_multirank_dump_case("cholinv_p8_n192_ci0_s1_bc-3", 192, 0, 1, -3, 1)
+    cholinv_multirank_dump_case("cholinv_p8_n250_ci1_s1_bc-2", 250, 1, 1, -2, 2)
     cacqr_case("cacqr1_m192_n12", 1, 192, 12)
     cacqr_case("cacqr2_m256_n16", 2, 256, 16)

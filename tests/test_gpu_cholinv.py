@@ -52,6 +52,30 @@ def test_matches_reference_dump(golden_dir, name):
     assert relerr(cholinv.construct_R(pack2).to_numpy(), np.triu(g["R"])) < 1e-14
 
 
+GOLD8 = sorted(os.path.basename(p) for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "cholinv_p8_n*.npz")))
+
+
+@pytest.mark.parametrize("name", GOLD8)
+def test_matches_8rank_reference_dump(golden_dir, name):
+    """R and R^-1 of the REAL reference run on 8 MPI ranks (2 x 2 x 2 grid; gathered from the ranks' cyclic pieces): the GPU
+    plan with the same knobs gives the same factors (the factor does not depend on the process grid; for complete_inv = 0 the
+    reference's empty Rinv block is cut at (local n >> split) * d, which equals n >> split for these even sizes)."""
+    from capital_amd import cholinv
+    g = np.load(os.path.join(golden_dir, name))
+    n, ci, split, bc = int(g["n"]), int(g["complete_inv"]), int(g["split"]), int(g["bc_mult_dim"])
+    A, pack = _factor(n, ci, split, bc)
+    assert np.array_equal(A.to_numpy(), g["A"])
+    R = cholinv.construct_R(pack).to_numpy(); Ri = cholinv.construct_Rinv(pack).to_numpy()
+    assert pack.last_info() == 0
+    assert relerr(R, np.triu(g["R"])) < 1e-14
+    assert relerr(Ri, np.triu(g["Rinv"])) < 1e-13
+    assert np.array_equal(Ri != 0, np.triu(g["Rinv"]) != 0)
+    res = orc.cholesky_residual(g["A"], R)
+    assert res < RES_TOL and res < 10 * float(g["ref_residual"])
+    _, pack2 = _factor(n, -1, split, bc)
+    assert relerr(cholinv.construct_R(pack2).to_numpy(), np.triu(g["R"])) < 1e-14
+
+
 @pytest.mark.parametrize("n,ci,split,bc", [(512, 1, 1, -2), (1000, 0, 1, -3), (1000, 1, 2, -3), (777, -1, 1, -2),
                                            (2048, 0, 1, -2), (2048, -1, 1, -3), (1, 1, 1, 0), (3, 0, 1, 0), (130, 1, 1, -1)])
 def test_matches_oracle(n, ci, split, bc):
