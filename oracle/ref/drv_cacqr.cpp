@@ -5,7 +5,10 @@
 //
 // argv: variant(1|2) M N c complete_inv split bcMult [dumpfile] [num_iter]
 //   c = depth of the c x d x c grid (1 => the 1D path, cacqr.hpp:229).
-// dumpfile (1 rank only, "-" = none): A (M*N), Q (M*N), R (N*N) col-major doubles.
+// dumpfile ("-" = none): 1 rank: A (M*N), Q (M*N), R (N*N) col-major doubles.  More ranks: every rank writes <dumpfile>.<rank> =
+//   10 int64 (rank, x, y, z, d, c, local rows / columns of A, local rows / columns of R) followed by its local pieces of A, Q
+//   (element-cyclic: rows y, y+d, ..., columns x, x+c, ...) and of R (what construct_R returns) - tests/golden/make_golden.py
+//   reassembles the global matrices.
 #include "ref/src/alg/qr/cacqr/cacqr.h"
 #include "ref/test/qr/validate.h"
 #include <algorithm>
@@ -48,6 +51,18 @@ int main(int argc, char** argv) {
       auto Q = QT::construct_Q(pack, topo); auto R = QT::construct_R(pack, topo);
       FILE* f = fopen(dump, "wb");
       fwrite(A.data(), 8, m * n, f); fwrite(Q.data(), 8, m * n, f); fwrite(R.data(), 8, n * n, f);
+      fclose(f);
+    } else if (dump) {
+      auto Q = QT::construct_Q(pack, topo); auto R = QT::construct_R(pack, topo);
+      char name[4096]; snprintf(name, sizeof(name), "%s.%d", dump, rank);
+      FILE* f = fopen(name, "wb");
+      int64_t hdr[10] = {rank, (int64_t)topo.x, (int64_t)topo.y, (int64_t)topo.z, (int64_t)topo.d, (int64_t)topo.c,
+                         (int64_t)A.num_rows_local(), (int64_t)A.num_columns_local(), (int64_t)R.num_rows_local(),
+                         (int64_t)R.num_columns_local()};
+      fwrite(hdr, 8, 10, f);
+      const size_t nl = (size_t)A.num_rows_local() * (size_t)A.num_columns_local();
+      fwrite(A.data(), 8, nl, f); fwrite(Q.data(), 8, nl, f);
+      fwrite(R.data(), 8, (size_t)R.num_rows_local() * (size_t)R.num_columns_local(), f);
       fclose(f);
     }
     double g1, g2; MPI_Reduce(&res, &g1, 1, MPI_DOUBLE, MPI_MAX, 0, MPI_COMM_WORLD);

@@ -101,6 +101,39 @@ def cacqr_case(name, variant, m, n):
     print(name, out.strip())
 
 
+def cacqr_multirank_dump_case(name, variant, m, n, c, ranks=8):
+    """The real reference's CholeskyQR on `ranks` MPI ranks: c = 1 -> the 1D path on a 1 x ranks x 1 grid (cacqr.hpp:229),
+    c = 2 -> sweep_3d on the 2 x 2 x 2 grid (cacqr.hpp:75-120).  Every rank dumps its element-cyclic pieces of A and Q and
+    what construct_R returns (oracle/ref/drv_cacqr.cpp); layer z = 0 is reassembled here."""
+    with tempfile.TemporaryDirectory() as td:
+        dump = os.path.join(td, "q.bin")
+        out = subprocess.check_output([MPIEXEC, "-n", str(ranks), os.path.join(REFDIR, "cacqr_ref"), str(variant), str(m),
+                                       str(n), str(c), "1", "1", "0", dump, "1"], env=ENV).decode()
+        kv = _kv(out)
+        a = np.zeros((m, n)); q = np.zeros((m, n)); r = np.zeros((n, n))
+        keys = []
+        for rk in range(ranks):
+            raw = open("%s.%d" % (dump, rk), "rb").read()
+            rank, x, y, z, d, cc, rl, cl, rr, rc = (int(v) for v in np.frombuffer(raw[:80], dtype=np.int64))
+            b = np.frombuffer(raw[80:], dtype=np.float64)
+            al = b[:rl * cl].reshape(cl, rl).T; ql = b[rl * cl:2 * rl * cl].reshape(cl, rl).T
+            rloc = b[2 * rl * cl:].reshape(rc, rr).T
+            keys.append((rank, x, y, z, rank // cc))
+            if z != 0:
+                continue
+            nr, nc = len(range(y, m, d)), len(range(x, n, cc))
+            a[y::d, x::cc] = al[:nr, :nc]; q[y::d, x::cc] = ql[:nr, :nc]
+            if cc == 1:
+                if rank == 0:
+                    r[:, :] = rloc                               # replicated n x n factor
+            else:
+                r[(y % cc)::cc, x::cc] = rloc                    # the c x c cyclic piece (rows y mod c, columns x)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), A=a, Q=q, R=r, m=m, n=n, variant=variant, ranks=ranks, c=cc, d=d,
+                        rank_coords=np.array(keys, dtype=np.int64), ref_residual=float(kv["residual"]),
+                        ref_orthogonality=float(kv["orthogonality"]), ref_stdout=out.strip())
+    print(name, out.strip())
+
+
 if __name__ == "__main__":
     cholinv_case("cholinv_n64_ci0_s1_bc-2", 64, 0, 1, -2)
     cholinv_case("cholinv_n64_ci1_s1_bc-3", 64, 1, 1, -3)
@@ -114,3 +147,6 @@ if __name__ == "__main__":
     cholinv_multirank_dump_case("cholinv_p8_n250_ci1_s1_bc-2", 250, 1, 1, -2, 2)
     cacqr_case("cacqr1_m192_n12", 1, 192, 12)
     cacqr_case("cacqr2_m256_n16", 2, 256, 16)
+    cacqr_multirank_dump_case("cacqr2_p8_c1_m256_n16", 2, 256, 16, 1)     # 1D grid, 8 ranks
+    cacqr_multirank_dump_case("cacqr2_p8_c2_m256_n16", 2, 256, 16, 2)     # 3D: 2 x 2 x 2
+    cacqr_multirank_dump_case("cacqr1_p8_c2_m200_n12", 1, 200, 12, 2)     # 3D, one sweep, M not a multiple of d * anything special
