@@ -224,9 +224,13 @@ def test_summa_gemm_on_process_grids(nproc, c, M, N, K, chunks):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproc,c,m,n", [(8, 2, 4096, 64), (4, 1, 3000, 48), (16, 2, 6000, 96), (8, 2, 1001, 32)])
+@pytest.mark.parametrize("nproc,c,m,n", [(8, 2, 4096, 64), (4, 1, 3000, 48), (16, 2, 6000, 96), (8, 2, 1001, 32), (8, 2, 256, 16),
+                                         (8, 1, 256, 16)])
 def test_cacqr_3d_and_tunable_grid(nproc, c, m, n):
-    """CholeskyQR2 on c x d x c grids: 2 x 2 x 2 (sweep_3d), 1 x 4 x 1 (degenerates to 1D), 2 x 4 x 2 (sweep_tune), ragged rows."""
-    r = _launch(nproc, "cacqr3d", m, n, 29721 + nproc + c, ("--c", c))
+    """CholeskyQR2 on c x d x c grids: 2 x 2 x 2 (sweep_3d), 1 x 4 x 1 (degenerates to 1D), 2 x 4 x 2 (sweep_tune), ragged rows;
+    256 x 16 on 2 x 2 x 2 and 1 x 8 x 1 are also compared with the real reference's 8-rank dumps (tests/golden/cacqr2_p8_*)."""
+    r = _launch(nproc, "cacqr3d", m, n, 29721 + nproc + c + (m == 256), ("--c", c))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "CACQR3D-OK" in r.stdout, r.stdout[-2000:]
+    if m == 256:
+        assert "golden=ok" in r.stdout, r.stdout[-2000:]
