@@ -85,8 +85,9 @@ int rec_cholinv(const RecCtx& c, int64_t off, int64_t n, bool is_root, int64_t i
 int64_t rec_work_size(int64_t n) { return cap_round_up(std::max<int64_t>((n / 2 + 1) * (n / 2 + 1), 128 * n), 2); }
 
 // Diagonal-block fast path (n = 64 * nblk <= 1024): 64-blocked right-looking potrf with ONE fused launch per step
-// (cap_panel64_solve_update) + the inverse assembled level by level with batched products - 3 nblk - 1 + 2 log2(nblk)
-// dependent launches instead of the recursion's ~5.4 nblk (21 instead of 43 at n = 512).  Same arithmetic,
+// (cap_panel64_solve_update; its diagonal workgroup also runs the next leaf) + the inverse assembled level by level, one fused
+// launch per level (cap_trinv_merge): nblk + log2(nblk) dependent launches instead of the recursion's ~5.4 nblk (11 instead of
+// 43 at n = 512; 21 before the leaf was folded in and the two products of a level were fused).  Same arithmetic,
 // different association order.  Ri's strictly-lower blocks must be zero on entry (they are never written).
 int blocked_cholinv(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, double* W, int64_t wcap, int* info,
                     int64_t info_base, hipStream_t s) {
@@ -627,7 +628,7 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   // two-level blocking defaults (tools/sweep.sh on MI355X): K = 2 nb bulk updates while the trailing matrix is
   // large, nb-wide strips for the last n/8 columns where the strip chain could no longer hide
   p->outer = n >= 8192 ? 2 * p->nb : p->nb; p->tail = n >= 8192 ? n / 8 : 0; p->reserve = 0;
-  // fused 64-blocked diagonal-block path (28 dependent launches per 512 panel instead of 43; N = 8192 alone:
+  // fused 64-blocked diagonal-block path (11 dependent launches per 512 panel instead of 43; N = 8192 alone, first version:
   // 20.8 -> 15.5 ms).  Its workgroups use 84 KiB of LDS so that they fit into ONE slot vacated by a bulk
   // workgroup - a first 135 KiB version needed a fully idle CU and lost 4 % under a concurrent bulk update.
   p->fastdiag = getenv("CAP_FASTDIAG") ? atoi(getenv("CAP_FASTDIAG")) : 1;
