@@ -48,6 +48,49 @@ def test_status_strings_and_pure_helpers(built):
     assert L.cap_bc_owner(11, 8) == 3 and L.cap_bc_local_block(11, 8) == 1
 
 
+def test_block_cyclic_and_grid_maps_property(built):
+    """Pure index maps of the C ABI against the reference's definitions, on random shapes (hypothesis): the 1 x P
+    block-column-cyclic layout (every block column has one owner and a dense local slot, local column counts add up, ragged
+    last block included) and the rank -> (x, y, z) maps of topo::square / topo::rect (topology.h:44-50,75-83) - bijective,
+    and equal to the Python mirror the tests use."""
+    import ctypes as C
+    from hypothesis import given, settings, strategies as st
+    from capital_amd import _lib, topo
+    L = _lib.lib()
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(1, 70000), st.sampled_from([64, 128, 256, 512, 1024]), st.integers(1, 16))
+    def bc(n, nb, P):
+        nblk = (n + nb - 1) // nb
+        slots = set()
+        for J in range(nblk):
+            o, lb = L.cap_bc_owner(J, P), L.cap_bc_local_block(J, P)
+            assert o == J % P and lb == J // P
+            slots.add((o, lb))
+        assert len(slots) == nblk
+        cols = [L.cap_bc_num_local_cols(n, nb, P, p) for p in range(P)]
+        assert sum(cols) == n and all(c >= 0 for c in cols)
+        for p in range(P):                     # blocks J = p, p + P, ...; the last global block may be ragged
+            exp = sum(min(nb, n - J * nb) for J in range(p, nblk, P))
+            assert cols[p] == exp
+
+    @settings(max_examples=100, deadline=None)
+    @given(st.integers(1, 4), st.integers(1, 6), st.booleans())
+    def grid(c, d, square):
+        size = c * d * d if square else c * c * d
+        seen = set()
+        for rank in range(size):
+            dd, x, y, z = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            assert L.cap_topo_coords(0 if square else 1, rank, size, c, C.byref(dd), C.byref(x), C.byref(y), C.byref(z)) == 0
+            ref = (topo.square_coords if square else topo.rect_coords)(rank, size, c)
+            assert (dd.value, x.value, y.value, z.value) == (ref["d"], ref["x"], ref["y"], ref["z"])
+            assert 0 <= z.value < c and 0 <= y.value < d and 0 <= x.value < (d if square else c)
+            seen.add((x.value, y.value, z.value))
+        assert len(seen) == size
+
+    bc(); grid()
+
+
 def test_hot_kernels_use_no_scratch(built):
     """The compiler's own resource remarks, saved by the build: hot kernels must keep their accumulators in registers."""
     from capital_amd import build as b
