@@ -52,7 +52,6 @@ def parse():
     ap.add_argument("--outer", type=int, default=0, help="outer strip height NB override (0 = library default)")
     ap.add_argument("--tail", type=int, default=-1, help="trailing size below which strips are nb wide (-1 = default)")
     ap.add_argument("--depth2", type=int, default=-1, help="look-ahead depth 2 (split bulk updates): 1/0, -1 = library default")
-    ap.add_argument("--bulk-wgs", type=int, default=-1, help="(no effect since the persistent bulk grid was removed; accepted for old command lines)")
     ap.add_argument("--reserve", type=int, default=-1, help="CUs reserved for the panel chain (-1 = library default)")
     ap.add_argument("--occ1-m", type=int, default=-1, help="columns left below which bulk updates run one workgroup per CU (-1 = library default 16384, 0 = never)")
     ap.add_argument("--inner-la", type=int, default=-1, help="column-split look-ahead 1/0 (-1 = library default: off)")
@@ -240,7 +239,7 @@ def bench_cholesky(args, torch, L, C, rank, world, dist, emulate, timed, allredu
             for key, v in (("nb", args.nb), ("outer", args.outer)):
                 if v:
                     pack.set_option(key, v)
-            for key, v in (("tail", args.tail), ("reserve", args.reserve), ("depth2", args.depth2), ("bulk_wgs", args.bulk_wgs), ("serial_m", args.serial_m),
+            for key, v in (("tail", args.tail), ("reserve", args.reserve), ("depth2", args.depth2), ("serial_m", args.serial_m),
                            ("occ1_m", args.occ1_m), ("inner_la", args.inner_la)):
                 if v >= 0:
                     pack.set_option(key, v)

@@ -1,7 +1,37 @@
 // HBM-bound helper kernels: generators, window copies (serialize), triangle masks, norms.
 // Replaces src/matrix/structure.hpp:68-129 (generators), src/matrix/serialize.hpp:12-150,
 // src/util/util.hpp:25-53,266-318.  All coalesced along the column-major fast axis.
+#include <dlfcn.h>
+
+#include <mutex>
+
 #include "common.h"
+
+// ---- roctx ranges, resolved at first use (rocprofiler-sdk's roctx first: that is what rocprofv3 --marker-trace reads)
+namespace {
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)();
+roctx_push_fn g_roctx_push = nullptr;
+roctx_pop_fn g_roctx_pop = nullptr;
+std::once_flag g_roctx_once;
+void roctx_resolve() {
+  for (const char* lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+    void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) continue;
+    g_roctx_push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+    g_roctx_pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+    if (g_roctx_push && g_roctx_pop) return;
+    g_roctx_push = nullptr; g_roctx_pop = nullptr;
+  }
+}
+}  // namespace
+void cap_range_push(const char* name) {
+  std::call_once(g_roctx_once, roctx_resolve);
+  if (g_roctx_push) (void)g_roctx_push(name);
+}
+void cap_range_pop() {
+  if (g_roctx_pop) (void)g_roctx_pop();
+}
 
 namespace {
 

@@ -124,6 +124,9 @@ int cap_cacqr_plan_create_grid(cap_cacqr_plan** plan, int64_t m_global, int64_t 
   if (cap_topo_get(topo, 9) != 1) return CAP_ERR_ARG;                  // topo::rect
   const int c = cap_topo_get(topo, 2), d = cap_topo_get(topo, 3);
   if (n_global % c) return CAP_ERR_UNSUPPORTED;
+  // the Gram block is summed by all-reduce(column_contig) then all-reduce(column_alt): that covers all d process rows
+  // only when the column splits into whole groups of c (the same reduce + all-reduce pair as cacqr.hpp:147-148 over topology.h:38-39's splits)
+  if (d % c) return CAP_ERR_UNSUPPORTED;
   cap_cacqr_plan* p = new (std::nothrow) cap_cacqr_plan();
   if (!p) return CAP_ERR_ALLOC;
   memset(p, 0, sizeof(*p));

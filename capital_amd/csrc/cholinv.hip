@@ -39,6 +39,7 @@ struct RecCtx {
   int64_t split;             // root split shift (cholinv.hpp:107)
   int complete_inv;
   hipStream_t s;
+  int ctag = 0;              // CAP_TAG_NO_ATOMIC when R is unverified caller memory (cap_dpotrf)
 };
 
 int64_t pick_split(int64_t n, int64_t leaf) {
@@ -72,7 +73,7 @@ int rec_cholinv(const RecCtx& c, int64_t off, int64_t n, bool is_root, int64_t i
   CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n1, n2, n1, 1.0, Ri, c.ldi, R12, c.ldr, 0.0, c.W, n1, 0, c.s, 2 | 16));
   CAP_TRY(cap_copy_rect(c.W, n1, R12, c.ldr, n1, n2, c.s));
   // A22 -= R12^T R12 on upper tiles
-  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n2, n2, n1, -1.0, R12, c.ldr, R12, c.ldr, 1.0, R22, c.ldr, 1, c.s, 2));
+  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n2, n2, n1, -1.0, R12, c.ldr, R12, c.ldr, 1.0, R22, c.ldr, 1, c.s, 2 | c.ctag));
   CAP_TRY(rec_cholinv(c, off + n1, n2, false, info_base));
   if (!(is_root && c.complete_inv == 0)) {
     // Ri12 = -Ri11 * (R12 * Ri22)
@@ -157,6 +158,61 @@ int rec_trtri(double* R, int64_t ldr, int64_t n, double* W, int64_t wcap, int64_
   return CAP_OK;
 }
 
+// ---- R^-1 of the blocked factorization (complete_inv = 0 / 1 on matrices of several panels) -------------------------------
+// The panel chain of the right-looking sweep already inverts every nb x nb diagonal block; the rest of R^-1 is assembled
+// by a binary tree over the panels: node (a, mid, b) fills  Ri[a:mid, mid:b] = -Ri[a:mid, a:mid] R[a:mid, mid:b] Ri[mid:b, mid:b]
+// (the reference's inverse completion, cholinv.hpp:144-159, at every level instead of only along the recursion).  Each node is
+// split so that as little as possible is left for the end of the factorization:
+//   phase 1   W = -Ri11 R12     ready once panel mid/nb - 1 is factored and solved (Ri11 and the rows of R12 are final)
+//   phase 2   Ri12 = W Ri22     ready once the diagonal block of panel b/nb - 1 is inverted
+// One node per tree depth is pending at a time, so W lives in one scratch slot per depth.
+struct InvNode { int64_t a, mid, b; int depth; int64_t woff; };
+struct InvTree {
+  std::vector<InvNode> nodes;                 // post-order: children before parents, non-decreasing b
+  std::vector<std::vector<int>> ph1, ph2;     // per panel k: nodes whose phase 1 / phase 2 becomes ready after panel k
+  int64_t scratch = 0;                        // doubles
+};
+
+void inv_tree_rec(InvTree& t, const std::vector<int64_t>& pb, int ia, int ib, int root_mid, int depth) {
+  if (ib - ia < 2) return;
+  int im = root_mid > ia && root_mid < ib ? root_mid : ia + (ib - ia + 1) / 2;
+  inv_tree_rec(t, pb, ia, im, -1, depth + 1);
+  inv_tree_rec(t, pb, im, ib, -1, depth + 1);
+  t.nodes.push_back(InvNode{pb[(size_t)ia], pb[(size_t)im], pb[(size_t)ib], depth, 0});
+  t.ph1[(size_t)im - 1].push_back((int)t.nodes.size() - 1);
+  t.ph2[(size_t)ib - 1].push_back((int)t.nodes.size() - 1);
+}
+
+// pb: panel boundaries (0 = pb[0] < ... < pb[np] = n); root_mid: forced panel index of the root split (or -1);
+// skip_root: the root node is left out (complete_inv == 0 with the root partition on a panel boundary)
+InvTree inv_tree_build(const std::vector<int64_t>& pb, int root_mid, bool skip_root) {
+  InvTree t;
+  const int np = (int)pb.size() - 1;
+  t.ph1.assign((size_t)std::max(np, 1), {}); t.ph2.assign((size_t)std::max(np, 1), {});
+  inv_tree_rec(t, pb, 0, np, root_mid, 0);
+  if (skip_root && !t.nodes.empty()) {
+    const int r = (int)t.nodes.size() - 1;            // post-order: the root is last
+    for (auto* v : {&t.ph1, &t.ph2}) for (auto& l : *v) l.erase(std::remove(l.begin(), l.end(), r), l.end());
+    t.nodes.pop_back();
+  }
+  int maxd = -1;
+  for (const InvNode& nd : t.nodes) maxd = std::max(maxd, nd.depth);
+  std::vector<int64_t> need((size_t)(maxd + 1), 0);
+  for (const InvNode& nd : t.nodes) need[(size_t)nd.depth] = std::max(need[(size_t)nd.depth], cap_round_up((nd.mid - nd.a) * (nd.b - nd.mid), 2));
+  std::vector<int64_t> off((size_t)(maxd + 2), 0);
+  for (int d = 0; d <= maxd; d++) off[(size_t)d + 1] = off[(size_t)d] + need[(size_t)d];
+  for (InvNode& nd : t.nodes) nd.woff = off[(size_t)nd.depth];
+  t.scratch = off[(size_t)(maxd + 1)];
+  return t;
+}
+
+std::vector<int64_t> panel_bounds(int64_t n, int64_t nb) {
+  std::vector<int64_t> pb;
+  for (int64_t j = 0; j < n; j += nb) pb.push_back(j);
+  pb.push_back(n);
+  return pb;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -171,8 +227,8 @@ struct cap_cholinv_plan {
   int64_t tail;    // trailing sizes <= tail fall back to nb-wide strips
   int64_t serial_m; // remaining rows below which the chain is no longer overlapped with the bulk update (see right_looking)
   int fastdiag;     // diagonal blocks by the 64-blocked fused path (default) instead of the recursion
+  int ctag;         // CAP_TAG_NO_ATOMIC when the factor lives in caller memory that is not a plain device allocation (cap_dpotrf)
   int depth2;       // split each bulk update into head (next-next strip's rows) + rest: look-ahead depth 2
-  int64_t bulk_wgs; // accepted, no effect: the persistent bulk grid it sized was removed; kept so option files still load
   // device state
   double* R; int64_t ldr;
   double* Rinv; int64_t ldi;      // n x n (complete_inv >= 0) or nb x nb diagonal-block inverse
@@ -200,6 +256,13 @@ struct cap_cholinv_plan {
   std::vector<hipEvent_t>* prof_ev; std::vector<double>* prof_flops; int prof_used;
   // multi-GPU plans (comm size > 1): the 1 x P block-cyclic schedule of dist.hip behind the same handle
   cap_dist_plan* dist;
+  // R^-1 on top of the blocked factorization (complete_inv >= 0, see InvTree): its own stream, one event per panel
+  int inv_fast;         // 1: blocked factorization + inverse tree (default for n >= 2 nb), 0: the plain recursion of cholinv.hpp:85-165
+  int inv_overlap;      // 1: tree nodes are enqueued as their inputs become final (overlapped with the sweep), 0: after it
+  int64_t inv_start_m;  // overlapped mode: nothing of the tree is enqueued while more than this many columns are left to factor
+  InvTree* itree; bool inv_active; int inv_tree_skip; int64_t inv_tree_mid;
+  double* inv_W;        // tree scratch (inside `work`)
+  hipStream_t s_inv; std::vector<hipEvent_t>* ev_pf; hipEvent_t ev_inv_done; bool inv_ready; int inv_pending_from;
 };
 
 namespace {
@@ -231,7 +294,9 @@ int plan_alloc(cap_cholinv_plan* p) {
     p->ldi = cap_round_up(n, 2);
     CAP_HIP(hipMalloc((void**)&p->Rinv, sizeof(double) * p->ldi * n));
     CAP_HIP(hipMemset(p->Rinv, 0, sizeof(double) * p->ldi * n));
-    p->work_elems = rec_work_size(n);
+    // plain recursion: (n/2 + 1)^2; blocked factorization + inverse tree: chain scratch + panel scratch + tree scratch
+    // (checked again - and grown if an option changed the panel width - by ensure_inverse_work at factor time)
+    p->work_elems = std::max(rec_work_size(n), rec_work_size(1024) + cap_round_up(1024 * n, 2) + (n / 2 + 1024) * (n / 2 + 1024) * 3 / 2);
   } else {
     p->ldi = p->nb;
     CAP_HIP(hipMalloc((void**)&p->Rinv, sizeof(double) * p->nb * p->nb));
@@ -275,6 +340,7 @@ int ensure_bulk_stream(cap_cholinv_plan* p) {
 
 // diagonal block of the nb-wide panel starting at j0: R_jj and Dinv = R_jj^-1 (jb x jb, ld = nb, strictly-lower part stays zero)
 int panel_chain(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t j0, int64_t jb, double* Dinv, hipStream_t s) {
+  CapRange range("CI::factor_diag");            // cholinv.hpp:95-99
   double* Wrec = p->work;                       // rec scratch
   if (p->fastdiag && jb % 64 == 0 && jb >= 128 && jb <= 1024 && (jb & (jb - 1)) == 0 && p->leaf == CAP_LEAF_MAX) {
     hipStream_t sc = s;
@@ -289,7 +355,7 @@ int panel_chain(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t j0, int64_t
       CAP_HIP(hipStreamWaitEvent(s, p->ev_chain[1], 0));
     }
   } else {
-    RecCtx c{R + j0 + j0 * ldr, ldr, Dinv, p->ldi, Wrec, rec_work_size(p->nb), p->info_dev, p->leaf, 1, 1, s};
+    RecCtx c{R + j0 + j0 * ldr, ldr, Dinv, p->ldi, Wrec, rec_work_size(p->nb), p->info_dev, p->leaf, 1, 1, s, p->ctag};
     CAP_TRY(rec_cholinv(c, 0, jb, false, j0));
   }
   return CAP_OK;
@@ -301,6 +367,7 @@ int panel_solve(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t j0, int64_t
                 double* Wp, hipStream_t s) {
   const int64_t m = c1 - c0;
   if (m <= 0) return CAP_OK;
+  CapRange range("CI::trsm");                   // cholinv.hpp:114-125
   double* Rpan = R + j0 + c0 * ldr;
   double* W = Wp + c0 * jb;
   CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, m, jb, 1.0, Dinv, p->ldi, Rpan, ldr, 0.0, W, jb, 0, s, 2 | 16));
@@ -309,9 +376,15 @@ int panel_solve(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t j0, int64_t
 }
 
 // factor the nb-wide panel starting at j0: diagonal block (R, Dinv), then the block row solve
+int inverse_after_panel(cap_cholinv_plan* p, int64_t k, int64_t cols_left, hipStream_t s);
+
 int panel_factor(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t j0, int64_t jb, hipStream_t s) {
-  CAP_TRY(panel_chain(p, R, ldr, j0, jb, p->Rinv, s));
-  return panel_solve(p, R, ldr, j0, jb, p->Rinv, j0 + jb, n, p->work + rec_work_size(p->nb), s);
+  // complete_inv >= 0 on the blocked path: the diagonal-block inverse IS the diagonal block of R^-1 (written in place, ld = ldi)
+  double* Dinv = p->inv_active ? p->Rinv + j0 + j0 * p->ldi : p->Rinv;
+  CAP_TRY(panel_chain(p, R, ldr, j0, jb, Dinv, s));
+  CAP_TRY(panel_solve(p, R, ldr, j0, jb, Dinv, j0 + jb, n, p->work + rec_work_size(p->nb), s));
+  if (p->inv_active) CAP_TRY(inverse_after_panel(p, j0 / p->nb, n - (j0 + jb), s));
+  return CAP_OK;
 }
 
 // trailing update C[M x N] -= A^T B on upper tiles (the dominant kernel), optionally bracketed by events.
@@ -319,6 +392,7 @@ int panel_factor(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t
 // that the panel chain of the step after next can start early (look-ahead depth 2).
 int trailing_update(cap_cholinv_plan* p, int64_t M, int64_t N, int64_t k, const double* A, const double* B, double* C,
                     int64_t ldr, hipStream_t s) {
+  CapRange range("CI::tmu");                    // cholinv.hpp:129-136
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (p->profile && p->prof_ev) {
     if ((size_t)p->prof_used + 2 > p->prof_ev->size()) {
@@ -329,7 +403,7 @@ int trailing_update(cap_cholinv_plan* p, int64_t M, int64_t N, int64_t k, const 
   }
   // chain-bound tail (N columns left <= occ1_m): one bulk workgroup per CU instead of two, see launch_tn_dma
   const int occ = (p->occ1_m > 0 && N <= p->occ1_m) ? -1 : 0;
-  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, M, N, k, -1.0, A, ldr, B, ldr, 1.0, C, ldr, 1, s, 1, occ));
+  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, M, N, k, -1.0, A, ldr, B, ldr, 1.0, C, ldr, 1, s, 1 | p->ctag, occ));
   if (e0) {
     CAP_HIP(hipEventRecord(e1, s));
     p->prof_used += 2;
@@ -351,10 +425,53 @@ int factor_strip(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t
     if (rows_left > 0 && cols > 0) {
       double* Rpan = R + j0 + j1 * ldr;            // jb x cols block row just solved
       CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows_left, cols, jb, -1.0, Rpan, ldr, Rpan, ldr, 1.0,
-                              R + j1 + j1 * ldr, ldr, 1, s));
+                              R + j1 + j1 * ldr, ldr, 1, s, p->ctag));
     }
   }
   return CAP_OK;
+}
+
+// ---- inverse tree on its own stream (see InvTree) ------------------------------------------------------------------------
+int inv_node_phase(cap_cholinv_plan* p, const InvNode& nd, int phase, hipStream_t s) {
+  CapRange range(phase == 1 ? "CI::inverse_ph1" : "CI::inverse_ph2");   // cholinv.hpp:145-158 (CI::tmu upstream)
+  const int64_t h1 = nd.mid - nd.a, h2 = nd.b - nd.mid;
+  double* W = p->inv_W + nd.woff;
+  double* Ri = p->Rinv;
+  if (phase == 1)   // W = -Ri11 R12   (Ri11 upper triangular: K range of a row tile starts at its diagonal)
+    return cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, h1, h2, h1, -1.0, Ri + nd.a + nd.a * p->ldi, p->ldi, p->R + nd.a + nd.mid * p->ldr, p->ldr,
+                           0.0, W, h1, 0, s, 32);
+  // Ri12 = W Ri22   (Ri22 upper triangular: K range of a column tile stops at its diagonal)
+  return cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, h1, h2, h2, 1.0, W, h1, Ri + nd.mid + nd.mid * p->ldi, p->ldi, 0.0,
+                         Ri + nd.a + nd.mid * p->ldi, p->ldi, 0, s, 8);
+}
+
+// everything of the tree that became ready with the panels [inv_pending_from, k]
+int inverse_flush(cap_cholinv_plan* p, int64_t k) {
+  const InvTree& t = *p->itree;
+  for (int64_t kk = p->inv_pending_from; kk <= k; kk++) {
+    if (t.ph1[(size_t)kk].empty() && t.ph2[(size_t)kk].empty()) continue;
+    CAP_HIP(hipStreamWaitEvent(p->s_inv, (*p->ev_pf)[(size_t)kk], 0));
+    for (int i : t.ph2[(size_t)kk]) CAP_TRY(inv_node_phase(p, t.nodes[(size_t)i], 2, p->s_inv));   // inner nodes first (post-order)
+    for (int i : t.ph1[(size_t)kk]) CAP_TRY(inv_node_phase(p, t.nodes[(size_t)i], 1, p->s_inv));
+  }
+  p->inv_pending_from = (int)(k + 1);
+  return CAP_OK;
+}
+
+int inverse_after_panel(cap_cholinv_plan* p, int64_t k, int64_t cols_left, hipStream_t s) {
+  CAP_HIP(hipEventRecord((*p->ev_pf)[(size_t)k], s));
+  if (p->inv_overlap && cols_left <= p->inv_start_m) CAP_TRY(inverse_flush(p, k));
+  return CAP_OK;
+}
+
+void release_inverse(cap_cholinv_plan* p) {
+  if (p->inv_ready) {
+    (void)hipStreamSynchronize(p->s_inv); (void)hipStreamDestroy(p->s_inv);
+    (void)hipEventDestroy(p->ev_inv_done);
+    p->inv_ready = false;
+  }
+  if (p->ev_pf) { for (hipEvent_t e : *p->ev_pf) (void)hipEventDestroy(e); delete p->ev_pf; p->ev_pf = nullptr; }
+  delete p->itree; p->itree = nullptr;
 }
 
 void release_split(cap_cholinv_plan* p) {
@@ -528,7 +645,7 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
     }
     return CAP_OK;
   }
-  if (p->inner_la && p->serial_m == 0 && p->reserve == 0 && NB / nb <= 8) return right_looking_split(p, R, ldr, n, s0, bnd);
+  if (p->inner_la && p->serial_m == 0 && p->reserve == 0 && NB / nb <= 8 && !p->inv_active) return right_looking_split(p, R, ldr, n, s0, bnd);
   CAP_TRY(ensure_streams(p));
   CAP_TRY(ensure_bulk_stream(p));
   hipStream_t s1 = p->s_panel;
@@ -569,7 +686,7 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
     //     needs strip k (same stream) and the HEAD of the bulk update of step k-1 (main stream): the head is the
     //     part of that update that touches strip k+1's rows, so the chain runs one more step ahead of the bulk
     if (k > 0) CAP_HIP(hipStreamWaitEvent(s1, p->ev_update[(k - 1) & 1], 0));
-    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows1, m, rows, -1.0, S, ldr, S, ldr, 1.0, R + J1 + J1 * ldr, ldr, 1, s1));
+    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows1, m, rows, -1.0, S, ldr, S, ldr, 1.0, R + J1 + J1 * ldr, ldr, 1, s1, p->ctag));
     CAP_TRY(factor_strip(p, R, ldr, n, J1, rows1, s1));
     CAP_HIP(hipEventRecord(p->ev_panel[(k + 1) & 1], s1));
     // (b) main stream: bulk of the trailing update (rows below strip k+1)
@@ -597,6 +714,57 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
   CAP_HIP(hipEventRecord(p->ev_join, s1));
   CAP_HIP(hipStreamWaitEvent(s_user, p->ev_join, 0));
   if (s0 != s_user) { CAP_HIP(hipEventRecord(p->ev_join_b, s0)); CAP_HIP(hipStreamWaitEvent(s_user, p->ev_join_b, 0)); }
+  return CAP_OK;
+}
+
+// complete_inv = 0 / 1 on a matrix of several panels: R by the blocked right-looking sweep (look-ahead, fused diagonal-block
+// chain - the same schedule as complete_inv = -1), R^-1 by the inverse tree, overlapped with the sweep's chain-bound tail.
+// Same results as the recursion of cholinv.hpp:85-165 up to the association order: R^-1's diagonal blocks [0, n1) and
+// [n1, n) (n1 = n >> split) are complete, the root block Ri[0:n1, n1:n] stays empty when complete_inv == 0 (cholinv.hpp:147).
+int factor_with_inverse(cap_cholinv_plan* p, bool root_is_base, hipStream_t s) {
+  const int64_t n = p->n, nb = p->nb;
+  const int eff_ci = root_is_base ? 1 : p->complete_inv;
+  const int64_t n1 = n >> p->split;
+  int root_mid = -1; bool skip_root = false; int64_t zero_n1 = 0;
+  if (!root_is_base && n1 > 0 && n1 < n) {
+    if (n1 % nb == 0) { root_mid = (int)(n1 / nb); skip_root = eff_ci == 0; }
+    else if (eff_ci == 0) zero_n1 = n1;      // root partition inside a panel: build the full inverse, then empty the root block
+  }
+  if (!p->itree || p->inv_tree_skip != (skip_root ? 0 : 1) || p->inv_tree_mid != root_mid) {
+    delete p->itree;
+    p->itree = new (std::nothrow) InvTree(inv_tree_build(panel_bounds(n, nb), root_mid, skip_root));
+    if (!p->itree) return CAP_ERR_ALLOC;
+    p->inv_tree_skip = skip_root ? 0 : 1; p->inv_tree_mid = root_mid;
+  }
+  const int64_t np = cap_ceil_div(n, nb);
+  // workspace: [chain scratch | panel scratch nb x n | tree scratch]
+  const int64_t base = rec_work_size(nb) + cap_round_up(nb * n, 2);
+  if (base + p->itree->scratch > p->work_elems) {
+    CAP_HIP(hipDeviceSynchronize());
+    (void)hipFree(p->work); p->work = nullptr;
+    p->work_elems = std::max(rec_work_size(n), base + p->itree->scratch);
+    CAP_HIP(hipMalloc((void**)&p->work, sizeof(double) * p->work_elems));
+  }
+  p->inv_W = p->work + base;
+  if (!p->inv_ready) {
+    CAP_HIP(hipStreamCreateWithFlags(&p->s_inv, hipStreamNonBlocking));
+    CAP_HIP(hipEventCreateWithFlags(&p->ev_inv_done, hipEventDisableTiming));
+    p->inv_ready = true;
+  }
+  if (!p->ev_pf) p->ev_pf = new (std::nothrow) std::vector<hipEvent_t>();
+  if (!p->ev_pf) return CAP_ERR_ALLOC;
+  while ((int64_t)p->ev_pf->size() < np) { hipEvent_t e; CAP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); p->ev_pf->push_back(e); }
+  p->inv_pending_from = 0;
+  p->inv_active = true;
+  int st = right_looking(p, p->R, p->ldr, n, s);
+  p->inv_active = false;
+  CAP_TRY(st);
+  // whatever of the tree has not been enqueued yet (everything when inv_overlap == 0: then it also waits for the sweep's join)
+  if (!p->inv_overlap) { CAP_HIP(hipEventRecord(p->ev_inv_done, s)); CAP_HIP(hipStreamWaitEvent(p->s_inv, p->ev_inv_done, 0)); }
+  CAP_TRY(inverse_flush(p, np - 1));
+  CAP_HIP(hipEventRecord(p->ev_inv_done, p->s_inv));
+  CAP_HIP(hipStreamWaitEvent(s, p->ev_inv_done, 0));
+  if (zero_n1) CAP_TRY(cap_zero_rect(p->Rinv + zero_n1 * p->ldi, p->ldi, zero_n1, n - zero_n1, s));
   return CAP_OK;
 }
 
@@ -638,6 +806,10 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   // update (m^2 x 1024 flops): from there on the bulk runs one workgroup per CU (N = 32768: 59.3 -> 61.2 TF, 16384: 34.4 -> 37.1)
   p->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
   p->depth2 = n >= 24576;     // look-ahead depth 2 pays once a bulk update is long enough to split (+2 % at N = 32768)
+  // reference semantics (R and R^-1): blocked factorization + inverse tree; the tree starts once the sweep is chain-bound
+  p->inv_fast = getenv("CAP_INV_FAST") ? atoi(getenv("CAP_INV_FAST")) : 1;
+  p->inv_overlap = getenv("CAP_INV_OVERLAP") ? atoi(getenv("CAP_INV_OVERLAP")) : 1;
+  p->inv_start_m = getenv("CAP_INV_START_M") ? atoll(getenv("CAP_INV_START_M")) : std::max<int64_t>(16384, n / 2);
   int st = plan_alloc(p);
   if (st != CAP_OK) { cap_cholinv_plan_destroy(p); return st; }
   *plan = p;
@@ -661,6 +833,7 @@ int cap_cholinv_plan_destroy(cap_cholinv_plan* p) {
     for (int i = 0; i < 2; i++) (void)hipEventDestroy(p->ev_chain[i]);
   }
   release_split(p);
+  release_inverse(p);
   if (p->prof_ev) { for (hipEvent_t e : *p->prof_ev) (void)hipEventDestroy(e); delete p->prof_ev; delete p->prof_flops; }
   delete p;
   return CAP_OK;
@@ -682,8 +855,12 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
     return cap_dist_set_option(p->dist, key, value);
   }
   if (k == "nb") {
-    if (p->complete_inv >= 0) { p->nb = value; return CAP_OK; }
     if (value < 64 || value % 64) return CAP_ERR_ARG;
+    if (p->complete_inv >= 0) {          // workspace is re-checked at factor time (ensure_inverse_work); the tree follows the panels
+      if (value > 1024) return CAP_ERR_ARG;
+      if (value != p->nb) { delete p->itree; p->itree = nullptr; }
+      p->nb = value; return CAP_OK;
+    }
     if (value == p->nb) return CAP_OK;
     // workspace depends on nb: reallocate
     release_split(p);
@@ -701,11 +878,13 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
   if (k == "outer") { if (value < 64) return CAP_ERR_ARG; p->outer = value; return CAP_OK; }
   if (k == "tail") { if (value < 0) return CAP_ERR_ARG; p->tail = value; return CAP_OK; }
   if (k == "serial_m") { if (value < 0) return CAP_ERR_ARG; p->serial_m = value; return CAP_OK; }
-  if (k == "bulk_wgs") { if (value < 0 || value > 2048) return CAP_ERR_ARG; p->bulk_wgs = value; return CAP_OK; }
   if (k == "depth2") { p->depth2 = value != 0; return CAP_OK; }
   if (k == "inner_la") { p->inner_la = value != 0; return CAP_OK; }
   if (k == "occ1_m") { if (value < 0) return CAP_ERR_ARG; p->occ1_m = value; return CAP_OK; }
   if (k == "fastdiag") { p->fastdiag = value != 0; return CAP_OK; }
+  if (k == "inv_fast") { p->inv_fast = value != 0; return CAP_OK; }
+  if (k == "inv_overlap") { p->inv_overlap = value != 0; return CAP_OK; }
+  if (k == "inv_start_m") { if (value < 0) return CAP_ERR_ARG; p->inv_start_m = value; return CAP_OK; }
   if (k == "reserve") {   // CUs kept free for the panel chain (multiple of 8 keeps the XCDs balanced); 0 = off
     if (value < 0 || value > 64) return CAP_ERR_ARG;
     if (p->bulk_ready) {
@@ -741,7 +920,9 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
   if (k == "outer") return p->outer;
   if (k == "tail") return p->tail;
   if (k == "serial_m") return p->serial_m;
-  if (k == "bulk_wgs") return p->bulk_wgs;
+  if (k == "inv_fast") return p->inv_fast;
+  if (k == "inv_overlap") return p->inv_overlap;
+  if (k == "inv_start_m") return p->inv_start_m;
   if (k == "depth2") return p->depth2;
   if (k == "fastdiag") return p->fastdiag;
   if (k == "reserve") return p->reserve;
@@ -764,7 +945,6 @@ int cap_cholinv_factor(cap_cholinv_plan* p, const double* A, int64_t lda, void* 
   // serialize<uppertri,uppertri>(A -> R), cholinv.hpp:13: only A's upper triangle is consumed
   CAP_TRY(cap_copy_window(A, 0, lda, 0, 0, p->R, 0, p->ldr, 0, 0, n, n, 1, 0, stream));
   if (p->complete_inv < 0) return right_looking(p, p->R, p->ldr, n, s);
-  RecCtx c{p->R, p->ldr, p->Rinv, p->ldi, p->work, p->work_elems, p->info_dev, p->leaf, p->split, p->complete_inv, s};
   // upstream's leaf test at the root (cholinv.hpp:93 with c = d = 1): a root that is itself a base
   // case gets the full inverse whatever complete_inv says (policy.h:199-201 always runs trtri)
   int64_t bc = 1;
@@ -772,6 +952,8 @@ int cap_cholinv_factor(cap_cholinv_plan* p, const double* A, int64_t lda, void* 
   bc = std::max<int64_t>(1, std::min<int64_t>(n, bc));
   const int64_t bc_dim = n / bc;
   const bool root_is_base = (n <= bc_dim) || ((n >> p->split) < p->split);
+  if (p->inv_fast && n >= 2 * p->nb && p->leaf == CAP_LEAF_MAX) return factor_with_inverse(p, root_is_base, s);
+  RecCtx c{p->R, p->ldr, p->Rinv, p->ldi, p->work, p->work_elems, p->info_dev, p->leaf, p->split, p->complete_inv, s};
   return rec_cholinv(c, 0, n, !root_is_base, 0);
 }
 
@@ -862,7 +1044,8 @@ int cap_dpotrf(int uplo, int64_t n, double* A, int64_t lda, int* info, double* w
   cap_cholinv_plan& p = ctx.plan;
   p.n = n; p.complete_inv = -1; p.leaf = CAP_LEAF_MAX; p.fastdiag = 1;
   potrf_knobs(n, &p.nb, &p.outer, &p.tail, &p.depth2);
-  p.serial_m = 0;
+  p.serial_m = 0; p.inner_la = 0;
+  p.ctag = cap_plain_device_ptr(A) ? 0 : CAP_TAG_NO_ATOMIC;
   p.lookahead = n >= 4096;
   p.ldi = p.nb;
   p.Rinv = work;                                // nb x nb
@@ -950,7 +1133,8 @@ int cap_dtrsm(int side, int uplo, int trans, int64_t m, int64_t n, double alpha,
   CAP_TRY(cap_trsm_prepare(T, ldt, td, tb, Inv, W, s));
   // alpha once, up front (B <- alpha B through the GEMM launcher's scaling path); the sweep then solves op(T) X = B
   if (alpha != 1.0) CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, m, n, 0, 0.0, B, ldb, B, ldb, alpha, B, ldb, 0, s));
-  return cap_trsm_apply(side, trans, m, n, T, ldt, Inv, tb, B, ldb, X, s);
+  // B is caller memory: atomic-add epilogue of the block updates only on plain device allocations
+  return cap_trsm_apply(side, trans, m, n, T, ldt, Inv, tb, B, ldb, X, s, cap_plain_device_ptr(B) ? 0 : CAP_TAG_NO_ATOMIC);
 }
 
 }  // extern "C"
@@ -973,7 +1157,7 @@ int cap_trsm_prepare(const double* T, int64_t ldt, int64_t td, int64_t tb, doubl
 }
 
 int cap_trsm_apply(int side, int trans, int64_t m, int64_t n, const double* T, int64_t ldt, const double* Inv, int64_t tb, double* B,
-                   int64_t ldb, double* X, hipStream_t s) {
+                   int64_t ldb, double* X, hipStream_t s, int ctag) {
   const bool left = side == CAP_LEFT, tr = trans == CAP_TRANS;
   const int64_t td = left ? m : n;
   const int64_t nblk = cap_ceil_div(td, tb);
@@ -988,9 +1172,9 @@ int cap_trsm_apply(int side, int trans, int64_t m, int64_t n, const double* T, i
       CAP_TRY(cap_copy_rect(X, w, B + o, ldb, w, n, s));
       if (tr) {          // rows below: B_r -= T(i, r)^T X_i
         const int64_t r0 = o + w, rows = td - r0;
-        if (rows > 0) CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows, n, w, -1.0, T + o + r0 * ldt, ldt, X, w, 1.0, B + r0, ldb, 0, s));
+        if (rows > 0) CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows, n, w, -1.0, T + o + r0 * ldt, ldt, X, w, 1.0, B + r0, ldb, 0, s, ctag));
       } else {           // rows above: B_r -= T(r, i) X_i
-        if (o > 0) CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, o, n, w, -1.0, T + o * ldt, ldt, X, w, 1.0, B, ldb, 0, s));
+        if (o > 0) CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, o, n, w, -1.0, T + o * ldt, ldt, X, w, 1.0, B, ldb, 0, s, ctag));
       }
     } else {
       // X_j = B_j * op(Tjj^-1)   (m x w)
@@ -998,9 +1182,9 @@ int cap_trsm_apply(int side, int trans, int64_t m, int64_t n, const double* T, i
       CAP_TRY(cap_copy_rect(X, m, B + o * ldb, ldb, m, w, s));
       if (!tr) {         // columns to the right: B_c -= X_j T(j, c)
         const int64_t c0 = o + w, cols = td - c0;
-        if (cols > 0) CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, m, cols, w, -1.0, X, m, T + o + c0 * ldt, ldt, 1.0, B + c0 * ldb, ldb, 0, s));
+        if (cols > 0) CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, m, cols, w, -1.0, X, m, T + o + c0 * ldt, ldt, 1.0, B + c0 * ldb, ldb, 0, s, ctag));
       } else {           // columns to the left: B_c -= X_j T(c, j)^T
-        if (o > 0) CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_TRANS, m, o, w, -1.0, X, m, T + o * ldt, ldt, 1.0, B, ldb, 0, s));
+        if (o > 0) CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_TRANS, m, o, w, -1.0, X, m, T + o * ldt, ldt, 1.0, B, ldb, 0, s, ctag));
       }
     }
   }

@@ -26,8 +26,32 @@ typedef double d2 __attribute__((ext_vector_type(2)));
   } while (0)
 
 static inline hipStream_t cap_stream(void* s) { return (hipStream_t)s; }
+// Timing-surgery kernel variants (CAP_DIAG, CAP_CQR_DIAG: results are WRONG by construction) are only compiled into
+// experiment builds: set this to true, rebuild, measure, set it back.  Release libraries cannot be switched into them.
+constexpr bool CAP_EXPERIMENTS = false;
+// tag bit of cap_gemm_launch: C is caller-supplied memory that has not been verified to be plain device memory -
+// the fire-and-forget atomic epilogue (hardware fp64 atomics are dropped on fine-grained / host-mapped memory) is off
+constexpr int CAP_TAG_NO_ATOMIC = 64;
+// true when `p` is plain hipMalloc'ed device memory (not managed, not host-mapped): the operator seam's check
+static inline bool cap_plain_device_ptr(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeDevice && !a.isManaged;
+}
 static inline int64_t cap_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t cap_round_up(int64_t a, int64_t b) { return cap_ceil_div(a, b) * b; }
+
+// Named profiling regions (the reference brackets CI::factor_diag / CI::trsm / CI::tmu / CQR::gram with critter's
+// CRITTER_START/STOP, cholinv.hpp:94-96,113-137, shared.h:26-35): roctx ranges around the ENQUEUE of each group of launches,
+// visible in rocprofv3 --marker-trace.  The roctx library is resolved lazily with dlopen (aux.hip); absent -> no-ops.
+void cap_range_push(const char* name);
+void cap_range_pop();
+struct CapRange {
+  explicit CapRange(const char* name) { cap_range_push(name); }
+  ~CapRange() { cap_range_pop(); }
+  CapRange(const CapRange&) = delete;
+  CapRange& operator=(const CapRange&) = delete;
+};
 
 // internal launchers shared between translation units ---------------------------------------
 // C = alpha*op(A)*op(B) + beta*C with optional "upper tiles only" (SYRK-style) masking:
@@ -72,7 +96,7 @@ int64_t cap_trsm_block(int64_t td);
 int64_t cap_trsm_prepare_work(int64_t tb);
 int cap_trsm_prepare(const double* T, int64_t ldt, int64_t td, int64_t tb, double* Inv, double* W, hipStream_t s);
 int cap_trsm_apply(int side, int trans, int64_t m, int64_t n, const double* T, int64_t ldt, const double* Inv, int64_t tb, double* B,
-                   int64_t ldb, double* X, hipStream_t s);
+                   int64_t ldb, double* X, hipStream_t s, int ctag = 0);
 int cap_rec_cholinv_full(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, double* W, int64_t wcap, int* info,
                          hipStream_t s, int64_t info_base);
 int64_t cap_rec_work_size(int64_t n);

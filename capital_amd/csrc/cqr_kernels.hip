@@ -300,14 +300,17 @@ int cap_qrapply256_launch(const double* Qin, int64_t ldin, const double* Ri, dou
   ApplyArgs g{Qin, ldin, Ri, Qout, ldout, (int)(m / 128), contig};
   const int grid = (int)std::min<int64_t>(cus, g.ntiles);
   // CAP_CQR_DIAG is timing surgery only (1 = no stores, 2 = no MFMA: results are wrong); CAP_CQR_PIPE picks the loop form
-  static const int diag = getenv("CAP_CQR_DIAG") ? atoi(getenv("CAP_CQR_DIAG")) : 0;
   static const int pipe = getenv("CAP_CQR_PIPE") ? atoi(getenv("CAP_CQR_PIPE")) : 1;
   const size_t lds = (A_NST * TA + B_NST * TB) * sizeof(double);
   const dim3 gr((unsigned)grid), bl(512);
-  if (diag == 1) hipLaunchKernelGGL((qrapply256_kernel<1, 0>), gr, bl, lds, s, g);
-  else if (diag == 2) hipLaunchKernelGGL((qrapply256_kernel<2, 0>), gr, bl, lds, s, g);
-  else if (diag == 3) hipLaunchKernelGGL((qrapply256_kernel<3, 0>), gr, bl, lds, s, g);
-  else if (pipe == 1) hipLaunchKernelGGL((qrapply256_kernel<0, 1>), gr, bl, lds, s, g);
+  if constexpr (CAP_EXPERIMENTS) {
+    static const int diag = getenv("CAP_CQR_DIAG") ? atoi(getenv("CAP_CQR_DIAG")) : 0;
+    if (diag == 1) hipLaunchKernelGGL((qrapply256_kernel<1, 0>), gr, bl, lds, s, g);
+    else if (diag == 2) hipLaunchKernelGGL((qrapply256_kernel<2, 0>), gr, bl, lds, s, g);
+    else if (diag == 3) hipLaunchKernelGGL((qrapply256_kernel<3, 0>), gr, bl, lds, s, g);
+    if (diag >= 1 && diag <= 3) { CAP_HIP(hipGetLastError()); return CAP_OK; }
+  }
+  if (pipe == 1) hipLaunchKernelGGL((qrapply256_kernel<0, 1>), gr, bl, lds, s, g);
   else hipLaunchKernelGGL((qrapply256_kernel<0, 0>), gr, bl, lds, s, g);
   CAP_HIP(hipGetLastError());
   return CAP_OK;

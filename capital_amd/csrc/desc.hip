@@ -129,6 +129,9 @@ int cap_desc_import_host(cap_desc* d, const double* host, int64_t ld_host, void*
     return CAP_OK;
   }
   CAP_TRY(ensure_staging(d));
+  // a previous import may still have H2D copies in flight that READ the two pinned buffers (this call returns before they
+  // finish, by design): drain the copy stream before the host refills them
+  CAP_HIP(hipStreamSynchronize(d->s_copy));
   CAP_HIP(hipEventRecord(d->ev_done, s));                 // earlier users of the device buffer
   CAP_HIP(hipStreamWaitEvent(d->s_copy, d->ev_done, 0));
   const int64_t cpc = std::max<int64_t>(1, d->pin_elems / rows);   // columns per chunk (a column longer than the chunk is split below)

@@ -88,7 +88,7 @@ __global__ void fill_symmetric_bc_kernel(double* out, int64_t ld, int64_t n, int
 __global__ void pad_identity_kernel(double* R, int64_t ld, int64_t n, int64_t npad, int64_t nb, int P, int p, int64_t row0,
                                     int64_t col0, int64_t rows, int64_t cols) {
   int64_t row = row0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int64_t lcol = col0 + blockIdx.y;
+  int64_t lcol = col0 + blockIdx.y + (int64_t)blockIdx.z * 65535;
   if (row >= row0 + rows || lcol >= col0 + cols) return;
   int64_t gcol = ((lcol / nb) * P + p) * nb + lcol % nb;
   if (row >= n || gcol >= n) R[row + lcol * ld] = (row == gcol) ? 1.0 : 0.0;
@@ -307,9 +307,10 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
   if (d->lc_valid > 0) CAP_TRY(cap_copy_rect(Aloc, lda, d->R, ld, n, d->lc_valid, s0));
   if (npad != n && d->lc > 0) {
     // rows [n, npad) of every local column, and the padding columns of the last block on its owner
-    hipLaunchKernelGGL(pad_identity_kernel, dim3((unsigned)cap_ceil_div(npad - n, 256), (unsigned)d->lc), dim3(256), 0, s0, d->R, ld, n,
+    hipLaunchKernelGGL(pad_identity_kernel, dim3((unsigned)cap_ceil_div(npad - n, 256), (unsigned)std::min<int64_t>(d->lc, 65535),
+                                                 (unsigned)cap_ceil_div(d->lc, 65535)), dim3(256), 0, s0, d->R, ld, n,
                        npad, nb, (int)P, (int)p, n, (int64_t)0, npad - n, d->lc);
-    if (d->lc > d->lc_valid)
+    if (d->lc > d->lc_valid)      // (at most nb columns: no grid.z folding needed, the kernel tolerates it anyway)
       hipLaunchKernelGGL(pad_identity_kernel, dim3((unsigned)cap_ceil_div(npad, 256), (unsigned)(d->lc - d->lc_valid)), dim3(256), 0, s0,
                          d->R, ld, n, npad, nb, (int)P, (int)p, (int64_t)0, d->lc_valid, npad, d->lc - d->lc_valid);
     CAP_HIP(hipGetLastError());

@@ -577,9 +577,15 @@ int launch_tn_dma(GemmArgs g, int grid, hipStream_t stream, int persist_wgs = 0)
   // CU.  Used for the bulk updates of the chain-bound tail (cholinv.hip, option occ1_m): the bulk update has slack there,
   // and a CU that runs one bulk workgroup always has room (LDS, VGPRs) for a workgroup of the diagonal-block chain.
   size_t lds = (persist_wgs == -1 ? 6 : 4) * DMA_TILE * sizeof(double);
-  static const int diag_env = getenv("CAP_DIAG") ? atoi(getenv("CAP_DIAG")) : 0;    // timing experiments only
-  if (diag_env == 1 && TAG == 0) hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, false, 1, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
-  else if (g.skip && g.usebuf) hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, false, 0, true, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+  if constexpr (CAP_EXPERIMENTS && TAG == 0) {                       // timing experiments only (results are wrong)
+    static const int diag_env = getenv("CAP_DIAG") ? atoi(getenv("CAP_DIAG")) : 0;
+    if (diag_env == 1) {
+      hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, false, 1, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
+      CAP_HIP(hipGetLastError());
+      return CAP_OK;
+    }
+  }
+  if (g.skip && g.usebuf) hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, false, 0, true, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
   else if (g.skip) hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, false, 0, false, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
   else if (g.usebuf) hipLaunchKernelGGL((dgemm_tn_dma_kernel<TAG, false, 0, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
   else hipLaunchKernelGGL((dgemm_tn_dma_kernel<TAG, false, 0, false>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
@@ -798,6 +804,7 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.beta = beta; g.tri = tri;
   g.hiprio = (tag & 2) ? 1 : 0; g.bupper = (tag & 8) ? 1 : 0;
   g.aupt = ((tag & 16) && transa == CAP_TRANS) ? 1 : 0; g.aupn = ((tag & 32) && transa != CAP_TRANS) ? 1 : 0;
+  const bool no_atomic = (tag & CAP_TAG_NO_ATOMIC) != 0;
   tag &= 1; g.ctr = nullptr;
   g.atomic_c = 0; g.usebuf = 0; g.skip = 0;
   g.stair = 0; g.gather = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0;
@@ -836,7 +843,7 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
 
   {
     static const int atomic_env = getenv("CAP_ATOMIC_C") ? atoi(getenv("CAP_ATOMIC_C")) : 1;
-    g.atomic_c = (atomic_env && beta == 1.0 && g.ksplit == 1) ? 1 : 0;
+    g.atomic_c = (atomic_env && !no_atomic && beta == 1.0 && g.ksplit == 1) ? 1 : 0;
     static const int skip_env = getenv("CAP_SKIP") ? atoi(getenv("CAP_SKIP")) : 1;
     g.skip = (skip_env && tag != 1 && (g.bupper || g.aupt || g.aupn || (tri == 1 && g.tm <= 8))) ? 1 : 0;
     static const int buf_env = getenv("CAP_DMA_BUF") ? atoi(getenv("CAP_DMA_BUF")) : 1;
@@ -916,14 +923,18 @@ int cap_gemm_small_batched(int transa, int transb, int64_t m, int64_t n, int64_t
 
 extern "C" int cap_dgemm(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
                          int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, void* stream) {
-  return cap_gemm_launch(transa, transb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0, cap_stream(stream));
+  // caller memory: the atomic epilogue only on plain device allocations (fp64 hardware atomics are silently
+  // dropped on fine-grained / managed / host-mapped buffers)
+  const int tag = (beta == 1.0 && !cap_plain_device_ptr(C)) ? CAP_TAG_NO_ATOMIC : 0;
+  return cap_gemm_launch(transa, transb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0, cap_stream(stream), tag);
 }
 
 extern "C" int cap_dsyrk(int uplo, int trans, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
                          double beta, double* C, int64_t ldc, void* stream) {
   // trans: C = alpha*A^T*A + beta*C with A k x n;  notrans: C = alpha*A*A^T + beta*C with A n x k
   int tri = (uplo == CAP_UPPER) ? 1 : 2;
+  const int tag = (beta == 1.0 && !cap_plain_device_ptr(C)) ? CAP_TAG_NO_ATOMIC : 0;
   if (trans == CAP_TRANS)
-    return cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n, n, k, alpha, A, lda, A, lda, beta, C, ldc, tri, cap_stream(stream));
-  return cap_gemm_launch(CAP_NOTRANS, CAP_TRANS, n, n, k, alpha, A, lda, A, lda, beta, C, ldc, tri, cap_stream(stream));
+    return cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n, n, k, alpha, A, lda, A, lda, beta, C, ldc, tri, cap_stream(stream), tag);
+  return cap_gemm_launch(CAP_NOTRANS, CAP_TRANS, n, n, k, alpha, A, lda, A, lda, beta, C, ldc, tri, cap_stream(stream), tag);
 }

@@ -217,8 +217,10 @@ int cap_mpchol_plan_create(cap_mpchol_plan** plan, int64_t n, int64_t nrhs_max) 
   cap_mpchol_plan* p = new (std::nothrow) cap_mpchol_plan();
   if (!p) return CAP_ERR_ALLOC;
   memset(p, 0, sizeof(*p));
-  p->n = n; p->nb = std::min<int64_t>(1024, n); p->nrhs_cap = cap_round_up(nrhs_max, 128);
-  while (p->nb > 128 && ((p->nb & (p->nb - 1)) || p->nb > n)) p->nb /= 2;   // power of two <= n: the fused diagonal-block chain
+  p->n = n; p->nb = 1024; p->nrhs_cap = cap_round_up(nrhs_max, 128);
+  // largest power of two <= min(n, 1024) (>= 128 because n % 128 == 0): the fused diagonal-block chain and the bf16 tile
+  // kernel (k % 64, m % 128) need it; the last panel of a non-power-of-two n is a shorter multiple of 128
+  while (p->nb > n) p->nb /= 2;
   p->wcap = cap_rec_work_size(p->nb);
   p->tb = p->nb;                      // the TRSM blocks ARE the panels: their inverses fall out of the factorization
   const int64_t nb = p->nb, w = p->nrhs_cap, nblk = cap_ceil_div(n, p->tb);

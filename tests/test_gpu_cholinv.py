@@ -100,9 +100,62 @@ def test_matches_oracle(n, ci, split, bc):
             cholinv.construct_Rinv(pack)
 
 
+@pytest.mark.parametrize("n,ci,split,bc,opts", [
+    (2048, 0, 2, -2, {}),                       # root partition n >> 2 = 512 on a panel boundary: unbalanced tree, root node skipped
+    (2048, 1, 2, -2, {}),
+    (1536, 1, 1, -2, {"nb": 256}),              # 6 panels: non-power-of-two tree
+    (1792, 0, 1, -2, {"nb": 256}),              # 7 panels, root partition 896 inside a panel: full tree, root block emptied afterwards
+    (1100, 1, 1, -2, {"nb": 128}),              # ragged last panel (76 columns)
+    (1100, 0, 1, -2, {"nb": 256}),
+    (2048, 1, 1, -2, {"nb": 128, "outer": 256, "tail": 512, "depth2": 1}),
+    (4096, 0, 1, -3, {"nb": 512}),
+    (1536, 1, 1, -2, {"nb": 256, "lookahead": 0}),
+    (3072, 1, 1, -3, {"nb": 256, "inv_overlap": 0}),
+    (3072, 1, 1, -3, {"nb": 256, "inv_start_m": 0}),            # overlapped mode that never starts early = flush at the end
+    (3072, 0, 1, -3, {"nb": 256, "inv_start_m": 1 << 30}),      # tree enqueued from the first panel on
+])
+def test_inverse_tree_on_blocked_factorization(n, ci, split, bc, opts):
+    """complete_inv = 0 / 1 on matrices of several panels: blocked right-looking sweep + inverse tree (cholinv.hip,
+    factor_with_inverse) against the oracle's recursion (cholinv.hpp:85-165) and against the plain recursion on the GPU."""
+    from capital_amd import cholinv
+    a = orc.symmetric_global(n, True)
+    r_ref, ri_ref = orc.cholinv(a, ci, split, bc, 1, 1)
+    A, pack = _factor(n, ci, split, bc, opts=opts)
+    assert pack.get_option("inv_fast") == 1 and n >= 2 * pack.get_option("nb")
+    assert pack.last_info() == 0
+    R = cholinv.construct_R(pack).to_numpy(); Ri = cholinv.construct_Rinv(pack).to_numpy()
+    assert relerr(R, r_ref) < 1e-13
+    assert relerr(Ri, ri_ref) < 1e-12
+    assert np.array_equal(Ri != 0, ri_ref != 0)               # same empty root block (cholinv.hpp:147), same triangle
+    assert orc.cholesky_residual(a, R) < RES_TOL
+    n1 = n >> split
+    for (lo, hi) in ((0, n1), (n1, n)) if ci == 0 else ((0, n),):
+        blk = Ri[lo:hi, lo:hi] @ R[lo:hi, lo:hi]
+        assert np.linalg.norm(blk - np.eye(hi - lo)) / np.sqrt(hi - lo) < 1e-13
+    # plan reuse is deterministic bit for bit (the tree's GEMMs are beta = 0 products: no atomics, fixed order)
+    cholinv.factor(A, pack, None)
+    assert np.array_equal(cholinv.construct_Rinv(pack).to_numpy(), Ri)
+    # the plain recursion (inv_fast = 0) on the same input: same factors up to association order
+    _, pack0 = _factor(n, ci, split, bc, opts={"inv_fast": 0})
+    assert relerr(cholinv.construct_Rinv(pack0).to_numpy(), Ri) < 1e-12
+    assert relerr(cholinv.construct_R(pack0).to_numpy(), R) < 1e-13
+
+
+def test_inverse_tree_overlap_modes_are_bitwise_identical():
+    from capital_amd import cholinv
+    n = 2560
+    outs = []
+    for opts in ({"nb": 256, "inv_overlap": 0}, {"nb": 256, "inv_overlap": 1, "inv_start_m": 0}, {"nb": 256, "inv_overlap": 1, "inv_start_m": 1 << 30},
+                 {"nb": 256, "inv_overlap": 1, "inv_start_m": 1024}):
+        _, pack = _factor(n, 1, 1, -3, opts=opts)
+        outs.append((cholinv.construct_R(pack).to_numpy(), cholinv.construct_Rinv(pack).to_numpy()))
+    for (r, ri) in outs[1:]:
+        assert np.array_equal(r, outs[0][0]) and np.array_equal(ri, outs[0][1])
+
+
 @pytest.mark.parametrize("opts", [{"lookahead": 0}, {"lookahead": 1, "nb": 128}, {"nb": 256}, {"nb": 512, "leaf": 32}, {"leaf": 16},
                                   {"nb": 128, "outer": 512, "tail": 256}, {"nb": 128, "outer": 256, "depth2": 1},
-                                  {"nb": 128, "outer": 256, "tail": 512, "depth2": 1, "bulk_wgs": 64}, {"nb": 256, "reserve": 8}, {"nb": 512, "fastdiag": 1}, {"nb": 256, "fastdiag": 1, "lookahead": 0},
+                                  {"nb": 128, "outer": 256, "tail": 512, "depth2": 1}, {"nb": 256, "reserve": 8}, {"nb": 512, "fastdiag": 1}, {"nb": 256, "fastdiag": 1, "lookahead": 0},
                                   {"nb": 128, "fastdiag": 1, "outer": 256},
                                   # column-split look-ahead (panel stream on the next chains' columns only, the rest on s_rest)
                                   {"nb": 128, "outer": 256, "inner_la": 1}, {"nb": 128, "outer": 512, "tail": 512, "depth2": 1, "inner_la": 1},

@@ -17,7 +17,9 @@ def _spd(n, kind, seed=0):
     return b @ b.T / n + (0.5 if kind == "gram" else 0.02) * np.eye(n)      # kappa ~ 10 / ~ 200
 
 
-@pytest.mark.parametrize("n,kind,nrhs", [(128, "reference", 1), (1024, "reference", 3), (2048, "gram", 130), (1152, "gram", 7), (4096, "reference", 16)])
+@pytest.mark.parametrize("n,kind,nrhs", [(128, "reference", 1), (1024, "reference", 3), (2048, "gram", 130), (1152, "gram", 7), (4096, "reference", 16),
+                                         # n % 128 == 0 but not a power of two below 1024: panel width = the power of two below n
+                                         (384, "reference", 2), (640, "gram", 5), (896, "reference", 1)])
 def test_solve_reaches_fp64_accuracy(n, kind, nrhs):
     from capital_amd import mixed
     from capital_amd.matrix import matrix
