@@ -57,6 +57,13 @@ def parse():
     ap.add_argument("--inner-la", type=int, default=-1, help="column-split look-ahead 1/0 (-1 = library default: off)")
     ap.add_argument("--serial-m", type=int, default=-1, help="remaining rows below which chain and bulk update are not overlapped (-1 = default)")
     ap.add_argument("--strip", type=int, default=0, help="multi-GPU: block rows per strip (0 = library default)")
+    ap.add_argument("--dist-mode", default="auto", choices=["auto", "safe", "overlap"],
+                    help="multi-GPU: safe = one communicator + one communication stream; overlap = small messages on their own "
+                         "communicator/stream; auto = safe first (warm-up + residual check + timing), then overlap under a host "
+                         "watchdog, the better of the two is reported (fallback to the safe figure if overlap makes no progress)")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "ipc"], help="multi-GPU strip exchange: RCCL all-gather or IPC peer copies")
+    ap.add_argument("--grid-rows", type=int, default=1, help="multi-GPU: process rows Pr of the Pr x Pc block-cyclic layout (1 = block columns only)")
+    ap.add_argument("--watchdog-s", type=float, default=0.0, help="multi-GPU: seconds without completion before a step counts as hung (0 = auto)")
     ap.add_argument("--complete-inv", type=int, default=-1,
                     help="-1 blocked Cholesky (headline), 0/1 reference cholinv semantics (R and R^-1)")
     ap.add_argument("--qr-rows", type=int, default=1 << 21, help="cacqr: rows per GPU")
@@ -72,37 +79,76 @@ def parse():
     return args
 
 
-def cpu_baseline(cpu_n):
-    """Reference CPU/MPI path on the host cores, bounded sample (about 10-30 s)."""
+def _largest_cube(limit):
+    c = 1
+    while (c + 1) ** 3 <= limit:
+        c += 1
+    return c ** 3
+
+
+def cpu_baseline(cpu_n, budget_s=90.0):
+    """Reference CPU/MPI path on the host cores (protocol bench/cholesky/cholinv.cpp:44-60), bounded to about `budget_s`
+    seconds: the REAL reference (oracle/_ref) on the largest cube of MPI ranks the host holds (up to 64 = its 4 x 4 x 4 grid;
+    upstream needs c == d), MKL 1 thread per rank, bcMult sweep at N = cpu_n, then N = 2 cpu_n with the best knobs if the
+    budget allows, plus the one-rank all-cores variant (MKL_THREADING_LAYER=GNU).  The best TFLOP/s (N^3/3) is reported
+    with the cores that produced it; every run is listed in `runs`."""
     exe = os.path.join(ROOT, "oracle", "_ref", "cholinv_ref")
     mpiexec = "/opt/conda/bin/mpiexec"
-    host = "%d host cores" % (os.cpu_count() or 0)
+    ncores = os.cpu_count() or 1
+    host = "%d host cores" % ncores
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")]
         if model:
             host += " (%s)" % model[0]
     except Exception:
         pass
+    t_start = time.time()
+    runs = []
+
+    def run_ref(ranks, nn, bc, threads, timeout):
+        env = dict(os.environ, MKL_NUM_THREADS=str(threads), OMP_NUM_THREADS=str(threads))
+        if threads > 1:
+            env["MKL_THREADING_LAYER"] = "GNU"        # the default Intel-OpenMP layer gives wrong answers here (SURVEY 8c)
+        try:
+            out = subprocess.run([mpiexec, "-n", str(ranks), exe, str(nn), "0", "1", str(bc), "0", "0", "1", "-", "1"],
+                                 env=env, capture_output=True, text=True, timeout=max(5.0, timeout)).stdout
+        except Exception:
+            return None
+        m = re.search(r"time=([\d.eE+-]+) residual=([\d.eE+-]+)", out)
+        if not m:
+            return None
+        t, res = float(m.group(1)), float(m.group(2))
+        r = {"ranks": ranks, "threads_per_rank": threads, "cores": ranks * threads, "n": nn, "bcMult": bc, "seconds": t,
+             "tflops": nn ** 3 / 3.0 / t / 1e12, "residual": res}
+        if res < 1e-14:
+            runs.append(r)
+            return r
+        return None
+
     if os.path.exists(exe) and os.path.exists(mpiexec):
-        env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
-        best = None
-        for bc in (-3, -2):
-            try:
-                out = subprocess.run([mpiexec, "-n", "8", exe, str(cpu_n), "0", "1", str(bc), "0", "0", "1", "-", "1"],
-                                     env=env, capture_output=True, text=True, timeout=300).stdout
-                m = re.search(r"time=([\d.eE+-]+) residual=([\d.eE+-]+)", out)
-                if m:
-                    t, res = float(m.group(1)), float(m.group(2))
-                    if res < 1e-14 and (best is None or t < best[0]):
-                        best = (t, bc, res)
-            except Exception:
-                pass
-        if best:
-            t, bc, res = best
-            return {"value": cpu_n ** 3 / 3.0 / t / 1e12, "unit": "TFLOP/s", "cores": 8, "kind": "reference", "host": host,
-                    "sample": "N=%d (bounded sample of the N=65536 workload): upstream cholinv, 8 MPI ranks (its own "
-                              "2x2x2 grid), MKL 1 thread/rank, Serialize+ReplicateCommComp, bcMult=%d, complete_inv=0, "
-                              "%.3f s/factor, residual %.2e" % (cpu_n, bc, t, res)}
+        ranks = _largest_cube(min(ncores, 64))
+        left = lambda: budget_s - (time.time() - t_start)
+        best_bc = None
+        for bc in (-2, -3, -1, 0):
+            if left() < 8:
+                break
+            r = run_ref(ranks, cpu_n, bc, 1, left())
+            if r and (best_bc is None or r["seconds"] < best_bc[0]):
+                best_bc = (r["seconds"], bc)
+        if best_bc and ncores >= 16 and left() > 32 * best_bc[0] + 10:     # next size up, same grid, best knob (8x the flops; a run = warm-up + timed factor + validation)
+            run_ref(ranks, 2 * cpu_n, best_bc[1], 1, left())
+        if left() > 15:                                                        # one rank, all cores inside MKL
+            run_ref(1, min(cpu_n, 16384), -2, min(ncores, 128), left())
+        if ranks != 8 and left() > 15:                                         # upstream's own 2 x 2 x 2 grid (round 1-2 comparator)
+            run_ref(8, cpu_n, best_bc[1] if best_bc else -2, 1, left())
+        if runs:
+            b = max(runs, key=lambda r: r["tflops"])
+            return {"value": b["tflops"], "unit": "TFLOP/s", "cores": b["cores"], "kind": "reference", "host": host,
+                    "sample": "N=%d (bounded sample of the N=65536 workload): upstream cholinv on %d MPI ranks x %d MKL thread(s), "
+                              "Serialize+ReplicateCommComp, bcMult=%d, complete_inv=0, %.3f s/factor, residual %.2e; best of %d runs "
+                              "in %.0f s" % (b["n"], b["ranks"], b["threads_per_rank"], b["bcMult"], b["seconds"], b["residual"],
+                                             len(runs), time.time() - t_start),
+                    "runs": runs}
     # fallback: the NumPy/LAPACK port of the same factorization on all host cores
     import numpy as np
     from oracle import capital_oracle as orc
@@ -226,6 +272,14 @@ def main():
         sys.exit(1)
 
 
+def _librccl_path():
+    try:
+        libs = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
+        return libs[0] if libs else None
+    except Exception:
+        return None
+
+
 def bench_cholesky(args, torch, L, C, rank, world, dist, emulate, timed, allreduce_sum):
     from capital_amd import _lib, cholinv, validate
     from capital_amd.matrix import matrix
@@ -246,34 +300,29 @@ def bench_cholesky(args, torch, L, C, rank, world, dist, emulate, timed, allredu
         sec = timed(lambda: cholinv.factor(A, pack, None), steps, warmup)
         return A, pack, sec
 
+    diag = {}
     if world == 1:
         A, pack, sec = single_gpu_case(n, args.complete_inv, args.steps, args.warmup)
         info = pack.last_info()
         parallelism = "1 GPU"
     else:
-        from capital_amd import dist_cholesky
-        ctx = dist_cholesky.setup(n, nb=args.nb or 0, comm=dist_cholesky.HostStagedComm() if emulate else None)
-        if args.strip:
-            ctx.set_option("strip", args.strip)
-        if args.depth2 >= 0:
-            ctx.set_option("depth2", args.depth2)
-        sec = timed(ctx.factor, args.steps, args.warmup)
-        info = ctx.last_info()
-        parallelism = "1x%d block-cyclic columns (nb=%d), RCCL over xGMI" % (world, ctx.nb)
+        ctx, sec, info, diag = multi_gpu_case(args, torch, L, C, rank, world, dist, emulate, allreduce_sum)
+        parallelism = diag.pop("parallelism")
 
-    tflops = n ** 3 / 3.0 / sec / 1e12
+    tflops = (n ** 3 / 3.0 / sec / 1e12) if sec else None
     out = {"metric": "fp64 Cholesky TFLOP/s (N^3/3 per wall-second of one warm factor call), N=%d" % n,
            "value": tflops, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "ms_per_step": sec * 1e3 if sec else None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "N=%d fp64 Cholesky A=R^T R, upstream distribute_symmetric(diag-dominant) input generated on "
                                   "the GPU, resident in HBM; complete_inv=%d" % (n, args.complete_inv),
                       "parallelism": parallelism, "info": int(info),
-                      "pct_of_fp64_mfma_peak_per_gpu": 100.0 * tflops / (FP64_MFMA_PEAK_TF * world)}}
-    ok = int(info) == 0
+                      "pct_of_fp64_mfma_peak_per_gpu": (100.0 * tflops / (FP64_MFMA_PEAK_TF * world)) if tflops else None}}
+    out["config"].update(diag)
+    ok = int(info) == 0 and sec is not None
 
     # ---- parity of the result the timed loop left behind (outside the timed region)
-    if not args.no_check:
+    if not args.no_check and sec is not None:
         if world == 1:
             res = validate.cholesky.residual(A, pack)
             R = cholinv.construct_R(pack)
@@ -281,10 +330,7 @@ def bench_cholesky(args, torch, L, C, rank, world, dist, emulate, timed, allredu
             del R
         else:
             res = None
-            Rl = ctx.local_R_device()
-            gcols = torch.from_numpy(dist_cholesky.global_cols_of_rank(n, ctx.nb, world, rank)).to(ctx.device)
-            probe = validate.cholesky.probe(ctx.A[: ctx.local_cols, :n].t(), Rl[: ctx.local_cols, :n].t(), gcols, allreduce=allreduce_sum)
-            del Rl
+            probe = ctx.probe(allreduce_sum)
         out["config"]["residual"] = res if res is not None else probe
         out["config"]["residual_kind"] = ("||R^T R - A||_F/||A||_F over the upper triangle (test/cholesky/validate.hpp:33-46)"
                                           if res is not None else "probe")
@@ -305,21 +351,12 @@ def bench_cholesky(args, torch, L, C, rank, world, dist, emulate, timed, allredu
                                "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF,
                                "launches": nl.value, "avg_launch_ms": ms.value / nl.value,
                                "algorithmic_flops_per_launch_avg": fl.value / nl.value, "traffic": traffic_from_profile(n, args)}
-    if world > 1 and not emulate:
-        ctx.set_option("profile", 1)
-        ctx.factor(); torch.cuda.synchronize()
-        nl, ms, fl = C.c_int64(0), C.c_double(0), C.c_double(0)
-        _lib.check(L.cap_dist_profile(ctx.plan, C.byref(nl), C.byref(ms), C.byref(fl)))
-        ctx.set_option("profile", 0)
-        if rank == 0 and nl.value:
-            ach = fl.value / (ms.value * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "dgemm_tn_dma_kernel<1> (rank 0's share of the trailing update)",
-                               "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF,
-                               "launches": nl.value, "avg_launch_ms": ms.value / nl.value,
-                               "algorithmic_flops_per_launch_avg": fl.value / nl.value, "traffic": None,
-                               "busy_ms_of_step": ms.value}
+    if world > 1 and sec is not None and not emulate:
+        r = ctx.roofline(L, C)
+        if rank == 0 and r:
+            out["roofline"] = r
 
-    # ---- the other single-GPU configurations the judge asked to see in a driver-run record
+    # ---- the other configurations the judge asked to see in a driver-run record (1 GPU, default run only)
     if rank == 0 and world == 1 and not args.no_extra and args.complete_inv < 0 and n == 65536:
         del A, pack
         torch.cuda.empty_cache()
@@ -330,18 +367,180 @@ def bench_cholesky(args, torch, L, C, rank, world, dist, emulate, timed, allredu
             i2 = p2.last_info()
             r2 = validate.cholesky.residual(A2, p2) if not args.no_check else None
             tf = nn ** 3 / 3.0 / s2 / 1e12
-            extra.append({"workload": label, "n": nn, "complete_inv": ci, "value": tf, "unit": "TFLOP/s (N^3/3)", "ms_per_step": s2 * 1e3,
-                          "pct_of_fp64_mfma_peak": 100.0 * tf / FP64_MFMA_PEAK_TF, "info": int(i2), "residual": r2})
+            e = {"workload": label, "n": nn, "complete_inv": ci, "value": tf, "unit": "TFLOP/s (N^3/3)", "ms_per_step": s2 * 1e3,
+                 "pct_of_fp64_mfma_peak": 100.0 * tf / FP64_MFMA_PEAK_TF, "info": int(i2), "residual": r2}
+            if ci == 0:   # true flops: N^3/3 (factor) + 2 (N/2)^3/3 (the two diagonal blocks of R^-1, split = 1)
+                true_tf = (nn ** 3 / 3.0 + nn ** 3 / 12.0) / s2 / 1e12
+                e["true_flops_tflops"] = true_tf; e["true_flops_frac_of_peak"] = true_tf / FP64_MFMA_PEAK_TF
+            extra.append(e)
             ok = ok and int(i2) == 0 and (r2 is None or r2 <= RES_TOL)
             del A2, p2
+            torch.cuda.empty_cache()
+        # BASELINE configs[3] (per-GPU shape) and configs[4]'s method on one GPU, each with its own roofline and residual
+        class _Sub:
+            pass
+        for wl in ("cacqr", "mixed"):
+            sub = _Sub(); sub.__dict__.update(vars(args))
+            sub.no_cpu_baseline = True; sub.warmup = 1
+            try:
+                if wl == "cacqr":
+                    sub.steps = 20
+                    o2, k2 = bench_cacqr(sub, torch, L, C, rank, world, dist, emulate, timed, allreduce_sum)
+                else:
+                    sub.steps = 2
+                    o2, k2 = bench_mixed(sub, torch, L, C, rank, world, timed)
+            except Exception as ex:      # an extra must not take the headline down with it; it is reported as failed
+                o2, k2 = {"metric": wl, "value": None, "error": repr(ex)}, False
+            extra.append({"workload": o2.get("metric"), "value": o2.get("value"), "unit": o2.get("unit"), "ms_per_step": o2.get("ms_per_step"),
+                          "steps": o2.get("steps"), "dtype": o2.get("dtype"), "config": o2.get("config"), "roofline": o2.get("roofline"),
+                          "error": o2.get("error")})
+            ok = ok and k2
             torch.cuda.empty_cache()
         out["extra_configs"] = extra
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n)
     if not ok:
         out["value"] = None
-        out["error"] = "factorization failed its parity gate (info != 0 or residual above %g)" % RES_TOL
+        out["error"] = "factorization failed its parity gate (info != 0 or residual above %g)" % RES_TOL if sec is not None else \
+                       "no mode of the multi-GPU schedule completed (see config.watchdog)"
     return out, ok
+
+
+def multi_gpu_case(args, torch, L, C, rank, world, dist, emulate, allreduce_sum):
+    """N > 1: the distributed schedule (csrc/dist.hip) with self-diagnosis.  Returns (ctx, seconds per factor or None, info, diag).
+
+    First contact with real multi-rank RCCL must yield a number, not a hang:
+      1. safe mode (one communicator, one communication stream, collectives in program order): warm-up, residual check, timing;
+      2. overlapped mode under a HOST watchdog: completion is polled (event query), never waited for; if a step makes no
+         progress within the limit, every rank prints how far its event chain got (cap_dist_progress) and the safe-mode
+         figure is reported with "fallback": true.  The control plane (barriers, max over ranks) runs over gloo on the host
+         so a stuck GPU queue cannot block it."""
+    import ctypes
+    from capital_amd import _lib, dist_cholesky
+    n = args.n
+    ctl = None if emulate else dist.new_group(backend="gloo")
+
+    def ctl_barrier():
+        dist.barrier(group=ctl)
+
+    def ctl_max(x):
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
+        return float(t.item())
+
+    if emulate:
+        from tests.host_staged import HostStagedComm
+        comm = HostStagedComm()
+    else:
+        comm = dist_cholesky.RcclComm()
+    ctx = dist_cholesky.setup(n, nb=args.nb or 0, comm=comm, grid_rows=args.grid_rows)
+    if args.strip:
+        ctx.set_option("strip", args.strip)
+    if args.depth2 >= 0:
+        ctx.set_option("depth2", args.depth2)
+    if args.exchange == "ipc":
+        ctx.set_option("ipc", 1)
+    nr, rk, dev = C.c_int(0), C.c_int(0), C.c_int(0)
+    _lib.check(L.cap_comm_query(comm.handle, C.byref(nr), C.byref(rk), C.byref(dev)))
+    diag = {"n_ranks_seen": nr.value, "rank_seen": rk.value, "device": dev.value, "librccl": _librccl_path(),
+            "comm_backend": {0: "self", 1: "rccl", 2: "host-staged (emulation)"}[int(L.cap_comm_backend(comm.handle))],
+            "exchange": args.exchange, "grid": "%dx%d" % (ctx.grid_rows, world // ctx.grid_rows),
+            "parallelism": "%dx%d block-cyclic (nb=%d), RCCL over xGMI" % (ctx.grid_rows, world // ctx.grid_rows, ctx.nb)}
+    seen = ctl_max(-nr.value)            # every rank must see the same communicator size
+    if int(-seen) != world or nr.value != world:
+        diag["error"] = "communicator reports %d ranks, launcher %d" % (nr.value, world)
+
+    def wait_gpu(limit_s):
+        """Completion of everything enqueued on the current stream (the factor joins its helper streams into it), polled."""
+        ev = torch.cuda.Event(); ev.record()
+        t0 = time.perf_counter()
+        while not ev.query():
+            if time.perf_counter() - t0 > limit_s:
+                return False
+            time.sleep(2e-4)
+        return True
+
+    def progress():
+        out9 = (ctypes.c_int64 * 9)()
+        L.cap_dist_progress(ctx.plan, out9)
+        v = list(out9)
+        return {"fact": v[0], "msg": v[1], "rowdone": v[2], "solved": v[3], "gather": v[4], "head2": v[5], "rest": v[6],
+                "block_rows": v[7], "strips": v[8]}
+
+    def timed_watch(steps, warmup, limit_s):
+        """barrier + sync | K factor calls | sync + barrier, max over ranks - with the syncs polled; None when a rank hangs."""
+        for _ in range(warmup):
+            ctx.factor()
+        hung = ctl_max(0.0 if wait_gpu(limit_s * max(warmup, 1)) else 1.0)
+        if hung:
+            return None
+        ctl_barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.factor()
+        okw = wait_gpu(limit_s * steps)
+        if ctl_max(0.0 if okw else 1.0):
+            return None
+        torch.cuda.synchronize()
+        ctl_barrier()
+        return ctl_max(time.perf_counter() - t0) / steps
+
+    limit = args.watchdog_s or max(60.0, 20.0 * (n / 65536.0) ** 3 * 4.0)
+    modes = {"auto": ["safe", "overlap"], "safe": ["safe"], "overlap": ["overlap"]}[args.dist_mode]
+    results, wd = {}, {}
+    for mode in modes:
+        ctx.set_option("safe", 1 if mode == "safe" else 0)
+        sec = timed_watch(args.steps, max(args.warmup, 1), limit)
+        if sec is None:
+            wd[mode] = {"hung": True, "limit_s": limit, "progress_rank%d" % rank: progress()}
+            print("[bench rank %d] %s mode made no progress within %.0f s: %s" % (rank, mode, limit, json.dumps(wd[mode])), file=sys.stderr, flush=True)
+            break                        # the GPU queues are stuck: nothing further can run in this process
+        info = ctx.last_info()
+        probe = ctx.probe(allreduce_sum) if not args.no_check else 0.0
+        results[mode] = {"sec": sec, "info": int(info), "probe": probe, "tflops": n ** 3 / 3.0 / sec / 1e12}
+        if int(info) != 0 or not (probe <= 1e-13):
+            break
+    diag["modes"] = {m: {"tflops": r["tflops"], "ms_per_step": r["sec"] * 1e3, "info": r["info"], "probe_residual": r["probe"]} for m, r in results.items()}
+    if wd:
+        diag["watchdog"] = wd
+    good = {m: r for m, r in results.items() if r["info"] == 0 and r["probe"] <= 1e-13}
+    if not good:
+        if wd:
+            _emit_and_exit_on_hang(args, rank, n, world, diag, None)
+        return ctx, None, (list(results.values())[0]["info"] if results else -1), diag
+    best = min(good, key=lambda m: good[m]["sec"])
+    diag["mode"] = best
+    diag["fallback"] = bool(wd)
+    if wd:
+        # a mode hung: its kernels still occupy the queues, so nothing more can be measured or checked in this process -
+        # report the mode that completed, and leave without touching the GPU again
+        _emit_and_exit_on_hang(args, rank, n, world, diag, good[best])
+    if list(results)[-1] != best:        # leave the plan holding the result of the reported mode
+        ctx.set_option("safe", 1 if best == "safe" else 0)
+        ctx.factor(); torch.cuda.synchronize()
+    return ctx, good[best]["sec"], good[best]["info"], diag
+
+
+def _emit_and_exit_on_hang(args, rank, n, world, diag, res):
+    if rank == 0:
+        par = diag.pop("parallelism", "")
+        out = {"metric": "fp64 Cholesky TFLOP/s (N^3/3 per wall-second of one warm factor call), N=%d" % n,
+               "value": res["tflops"] if res else None, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": res["sec"] * 1e3 if res else None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic", "fallback": True,
+               "config": dict({"workload": "N=%d fp64 Cholesky A=R^T R, upstream distribute_symmetric(diag-dominant) input generated on the "
+                                           "GPU, resident in HBM; complete_inv=-1" % n, "parallelism": par,
+                               "info": res["info"] if res else -1, "residual": res["probe"] if res else None, "residual_kind": "probe",
+                               "pct_of_fp64_mfma_peak_per_gpu": 100.0 * res["tflops"] / (FP64_MFMA_PEAK_TF * world) if res else None}, **diag)}
+        if not res:
+            out["error"] = "no mode of the multi-GPU schedule completed (see config.watchdog)"
+        print(json.dumps(out), flush=True)
+    sys.stdout.flush(); sys.stderr.flush()
+    time.sleep(1.0)
+    os._exit(0 if res else 1)
+
+
+BF16_MFMA_PEAK_TF = 2500.0    # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline figure includes 2:1 sparsity)
 
 
 def bench_mixed(args, torch, L, C, rank, world, timed):
@@ -349,7 +548,7 @@ def bench_mixed(args, torch, L, C, rank, world, timed):
     sides to fp64 accuracy; value = fp64-equivalent TFLOP/s (N^3/3 per second of factor + solve)."""
     if world != 1:
         raise SystemExit("--workload mixed runs on one GPU (the multi-GPU form of config 5 is not built)")
-    from capital_amd import mixed, cholinv
+    from capital_amd import blas, cholinv, mixed
     from capital_amd.matrix import matrix
     n, nrhs = args.n, 8
     A = matrix(n, n, 1, 1); A.distribute_symmetric(0, 0, 1, 1, 0, True)
@@ -365,10 +564,38 @@ def bench_mixed(args, torch, L, C, rank, world, timed):
     info = p.last_info()
     tf_only = timed(lambda: p.factor(A), 2, 0)
     tflops = n ** 3 / 3.0 / sec / 1e12
-    # independent check of the solution: ||A X - B||_F / ||B||_F with torch fp64 matmul
+    # check 1: ||A X - B||_F / ||B||_F recomputed with torch's fp64 matmul (rocBLAS), not this library's GEMM.  On the
+    # reference's diagonally dominant input (a_ii ~ N, kappa ~ 1) both residual GEMMs round to the same values element by
+    # element - every dot product is dominated by one O(N) term, the rest sums to far below its ulp - so the two norms agree to
+    # the last digit although the kernels differ; the perturbation below shows the check reacts to X.
     r = A.view() @ X.view() - B.view()
     indep = float(r.norm() / B.view().norm())
-    ok = int(info) == 0 and relres == relres and relres <= 1e-14 and indep <= 1e-13
+    Xp = X.view().clone(); Xp[0, 0] *= (1.0 + 1e-10)
+    indep_perturbed = float((A.view() @ Xp - B.view()).norm() / B.view().norm())
+    del r, Xp
+    # check 2: the same system through the fp64 path of this library (blocked Cholesky + two blocked TRSMs): a different algorithm
+    x_diff = None
+    if not args.no_check:
+        pack = cholinv.info(-1, 1, -5, 'U'); cholinv.factor(A, pack, None)
+        R = cholinv.construct_R(pack)
+        Xf = matrix(nrhs, n, 1, 1); Xf.view().copy_(B.view())
+        for trans in (1, 0):
+            blas.engine._trsm(R.data(), Xf.data(), n, nrhs, R.ld(), Xf.ld(),
+                              blas.ArgPack_trmm(blas.Order.AblasColumnMajor, blas.Side.AblasLeft, blas.UpLo.AblasUpper, blas.Transpose(trans),
+                                                blas.Diag.AblasNonUnit, 1.0))
+        x_diff = float((X.view() - Xf.view()).norm() / Xf.view().norm())
+        del pack, R, Xf
+        torch.cuda.empty_cache()
+    ok = int(info) == 0 and relres == relres and relres <= 1e-14 and indep <= 1e-13 and indep_perturbed > 10 * indep and (x_diff is None or x_diff <= 1e-12)
+    # roofline of the dominant kernel (bf16 trailing update), measured live with HIP events on its launch stream
+    nl, ms, fl, by = p.profile_update(A)
+    roof = {"bound": "hbm", "kernel": "bf16_tn_kernel (trailing update C32 -= P16^T P16: fp32 C read-modify-write, K/4 flop per byte = 256 at K = 1024 "
+                                      "against a ridge of 312)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+    if nl:
+        gbs, tf16 = by / (ms * 1e-3) / 1e9, fl / (ms * 1e-3) / 1e12
+        roof.update({"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "launches": nl, "avg_launch_ms": ms / nl,
+                     "algorithmic_bytes_per_launch_avg": by / nl, "algorithmic_flops_per_launch_avg": fl / nl,
+                     "mfma": {"achieved": tf16, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s (bf16, dense)", "frac": tf16 / BF16_MFMA_PEAK_TF}})
     out = {"metric": "fp64-equivalent Cholesky-solve TFLOP/s (N^3/3 per wall-second of bf16-MFMA factor + fp64 refinement), N=%d" % n,
            "value": tflops if ok else None, "unit": "TFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16 MFMA (fp32 accumulate) factor, f64 refinement",
@@ -376,11 +603,13 @@ def bench_mixed(args, torch, L, C, rank, world, timed):
            "config": {"workload": "N=%d mixed-precision Cholesky solve, %d right-hand sides, upstream distribute_symmetric input resident in HBM" % (n, nrhs),
                       "parallelism": "1 GPU", "info": int(info), "refinement_sweeps": int(sweeps), "residual": relres,
                       "residual_kind": "||B - A X||_F/||B||_F (fp64, library kernels)", "independent_residual": indep,
-                      "factor_ms": tf_only * 1e3, "factor_fp64_equiv_tflops": n ** 3 / 3.0 / tf_only / 1e12},
-           "roofline": {"bound": "hbm", "kernel": "bf16_tn_kernel (trailing update, fp32 C read-modify-write: K/4 flop per byte at K = 1024)",
-                        "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}}
+                      "independent_residual_kind": "same norm with torch fp64 matmul (rocBLAS); after scaling X[0,0] by 1+1e-10 it reads "
+                                                   "independent_residual_perturbed", "independent_residual_perturbed": indep_perturbed,
+                      "x_vs_fp64_path": x_diff, "factor_ms": tf_only * 1e3, "factor_fp64_equiv_tflops": n ** 3 / 3.0 / tf_only / 1e12},
+           "roofline": roof}
     if not ok:
         out["error"] = "mixed-precision solve failed its parity gate"
+    p.close()
     return out, ok
 
 
@@ -394,7 +623,11 @@ def bench_cacqr(args, torch, L, C, rank, world, dist, emulate, timed, allreduce_
         pass
     topo = None
     if world > 1:
-        comm = dist_cholesky.HostStagedComm() if emulate else dist_cholesky.RcclComm()
+        if emulate:
+            from tests.host_staged import HostStagedComm      # tests only (CAPITAL_BENCH_EMULATE=1)
+            comm = HostStagedComm()
+        else:
+            comm = dist_cholesky.RcclComm()
         topo = Topo(); topo.c, topo.d, topo.x, topo.y, topo.z = 1, world, 0, rank, 0
         topo.rank, topo.size, topo.world = rank, world, comm.handle
     A = matrix(n, m * world, 1, world)

@@ -53,6 +53,7 @@ SIGNATURES = {
     "cap_comm_split": (cint, [ptr, cint, cint, C.POINTER(ptr)]),
     "cap_comm_dup": (cint, [ptr, C.POINTER(ptr)]),
     "cap_comm_backend": (cint, [ptr]),
+    "cap_comm_query": (cint, [ptr, C.POINTER(cint), C.POINTER(cint), C.POINTER(cint)]),
     "cap_comm_reduce_sum": (cint, [ptr, ptr, i64, cint, ptr]),
     "cap_topo_coords": (cint, [cint, cint, cint, cint, C.POINTER(cint), C.POINTER(cint), C.POINTER(cint), C.POINTER(cint)]),
     "cap_topo_create": (cint, [C.POINTER(ptr), cint, ptr, cint, cint, cint]),
@@ -88,6 +89,8 @@ SIGNATURES = {
     "cap_dist_set_option": (cint, [ptr, C.c_char_p, i64]),
     "cap_dist_get_option": (i64, [ptr, C.c_char_p]),
     "cap_dist_profile": (cint, [ptr, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]),
+    "cap_dist_profile_streams": (cint, [ptr, C.POINTER(dbl)]),
+    "cap_dist_progress": (cint, [ptr, C.POINTER(i64)]),
     "cap_fill_symmetric_bc": (cint, [ptr, i64, i64, i64, cint, cint, cint, ptr]),
     "cap_bc_owner": (cint, [i64, cint]),
     "cap_bc_local_block": (i64, [i64, cint]),
@@ -102,6 +105,8 @@ SIGNATURES = {
     "cap_mpchol_info": (cint, [ptr, ptr, C.POINTER(i64)]),
     "cap_mpchol_solve": (cint, [ptr, ptr, i64, ptr, i64, ptr, i64, i64, cint, dbl, C.POINTER(cint), C.POINTER(dbl), ptr]),
     "cap_mpchol_R32_ptr": (ptr, [ptr, C.POINTER(i64)]),
+    "cap_mpchol_set_option": (cint, [ptr, C.c_char_p, i64]),
+    "cap_mpchol_profile": (cint, [ptr, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]),
     "cap_cacqr_plan_create": (cint, [C.POINTER(ptr), i64, i64, cint, ptr]),
     "cap_cacqr_plan_create_grid": (cint, [C.POINTER(ptr), i64, i64, cint, ptr]),
     "cap_cacqr_local_cols": (i64, [ptr]),

@@ -149,6 +149,20 @@ int cap_comm_size(const cap_comm* c) { return c ? c->size : 1; }
 // 0 self / NULL, 1 RCCL, 2 host-staged
 int cap_comm_backend(const cap_comm* c) { return (!c || c->self) ? 0 : (c->cb_allgather ? 2 : 1); }
 
+// What the communication library itself reports (self-diagnosis of multi-GPU runs): ranks and this rank's index as seen by
+// RCCL (ncclCommCount / ncclCommUserRank) and the device the communicator is bound to; for the other backends the stored values.
+int cap_comm_query(const cap_comm* c, int* nranks, int* rank, int* device) {
+  if (!nranks || !rank || !device) return CAP_ERR_ARG;
+  *nranks = c ? c->size : 1; *rank = c ? c->rank : 0; *device = -1;
+  (void)hipGetDevice(device);
+  if (c && c->nccl) {
+    CAP_NCCL(ncclCommCount(c->nccl, nranks));
+    CAP_NCCL(ncclCommUserRank(c->nccl, rank));
+    CAP_NCCL(ncclCommCuDevice(c->nccl, device));
+  }
+  return CAP_OK;
+}
+
 // MPI_Allreduce(MPI_IN_PLACE, SUM) - summa.hpp:236, cacqr/policy.h:22,82
 int cap_comm_allreduce_sum(cap_comm* c, double* buf, int64_t count, void* stream) {
   if (!c || c->self || count == 0) return CAP_OK;

@@ -63,6 +63,14 @@ struct cap_dist_plan {
   uint64_t jitter_state; int jitter_max_us;
   // live profile of the bulk update (HIP events on its stream)
   int profile; std::vector<hipEvent_t> prof_ev; std::vector<double> prof_flops; int prof_used;
+  // profile mode also brackets the other launch groups: busy ms per stream role (cap_dist_profile_streams)
+  //   0 panel: diagonal-block chains   1 panel: block-row solves + in-strip updates   2 panel: HEAD updates
+  //   3 msg broadcasts                 4 strip exchange (all-gather / peer copies)    5 main: bulk updates
+  std::vector<hipEvent_t> bk_ev; std::vector<int> bk_kind; int bk_used;
+  // safe mode: ONE communicator and ONE communication stream - broadcasts and strip exchanges are issued in program order
+  // (the data dependencies order them anyway: msg(a), msg(b), exchange(t), msg(a'), ...); the default keeps the small
+  // messages on their own communicator + stream
+  int safe;
 };
 
 namespace {
@@ -120,6 +128,21 @@ int jitter(cap_dist_plan* d, hipStream_t s) {
   return CAP_OK;
 }
 
+// profile mode: bracket a launch group on stream s (kind: see cap_dist_plan::bk_kind)
+struct Bucket {
+  cap_dist_plan* d; hipStream_t s; hipEvent_t e1; bool on;
+  Bucket(cap_dist_plan* d_, int kind, hipStream_t s_) : d(d_), s(s_), e1(nullptr), on(false) {
+    if (!d->profile) return;
+    if ((size_t)d->bk_used + 2 > d->bk_ev.size())
+      for (int i = 0; i < 64; i++) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; d->bk_ev.push_back(e); d->bk_kind.push_back(0); }
+    hipEvent_t e0 = d->bk_ev[(size_t)d->bk_used]; e1 = d->bk_ev[(size_t)d->bk_used + 1];
+    d->bk_kind[(size_t)d->bk_used] = kind;
+    if (hipEventRecord(e0, s) != hipSuccess) return;
+    on = true;
+  }
+  ~Bucket() { if (on && hipEventRecord(e1, s) == hipSuccess) d->bk_used += 2; }
+};
+
 int ensure_events(cap_dist_plan* d) {
   if (!d->ev_msg.empty()) return CAP_OK;
   auto mk = [&](std::vector<hipEvent_t>& v, size_t cnt) -> int {
@@ -146,6 +169,7 @@ int ensure_events(cap_dist_plan* d) {
 int update(cap_dist_plan* d, int64_t m, int64_t nloc, int64_t K, const double* G, int64_t piece, const int* gstart, const double* B,
            double* C, int64_t J0, int64_t lb0, hipStream_t s, bool prof) {
   if (m <= 0 || nloc <= 0) return CAP_OK;
+  CapRange range("CI::tmu");
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (prof && d->profile) {
     if ((size_t)d->prof_used + 2 > d->prof_ev.size())
@@ -219,7 +243,7 @@ int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* 
   d->strip = d->nblk >= 8 ? 2 : 1; d->depth2 = 1;
   d->jitter_state = 0x9E3779B97F4A7C15ull * (uint64_t)(d->p + 1); d->jitter_max_us = 0;
   d->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
-  d->profile = 0; d->prof_used = 0;
+  d->profile = 0; d->prof_used = 0; d->bk_used = 0; d->safe = 0;
   d->wcap = cap_rec_work_size(nb);
   if (cap_comm_size(comm) > 1 || cap_comm_backend(comm) != 0) {
     int st = cap_comm_dup(comm, &d->comm2);
@@ -261,6 +285,7 @@ int cap_dist_plan_destroy(cap_dist_plan* d) {
     (void)hipStreamDestroy(d->s_panel); (void)hipStreamDestroy(d->s_comm); (void)hipStreamDestroy(d->s_msg);
   }
   for (hipEvent_t e : d->prof_ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : d->bk_ev) (void)hipEventDestroy(e);
   if (d->comm2) cap_comm_destroy(d->comm2);
   delete d;
   return CAP_OK;
@@ -275,6 +300,7 @@ int cap_dist_set_option(cap_dist_plan* d, const char* key, int64_t value) {
   if (k == "jitter_us") { if (value < 0 || value > 100000) return CAP_ERR_ARG; d->jitter_max_us = (int)value; return CAP_OK; }
   if (k == "jitter_seed") { d->jitter_state = 0x9E3779B97F4A7C15ull * (uint64_t)(value + 1) + (uint64_t)d->p; return CAP_OK; }
   if (k == "profile") { d->profile = value != 0; return CAP_OK; }
+  if (k == "safe") { d->safe = value != 0; return CAP_OK; }
   return CAP_ERR_ARG;
 }
 
@@ -285,6 +311,7 @@ int64_t cap_dist_get_option(const cap_dist_plan* d, const char* key) {
   if (k == "depth2") return d->depth2;
   if (k == "occ1_m") return d->occ1_m;
   if (k == "jitter_us") return d->jitter_max_us;
+  if (k == "safe") return d->safe;
   if (k == "nb") return d->nb;
   if (k == "n") return d->n;
   if (k == "npad") return d->npad;
@@ -299,10 +326,11 @@ double* cap_dist_R_ptr(cap_dist_plan* d, int64_t* ld) { if (!d) return nullptr; 
 int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* stream) {
   if (!d || (d->lc_valid > 0 && (!Aloc || lda < d->n))) return CAP_ERR_ARG;
   CAP_TRY(ensure_events(d));
-  hipStream_t s0 = cap_stream(stream), s1 = d->s_panel, sc = d->s_comm, sm = d->s_msg;
+  hipStream_t s0 = cap_stream(stream), s1 = d->s_panel, sc = d->s_comm, sm = d->safe ? d->s_comm : d->s_msg;
+  cap_comm* cmsg = (d->safe || !d->comm2) ? d->comm : d->comm2;
   const int64_t n = d->n, npad = d->npad, nb = d->nb, nblk = d->nblk, P = d->P, p = d->p, ld = d->ld;
   const int64_t nb2 = nb * nb;
-  d->prof_used = 0; d->prof_flops.clear();
+  d->prof_used = 0; d->prof_flops.clear(); d->bk_used = 0;
   CAP_HIP(hipMemsetAsync(d->info_dev, 0, sizeof(int), s0));
   if (d->lc_valid > 0) CAP_TRY(cap_copy_rect(Aloc, lda, d->R, ld, n, d->lc_valid, s0));
   if (npad != n && d->lc > 0) {
@@ -346,7 +374,10 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
           const double* Sab = S + (k / P - lbS) * nb * ldS;
           CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, nb, nb, -1.0, Sab, ldS, Sab, ldS, 1.0, D, ld, 1, s1, 2));
         }
-        CAP_TRY(cap_rec_cholinv_full(D, ld, Dinv, nb, nb, d->W, d->wcap, d->info_dev, s1, k * nb));
+        {
+          CapRange range("CI::factor_diag"); Bucket bk(d, 0, s1);
+          CAP_TRY(cap_rec_cholinv_full(D, ld, Dinv, nb, nb, d->W, d->wcap, d->info_dev, s1, k * nb));
+        }
         if (r == 1) CAP_TRY(cap_copy_rect(S + (k / P - lbS) * nb * ldS, ldS, mb, nb, nb, nb, s1));   // R(a,b) rides along
         CAP_HIP(hipEventRecord(d->ev_fact[k], s1));
         CAP_HIP(hipStreamWaitEvent(sm, d->ev_fact[k], 0));
@@ -355,7 +386,7 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
       }
       // ---- msg: msg(k) = [ R(k-1,k) | Dinv(k) ] from the owner, on the small-message communicator
       CAP_TRY(jitter(d, sm));
-      CAP_TRY(cap_comm_bcast(d->comm2, mb, 2 * nb2, owner, (void*)sm));
+      { Bucket bk(d, 3, sm); CAP_TRY(cap_comm_bcast(cmsg, mb, 2 * nb2, owner, (void*)sm)); }
       CAP_HIP(hipEventRecord(d->ev_msg[k], sm));
 
       // ---- panel, every rank: block row k of my columns J > k
@@ -364,6 +395,7 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
       const int64_t lbk = lbfirst(p, k, P);
       const int64_t ncols = (d->nloc_blocks - lbk) * nb;
       if (ncols > 0) {
+        CapRange range("CI::trsm"); Bucket bk(d, 1, s1);
         CAP_TRY(jitter(d, s1));
         double* Rrow = d->R + k * nb + lbk * nb * ld;
         double* Scol = S + (lbk - lbS) * nb * ldS;                // my columns J > k inside the strip buffer
@@ -389,7 +421,7 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
     CAP_HIP(hipStreamWaitEvent(sc, d->ev_solved[t], 0));
     if (t >= 2) CAP_HIP(hipStreamWaitEvent(sc, d->ev_rest[t - 2], 0));   // G[par] was read by the bulk update of strip t-2
     CAP_TRY(jitter(d, sc));
-    CAP_TRY(cap_comm_allgather(d->comm, S + (lbe - lbS) * nb * ldS, G, piece, (void*)sc));
+    { Bucket bk(d, 4, sc); CAP_TRY(cap_comm_allgather(d->comm, S + (lbe - lbS) * nb * ldS, G, piece, (void*)sc)); }
     CAP_HIP(hipEventRecord(d->ev_gather[t], sc));
 
     // ---- panel: HEAD - bring the rows of strip t+1 up to date with strip t (my columns J >= e)
@@ -398,7 +430,7 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
     CAP_HIP(hipStreamWaitEvent(s1, d->ev_gather[t], 0));
     if (t >= 1) CAP_HIP(hipStreamWaitEvent(s1, d->ev_head2[t - 1], 0));   // strip t-1's bulk update has passed these rows
     CAP_TRY(jitter(d, s1));
-    CAP_TRY(update(d, q1 * nb, ncols_e, ldS, G, piece, gstart, G + p * piece, d->R + e * nb + lbe * nb * ld, e, lbe, s1, false));
+    { Bucket bk(d, 2, s1); CAP_TRY(update(d, q1 * nb, ncols_e, ldS, G, piece, gstart, G + p * piece, d->R + e * nb + lbe * nb * ld, e, lbe, s1, false)); }
 
     // ---- main: bulk update of the rows below strip t+1 (my columns J >= e2), upper staircase
     CAP_HIP(hipStreamWaitEvent(s0, d->ev_gather[t], 0));
@@ -475,6 +507,52 @@ int cap_dist_profile(cap_dist_plan* d, int64_t* launches, double* ms_total, doub
     CAP_HIP(hipEventElapsedTime(&ms, d->prof_ev[i], d->prof_ev[i + 1]));
     *ms_total += ms; *flops_total += d->prof_flops[i / 2]; (*launches)++;
   }
+  return CAP_OK;
+}
+
+// busy milliseconds per stream role of the LAST factor call in profile mode (see cap_dist_plan::bk_kind): out[0..5] =
+// chains, row solves, HEAD updates, message broadcasts, strip exchanges, bulk updates.  Synchronises on the recorded events.
+int cap_dist_profile_streams(cap_dist_plan* d, double* out6) {
+  if (!d || !out6) return CAP_ERR_ARG;
+  for (int i = 0; i < 6; i++) out6[i] = 0.0;
+  for (int i = 0; i + 1 < d->bk_used; i += 2) {
+    CAP_HIP(hipEventSynchronize(d->bk_ev[(size_t)i + 1]));
+    float ms = 0;
+    CAP_HIP(hipEventElapsedTime(&ms, d->bk_ev[(size_t)i], d->bk_ev[(size_t)i + 1]));
+    const int kind = d->bk_kind[(size_t)i];
+    if (kind >= 0 && kind < 5) out6[kind] += ms;
+  }
+  for (int i = 0; i + 1 < d->prof_used; i += 2) {
+    CAP_HIP(hipEventSynchronize(d->prof_ev[(size_t)i + 1]));
+    float ms = 0;
+    CAP_HIP(hipEventElapsedTime(&ms, d->prof_ev[(size_t)i], d->prof_ev[(size_t)i + 1]));
+    out6[5] += ms;
+  }
+  return CAP_OK;
+}
+
+// Watchdog support: how far the event chain of the factor call in flight has got, WITHOUT blocking.  out[0..6] = number of
+// leading events already complete among  fact (owner's diagonal block), msg (broadcast), rowdone (block row solved) - per
+// block row - and solved, gather (strip exchanged), head2, rest (bulk update) - per strip; out[7] = block rows, out[8] = strips.
+int cap_dist_progress(cap_dist_plan* d, int64_t* out9) {
+  if (!d || !out9) return CAP_ERR_ARG;
+  for (int i = 0; i < 9; i++) out9[i] = 0;
+  if (d->ev_msg.empty()) return CAP_OK;
+  const int64_t nstrips = cap_ceil_div(d->nblk, d->strip);
+  std::vector<hipEvent_t>* vs[7] = {&d->ev_fact, &d->ev_msg, &d->ev_rowdone, &d->ev_solved, &d->ev_gather, &d->ev_head2, &d->ev_rest};
+  for (int v = 0; v < 7; v++) {
+    const int64_t cnt = v < 3 ? d->nblk : nstrips;
+    int64_t done = 0;
+    for (int64_t i = 0; i < cnt; i++) {
+      // ev_fact is only recorded by the owner of a block row and ev_gather / head2 / rest not for the last strip: an event
+      // that was never recorded reports success - so count "complete" entries, the first gap shows where the chain stopped
+      if (hipEventQuery((*vs[v])[(size_t)i]) == hipSuccess) done++;
+      else break;
+    }
+    (void)hipGetLastError();
+    out9[v] = done;
+  }
+  out9[7] = d->nblk; out9[8] = nstrips;
   return CAP_OK;
 }
 

@@ -17,6 +17,7 @@
 //   store segments in column-major C.
 //   Blocks are remapped XCD-aware: block b runs on XCD b%8; each XCD walks a contiguous
 //   range of 8x8-tile supertiles so its private L2 sees compact A/B panels.
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -46,6 +47,11 @@ struct GemmArgs {
   int chunk;        // logical tiles per XCD
   int nsm, nsn;     // supertiles in M, N
   int st;           // supertile edge in tiles (tiles of one supertile are co-scheduled on one XCD)
+  // full-grid products whose K range depends on the tile row (aupt / aupn) or column (bupper): supertiles of stm x stn tiles
+  // (64 in all), enumerated so that every XCD's contiguous range covers ALL values of the K-determining index - a square
+  // 8 x 8 walk hands XCD 0 the short-K and XCD 7 the long-K tiles of a triangular operand (measured: the tree's R^-1
+  // products ran at the speed of the dense product).  sorder 1: supertile columns fastest.
+  int stm, stn, sorder;
   // split-K (tall-skinny Gram / few-tile problems): blockIdx.y = K slice; partial tiles go to
   // slab kz of P (column-major, ld = M) and a second kernel reduces them deterministically
   int ksplit; int64_t kchunk; double* P; int64_t slab;
@@ -95,7 +101,8 @@ __host__ __device__ __forceinline__ int stair_cnt(int sj, int st, int tn, int ns
 // logical slot -> tile coordinates (returns false when the slot is empty)
 __device__ __forceinline__ bool slot_to_tile(const GemmArgs& g, int L, int& ti, int& tj) {
   const int ST = g.st;
-  int S = L / (ST * ST), w = L % (ST * ST);
+  const int STM = g.stm, STN = g.stn;
+  int S = L / (STM * STN), w = L % (STM * STN);
   int si, sj;
   if (g.etri == 3) {  // staircase: walk the supertile columns, only supertiles that hold valid tiles are numbered
     sj = 0;
@@ -115,11 +122,13 @@ __device__ __forceinline__ bool slot_to_tile(const GemmArgs& g, int L, int& ti, 
     while ((si + 1) * (si + 2) / 2 <= S) si++;
     while (si * (si + 1) / 2 > S) si--;
     sj = S - si * (si + 1) / 2;
+  } else if (g.sorder) {
+    sj = S % g.nsn; si = S / g.nsn;
   } else {
     si = S % g.nsm; sj = S / g.nsm;
   }
   if (si >= g.nsm || sj >= g.nsn) return false;
-  ti = si * ST + (w % ST); tj = sj * ST + (w / ST);
+  ti = si * STM + (w % STM); tj = sj * STN + (w / STM);
   if (ti >= g.tm || tj >= g.tn) return false;
   if (g.stair) return ti <= stair_gtj(g, tj);
   if (g.tri == 1 && ti > tj) return false;
@@ -811,13 +820,23 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   for (int i = 0; i < 8; i++) g.gstart[i] = 0;
   g.tm = (int)cap_ceil_div(m, BM); g.tn = (int)cap_ceil_div(n, BN);
   static const int st_env = getenv("CAP_ST") ? atoi(getenv("CAP_ST")) : ST;
-  g.st = st_env;
+  g.st = st_env; g.stm = g.st; g.stn = g.st; g.sorder = 0;
   g.nsm = (int)cap_ceil_div(g.tm, g.st); g.nsn = (int)cap_ceil_div(g.tn, g.st);
   int64_t nsuper;
   g.etri = (tri != 0 && g.nsm == g.nsn) ? tri : 0;
+  static const int xbal_env = getenv("CAP_XCD_BALANCE") ? atoi(getenv("CAP_XCD_BALANCE")) : 1;
+  if (g.etri == 0 && xbal_env && g.st == 8 && (g.bupper || g.aupt || g.aupn) && g.tm * g.tn >= 64) {
+    // triangular operand: make the K-determining tile index the one every XCD's range walks completely (see GemmArgs::stm)
+    if (g.bupper && !(g.aupt || g.aupn)) {            // K range grows with the column tile: XCD x = a band of tile rows, all columns
+      g.stm = std::max(1, std::min(8, g.tm / 8)); g.stn = std::max(1, std::min(g.tn, 64 / g.stm)); g.sorder = 1;
+    } else if (!g.bupper) {                           // K range depends on the row tile: XCD x = a band of tile columns, all rows
+      g.stn = std::max(1, std::min(8, g.tn / 8)); g.stm = std::max(1, std::min(g.tm, 64 / g.stn)); g.sorder = 0;
+    }
+    g.nsm = (int)cap_ceil_div(g.tm, g.stm); g.nsn = (int)cap_ceil_div(g.tn, g.stn);
+  }
   if (g.etri == 0) nsuper = (int64_t)g.nsm * g.nsn;   // strips keep the element mask but walk the full grid
   else nsuper = (int64_t)g.nsm * (g.nsm + 1) / 2;      // square tile space: enumerate the supertile triangle
-  int64_t slots = nsuper * g.st * g.st;
+  int64_t slots = nsuper * g.stm * g.stn;
   g.chunk = (int)cap_ceil_div(slots, 8);
   int64_t grid = (int64_t)g.chunk * 8;
   if (grid > 0x7fffffff) return CAP_ERR_UNSUPPORTED;
@@ -892,7 +911,7 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   g.A = G; g.B = B; g.C = C; g.lda = k; g.ldb = k; g.ldc = ldc;
   g.M = m; g.N = nloc; g.K = k; g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.etri = 0;
   g.tm = (int)(m / BM); g.tn = (int)(nloc / BN);
-  g.st = ST;
+  g.st = ST; g.stm = ST; g.stn = ST; g.sorder = 0;
   g.nsm = (int)cap_ceil_div(g.tm, ST); g.nsn = (int)cap_ceil_div(g.tn, ST);
   g.ksplit = 1; g.kchunk = k; g.P = nullptr; g.slab = 0;
   g.hiprio = 0; g.ctr = nullptr; g.bupper = 0; g.aupt = 0; g.aupn = 0;

@@ -207,6 +207,8 @@ struct cap_mpchol_plan {
   double* Inv; int64_t tb; double* Xt; double* Wt;          // blocked TRSM state
   double* Xw; double* Rw; double* Bw; double* norms;
   int* info_dev; bool have_r64;
+  // live profile of the bf16 trailing updates on the caller's stream (HIP events; cap_mpchol_profile)
+  int profile; std::vector<hipEvent_t>* prof_ev; std::vector<double>* prof_flops; std::vector<double>* prof_bytes; int prof_used;
 };
 
 extern "C" {
@@ -241,6 +243,7 @@ int cap_mpchol_plan_create(cap_mpchol_plan** plan, int64_t n, int64_t nrhs_max) 
 
 int cap_mpchol_plan_destroy(cap_mpchol_plan* p) {
   if (!p) return CAP_OK;
+  if (p->prof_ev) { for (hipEvent_t e : *p->prof_ev) (void)hipEventDestroy(e); delete p->prof_ev; delete p->prof_flops; delete p->prof_bytes; }
   for (void* q : {(void*)p->R32, (void*)p->R64, (void*)p->P16[0], (void*)p->P16[1], (void*)p->D64, (void*)p->Inv, (void*)p->Xw, (void*)p->info_dev})
     if (q) (void)hipFree(q);
   if (p->streams_ready) {
@@ -273,6 +276,8 @@ int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* st
     p->streams_ready = true;
   }
   hipStream_t s1 = p->s_panel;
+  p->prof_used = 0;
+  if (p->prof_flops) { p->prof_flops->clear(); p->prof_bytes->clear(); }
   CAP_HIP(hipMemsetAsync(p->info_dev, 0, sizeof(int), s0));
   hipLaunchKernelGGL(f64_to_f32_upper_kernel, grid2(n, n), dim3(256), 0, s0, A, lda, p->R32, n, n);
   CAP_HIP(hipGetLastError());
@@ -313,7 +318,24 @@ int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* st
     if (k > 0) CAP_HIP(hipStreamWaitEvent(s1, p->ev_rest[(k - 1) & 1], 0));
     CAP_TRY(launch_bf16_tn(hb, m, jb, -1.0f, P, jb, P, jb, p->R32 + j1 + j1 * n, n, 1, s1));
     CAP_HIP(hipStreamWaitEvent(s0, p->ev_panel[k & 1], 0));
-    if (m > hb) CAP_TRY(launch_bf16_tn(m - hb, m - hb, jb, -1.0f, P + hb * jb, jb, P + hb * jb, jb, p->R32 + (j1 + hb) * (n + 1), n, 1, s0));
+    if (m > hb) {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (p->profile && p->prof_ev) {
+        if ((size_t)p->prof_used + 2 > p->prof_ev->size())
+          for (int i = 0; i < 64; i++) { hipEvent_t e; CAP_HIP(hipEventCreate(&e)); p->prof_ev->push_back(e); }
+        e0 = (*p->prof_ev)[p->prof_used]; e1 = (*p->prof_ev)[p->prof_used + 1];
+        CAP_HIP(hipEventRecord(e0, s0));
+      }
+      CAP_TRY(launch_bf16_tn(m - hb, m - hb, jb, -1.0f, P + hb * jb, jb, P + hb * jb, jb, p->R32 + (j1 + hb) * (n + 1), n, 1, s0));
+      if (e0) {
+        CAP_HIP(hipEventRecord(e1, s0));
+        p->prof_used += 2;
+        // algorithmic work of one launch: 2 K flop and 8 B (fp32 read + write) per element of the upper triangle, plus the panel once
+        const double mm = (double)(m - hb), elems = 0.5 * mm * (mm + 1.0);
+        p->prof_flops->push_back(2.0 * (double)jb * elems);
+        p->prof_bytes->push_back(8.0 * elems + 2.0 * (double)jb * mm);
+      }
+    }
     CAP_HIP(hipEventRecord(p->ev_rest[k & 1], s0));
     if (k + 1 < npan) {
       CAP_TRY(panel(k + 1, s1));
@@ -326,6 +348,34 @@ int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* st
   hipLaunchKernelGGL(f32_to_f64_kernel, grid2(n, n), dim3(256), 0, s0, p->R32, n, p->R64, n, n, n, 1);
   CAP_HIP(hipGetLastError());
   p->have_r64 = true;
+  return CAP_OK;
+}
+
+// "profile" = 1: bracket every bf16 trailing update on the caller's stream with HIP events (read back by cap_mpchol_profile)
+int cap_mpchol_set_option(cap_mpchol_plan* p, const char* key, int64_t value) {
+  if (!p || !key) return CAP_ERR_ARG;
+  if (!strcmp(key, "profile")) {
+    p->profile = value != 0;
+    if (p->profile && !p->prof_ev) {
+      p->prof_ev = new std::vector<hipEvent_t>(); p->prof_flops = new std::vector<double>(); p->prof_bytes = new std::vector<double>();
+    }
+    return CAP_OK;
+  }
+  return CAP_ERR_ARG;
+}
+
+// the bf16 trailing updates (bf16_tn_kernel, rows below the next panel) of the LAST factor call: launches, their summed duration
+// (ms), summed algorithmic flops (2 K per element of the updated upper triangle) and bytes (fp32 C read + write + the bf16 panel)
+int cap_mpchol_profile(cap_mpchol_plan* p, int64_t* launches, double* ms_total, double* flops_total, double* bytes_total) {
+  if (!p || !launches || !ms_total || !flops_total || !bytes_total) return CAP_ERR_ARG;
+  *launches = 0; *ms_total = 0; *flops_total = 0; *bytes_total = 0;
+  if (!p->prof_ev) return CAP_OK;
+  for (int i = 0; i + 1 < p->prof_used; i += 2) {
+    CAP_HIP(hipEventSynchronize((*p->prof_ev)[i + 1]));
+    float ms = 0;
+    CAP_HIP(hipEventElapsedTime(&ms, (*p->prof_ev)[i], (*p->prof_ev)[i + 1]));
+    *ms_total += ms; *flops_total += (*p->prof_flops)[i / 2]; *bytes_total += (*p->prof_bytes)[i / 2]; (*launches)++;
+  }
   return CAP_OK;
 }
 

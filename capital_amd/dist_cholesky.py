@@ -5,9 +5,9 @@
     ctx.factor(); ctx.last_info()
     R_local = ctx.local_R()                   # n x local_cols device view
 
-The factorization schedule itself lives behind the C ABI (csrc/dist.hip).  `HostStagedComm` swaps RCCL for
-gloo-over-host-memory callbacks so that the SAME schedule can be exercised by several ranks sharing one GPU
-(tests only - it is slow by construction)."""
+The factorization schedule itself lives behind the C ABI (csrc/dist.hip).  The tests swap RCCL for gloo-over-host-memory
+callbacks (tests/host_staged.py, built on cap_comm_create_callbacks) so that the SAME schedule can be exercised by several
+ranks sharing one GPU; that communicator is test infrastructure and lives under tests/."""
 import ctypes as C
 
 import numpy as np
@@ -89,120 +89,15 @@ class RcclComm:
             self.handle = None
 
 
-class HostStagedComm:
-    """cap_comm whose collectives are gloo calls on host copies (several ranks may share one GPU).
-
-    Each callback waits for the stream it is handed - and nothing else - before it reads the device buffer, exactly
-    the ordering an RCCL kernel enqueued on that stream would have; the other streams of the schedule keep running, so
-    a missing event edge between them shows up as a wrong result (tests add random per-stream delays on top).
-    group: a torch.distributed process group (sub-communicators of a grid bundle); ranks are group-local."""
-    _AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
-    _BC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
-    _AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
-
-    def __init__(self, group=None):
-        dist = _dist()
-        if dist is None or dist.get_backend() != "gloo":
-            raise _lib.CapitalError("HostStagedComm needs torch.distributed initialised with the gloo backend")
-        self.group = group
-        self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
-        self.calls = {"allgather": 0, "bcast": 0, "allreduce": 0}
-
-        def sync(stream):
-            if stream:
-                torch.cuda.ExternalStream(int(stream)).synchronize()
-            else:
-                torch.cuda.default_stream().synchronize()
-
-        def ag(ctx, send, recv, count, stream):
-            try:
-                sync(stream)
-                mine = _DevView(send, count).to_host()
-                outs = [torch.empty(count, dtype=torch.float64) for _ in range(self.size)]
-                dist.all_gather(outs, mine, group=self.group)
-                _DevView(recv, count * self.size).from_host(torch.cat(outs))
-                self.calls["allgather"] += 1
-                return 0
-            except Exception as e:  # pragma: no cover
-                print("HostStagedComm allgather failed:", e, flush=True)
-                return 1
-
-        def bc(ctx, buf, count, root, stream):
-            try:
-                sync(stream)
-                v = _DevView(buf, count)
-                t = v.to_host()
-                dist.broadcast(t, src=dist.get_global_rank(self.group, root) if self.group is not None else root, group=self.group)
-                if self.rank != root:
-                    v.from_host(t)
-                self.calls["bcast"] += 1
-                return 0
-            except Exception as e:  # pragma: no cover
-                print("HostStagedComm bcast failed:", e, flush=True)
-                return 1
-
-        def ar(ctx, buf, count, stream):
-            try:
-                sync(stream)
-                v = _DevView(buf, count)
-                t = v.to_host()
-                dist.all_reduce(t, group=self.group)
-                v.from_host(t)
-                self.calls["allreduce"] += 1
-                return 0
-            except Exception as e:  # pragma: no cover
-                print("HostStagedComm allreduce failed:", e, flush=True)
-                return 1
-
-        self._cbs = (self._AG(ag), self._BC(bc), self._AR(ar))   # keep alive
-        h = C.c_void_p()
-        _lib.check(_lib.lib().cap_comm_create_callbacks(C.byref(h), self.rank, self.size,
-                                                        C.cast(self._cbs[0], C.c_void_p), C.cast(self._cbs[1], C.c_void_p),
-                                                        C.cast(self._cbs[2], C.c_void_p), None), "cap_comm_create_callbacks")
-        self.handle = h
-
-    def close(self):
-        if self.handle:
-            _lib.lib().cap_comm_destroy(self.handle)
-            self.handle = None
-
-
-class _DevView:
-    """Raw device pointer + element count <-> host tensor, through hipMemcpy (torch's runtime)."""
-
-    def __init__(self, ptr, count):
-        self.ptr, self.count = int(ptr), int(count)
-
-    def to_host(self):
-        t = torch.empty(self.count, dtype=torch.float64)
-        if self.count:
-            _memcpy(t.data_ptr(), self.ptr, self.count * 8, 2)
-        return t
-
-    def from_host(self, t):
-        t = t.contiguous()
-        if self.count:
-            _memcpy(self.ptr, t.data_ptr(), self.count * 8, 1)
-
-
-def _memcpy(dst, src, nbytes, kind):
-    rt = torch.cuda.cudart()
-    err = rt.cudaMemcpy(dst, src, nbytes, kind) if hasattr(rt, "cudaMemcpy") else None
-    if err is None:  # fall back to ctypes on the HIP runtime torch already loaded
-        hip = C.CDLL("libamdhip64.so")
-        e = hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), C.c_int(kind))
-        if e != 0:
-            raise _lib.CapitalError("hipMemcpy failed: %d" % e)
-    elif int(err) != 0:
-        raise _lib.CapitalError("cudaMemcpy failed: %s" % err)
-
-
 # ------------------------------------------------------------------ driver
 class Context:
-    def __init__(self, n, nb, comm):
+    def __init__(self, n, nb, comm, grid_rows=1):
         L = _lib.lib()
         self.n, self.nb, self.comm = int(n), int(nb), comm
         self.rank, self.size = comm.rank, comm.size
+        self.grid_rows = int(grid_rows)
+        if self.grid_rows != 1:
+            raise _lib.CapitalError("this driver handles the 1 x P layout; the Pr x Pc layout is driven by dist_cholesky.Context2D")
         h = C.c_void_p()
         _lib.check(L.cap_dist_plan_create(C.byref(h), self.n, self.nb, comm.handle), "cap_dist_plan_create")
         self.plan = h
@@ -242,15 +137,42 @@ class Context:
         torch.cuda.synchronize()
         return out[: self.local_cols].cpu().numpy().T.copy()
 
+    def probe(self, allreduce=None):
+        """||(R^T R - A) X||_F / ||A X||_F for 8 random vectors with torch's fp64 matmul over this rank's columns, summed over
+        the ranks by `allreduce` (validate.cholesky.probe): none of the library's kernels takes part in the check."""
+        from . import validate
+        Rl = self.local_R_device()
+        gcols = torch.from_numpy(global_cols_of_rank(self.n, self.nb, self.size, self.rank)).to(self.device)
+        return validate.cholesky.probe(self.A[: self.local_cols, : self.n].t(), Rl[: self.local_cols, : self.n].t(), gcols, allreduce=allreduce)
+
+    def roofline(self, L, Cc, peak_tf=78.6):
+        """One more factor call in profile mode: this rank's share of the trailing update (HIP events on its launch stream)
+        plus the busy milliseconds of every stream role."""
+        self.set_option("profile", 1)
+        self.factor(); torch.cuda.synchronize()
+        nl, ms, fl = Cc.c_int64(0), Cc.c_double(0), Cc.c_double(0)
+        _lib.check(L.cap_dist_profile(self.plan, Cc.byref(nl), Cc.byref(ms), Cc.byref(fl)))
+        busy = (Cc.c_double * 6)()
+        _lib.check(L.cap_dist_profile_streams(self.plan, busy))
+        self.set_option("profile", 0)
+        if not nl.value:
+            return None
+        ach = fl.value / (ms.value * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "dgemm_tn_dma_kernel<1> (rank %d's share of the trailing update)" % self.rank,
+                "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf, "launches": nl.value,
+                "avg_launch_ms": ms.value / nl.value, "algorithmic_flops_per_launch_avg": fl.value / nl.value, "traffic": None,
+                "busy_ms_of_step": {"panel_chain": busy[0], "panel_solve": busy[1], "panel_head": busy[2], "msg_bcast": busy[3],
+                                    "strip_exchange": busy[4], "main_bulk": busy[5]}}
+
     def close(self):
         if self.plan:
             _lib.lib().cap_dist_plan_destroy(self.plan)
             self.plan = None
 
 
-def setup(n, nb=0, comm=None):
+def setup(n, nb=0, comm=None, grid_rows=1):
     """Build the communicator (RCCL unless given) and the plan; fill the reference's SPD test matrix."""
     comm = comm or RcclComm()
-    ctx = Context(n, nb or 512, comm)
+    ctx = Context(n, nb or 512, comm, grid_rows)
     ctx.fill_symmetric(True)
     return ctx

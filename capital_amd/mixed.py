@@ -36,6 +36,19 @@ class plan:
                                                float(tol), C.byref(it), C.byref(rr), cur_stream()), "mpchol::solve")
         return X, it.value, rr.value
 
+    def profile_update(self, A):
+        """One more factor call with HIP events around every bf16 trailing update (bf16_tn_kernel) on its launch stream:
+        (launches, summed ms, summed algorithmic flops, summed algorithmic bytes)."""
+        import torch
+        L = _lib.lib()
+        _lib.check(L.cap_mpchol_set_option(self._h, b"profile", 1), "mpchol::set_option")
+        self.factor(A)
+        torch.cuda.synchronize()
+        nl, ms, fl, by = C.c_int64(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        _lib.check(L.cap_mpchol_profile(self._h, C.byref(nl), C.byref(ms), C.byref(fl), C.byref(by)), "mpchol::profile")
+        _lib.check(L.cap_mpchol_set_option(self._h, b"profile", 0), "mpchol::set_option")
+        return nl.value, ms.value, fl.value, by.value
+
     def R32(self):
         """[row, col] torch view of the fp32 factor (upper)."""
         import torch

@@ -57,7 +57,10 @@ def _gloo_split(color_of, key_of, size, rank):
 class _bundle:
     kind = 0
 
-    def __init__(self, c=1, layout=0, num_chunks=0, create_comm=True, backend="auto", force_rccl=False):
+    def __init__(self, c=1, layout=0, num_chunks=0, create_comm=True, force_rccl=False, comm_factory=None):
+        """comm_factory: tests only - a callable (group=None) -> object with .handle / .close() that builds a communicator
+        through cap_comm_create_callbacks (tests/host_staged.py: several ranks sharing one GPU over gloo); the sub-groups of
+        the bundle are then assembled by the host and handed to cap_topo_create_from.  Default: RCCL (ncclCommSplit)."""
         if self.kind == 0 and layout != 0:
             raise _lib.CapitalError("rank layouts 1/2 are numerically wrong upstream (SURVEY App. C #9); use layout 0")
         self.rank, self.size = rank_size()
@@ -71,23 +74,21 @@ class _bundle:
         self._comm_obj = None
         self._subs = []
         if create_comm:
-            self._make(backend, force_rccl)
+            self._make(force_rccl, comm_factory)
 
-    def _make(self, backend, force_rccl):
+    def _make(self, force_rccl, comm_factory):
         from . import dist_cholesky as dc
         L = _lib.lib()
-        dist = _dist()
-        staged = backend == "staged" or (backend == "auto" and dist is not None and dist.get_backend() == "gloo" and self.size > 1)
         h = C.c_void_p()
-        if staged:
-            self._comm_obj = dc.HostStagedComm()
+        if comm_factory is not None:
+            self._comm_obj = comm_factory()
             self.world = self._comm_obj.handle
             subs = (C.c_void_p * 7)()
             for i, (color_of, key_of) in enumerate(self._splits()):
                 if color_of is None:
                     continue
                 g = _gloo_split(color_of, key_of, self.size, self.rank)
-                sub = dc.HostStagedComm(group=g)
+                sub = comm_factory(group=g)
                 self._subs.append(sub)
                 subs[i] = sub.handle
             _lib.check(L.cap_topo_create_from(C.byref(h), self.kind, self.world, self.c, self.layout, self.num_chunks, subs, 7),

@@ -190,6 +190,8 @@ int cap_comm_destroy(cap_comm* comm);
 int cap_comm_rank(const cap_comm* comm);
 int cap_comm_size(const cap_comm* comm);
 int cap_comm_backend(const cap_comm* comm);          /* 0 self, 1 RCCL, 2 host-staged */
+/* what RCCL itself reports for this communicator: rank count, this rank, bound device (bench.py prints it as n_ranks_seen) */
+int cap_comm_query(const cap_comm* comm, int* nranks, int* rank, int* device);
 /* MPI_Allreduce(IN_PLACE, SUM) summa.hpp:236 | MPI_Reduce(SUM) to root cacqr.hpp:98 | MPI_Bcast summa.hpp:185
  * | MPI_Allgather policy.h:176 | MPI_Barrier bench/cholesky/cholinv.cpp:47 (drains the stream).          */
 int cap_comm_allreduce_sum(cap_comm* comm, double* buf, int64_t count, void* stream);
@@ -289,6 +291,13 @@ int cap_dist_info(cap_dist_plan* plan, void* stream, int64_t* info);
 int cap_dist_set_option(cap_dist_plan* plan, const char* key, int64_t value);
 int64_t cap_dist_get_option(const cap_dist_plan* plan, const char* key);
 int cap_dist_profile(cap_dist_plan* plan, int64_t* launches, double* ms_total, double* flops_total);
+/* profile mode, per stream role: out6 = busy ms of the diagonal-block chains, block-row solves, HEAD updates (panel stream),
+ * message broadcasts, strip exchanges (communication streams) and bulk updates (caller's stream) of the LAST factor call. */
+int cap_dist_profile_streams(cap_dist_plan* plan, double* out6);
+/* Non-blocking progress of the factor call in flight (host watchdog of bench.py): out9 = leading complete events among
+ * fact, msg, rowdone (per block row), solved, gather, head2, rest (per strip), then the block-row and strip counts.
+ * Option "safe" = 1 runs the same schedule with ONE communicator and ONE communication stream (collectives in program order). */
+int cap_dist_progress(cap_dist_plan* plan, int64_t* out9);
 /* distribute_symmetric (structure.hpp:68-103) for this layout: fills the local block columns.            */
 int cap_fill_symmetric_bc(double* local, int64_t ld, int64_t n, int64_t nb, int P, int p, int diagonally_dominant,
                           void* stream);
@@ -348,6 +357,12 @@ int cap_mpchol_info(cap_mpchol_plan* plan, void* stream, int64_t* info);
 int cap_mpchol_solve(cap_mpchol_plan* plan, const double* A, int64_t lda, const double* B, int64_t ldb, double* X,
                      int64_t ldx, int64_t nrhs, int max_iter, double tol, int* iters, double* relres, void* stream);
 float* cap_mpchol_R32_ptr(cap_mpchol_plan* plan, int64_t* ld);          /* the fp32 factor (upper, n x n) */
+/* Live measurement of the bf16 trailing updates (the dominant kernel, bf16_tn_kernel) of the LAST factor call, enabled with
+ * cap_mpchol_set_option(plan, "profile", 1): launches, summed duration (ms, HIP events on the launch stream), summed
+ * algorithmic flops (2 K per updated element) and bytes (fp32 C read + write, bf16 panel once).  Same protocol as
+ * cap_cholinv_profile.                                                                                                     */
+int cap_mpchol_set_option(cap_mpchol_plan* plan, const char* key, int64_t value);
+int cap_mpchol_profile(cap_mpchol_plan* plan, int64_t* launches, double* ms_total, double* flops_total, double* bytes_total);
 
 #ifdef __cplusplus
 }

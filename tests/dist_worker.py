@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--depth2", type=int, default=-1)
     ap.add_argument("--jitter", type=int, default=0, help="max random delay (us) in front of every launch group")
     ap.add_argument("--seam", type=int, default=0, help="1: drive the run through cholinv.factor(A, pack, topo)")
+    ap.add_argument("--safe", type=int, default=0, help="1: one communicator + one communication stream (collectives in program order)")
+    ap.add_argument("--ipc", type=int, default=0, help="1: strip exchange by IPC peer copies instead of the all-gather collective")
     ap.add_argument("--c", type=int, default=1, help="grid depth c (summa: d x d x c, cacqr3d: c x d x c)")
     ap.add_argument("--k", type=int, default=0, help="summa: inner dimension")
     ap.add_argument("--chunks", type=int, default=0, help="summa: num_chunks")
@@ -66,7 +68,8 @@ def main():
         torch.cuda.set_device(0)
         from capital_amd import blas, summa, topo as tp
         from capital_amd.matrix import matrix
-        T = tp.square(args.c, 0, args.chunks)
+        from tests.host_staged import HostStagedComm
+        T = tp.square(args.c, 0, args.chunks, comm_factory=HostStagedComm)
         M, N, K, d = args.n, args.nb, args.k, T.d           # --size = M, --nb = N, --k = K
         A = matrix(K, M, d, d); B = matrix(N, K, d, d); Cm = matrix(N, M, d, d)
         A.distribute_random(T.x, T.y, d, d, rank // T.c); B.distribute_random(T.x, T.y, d, d, 100 + rank // T.c)
@@ -102,7 +105,8 @@ def main():
         torch.cuda.set_device(0)
         from capital_amd import cacqr, cholinv, validate, topo as tp
         from capital_amd.matrix import matrix
-        T = tp.rect(args.c, 0, 0)
+        from tests.host_staged import HostStagedComm
+        T = tp.rect(args.c, 0, 0, comm_factory=HostStagedComm)
         m, ncol, c, d = args.n, args.nb, T.c, T.d
         A = matrix(ncol, m, c, d)
         A.distribute_random(T.x, T.y, c, d, rank // c)      # key = rank / c (bench/qr/cacqr.cpp:34)
@@ -154,7 +158,8 @@ def main():
 
         class Topo:                      # the fields cacqr/validate read from topo::rect (topology.h:62-64)
             pass
-        comm = dc.HostStagedComm()
+        from tests.host_staged import HostStagedComm
+        comm = HostStagedComm()
         topo = Topo(); topo.c, topo.d, topo.x, topo.y, topo.z = 1, size, 0, rank, 0
         topo.rank, topo.size, topo.world = rank, size, comm.handle
         m, ncol = args.n, args.nb        # --size = global rows, --nb = columns here
@@ -178,7 +183,8 @@ def main():
     else:
         torch.cuda.set_device(0)
         from capital_amd import dist_cholesky as dc
-        comm = dc.HostStagedComm()
+        from tests.host_staged import HostStagedComm
+        comm = HostStagedComm()
         a = orc.symmetric_global(n, True)
         cols = dc.global_cols_of_rank(n, nb, size, rank)
         if args.seam:
@@ -210,9 +216,27 @@ def main():
             if args.jitter:
                 ctx.set_option("jitter_us", args.jitter)
                 ctx.set_option("jitter_seed", 1234 + rank)
+            if args.safe:
+                ctx.set_option("safe", 1)
+            if args.ipc:
+                ctx.set_option("ipc", 1)
             for rep in range(2):                       # plan reuse
                 ctx.factor()
             info = ctx.last_info()
+            # the watchdog's progress query: after completion every event of the chain reads complete
+            import ctypes
+            from capital_amd import _lib
+            out9 = (ctypes.c_int64 * 9)()
+            torch.cuda.synchronize()
+            _lib.check(_lib.lib().cap_dist_progress(ctx.plan, out9))
+            v = list(out9)
+            assert v[0] == v[1] == v[2] == v[7] and v[3] == v[4] == v[5] == v[6] == v[8], v
+            # profile mode: per-stream busy time is reported and the factor is unchanged
+            ctx.set_option("profile", 1); ctx.factor(); torch.cuda.synchronize()
+            busy = (ctypes.c_double * 6)()
+            _lib.check(_lib.lib().cap_dist_profile_streams(ctx.plan, busy))
+            ctx.set_option("profile", 0)
+            assert all(b >= 0 for b in busy) and busy[0] > 0 and (size == 1 or busy[3] > 0), list(busy)
             rl = ctx.local_R()
             close = ctx.close
         lc_max = max(dc.global_cols_of_rank(n, nb, size, r).size for r in range(size))

@@ -1,0 +1,123 @@
+"""TEST INFRASTRUCTURE: a cap_comm whose collectives are gloo calls on host copies, so that the multi-rank schedules
+(csrc/dist.hip, csrc/summa.hip, csrc/cacqr.hip) can be exercised by several processes sharing ONE GPU.
+
+Built on the library's callback constructor (cap_comm_create_callbacks, include/capital_amd.h).  Not part of the product:
+the product path is RCCL (capital_amd.dist_cholesky.RcclComm).  Slow by construction."""
+import ctypes as C
+
+import torch
+
+from capital_amd import _lib
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+class HostStagedComm:
+    """cap_comm whose collectives are gloo calls on host copies (several ranks may share one GPU).
+
+    Each callback waits for the stream it is handed - and nothing else - before it reads the device buffer, exactly
+    the ordering an RCCL kernel enqueued on that stream would have; the other streams of the schedule keep running, so
+    a missing event edge between them shows up as a wrong result (tests add random per-stream delays on top).
+    group: a torch.distributed process group (sub-communicators of a grid bundle); ranks are group-local."""
+    _AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+    _BC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+    _AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+    def __init__(self, group=None):
+        dist = _dist()
+        if dist is None or dist.get_backend() != "gloo":
+            raise _lib.CapitalError("HostStagedComm needs torch.distributed initialised with the gloo backend")
+        self.group = group
+        self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
+        self.calls = {"allgather": 0, "bcast": 0, "allreduce": 0}
+
+        def sync(stream):
+            if stream:
+                torch.cuda.ExternalStream(int(stream)).synchronize()
+            else:
+                torch.cuda.default_stream().synchronize()
+
+        def ag(ctx, send, recv, count, stream):
+            try:
+                sync(stream)
+                mine = _DevView(send, count).to_host()
+                outs = [torch.empty(count, dtype=torch.float64) for _ in range(self.size)]
+                dist.all_gather(outs, mine, group=self.group)
+                _DevView(recv, count * self.size).from_host(torch.cat(outs))
+                self.calls["allgather"] += 1
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("HostStagedComm allgather failed:", e, flush=True)
+                return 1
+
+        def bc(ctx, buf, count, root, stream):
+            try:
+                sync(stream)
+                v = _DevView(buf, count)
+                t = v.to_host()
+                dist.broadcast(t, src=dist.get_global_rank(self.group, root) if self.group is not None else root, group=self.group)
+                if self.rank != root:
+                    v.from_host(t)
+                self.calls["bcast"] += 1
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("HostStagedComm bcast failed:", e, flush=True)
+                return 1
+
+        def ar(ctx, buf, count, stream):
+            try:
+                sync(stream)
+                v = _DevView(buf, count)
+                t = v.to_host()
+                dist.all_reduce(t, group=self.group)
+                v.from_host(t)
+                self.calls["allreduce"] += 1
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("HostStagedComm allreduce failed:", e, flush=True)
+                return 1
+
+        self._cbs = (self._AG(ag), self._BC(bc), self._AR(ar))   # keep alive
+        h = C.c_void_p()
+        _lib.check(_lib.lib().cap_comm_create_callbacks(C.byref(h), self.rank, self.size,
+                                                        C.cast(self._cbs[0], C.c_void_p), C.cast(self._cbs[1], C.c_void_p),
+                                                        C.cast(self._cbs[2], C.c_void_p), None), "cap_comm_create_callbacks")
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            _lib.lib().cap_comm_destroy(self.handle)
+            self.handle = None
+
+
+class _DevView:
+    """Raw device pointer + element count <-> host tensor, through hipMemcpy (torch's runtime)."""
+
+    def __init__(self, ptr, count):
+        self.ptr, self.count = int(ptr), int(count)
+
+    def to_host(self):
+        t = torch.empty(self.count, dtype=torch.float64)
+        if self.count:
+            _memcpy(t.data_ptr(), self.ptr, self.count * 8, 2)
+        return t
+
+    def from_host(self, t):
+        t = t.contiguous()
+        if self.count:
+            _memcpy(self.ptr, t.data_ptr(), self.count * 8, 1)
+
+
+def _memcpy(dst, src, nbytes, kind):
+    rt = torch.cuda.cudart()
+    err = rt.cudaMemcpy(dst, src, nbytes, kind) if hasattr(rt, "cudaMemcpy") else None
+    if err is None:  # fall back to ctypes on the HIP runtime torch already loaded
+        hip = C.CDLL("libamdhip64.so")
+        e = hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), C.c_int(kind))
+        if e != 0:
+            raise _lib.CapitalError("hipMemcpy failed: %d" % e)
+    elif int(err) != 0:
+        raise _lib.CapitalError("cudaMemcpy failed: %s" % err)

@@ -29,9 +29,10 @@ def test_defaults_match_the_baseline_metric():
 
 def test_cpu_baseline_leg_returns_a_reported_comparator():
     b = _bench()
-    r = b.cpu_baseline(1024)                                      # tiny bounded sample: seconds on any host
+    r = b.cpu_baseline(1024, budget_s=40)                          # tiny bounded sample: seconds on any host
     assert set(["value", "unit", "cores", "kind", "sample"]) <= set(r)
     assert r["unit"] == "TFLOP/s" and r["value"] > 0 and r["kind"] in ("reference", "port")
     assert r["cores"] >= 1
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "cholinv_ref")) and os.path.exists("/opt/conda/bin/mpiexec"):
-        assert r["kind"] == "reference" and r["cores"] == 8       # upstream's own 2x2x2 grid, 1 MKL thread per rank
+        assert r["kind"] == "reference" and 1 <= r["cores"] <= (os.cpu_count() or 1)    # largest cube of ranks the host holds / all-cores MKL
+        assert all(x["residual"] < 1e-14 for x in r["runs"]) and len(r["runs"]) >= 1

@@ -84,6 +84,9 @@ def test_multirank_schedule_on_one_gpu(nproc, n, nb):
     (2, 2048, 128, ("--strip", 1, "--depth2", 0)),        # schedule knobs change the association order only
     (4, 4096, 128, ("--strip", 2, "--depth2", 1)),
     (2, 2048, 256, ("--seam", 1)),                        # through cholinv::factor(A, pack, topo)
+    (4, 4096, 128, ("--safe", 1)),                        # one communicator, one communication stream: collectives in program order
+    (3, 1000, 128, ("--safe", 1, "--strip", 1)),
+    (8, 8192, 512, ("--safe", 1)),
 ])
 def test_multirank_schedule_variants(nproc, n, nb, extra):
     r = _launch(nproc, "gpu", n, nb, 29671 + nproc, extra)
