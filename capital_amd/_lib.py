@@ -95,6 +95,17 @@ SIGNATURES = {
     "cap_bc_owner": (cint, [i64, cint]),
     "cap_bc_local_block": (i64, [i64, cint]),
     "cap_bc_num_local_cols": (i64, [i64, i64, cint, cint]),
+    "cap_dist2d_plan_create": (cint, [C.POINTER(ptr), i64, i64, ptr, cint, ptr, ptr]),
+    "cap_dist2d_plan_destroy": (cint, [ptr]),
+    "cap_dist2d_get": (i64, [ptr, cint]),
+    "cap_dist2d_factor": (cint, [ptr, ptr, i64, ptr]),
+    "cap_dist2d_R_ptr": (ptr, [ptr, C.POINTER(i64)]),
+    "cap_dist2d_get_R": (cint, [ptr, ptr, i64, ptr]),
+    "cap_dist2d_info": (cint, [ptr, ptr, C.POINTER(i64)]),
+    "cap_dist2d_set_option": (cint, [ptr, C.c_char_p, i64]),
+    "cap_bc2d_local_extent": (i64, [i64, i64, cint, cint, cint, cint, cint]),
+    "cap_bc2d_rows_le": (cint, [cint, cint, cint, cint, cint, cint]),
+    "cap_fill_symmetric_bc2d": (cint, [ptr, i64, i64, i64, cint, cint, cint, cint, cint, ptr]),
     "cap_summa_plan_create": (cint, [C.POINTER(ptr), ptr, i64, i64, i64, cint]),
     "cap_summa_plan_destroy": (cint, [ptr]),
     "cap_summa_local_dims": (None, [ptr, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),

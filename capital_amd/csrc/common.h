@@ -73,9 +73,11 @@ int cap_zero_rect(double* dst, int64_t ldd, int64_t rows, int64_t cols, hipStrea
 double* cap_scratch(int64_t elems, hipStream_t stream);  // gemm.hip: per-stream device scratch (split-K partials)
 
 // gemm.hip: distributed (1 x P block-column-cyclic) trailing update with staircase mask + gathered A operand
+// Pr, pr, rlb0: rows of C block-cyclic over Pr process rows too (local row block b = global block pr + Pr (rlb0 + b));
+// the defaults are the 1 x P layout (rows global, origin at block J0)
 int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, int64_t piece, const int* gstart,
                            const double* B, double* C, int64_t ldc, int P, int p, int nb, int J0, int lb0,
-                           hipStream_t stream, int persist_wgs = 0);
+                           hipStream_t stream, int persist_wgs = 0, int Pr = 1, int pr = 0, int rlb0 = 0);
 
 // leaf.hip: fused block-row solve + rank-64 trailing update of the 64-blocked diagonal-block factorization
 // (Dnext != nullptr: the workgroup of block (i + 1, i + 1) also runs the leaf of step i + 1 and writes R_{i+1,i+1}, Dinv_{i+1};

@@ -71,6 +71,14 @@ struct cap_dist_plan {
   // (the data dependencies order them anyway: msg(a), msg(b), exchange(t), msg(a'), ...); the default keeps the small
   // messages on their own communicator + stream
   int safe;
+  // Strip exchange off the CUs (option "ipc"): every rank maps its peers' gathered-strip buffers (hipIpcGetMemHandle /
+  // hipIpcOpenMemHandle, exchanged once through the communicator) and PUSHES its piece into each of them with plain
+  // device-to-device copies on one copy stream per peer (SDMA engines, one xGMI link each) - no RCCL kernel competes with
+  // the bulk update for CU slots (the reference pipelines the same move with MPI_Ibcast, summa.hpp:185-214).  Two 8-byte
+  // all-reduces per strip carry the synchronisation: "every rank's buffer is free" before the pushes, "every push has
+  // landed" after them.  RCCL stays the default and the fallback (option off, or if mapping a peer fails).
+  int ipc; bool ipc_ready; bool ipc_failed;
+  double* peerG[8][2]; hipStream_t s_peer[8]; hipEvent_t ev_x0, ev_xr[8]; double* token; int ipc_nocu;
 };
 
 namespace {
@@ -142,6 +150,75 @@ struct Bucket {
   }
   ~Bucket() { if (on && hipEventRecord(e1, s) == hipSuccess) d->bk_used += 2; }
 };
+
+// map the peers' G buffers (collective over d->comm; synchronises).  On any failure the plan stays on the RCCL exchange.
+int ensure_ipc(cap_dist_plan* d, hipStream_t s) {
+  if (d->ipc_ready || d->ipc_failed || d->P == 1) return CAP_OK;
+  const int P = (int)d->P, p = (int)d->p;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  double* hx = nullptr;                                   // [P][2][8 doubles] handles + [16] mine
+  CAP_HIP(hipMalloc((void**)&hx, sizeof(double) * (16 * (P + 1))));
+  hipIpcMemHandle_t mine[2];
+  bool ok = true;
+  for (int b = 0; b < 2; b++) ok = ok && hipIpcGetMemHandle(&mine[b], d->G[b]) == hipSuccess;
+  if (!ok) { (void)hipGetLastError(); memset(mine, 0, sizeof(mine)); }
+  CAP_HIP(hipMemcpyAsync(hx + 16 * P, mine, 128, hipMemcpyHostToDevice, s));
+  CAP_TRY(cap_comm_allgather(d->comm, hx + 16 * P, hx, 16, (void*)s));
+  std::vector<hipIpcMemHandle_t> all((size_t)2 * P);
+  CAP_HIP(hipMemcpyAsync(all.data(), hx, (size_t)128 * P, hipMemcpyDeviceToHost, s));
+  CAP_HIP(hipStreamSynchronize(s));
+  (void)hipFree(hx);
+  hipIpcMemHandle_t zero; memset(&zero, 0, sizeof(zero));
+  for (int r = 0; r < P && ok; r++) {
+    if (r == p) continue;
+    for (int b = 0; b < 2 && ok; b++) {
+      if (!memcmp(&all[(size_t)2 * r + b], &zero, sizeof(zero))) { ok = false; break; }
+      void* q = nullptr;
+      if (hipIpcOpenMemHandle(&q, all[(size_t)2 * r + b], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+      d->peerG[r][b] = (double*)q;
+    }
+  }
+  // agree: one failing rank sends everybody back to RCCL (the exchange is collective)
+  if (!d->token) { CAP_HIP(hipMalloc((void**)&d->token, 2 * sizeof(double))); CAP_HIP(hipMemset(d->token, 0, 2 * sizeof(double))); }
+  double flag = ok ? 0.0 : 1.0, tot = 0.0;
+  CAP_HIP(hipMemcpyAsync(d->token + 1, &flag, sizeof(double), hipMemcpyHostToDevice, s));
+  CAP_TRY(cap_comm_allreduce_sum(d->comm, d->token + 1, 1, (void*)s));
+  CAP_HIP(hipMemcpyAsync(&tot, d->token + 1, sizeof(double), hipMemcpyDeviceToHost, s));
+  CAP_HIP(hipStreamSynchronize(s));
+  if (tot != 0.0) {
+    for (int r = 0; r < P; r++) for (int b = 0; b < 2; b++) if (d->peerG[r][b]) { (void)hipIpcCloseMemHandle(d->peerG[r][b]); d->peerG[r][b] = nullptr; }
+    d->ipc_failed = true;
+    fprintf(stderr, "capital_amd: IPC mapping of the peers' strip buffers failed on %s rank; using the RCCL all-gather\n", ok ? "another" : "this");
+    return CAP_OK;
+  }
+  for (int r = 0; r < P; r++) {
+    if (r == p) continue;
+    CAP_HIP(hipStreamCreateWithFlags(&d->s_peer[r], hipStreamNonBlocking));
+    CAP_HIP(hipEventCreateWithFlags(&d->ev_xr[r], hipEventDisableTiming));
+  }
+  CAP_HIP(hipEventCreateWithFlags(&d->ev_x0, hipEventDisableTiming));
+  d->ipc_ready = true;
+  return CAP_OK;
+}
+
+// the strip exchange: `piece` doubles from `src` into slot p of EVERY rank's gathered buffer G[par]
+int strip_exchange(cap_dist_plan* d, const double* src, int par, int64_t piece, hipStream_t sc) {
+  double* G = d->G[par];
+  if (!(d->ipc && d->ipc_ready)) return cap_comm_allgather(d->comm, src, G, piece, (void*)sc);
+  const int P = (int)d->P, p = (int)d->p;
+  const hipMemcpyKind kind = d->ipc_nocu ? hipMemcpyDeviceToDeviceNoCU : hipMemcpyDeviceToDevice;
+  CAP_TRY(cap_comm_allreduce_sum(d->comm, d->token, 1, (void*)sc));        // every rank's G[par] is free (each waited for its own readers)
+  CAP_HIP(hipEventRecord(d->ev_x0, sc));
+  for (int r = 0; r < P; r++) {
+    if (r == p) continue;
+    CAP_HIP(hipStreamWaitEvent(d->s_peer[r], d->ev_x0, 0));
+    CAP_HIP(hipMemcpyAsync(d->peerG[r][par] + (int64_t)p * piece, src, sizeof(double) * piece, kind, d->s_peer[r]));
+    CAP_HIP(hipEventRecord(d->ev_xr[r], d->s_peer[r]));
+  }
+  CAP_HIP(hipMemcpyAsync(G + (int64_t)p * piece, src, sizeof(double) * piece, hipMemcpyDeviceToDevice, sc));
+  for (int r = 0; r < P; r++) if (r != p) CAP_HIP(hipStreamWaitEvent(sc, d->ev_xr[r], 0));
+  return cap_comm_allreduce_sum(d->comm, d->token, 1, (void*)sc);          // every push into MY G[par] has landed
+}
 
 int ensure_events(cap_dist_plan* d) {
   if (!d->ev_msg.empty()) return CAP_OK;
@@ -244,6 +321,10 @@ int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* 
   d->jitter_state = 0x9E3779B97F4A7C15ull * (uint64_t)(d->p + 1); d->jitter_max_us = 0;
   d->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
   d->profile = 0; d->prof_used = 0; d->bk_used = 0; d->safe = 0;
+  d->ipc = getenv("CAP_DIST_IPC") ? atoi(getenv("CAP_DIST_IPC")) : 0; d->ipc_ready = false; d->ipc_failed = false; d->token = nullptr;
+  d->ipc_nocu = getenv("CAP_DIST_IPC_NOCU") ? atoi(getenv("CAP_DIST_IPC_NOCU")) : 0;
+  for (int r = 0; r < 8; r++) { d->peerG[r][0] = d->peerG[r][1] = nullptr; d->s_peer[r] = nullptr; d->ev_xr[r] = nullptr; }
+  d->ev_x0 = nullptr;
   d->wcap = cap_rec_work_size(nb);
   if (cap_comm_size(comm) > 1 || cap_comm_backend(comm) != 0) {
     int st = cap_comm_dup(comm, &d->comm2);
@@ -286,6 +367,13 @@ int cap_dist_plan_destroy(cap_dist_plan* d) {
   }
   for (hipEvent_t e : d->prof_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : d->bk_ev) (void)hipEventDestroy(e);
+  for (int r = 0; r < 8; r++) {
+    for (int b = 0; b < 2; b++) if (d->peerG[r][b]) (void)hipIpcCloseMemHandle(d->peerG[r][b]);
+    if (d->s_peer[r]) { (void)hipStreamSynchronize(d->s_peer[r]); (void)hipStreamDestroy(d->s_peer[r]); }
+    if (d->ev_xr[r]) (void)hipEventDestroy(d->ev_xr[r]);
+  }
+  if (d->ev_x0) (void)hipEventDestroy(d->ev_x0);
+  if (d->token) (void)hipFree(d->token);
   if (d->comm2) cap_comm_destroy(d->comm2);
   delete d;
   return CAP_OK;
@@ -301,6 +389,8 @@ int cap_dist_set_option(cap_dist_plan* d, const char* key, int64_t value) {
   if (k == "jitter_seed") { d->jitter_state = 0x9E3779B97F4A7C15ull * (uint64_t)(value + 1) + (uint64_t)d->p; return CAP_OK; }
   if (k == "profile") { d->profile = value != 0; return CAP_OK; }
   if (k == "safe") { d->safe = value != 0; return CAP_OK; }
+  if (k == "ipc") { d->ipc = value != 0; return CAP_OK; }
+  if (k == "ipc_nocu") { d->ipc_nocu = value != 0; return CAP_OK; }
   return CAP_ERR_ARG;
 }
 
@@ -312,6 +402,8 @@ int64_t cap_dist_get_option(const cap_dist_plan* d, const char* key) {
   if (k == "occ1_m") return d->occ1_m;
   if (k == "jitter_us") return d->jitter_max_us;
   if (k == "safe") return d->safe;
+  if (k == "ipc") return d->ipc;
+  if (k == "ipc_active") return (d->ipc && d->ipc_ready) ? 1 : 0;
   if (k == "nb") return d->nb;
   if (k == "n") return d->n;
   if (k == "npad") return d->npad;
@@ -326,6 +418,7 @@ double* cap_dist_R_ptr(cap_dist_plan* d, int64_t* ld) { if (!d) return nullptr; 
 int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* stream) {
   if (!d || (d->lc_valid > 0 && (!Aloc || lda < d->n))) return CAP_ERR_ARG;
   CAP_TRY(ensure_events(d));
+  if (d->ipc) CAP_TRY(ensure_ipc(d, cap_stream(stream)));
   hipStream_t s0 = cap_stream(stream), s1 = d->s_panel, sc = d->s_comm, sm = d->safe ? d->s_comm : d->s_msg;
   cap_comm* cmsg = (d->safe || !d->comm2) ? d->comm : d->comm2;
   const int64_t n = d->n, npad = d->npad, nb = d->nb, nblk = d->nblk, P = d->P, p = d->p, ld = d->ld;
@@ -421,7 +514,7 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
     CAP_HIP(hipStreamWaitEvent(sc, d->ev_solved[t], 0));
     if (t >= 2) CAP_HIP(hipStreamWaitEvent(sc, d->ev_rest[t - 2], 0));   // G[par] was read by the bulk update of strip t-2
     CAP_TRY(jitter(d, sc));
-    { Bucket bk(d, 4, sc); CAP_TRY(cap_comm_allgather(d->comm, S + (lbe - lbS) * nb * ldS, G, piece, (void*)sc)); }
+    { Bucket bk(d, 4, sc); CAP_TRY(strip_exchange(d, S + (lbe - lbS) * nb * ldS, par, piece, sc)); }
     CAP_HIP(hipEventRecord(d->ev_gather[t], sc));
 
     // ---- panel: HEAD - bring the rows of strip t+1 up to date with strip t (my columns J >= e)

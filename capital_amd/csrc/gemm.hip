@@ -64,6 +64,9 @@ struct GemmArgs {
   int* ctr;         // persistent launches: 8 per-XCD slot counters (zeroed on the stream before the launch)
   int hiprio;       // panel-stream launches: raise the waves' issue priority (they share CUs with the bulk update)
   int stair, gather, sP, sp, snbT, sJ0, slb0;
+  // rows of C block-cyclic over rP process rows as well (Pr x Pc layout): local row block b holds global block
+  // rp + rP (rlb0 + b).  rP = 1, rp = 0, rlb0 = sJ0 is the 1 x P layout (rows global, origin at block sJ0).
+  int rP, rp, rlb0;
   int64_t gpiece; int gstart[8];
   // epilogue of the beta == 1 update form as fire-and-forget fp64 atomic adds executed in L2 (global_atomic_add_f64):
   // no C read-back into registers, no load latency on the tile's critical path.  Every C element has exactly one
@@ -79,10 +82,17 @@ __device__ __forceinline__ int stair_gtj(const GemmArgs& g, int tj) {
   const int J = g.sp + g.sP * (g.slb0 + tj / g.snbT);
   return (J - g.sJ0) * g.snbT + tj % g.snbT;
 }
-// base of A's rows for row tile ti (K-contiguous operand, lda doubles per row)
+// global tile index (relative to the row origin sJ0) of local row tile ti under the staircase view
+__device__ __forceinline__ int stair_gti(const GemmArgs& g, int ti) {
+  const int I = g.rp + g.rP * (g.rlb0 + ti / g.snbT);
+  return (I - g.sJ0) * g.snbT + ti % g.snbT;
+}
+// base of A's rows for row tile ti (K-contiguous operand, lda doubles per row).  gather: global block I of the row tile
+// sits in piece (I % sP) / rP (the contributors of a process row are the columns pc' = rp mod rP, + rP, ...: all of them
+// when rP = 1) at that contributor's local block I / sP - gstart[piece]
 __device__ __forceinline__ const double* a_tile_base(const GemmArgs& g, int ti) {
   if (!g.gather) return g.A + (int64_t)ti * 128 * g.lda;
-  const int J = g.sJ0 + ti / g.snbT, r = J % g.sP, lb = J / g.sP - g.gstart[r];
+  const int I = g.rp + g.rP * (g.rlb0 + ti / g.snbT), r = (I % g.sP) / g.rP, lb = I / g.sP - g.gstart[r];
   return g.A + (int64_t)r * g.gpiece + ((int64_t)(lb * g.snbT + ti % g.snbT) * 128) * g.lda;
 }
 
@@ -91,10 +101,23 @@ __host__ __device__ __forceinline__ int stair_gtj_hd(int sp, int sP, int slb0, i
   const int J = sp + sP * (slb0 + tj / snbT);
   return (J - sJ0) * snbT + tj % snbT;
 }
-__host__ __device__ __forceinline__ int stair_cnt(int sj, int st, int tn, int nsm, int sp, int sP, int slb0, int snbT, int sJ0) {
+// number of LOCAL row tiles whose global tile index is <= X (rows block-cyclic over rP process rows, see GemmArgs::rP)
+__host__ __device__ __forceinline__ int stair_rows_le(int X, int snbT, int sJ0, int rP, int rp, int rlb0) {
+  if (X < 0) return 0;
+  const int Xb = X / snbT + sJ0, Xo = X % snbT;          // global block of tile X, offset inside it
+  // local blocks b >= 0 with  rp + rP (rlb0 + b) < Xb  are complete
+  int full = Xb - rp > 0 ? (Xb - rp + rP - 1) / rP - rlb0 : -rlb0;
+  if (full < 0) full = 0;
+  int cnt = full * snbT;
+  if (Xb >= rp && (Xb - rp) % rP == 0 && (Xb - rp) / rP >= rlb0) cnt += Xo + 1;     // the block of X itself is local
+  return cnt;
+}
+__host__ __device__ __forceinline__ int stair_cnt(int sj, int st, int tn, int nsm, int sp, int sP, int slb0, int snbT, int sJ0,
+                                                  int rP, int rp, int rlb0) {
   int tjm = sj * st + st - 1;
   if (tjm > tn - 1) tjm = tn - 1;
-  const int c = stair_gtj_hd(sp, sP, slb0, snbT, sJ0, tjm) / st + 1;
+  const int rows = stair_rows_le(stair_gtj_hd(sp, sP, slb0, snbT, sJ0, tjm), snbT, sJ0, rP, rp, rlb0);
+  const int c = (rows + st - 1) / st;
   return c < nsm ? c : nsm;
 }
 
@@ -107,7 +130,7 @@ __device__ __forceinline__ bool slot_to_tile(const GemmArgs& g, int L, int& ti, 
   if (g.etri == 3) {  // staircase: walk the supertile columns, only supertiles that hold valid tiles are numbered
     sj = 0;
     for (; sj < g.nsn; sj++) {
-      const int c = stair_cnt(sj, ST, g.tn, g.nsm, g.sp, g.sP, g.slb0, g.snbT, g.sJ0);
+      const int c = stair_cnt(sj, ST, g.tn, g.nsm, g.sp, g.sP, g.slb0, g.snbT, g.sJ0, g.rP, g.rp, g.rlb0);
       if (S < c) break;
       S -= c;
     }
@@ -130,7 +153,7 @@ __device__ __forceinline__ bool slot_to_tile(const GemmArgs& g, int L, int& ti, 
   if (si >= g.nsm || sj >= g.nsn) return false;
   ti = si * STM + (w % STM); tj = sj * STN + (w / STM);
   if (ti >= g.tm || tj >= g.tn) return false;
-  if (g.stair) return ti <= stair_gtj(g, tj);
+  if (g.stair) return stair_gti(g, ti) <= stair_gtj(g, tj);
   if (g.tri == 1 && ti > tj) return false;
   if (g.tri == 2 && ti < tj) return false;
   return true;
@@ -504,7 +527,7 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
 
   // epilogue: lane holds C[i0+wi+16i+lr][j0+wj+16j+kg+4r]; all branches are block-uniform
   const double alpha = g.alpha, beta = g.beta;
-  const bool diag_tile = g.stair ? (ti == stair_gtj(g, tj)) : ((g.tri != 0) && (ti == tj));
+  const bool diag_tile = g.stair ? (stair_gti(g, ti) == stair_gtj(g, tj)) : ((g.tri != 0) && (ti == tj));
   auto epilogue = [&](auto masked, auto with_beta, auto split) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -816,7 +839,7 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   const bool no_atomic = (tag & CAP_TAG_NO_ATOMIC) != 0;
   tag &= 1; g.ctr = nullptr;
   g.atomic_c = 0; g.usebuf = 0; g.skip = 0;
-  g.stair = 0; g.gather = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0;
+  g.stair = 0; g.gather = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0; g.rP = 1; g.rp = 0; g.rlb0 = 0;
   for (int i = 0; i < 8; i++) g.gstart[i] = 0;
   g.tm = (int)cap_ceil_div(m, BM); g.tn = (int)cap_ceil_div(n, BN);
   static const int st_env = getenv("CAP_ST") ? atoi(getenv("CAP_ST")) : ST;
@@ -904,9 +927,10 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
 // Requires m, nloc multiples of 128, nb multiple of 128, k multiple of 16.
 int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, int64_t piece, const int* gstart,
                            const double* B, double* C, int64_t ldc, int P, int p, int nb, int J0, int lb0,
-                           hipStream_t stream, int persist_wgs) {
+                           hipStream_t stream, int persist_wgs, int Pr, int pr, int rlb0) {
   if (m <= 0 || nloc <= 0) return CAP_OK;
-  if ((m % BM) || (nloc % BN) || (k % BK) || (nb % 128) || P < 1 || P > 8) return CAP_ERR_UNSUPPORTED;
+  if ((m % BM) || (nloc % BN) || (k % BK) || (nb % 128) || P < 1 || P > 8 || Pr < 1 || pr < 0 || pr >= Pr) return CAP_ERR_UNSUPPORTED;
+  if (Pr == 1) rlb0 = J0;                                  // rows are global: origin at block J0
   GemmArgs g;
   g.A = G; g.B = B; g.C = C; g.lda = k; g.ldb = k; g.ldc = ldc;
   g.M = m; g.N = nloc; g.K = k; g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.etri = 0;
@@ -921,11 +945,12 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
     g.usebuf = (128 * k * 8 + k * 8 < 0x7fffffffLL) ? 1 : 0; g.skip = 0;
   }
   g.stair = 1; g.gather = 1; g.sP = P; g.sp = p; g.snbT = nb / 128; g.sJ0 = J0; g.slb0 = lb0; g.gpiece = piece;
+  g.rP = Pr; g.rp = pr; g.rlb0 = rlb0;
   for (int i = 0; i < 8; i++) g.gstart[i] = i < P ? gstart[i] : 0;
   // only supertiles under the staircase are enumerated, so the 8 XCD ranges carry equal work
   g.etri = 3;
   int64_t nsuper = 0;
-  for (int sj = 0; sj < g.nsn; sj++) nsuper += stair_cnt(sj, ST, g.tn, g.nsm, p, P, lb0, nb / 128, J0);
+  for (int sj = 0; sj < g.nsn; sj++) nsuper += stair_cnt(sj, ST, g.tn, g.nsm, p, P, lb0, nb / 128, J0, Pr, pr, rlb0);
   int64_t slots = nsuper * ST * ST;
   g.chunk = (int)cap_ceil_div(slots, 8);
   return launch_tn_dma<1>(g, g.chunk * 8, stream, persist_wgs);
@@ -939,6 +964,11 @@ int cap_gemm_small_batched(int transa, int transb, int64_t m, int64_t n, int64_t
   if (nbatch > 65535) return CAP_ERR_UNSUPPORTED;
   return launch_small(transa, transb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0, 1, stream, nbatch, sa, sb, sc);
 }
+
+// pure index helper behind the staircase enumeration of the distributed update (tests check it against a brute-force count):
+// number of LOCAL row tiles (128 rows) of process row pr of Pr, starting at local row block rlb0, whose global tile index
+// relative to block J0 is <= X; nbT = nb / 128 tiles per block
+extern "C" int cap_bc2d_rows_le(int X, int nbT, int J0, int Pr, int pr, int rlb0) { return stair_rows_le(X, nbT, J0, Pr, pr, rlb0); }
 
 extern "C" int cap_dgemm(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
                          int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, void* stream) {

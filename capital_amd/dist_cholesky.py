@@ -97,7 +97,7 @@ class Context:
         self.rank, self.size = comm.rank, comm.size
         self.grid_rows = int(grid_rows)
         if self.grid_rows != 1:
-            raise _lib.CapitalError("this driver handles the 1 x P layout; the Pr x Pc layout is driven by dist_cholesky.Context2D")
+            raise _lib.CapitalError("this driver handles the 1 x P layout; the Pr x Pc layout is driven by dist_cholesky.Context2D (setup(grid_rows=...))")
         h = C.c_void_p()
         _lib.check(L.cap_dist_plan_create(C.byref(h), self.n, self.nb, comm.handle), "cap_dist_plan_create")
         self.plan = h
@@ -115,6 +115,9 @@ class Context:
 
     def set_option(self, key, value):
         _lib.check(_lib.lib().cap_dist_set_option(self.plan, key.encode(), int(value)), "cap_dist_set_option")
+
+    def get_option(self, key):
+        return int(_lib.lib().cap_dist_get_option(self.plan, key.encode()))
 
     def factor(self):
         _lib.check(_lib.lib().cap_dist_factor(self.plan, self.A.data_ptr(), self.n, cur_stream()), "cap_dist_factor")
@@ -170,9 +173,112 @@ class Context:
             self.plan = None
 
 
-def setup(n, nb=0, comm=None, grid_rows=1):
+# ------------------------------------------------------------------ Pr x Pc block-cyclic (csrc/dist2d.hip)
+def global_index_2d(n, nb, Q, q):
+    """Global row (or column) indices stored on process coordinate q of Q, in local storage order."""
+    nblk = (n + nb - 1) // nb
+    idx = []
+    for lb in range(num_local_blocks(nblk, Q, q)):
+        I = lb * Q + q
+        idx.extend(range(I * nb, min(n, (I + 1) * nb)))
+    return np.asarray(idx, dtype=np.int64)
+
+
+class Context2D:
+    """Driver of the Pr x Pc block-cyclic plan: rank = pr * Pc + pc; `row` / `col` are optional communicator objects of my
+    process row / column (tests: host-staged groups), otherwise the library splits them off the world communicator."""
+
+    def __init__(self, n, nb, comm, grid_rows, row=None, col=None):
+        L = _lib.lib()
+        self.n, self.nb, self.comm = int(n), int(nb), comm
+        self.rank, self.size = comm.rank, comm.size
+        self.grid_rows = self.Pr = int(grid_rows)
+        self.Pc = self.size // self.Pr
+        self.pr, self.pc = self.rank // self.Pc, self.rank % self.Pc
+        self._row, self._col = row, col
+        h = C.c_void_p()
+        _lib.check(L.cap_dist2d_plan_create(C.byref(h), self.n, self.nb, comm.handle, self.Pr, row.handle if row else None,
+                                            col.handle if col else None), "cap_dist2d_plan_create")
+        self.plan = h
+        self.local_rows, self.local_cols = int(L.cap_dist2d_get(h, 0)), int(L.cap_dist2d_get(h, 1))
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.lda = max(self.local_rows, 1)
+        self.A = torch.zeros(max(self.local_cols, 1), self.lda, dtype=torch.float64, device=self.device)   # (cols, ld)
+
+    def fill_symmetric(self, diagonally_dominant=True):
+        _lib.check(_lib.lib().cap_fill_symmetric_bc2d(self.A.data_ptr(), self.lda, self.n, self.nb, self.Pr, self.Pc, self.pr, self.pc,
+                                                      1 if diagonally_dominant else 0, cur_stream()), "cap_fill_symmetric_bc2d")
+
+    def set_local(self, a):
+        """a: numpy (local_rows x local_cols)"""
+        if self.local_rows and self.local_cols:
+            self.A[: self.local_cols, : self.local_rows].copy_(torch.from_numpy(np.ascontiguousarray(a.T)).to(self.device))
+
+    def set_option(self, key, value):
+        _lib.check(_lib.lib().cap_dist2d_set_option(self.plan, key.encode(), int(value)), "cap_dist2d_set_option")
+
+    def factor(self):
+        _lib.check(_lib.lib().cap_dist2d_factor(self.plan, self.A.data_ptr(), self.lda, cur_stream()), "cap_dist2d_factor")
+
+    def last_info(self):
+        v = C.c_int64(0)
+        _lib.lib().cap_dist2d_info(self.plan, cur_stream(), C.byref(v))
+        return v.value
+
+    def local_R_device(self):
+        out = torch.zeros(max(self.local_cols, 1), self.lda, dtype=torch.float64, device=self.device)
+        _lib.check(_lib.lib().cap_dist2d_get_R(self.plan, out.data_ptr(), self.lda, cur_stream()), "cap_dist2d_get_R")
+        return out
+
+    def local_R(self):
+        """numpy (local_rows x local_cols): my piece of R, zero below the global diagonal."""
+        out = self.local_R_device()
+        torch.cuda.synchronize()
+        return out[: self.local_cols, : self.local_rows].cpu().numpy().T.copy()
+
+    def launch_counts(self):
+        L = _lib.lib()
+        return {"mfma_kernels": int(L.cap_dist2d_get(self.plan, 8)), "chains": int(L.cap_dist2d_get(self.plan, 9)),
+                "copies": int(L.cap_dist2d_get(self.plan, 10)), "collectives": int(L.cap_dist2d_get(self.plan, 11))}
+
+    def probe(self, allreduce=None):
+        """||(R^T R - A) X||_F / ||A X||_F over the distributed pieces with torch fp64 matmul (no library kernel):
+        R X needs the row-block sums over process columns, R^T (R X) the sums over process rows - both by `allreduce` of
+        zero-padded global-length vectors (cheap: 8 columns)."""
+        n, dev = self.n, self.device
+        rows = torch.from_numpy(global_index_2d(n, self.nb, self.Pr, self.pr)).to(dev)
+        cols = torch.from_numpy(global_index_2d(n, self.nb, self.Pc, self.pc)).to(dev)
+        g = torch.Generator(device="cpu"); g.manual_seed(11)
+        X = torch.rand(n, 8, dtype=torch.float64, generator=g).to(dev)
+        red = allreduce if allreduce is not None else (lambda t: t)
+        Rl = self.local_R_device()[: self.local_cols, : self.local_rows].t()        # local_rows x local_cols
+        Al = self.A[: self.local_cols, : self.local_rows].t()
+        # A is symmetric and fully stored: (A X)[rows] = sum over process columns of A_loc X[cols]
+        ax = torch.zeros(n, 8, dtype=torch.float64, device=dev); rx = torch.zeros_like(ax)
+        if rows.numel() and cols.numel():
+            ax[rows] += Al @ X[cols]; rx[rows] += Rl @ X[cols]
+        ax = red(ax); rx = red(rx)                  # every entry summed over all ranks: each (row, col) block counted once
+        rtrx = torch.zeros(n, 8, dtype=torch.float64, device=dev)
+        if rows.numel() and cols.numel():
+            rtrx[cols] += Rl.t() @ rx[rows]
+        rtrx = red(rtrx)
+        return float((rtrx - ax).norm() / ax.norm())
+
+    def roofline(self, L, Cc, peak_tf=78.6):
+        return None
+
+    def close(self):
+        if self.plan:
+            _lib.lib().cap_dist2d_plan_destroy(self.plan)
+            self.plan = None
+
+
+def setup(n, nb=0, comm=None, grid_rows=1, row=None, col=None):
     """Build the communicator (RCCL unless given) and the plan; fill the reference's SPD test matrix."""
     comm = comm or RcclComm()
-    ctx = Context(n, nb or 512, comm, grid_rows)
+    if grid_rows and grid_rows != 1:
+        ctx = Context2D(n, nb or 512, comm, grid_rows, row, col)
+    else:
+        ctx = Context(n, nb or 512, comm, 1)
     ctx.fill_symmetric(True)
     return ctx

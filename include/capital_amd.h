@@ -306,6 +306,32 @@ int cap_bc_owner(int64_t J, int P);
 int64_t cap_bc_local_block(int64_t J, int P);
 int64_t cap_bc_num_local_cols(int64_t n, int64_t nb, int P, int p);
 
+/* The same factorization on a 2D Pr x Pc BLOCK-CYCLIC process grid (csrc/dist2d.hip): block (I, J) of nb x nb elements on
+ * process (I % Pr, J % Pc) as local block (I / Pr, J / Pc), rank = pr * Pc + pc, local arrays column-major; Pr must divide
+ * Pc (1 x P, 2 x 2, 2 x 4, 4 x 4).  Per block row: diagonal block on its owner, Dinv broadcast along the owner's process row,
+ * block-row solve there, the solved row broadcast down the process columns (B operand) and re-broadcast along the process
+ * rows by the Pc / Pr columns that hold the blocks I = pr mod Pr (A operand), staircase MFMA update of the local blocks
+ * k < I <= J.  Replaces topo::square's row / column communicators + summa::distribute (topology.h:67-143, summa.hpp:163-221).
+ * row / col: communicators of my process row (ordered by pc) / column (ordered by pr), or NULL to split them off `world`
+ * (ncclCommSplit).  Alocal / get_R: the valid local piece (cap_bc2d_local_extent rows x columns, column-major).
+ * cap_dist2d_get: 0 valid local rows, 1 valid local columns, 2 Pr, 3 Pc, 4 pr, 5 pc, 6 nb, 7 padded n, 8..11 = MFMA kernels,
+ * diagonal-block chains, copy kernels, collectives issued by the last factor call on this rank.                        */
+typedef struct cap_dist2d_plan cap_dist2d_plan;
+int cap_dist2d_plan_create(cap_dist2d_plan** plan, int64_t n, int64_t nb, cap_comm* world, int Pr, cap_comm* row, cap_comm* col);
+int cap_dist2d_plan_destroy(cap_dist2d_plan* plan);
+int64_t cap_dist2d_get(const cap_dist2d_plan* plan, int which);
+int cap_dist2d_factor(cap_dist2d_plan* plan, const double* Alocal, int64_t lda, void* stream);
+double* cap_dist2d_R_ptr(cap_dist2d_plan* plan, int64_t* ld);
+int cap_dist2d_get_R(cap_dist2d_plan* plan, double* out, int64_t ld, void* stream);
+int cap_dist2d_info(cap_dist2d_plan* plan, void* stream, int64_t* info);
+int cap_dist2d_set_option(cap_dist2d_plan* plan, const char* key, int64_t value);     /* "occ1_m" */
+int64_t cap_bc2d_local_extent(int64_t n, int64_t nb, int Pr, int Pc, int pr, int pc, int which);   /* which: 0 rows, 1 columns */
+/* pure index helper of the update kernel's staircase enumeration: local row tiles (128 rows) of process row pr of Pr, from
+ * local row block rlb0 on, whose global tile index relative to block J0 is <= X (nbT = nb / 128)                        */
+int cap_bc2d_rows_le(int X, int nbT, int J0, int Pr, int pr, int rlb0);
+int cap_fill_symmetric_bc2d(double* local, int64_t ld, int64_t n, int64_t nb, int Pr, int Pc, int pr, int pc,
+                            int diagonally_dominant, void* stream);
+
 /* matmult::summa::invoke, GEMM overload (summa.hpp:6-44, distribute :163-221, collect :223-253; driver
  * bench/matmult/summa_gemm.cpp:7-55): C = alpha A B + beta C on the d x d x c grid of a topo::square bundle, operands
  * are the element-cyclic local pieces (ceil(M/d) x ceil(K/d) etc., zero padded).  Layer z walks the inner process

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--safe", type=int, default=0, help="1: one communicator + one communication stream (collectives in program order)")
     ap.add_argument("--ipc", type=int, default=0, help="1: strip exchange by IPC peer copies instead of the all-gather collective")
     ap.add_argument("--c", type=int, default=1, help="grid depth c (summa: d x d x c, cacqr3d: c x d x c)")
+    ap.add_argument("--pr", type=int, default=1, help="gpu2d: process rows Pr of the Pr x Pc block-cyclic grid")
     ap.add_argument("--k", type=int, default=0, help="summa: inner dimension")
     ap.add_argument("--chunks", type=int, default=0, help="summa: num_chunks")
     args = ap.parse_args()
@@ -63,6 +64,49 @@ def main():
         assert int(t.item()) == n
         if rank == 0:
             print("INDEX-OK world=%d n=%d nb=%d" % (size, n, nb), flush=True)
+    elif args.mode == "gpu2d":
+        # blocked Cholesky on the Pr x Pc block-cyclic grid (csrc/dist2d.hip), all ranks on cuda:0, host-staged row / column groups
+        torch.cuda.set_device(0)
+        from capital_amd import dist_cholesky as dc
+        from tests.host_staged import HostStagedComm, grid_groups
+        comm = HostStagedComm()
+        row, col = grid_groups(args.pr)
+        a = orc.symmetric_global(n, True)
+        ctx = dc.Context2D(n, nb, comm, args.pr, row, col)
+        rows = dc.global_index_2d(n, nb, ctx.Pr, ctx.pr); cols = dc.global_index_2d(n, nb, ctx.Pc, ctx.pc)
+        assert rows.size == ctx.local_rows and cols.size == ctx.local_cols
+        ctx.fill_symmetric(True)
+        torch.cuda.synchronize()
+        if rows.size and cols.size:
+            assert np.array_equal(ctx.A[: ctx.local_cols, : ctx.local_rows].cpu().numpy().T, a[np.ix_(rows, cols)]), "2D block-cyclic generator mismatch"
+        for rep in range(2):                       # plan reuse
+            ctx.factor()
+        info = ctx.last_info()
+        rl = ctx.local_R()
+
+        def allred(t):
+            h = t.cpu(); dist.all_reduce(h); return h.to(t.device)
+        probe = ctx.probe(allred)
+        counts = ctx.launch_counts()
+        pieces = [None] * size
+        dist.all_gather_object(pieces, (ctx.pr, ctx.pc, rows, cols, rl))
+        if rank == 0:
+            R = np.zeros((n, n))
+            seen = np.zeros((n, n), dtype=np.int32)
+            for (qr, qc, rr, cc, piece) in pieces:
+                if rr.size and cc.size:
+                    R[np.ix_(rr, cc)] = piece; seen[np.ix_(rr, cc)] += 1
+            assert np.array_equal(seen, np.ones_like(seen)), "every element has exactly one owner"
+            assert np.array_equal(np.tril(R, -1), np.zeros_like(R)), "construct_R must zero the part below the global diagonal"
+            ref = np.linalg.cholesky(a).T
+            err = np.linalg.norm(R - ref) / np.linalg.norm(ref)
+            res = orc.cholesky_residual(a, R)
+            assert info == 0, info
+            assert err < 1e-13, err
+            assert res < 1e-14, res
+            assert probe < 1e-13, probe
+            print("DIST2D-OK world=%d grid=%dx%d n=%d nb=%d err=%.2e residual=%.2e probe=%.2e launches(rank0)=%s" % (size, ctx.Pr, ctx.Pc, n, nb, err, res, probe, counts), flush=True)
+        ctx.close(); row.close(); col.close(); comm.close()
     elif args.mode == "summa":
         # matmult::summa::invoke on the d x d x c grid (bench/matmult/summa_gemm.cpp:32-38): element-cyclic pieces on every rank
         torch.cuda.set_device(0)
@@ -223,6 +267,8 @@ def main():
             for rep in range(2):                       # plan reuse
                 ctx.factor()
             info = ctx.last_info()
+            if args.ipc and size > 1:
+                assert ctx.get_option("ipc_active") == 1, "the peers' strip buffers were not mapped: the run fell back to the collective"
             # the watchdog's progress query: after completion every event of the chain reads complete
             import ctypes
             from capital_amd import _lib

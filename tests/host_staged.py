@@ -121,3 +121,23 @@ def _memcpy(dst, src, nbytes, kind):
             raise _lib.CapitalError("hipMemcpy failed: %d" % e)
     elif int(err) != 0:
         raise _lib.CapitalError("cudaMemcpy failed: %s" % err)
+
+
+def grid_groups(Pr, factory=None):
+    """Row / column communicators of the Pr x Pc process grid (rank = pr * Pc + pc) over the gloo world: every rank creates
+    every group in the same order (torch.distributed.new_group is collective) and keeps its own two."""
+    dist = _dist()
+    factory = factory or HostStagedComm
+    rank, size = dist.get_rank(), dist.get_world_size()
+    Pc = size // Pr
+    pr, pc = rank // Pc, rank % Pc
+    row = col = None
+    for r in range(Pr):
+        g = dist.new_group(ranks=[r * Pc + c for c in range(Pc)], backend="gloo")
+        if r == pr:
+            row = factory(group=g)
+    for c in range(Pc):
+        g = dist.new_group(ranks=[r * Pc + c for r in range(Pr)], backend="gloo")
+        if c == pc:
+            col = factory(group=g)
+    return row, col

@@ -145,3 +145,32 @@ def test_plain_c_host_compiles_against_the_header(built, tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert exe.exists()
+
+
+def test_2d_block_cyclic_index_maps(built):
+    """Pure index helpers of the Pr x Pc layout (csrc/dist2d.hip, csrc/gemm.hip): local extents partition the matrix, and the
+    staircase row count of the update kernel equals a brute-force count over local row tiles."""
+    from capital_amd import _lib, dist_cholesky as dc
+    L = _lib.lib()
+    for (n, nb, Pr, Pc) in [(4096, 512, 2, 4), (1000, 128, 2, 2), (2049, 256, 2, 4), (65536, 512, 2, 4), (1536, 128, 4, 4), (777, 128, 1, 3)]:
+        assert sum(L.cap_bc2d_local_extent(n, nb, Pr, Pc, pr, 0, 0) for pr in range(Pr)) == n
+        assert sum(L.cap_bc2d_local_extent(n, nb, Pr, Pc, 0, pc, 1) for pc in range(Pc)) == n
+        for pr in range(Pr):
+            assert L.cap_bc2d_local_extent(n, nb, Pr, Pc, pr, 0, 0) == dc.global_index_2d(n, nb, Pr, pr).size
+        for pc in range(Pc):
+            assert L.cap_bc2d_local_extent(n, nb, Pr, Pc, 0, pc, 1) == dc.global_index_2d(n, nb, Pc, pc).size
+    for nbT in (1, 2, 4):
+        for Pr in (1, 2, 4):
+            for pr in range(Pr):
+                for J0 in (0, 1, 5, 6):
+                    rlb0 = len([I for I in range(pr, J0, Pr)])            # local row blocks with I < J0
+                    nloc = 7
+                    gti = []                                             # global tile index (relative to J0) of every local row tile
+                    for b in range(nloc):
+                        I = pr + Pr * (rlb0 + b)
+                        gti += [(I - J0) * nbT + t for t in range(nbT)]
+                    for X in range(-2, (nloc * Pr + 2) * nbT):
+                        want = sum(1 for g in gti if g <= X) if X >= 0 else 0
+                        got = L.cap_bc2d_rows_le(X, nbT, J0, Pr, pr, rlb0)
+                        if X < (pr + Pr * (rlb0 + nloc - 1) - J0 + 1) * nbT:     # beyond the local extent the kernel clamps to its tile count
+                            assert got == want, (X, nbT, J0, Pr, pr, rlb0, got, want)

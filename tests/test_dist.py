@@ -87,6 +87,10 @@ def test_multirank_schedule_on_one_gpu(nproc, n, nb):
     (4, 4096, 128, ("--safe", 1)),                        # one communicator, one communication stream: collectives in program order
     (3, 1000, 128, ("--safe", 1, "--strip", 1)),
     (8, 8192, 512, ("--safe", 1)),
+    # strip exchange by IPC peer copies (hipIpcOpenMemHandle of the peers' gathered-strip buffers, pushes on per-peer copy
+    # streams, two 8-byte all-reduces as barriers) instead of the all-gather collective
+    (2, 2048, 128, ("--ipc", 1)), (4, 4096, 128, ("--ipc", 1, "--safe", 1)), (3, 1000, 128, ("--ipc", 1)), (8, 8192, 512, ("--ipc", 1)),
+    (4, 4096, 128, ("--ipc", 1, "--jitter", 200)),
 ])
 def test_multirank_schedule_variants(nproc, n, nb, extra):
     r = _launch(nproc, "gpu", n, nb, 29671 + nproc, extra)
@@ -103,6 +107,32 @@ def test_multirank_schedule_under_random_stream_delays(nproc, n, nb, jitter):
     r = _launch(nproc, "gpu", n, nb, 29681 + nproc, ("--jitter", jitter))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "DIST-OK" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,pr,n,nb", [
+    (4, 2, 2048, 128),        # 2 x 2
+    (8, 2, 4096, 128),        # 2 x 4: the node's 8 GPUs, two A-operand contributors per process row
+    (8, 2, 8192, 512),        # 2 x 4 at the driver's block size
+    (4, 2, 1000, 128),        # ragged N: identity-padded last block
+    (8, 2, 2049, 256),
+    (4, 1, 2048, 128),        # 1 x 4 through the 2D code: every column contributes to the A operand (cross-check of dist.hip)
+    (2, 1, 1536, 256),
+    (4, 4, 1536, 128),        # 4 x 1 is refused (Pr must divide Pc) - see below; 4 = 2 x 2 only
+    (16, 4, 4096, 128),       # 4 x 4
+    (1, 1, 1024, 128),
+])
+def test_2d_block_cyclic_schedule_on_one_gpu(nproc, pr, n, nb):
+    """The Pr x Pc block-cyclic plan (csrc/dist2d.hip) with all ranks sharing cuda:0: generator, factor, construct_R and the
+    distributed probe against the oracle; row / column communicators are host-staged gloo groups."""
+    if nproc // pr % pr:
+        # not a supported grid: the plan must refuse it (status, no hang)
+        r = _launch(nproc, "gpu2d", n, nb, 29741 + nproc + pr, ("--pr", pr))
+        assert r.returncode != 0 and "cap_dist2d_plan_create" in (r.stdout + r.stderr)
+        return
+    r = _launch(nproc, "gpu2d", n, nb, 29741 + nproc + pr, ("--pr", pr))
+    assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    assert "DIST2D-OK" in r.stdout, r.stdout[-2000:]
 
 
 @pytest.mark.gpu
