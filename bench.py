@@ -109,6 +109,7 @@ def cpu_baseline(cpu_n, budget_s=90.0):
         env = dict(os.environ, MKL_NUM_THREADS=str(threads), OMP_NUM_THREADS=str(threads))
         if threads > 1:
             env["MKL_THREADING_LAYER"] = "GNU"        # the default Intel-OpenMP layer gives wrong answers here
+        t0 = time.time()
         try:
             out = subprocess.run([mpiexec, "-n", str(ranks), exe, str(nn), "0", "1", str(bc), "0", "0", "1", "-", "1"],
                                  env=env, capture_output=True, text=True, timeout=max(5.0, timeout)).stdout
@@ -119,7 +120,7 @@ def cpu_baseline(cpu_n, budget_s=90.0):
             return None
         t, res = float(m.group(1)), float(m.group(2))
         r = {"ranks": ranks, "threads_per_rank": threads, "cores": ranks * threads, "n": nn, "bcMult": bc, "seconds": t,
-             "tflops": nn ** 3 / 3.0 / t / 1e12, "residual": res}
+             "tflops": nn ** 3 / 3.0 / t / 1e12, "residual": res, "wall_s": time.time() - t0}
         if res < 1e-14:
             runs.append(r)
             return r
@@ -127,30 +128,26 @@ def cpu_baseline(cpu_n, budget_s=90.0):
 
     if os.path.exists(exe) and os.path.exists(mpiexec):
         left = lambda: budget_s - (time.time() - t_start)
+        cap = lambda: min(left(), 0.3 * budget_s)      # no single candidate may eat the budget
         big = _largest_cube(min(ncores, 64))
         half_n = max(1024, cpu_n // 2)
-        # Candidates in order of expected value per second of budget (measured on the 256-core EPYC of the GPU box: 64 ranks
-        # at N = 16384 take 11 s per factor - slower than 8 ranks - and a run = generation + warm-up + timed factor + the
-        # validator's own SUMMA, about 5 factor times):
-        #   one rank with all cores inside MKL (GNU threading layer), whole matrix as one base case and the recursive split;
-        #   the rank sweeps on the half-size sample (1/8 of the flops): 8 ranks = upstream's 2 x 2 x 2 grid, the largest cube
-        #   the host holds (up to 4 x 4 x 4 = 64 ranks), 27 ranks; then the best multi-rank configuration at N = cpu_n.
         threads = min(ncores, 128)
-        if threads > 1:
-            for bc in (0, -2):
-                if left() > 12:
-                    run_ref(1, cpu_n, bc, threads, left())
-        multi = []
-        for ranks, bc in ((8, -3), (big, -2), (8, -2), (big, -3), (27, -2)):
-            if ranks > ncores or ranks < 8 or left() < 12 or (ranks, bc) in [(r["ranks"], r["bcMult"]) for r in multi]:
+        # Candidates on the half-size sample (1/8 of the flops), known-good first: upstream's own 2 x 2 x 2 grid, the largest
+        # cube the host holds (up to 4 x 4 x 4 = 64 ranks; measured on the GPU box's 256-core EPYC: 64 ranks are SLOWER than 8 -
+        # 11 s per factor at N = 16384), 27 ranks, and one rank with all cores inside MKL (GNU threading layer).  Then the best
+        # configuration once more at N = cpu_n if its predicted wall time (8x) fits.  A run = generation + warm-up + timed
+        # factor + the validator's own SUMMA product, i.e. several factor times.
+        cands = [(8, -3, 1), (8, -2, 1), (big, -2, 1), (1, 0, threads), (1, -2, threads), (27, -2, 1), (big, -3, 1)]
+        seen = set()
+        for ranks, bc, th in cands:
+            if (ranks, bc, th) in seen or ranks * (1 if th > 1 else 1) > ncores or (th == 1 and ranks < 8) or (th > 1 and threads <= 1) or left() < 8:
                 continue
-            r = run_ref(ranks, half_n, bc, 1, left())
-            if r:
-                multi.append(r)
-        if multi:
-            b = min(multi, key=lambda r: r["seconds"])
-            if left() > 40 * b["seconds"] + 5:          # 8x the flops, ~5 factor times per run
-                run_ref(b["ranks"], cpu_n, b["bcMult"], 1, left())
+            seen.add((ranks, bc, th))
+            run_ref(ranks, half_n, bc, th, cap())
+        if runs:
+            b = max(runs, key=lambda r: r["tflops"])
+            if left() > 8.0 * b["wall_s"] + 5:
+                run_ref(b["ranks"], cpu_n, b["bcMult"], b["threads_per_rank"], left())
         if runs:
             b = max(runs, key=lambda r: r["tflops"])
             return {"value": b["tflops"], "unit": "TFLOP/s", "cores": b["cores"], "kind": "reference", "host": host,

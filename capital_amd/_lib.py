@@ -86,6 +86,8 @@ SIGNATURES = {
     "cap_dist_R_ptr": (ptr, [ptr, C.POINTER(i64)]),
     "cap_dist_info": (cint, [ptr, ptr, C.POINTER(i64)]),
     "cap_dist_get_R": (cint, [ptr, ptr, i64, ptr]),
+    "cap_dist_get_Rinv": (cint, [ptr, ptr, i64, ptr]),
+    "cap_dist_Rinv_ptr": (ptr, [ptr, C.POINTER(i64)]),
     "cap_dist_set_option": (cint, [ptr, C.c_char_p, i64]),
     "cap_dist_get_option": (i64, [ptr, C.c_char_p]),
     "cap_dist_profile": (cint, [ptr, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]),

@@ -74,7 +74,7 @@ def factor(A, args, CommInfo=None):
         raise _lib.CapitalError("split must be > 0 (cholinv.hpp:9)")
     if CommInfo is not None and getattr(CommInfo, "size", 1) != 1:
         # multi-GPU: A is a `block_cyclic_columns` piece (this rank's block columns, all n rows) and CommInfo.world the
-        # communicator; the 1 x P schedule of csrc/dist.hip runs behind the same plan handle (complete_inv = -1 only)
+        # communicator; the 1 x P schedule of csrc/dist.hip runs behind the same plan handle (complete_inv = 0 / 1 add R^-1)
         n = A.num_rows_global()
         args._ensure(n, getattr(CommInfo, "world", None))
         _lib.check(_lib.lib().cap_cholinv_factor(args._plan, A.data_ptr(), A.ld(), cur_stream()), "cholinv::factor")

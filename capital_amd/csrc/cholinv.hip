@@ -778,9 +778,8 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   if (dir != 'U') return CAP_ERR_UNSUPPORTED;                      // assert(args.dir == 'U'), cholinv.hpp:9
   if (complete_inv < -1 || complete_inv > 1) return CAP_ERR_ARG;
   const bool multi = comm && cap_comm_size(comm) > 1;
-  // multi-GPU: only the blocked Cholesky (no explicit inverse) is distributed; R and R^-1 of upstream's
-  // d x d x c schedule stay single-GPU modes
-  if (multi && complete_inv != -1) return CAP_ERR_UNSUPPORTED;
+  // multi-GPU: the blocked Cholesky of dist.hip; complete_inv = 0 / 1 add R^-1 by one all-gather of R + a local block
+  // substitution per rank (dist.hip, dist_inverse) - upstream's R + R^-1 semantics on P > 1
   cap_cholinv_plan* p = new (std::nothrow) cap_cholinv_plan();
   if (!p) return CAP_ERR_ALLOC;
   memset(p, 0, sizeof(*p));
@@ -790,6 +789,8 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
     // A is this rank's block-cyclic column set (cap_bc_num_local_cols columns, all n rows); see dist.hip
     int st = cap_dist_plan_create(&p->dist, n, std::max<int64_t>(128, (p->nb / 128) * 128), comm);
     if (st != CAP_OK) { delete p; return st; }
+    (void)cap_dist_set_option(p->dist, "complete_inv", complete_inv);
+    (void)cap_dist_set_option(p->dist, "split", split);
     *plan = p;
     return CAP_OK;
   }
@@ -850,6 +851,8 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
       CAP_TRY(cap_dist_plan_create(&nd, p->n, value, p->comm));
       (void)cap_dist_plan_destroy(p->dist);
       p->dist = nd; p->nb = value;
+      (void)cap_dist_set_option(p->dist, "complete_inv", p->complete_inv);
+      (void)cap_dist_set_option(p->dist, "split", p->split);
       return CAP_OK;
     }
     return cap_dist_set_option(p->dist, key, value);
@@ -964,6 +967,7 @@ int cap_cholinv_get_R(cap_cholinv_plan* p, double* out, int64_t ld, void* stream
 }
 
 int cap_cholinv_get_Rinv(cap_cholinv_plan* p, double* out, int64_t ld, void* stream) {
+  if (p && p->dist) return p->complete_inv < 0 ? CAP_ERR_UNSUPPORTED : cap_dist_get_Rinv(p->dist, out, ld, stream);   // my block-cyclic columns
   if (!p || !out || ld < p->n) return CAP_ERR_ARG;
   if (p->complete_inv < 0) return CAP_ERR_UNSUPPORTED;   // this mode never builds R^-1
   return cap_copy_window(p->Rinv, 0, p->ldi, 0, 0, out, 0, ld, 0, 0, p->n, p->n, 1, 1, stream);
@@ -977,6 +981,7 @@ double* cap_cholinv_R_ptr(cap_cholinv_plan* p, int64_t* ld) {
 }
 double* cap_cholinv_Rinv_ptr(cap_cholinv_plan* p, int64_t* ld) {
   if (!p || p->complete_inv < 0) return nullptr;
+  if (p->dist) return cap_dist_Rinv_ptr(p->dist, ld);
   if (ld) *ld = p->ldi;
   return p->Rinv;
 }

@@ -77,6 +77,12 @@ struct cap_dist_plan {
   // the bulk update for CU slots (the reference pipelines the same move with MPI_Ibcast, summa.hpp:185-214).  Two 8-byte
   // all-reduces per strip carry the synchronisation: "every rank's buffer is free" before the pushes, "every push has
   // landed" after them.  RCCL stays the default and the fallback (option off, or if mapping a peer fails).
+  // R^-1 on the distributed factor (complete_inv = 0 / 1, the reference's semantics on P > 1): see dist_inverse
+  int complete_inv; int64_t split;
+  double* Rall;                  // all-gathered R: P pieces of npad x nmax0 (rank r's block columns), ld = npad
+  double* Dall;                  // every diagonal-block inverse (nblk x nb x nb), saved from the msg broadcasts
+  double* Ri;                    // my block columns of R^-1 (npad x nmax0, ld = npad)
+  double* Bacc;                  // right-hand-side accumulator of the block substitution (same shape)
   int ipc; bool ipc_ready; bool ipc_failed;
   double* peerG[8][2]; hipStream_t s_peer[8]; hipEvent_t ev_x0, ev_xr[8]; double* token; int ipc_nocu;
 };
@@ -273,6 +279,61 @@ int update(cap_dist_plan* d, int64_t m, int64_t nloc, int64_t K, const double* G
   }
   return CAP_OK;
 }
+// R^-1 of the distributed factor (complete_inv = 0 / 1 with P > 1: the reference's `factor` leaves both R and R^-1 on its
+// grid, cholinv.hpp:85-165 + the distributed TRMM of summa.hpp:46-83).  On the 1 x P layout every block column of R^-1 only
+// depends on R and on ITSELF:  R X = E_J  =>  X[i, J] = Dinv(i) (E[i, J] - sum_{i < k <= J} R[i, k] X[k, J]),  so after ONE
+// all-gather of R (the same volume as the factorization's strip exchanges) every rank back-substitutes its own block columns
+// with no further communication: block rows bottom-up,
+//     X[i, Js] = Dinv(i) Bacc[i, Js]            (Js = my blocks J >= i; Bacc[i, i] = I, i.e. X[i, i] = Dinv(i))
+//     Bacc[0:i, Js] -= R[0:i, i] X[i, Js]       (one MFMA GEMM, M = i nb, K = nb)
+// exactly (n^3 / 3) / P flops per rank.  Dinv(i) are the diagonal-block inverses every rank already received in msg(i).
+// complete_inv == 0: the root block Ri[0:n1, n1:n] (n1 = n >> split, cholinv.hpp:107,147) stays empty - the columns J >= n1
+// stop their substitution at block row n1 / nb (n1 on a block boundary), or the block is cleared afterwards (n1 inside a block).
+int dist_inverse(cap_dist_plan* d, hipStream_t s) {
+  CapRange range("CI::inverse");
+  const int64_t nb = d->nb, nblk = d->nblk, npad = d->npad, P = d->P, p = d->p, nb2 = nb * nb;
+  const int64_t pe = npad * d->nmax0;
+  // 1. replicate R: piece r = rank r's block columns (padded to nmax0 columns)
+  CAP_TRY(cap_comm_allgather(d->comm, d->R, d->Rall, pe, (void*)s));
+  if (d->nloc_blocks == 0) return CAP_OK;
+  CAP_HIP(hipMemsetAsync(d->Ri, 0, sizeof(double) * pe, s));
+  CAP_HIP(hipMemsetAsync(d->Bacc, 0, sizeof(double) * pe, s));
+  const int64_t n1 = d->n >> d->split;
+  const bool cut = d->complete_inv == 0 && n1 > 0 && n1 < d->n;
+  const int64_t kcut = (cut && n1 % nb == 0) ? n1 / nb : 0;          // block boundary of the root partition (0: none)
+  for (int64_t i = nblk - 1; i >= 0; i--) {
+    // my local blocks with J >= i ... and, above the root partition's row boundary, only those with J < kcut
+    const int64_t lb0 = lbfirst(p, i - 1, P);
+    int64_t lb1 = d->nloc_blocks;
+    if (kcut > 0 && i < kcut) lb1 = lbfirst(p, kcut - 1, P);
+    if (lb1 <= lb0) continue;
+    const double* Dinv = d->Dall + i * nb2;
+    double* Xi = d->Ri + i * nb + lb0 * nb * npad;                   // block row i of my columns from local block lb0 on
+    int64_t lbx = lb0;
+    if (lb0 * P + p == i) {                                          // I own block column i: X[i, i] = Dinv(i)
+      CAP_TRY(cap_copy_rect(Dinv, nb, Xi, npad, nb, nb, s));
+      lbx = lb0 + 1;
+    }
+    if (lb1 > lbx)
+      CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, nb, (lb1 - lbx) * nb, nb, 1.0, Dinv, nb, d->Bacc + i * nb + lbx * nb * npad, npad, 0.0,
+                              d->Ri + i * nb + lbx * nb * npad, npad, 0, s, 32));
+    if (i > 0) {
+      const double* Rcol = d->Rall + (i % P) * pe + (i / P) * nb * npad;   // R[0 : i nb, block column i]
+      CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, i * nb, (lb1 - lb0) * nb, nb, -1.0, Rcol, npad, Xi, npad, 1.0, d->Bacc + lb0 * nb * npad, npad,
+                              0, s));
+    }
+  }
+  if (cut && kcut == 0) {
+    // root partition inside a block: clear Ri[0:n1, columns >= n1] of my columns
+    for (int64_t lb = 0; lb < d->nloc_blocks; lb++) {
+      const int64_t c0 = (lb * P + p) * nb;
+      const int64_t from = std::max<int64_t>(c0, n1), to = c0 + nb;
+      if (from < to) CAP_TRY(cap_zero_rect(d->Ri + (lb * nb + (from - c0)) * npad, npad, n1, to - from, s));
+    }
+  }
+  return CAP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -321,6 +382,7 @@ int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* 
   d->jitter_state = 0x9E3779B97F4A7C15ull * (uint64_t)(d->p + 1); d->jitter_max_us = 0;
   d->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
   d->profile = 0; d->prof_used = 0; d->bk_used = 0; d->safe = 0;
+  d->complete_inv = -1; d->split = 1; d->Rall = d->Dall = d->Ri = d->Bacc = nullptr;
   d->ipc = getenv("CAP_DIST_IPC") ? atoi(getenv("CAP_DIST_IPC")) : 0; d->ipc_ready = false; d->ipc_failed = false; d->token = nullptr;
   d->ipc_nocu = getenv("CAP_DIST_IPC_NOCU") ? atoi(getenv("CAP_DIST_IPC_NOCU")) : 0;
   for (int r = 0; r < 8; r++) { d->peerG[r][0] = d->peerG[r][1] = nullptr; d->s_peer[r] = nullptr; d->ev_xr[r] = nullptr; }
@@ -330,7 +392,7 @@ int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* 
     int st = cap_comm_dup(comm, &d->comm2);
     if (st != CAP_OK) { delete d; return st; }
   }
-  hipError_t e = hipMalloc((void**)&d->R, sizeof(double) * std::max<int64_t>(d->npad * d->lc, 2));
+  hipError_t e = hipMalloc((void**)&d->R, sizeof(double) * std::max<int64_t>(d->npad * std::max(d->lc, d->nmax0), 2));   // nmax0 columns: the all-gather of R (dist_inverse) sends equal pieces
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
     // S: one extra block column - a rank that owns the strip's last block sends from one block further in, and the
     // equal-sized padded pieces are as wide as the widest rank's remainder
@@ -358,6 +420,7 @@ int cap_dist_plan_destroy(cap_dist_plan* d) {
   if (d->W) (void)hipFree(d->W);
   if (d->info_dev) (void)hipFree(d->info_dev);
   if (d->info_red) (void)hipFree(d->info_red);
+  for (double* q : {d->Rall, d->Dall, d->Ri, d->Bacc}) if (q) (void)hipFree(q);
   if (!d->ev_msg.empty()) {
     for (auto* v : {&d->ev_fact, &d->ev_msg, &d->ev_rowdone, &d->ev_solved, &d->ev_gather, &d->ev_head2, &d->ev_rest})
       for (auto e : *v) (void)hipEventDestroy(e);
@@ -390,6 +453,8 @@ int cap_dist_set_option(cap_dist_plan* d, const char* key, int64_t value) {
   if (k == "profile") { d->profile = value != 0; return CAP_OK; }
   if (k == "safe") { d->safe = value != 0; return CAP_OK; }
   if (k == "ipc") { d->ipc = value != 0; return CAP_OK; }
+  if (k == "complete_inv") { if (value < -1 || value > 1) return CAP_ERR_ARG; d->complete_inv = (int)value; return CAP_OK; }
+  if (k == "split") { if (value <= 0) return CAP_ERR_ARG; d->split = value; return CAP_OK; }
   if (k == "ipc_nocu") { d->ipc_nocu = value != 0; return CAP_OK; }
   return CAP_ERR_ARG;
 }
@@ -403,6 +468,8 @@ int64_t cap_dist_get_option(const cap_dist_plan* d, const char* key) {
   if (k == "jitter_us") return d->jitter_max_us;
   if (k == "safe") return d->safe;
   if (k == "ipc") return d->ipc;
+  if (k == "complete_inv") return d->complete_inv;
+  if (k == "split") return d->split;
   if (k == "ipc_active") return (d->ipc && d->ipc_ready) ? 1 : 0;
   if (k == "nb") return d->nb;
   if (k == "n") return d->n;
@@ -419,6 +486,14 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
   if (!d || (d->lc_valid > 0 && (!Aloc || lda < d->n))) return CAP_ERR_ARG;
   CAP_TRY(ensure_events(d));
   if (d->ipc) CAP_TRY(ensure_ipc(d, cap_stream(stream)));
+  if (d->complete_inv >= 0 && !d->Ri) {
+    const int64_t pe = d->npad * d->nmax0;
+    hipError_t e = hipMalloc((void**)&d->Rall, sizeof(double) * pe * d->P);
+    if (e == hipSuccess) e = hipMalloc((void**)&d->Dall, sizeof(double) * d->nblk * d->nb * d->nb);
+    if (e == hipSuccess) e = hipMalloc((void**)&d->Ri, sizeof(double) * pe);
+    if (e == hipSuccess) e = hipMalloc((void**)&d->Bacc, sizeof(double) * pe);
+    if (e != hipSuccess) return CAP_ERR_ALLOC;
+  }
   hipStream_t s0 = cap_stream(stream), s1 = d->s_panel, sc = d->s_comm, sm = d->safe ? d->s_comm : d->s_msg;
   cap_comm* cmsg = (d->safe || !d->comm2) ? d->comm : d->comm2;
   const int64_t n = d->n, npad = d->npad, nb = d->nb, nblk = d->nblk, P = d->P, p = d->p, ld = d->ld;
@@ -484,6 +559,7 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
 
       // ---- panel, every rank: block row k of my columns J > k
       CAP_HIP(hipStreamWaitEvent(s1, d->ev_msg[k], 0));
+      if (d->complete_inv >= 0) CAP_TRY(cap_copy_rect(Dinv, nb, d->Dall + k * nb2, nb, nb, nb, s1));   // kept for the inverse (dist_inverse)
       if (r == 0 && t >= 2) CAP_HIP(hipStreamWaitEvent(s1, d->ev_gather[t - 2], 0));   // S[par] was the all-gather source of strip t-2
       const int64_t lbk = lbfirst(p, k, P);
       const int64_t ncols = (d->nloc_blocks - lbk) * nb;
@@ -558,6 +634,7 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
   CAP_HIP(hipStreamWaitEvent(s0, d->ev_join_p, 0));
   CAP_HIP(hipStreamWaitEvent(s0, d->ev_join_c, 0));
   CAP_HIP(hipStreamWaitEvent(s0, d->ev_join_m, 0));
+  if (d->complete_inv >= 0) CAP_TRY(dist_inverse(d, s0));
   return CAP_OK;
 }
 
@@ -571,6 +648,19 @@ int cap_dist_get_R(cap_dist_plan* d, double* out, int64_t ldo, void* stream) {
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
+
+// construct_Rinv (cholinv.hpp:39-46) for this layout: my columns of R^-1 (n x local_cols), zero below the global diagonal
+int cap_dist_get_Rinv(cap_dist_plan* d, double* out, int64_t ldo, void* stream) {
+  if (!d || (d->lc_valid > 0 && (!out || ldo < d->n))) return CAP_ERR_ARG;
+  if (d->complete_inv < 0 || !d->Ri) return CAP_ERR_UNSUPPORTED;
+  if (d->lc_valid == 0) return CAP_OK;
+  dim3 grid((unsigned)cap_ceil_div(d->n, 256), (unsigned)std::min<int64_t>(d->lc_valid, 65535), (unsigned)cap_ceil_div(d->lc_valid, 65535));
+  hipLaunchKernelGGL(export_upper_bc_kernel, grid, dim3(256), 0, cap_stream(stream), d->Ri, d->ld, out, ldo, d->n, d->nb, d->P, d->p,
+                     d->lc_valid);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+double* cap_dist_Rinv_ptr(cap_dist_plan* d, int64_t* ld) { if (!d || !d->Ri) return nullptr; if (ld) *ld = d->ld; return d->Ri; }
 
 // Agreed on all ranks: 0, or the smallest 1-based failing pivot index any owner reported.  Collective on the
 // plan's communicator: call it on the stream cap_dist_factor was given (or after synchronising it).

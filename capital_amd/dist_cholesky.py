@@ -140,6 +140,13 @@ class Context:
         torch.cuda.synchronize()
         return out[: self.local_cols].cpu().numpy().T.copy()
 
+    def local_Rinv(self):
+        """numpy (n x local_cols) copy of this rank's columns of R^-1 (options complete_inv = 0 / 1), construct_Rinv."""
+        out = torch.zeros(max(self.local_cols, 1), self.n, dtype=torch.float64, device=self.device)
+        _lib.check(_lib.lib().cap_dist_get_Rinv(self.plan, out.data_ptr(), self.n, cur_stream()), "cap_dist_get_Rinv")
+        torch.cuda.synchronize()
+        return out[: self.local_cols].cpu().numpy().T.copy()
+
     def probe(self, allreduce=None):
         """||(R^T R - A) X||_F / ||A X||_F for 8 random vectors with torch's fp64 matmul over this rank's columns, summed over
         the ranks by `allreduce` (validate.cholesky.probe): none of the library's kernels takes part in the check."""

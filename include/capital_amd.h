@@ -232,9 +232,10 @@ int cap_topo_get(const cap_topo* topo, int field);
  *   bc_mult_dim:  base-case size knob (cholinv.hpp:15-18) -> panel width of the GPU schedule;
  *   dir:          'U' only, as upstream (cholinv.hpp:9).
  * comm = NULL or a size-1 communicator: single-GPU plan, A is the whole n x n matrix.
- * comm of size P > 1 (complete_inv = -1 only): the multi-GPU schedule of cap_dist_* behind the same
- * handle - A, get_R and R_ptr then refer to THIS RANK's block-cyclic columns (global block column J,
- * width nb, on rank J % P; cap_bc_num_local_cols columns, all n rows; option "nb" sets the width). */
+ * comm of size P > 1: the multi-GPU schedule of cap_dist_* behind the same handle - A, get_R / get_Rinv and
+ * the *_ptr accessors then refer to THIS RANK's block-cyclic columns (global block column J, width nb, on
+ * rank J % P; cap_bc_num_local_cols columns, all n rows; option "nb" sets the width); complete_inv = 0 / 1
+ * also build R^-1 there (cap_dist_get_Rinv).                                                          */
 typedef struct cap_cholinv_plan cap_cholinv_plan;
 int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv, int64_t split,
                             int64_t bc_mult_dim, char dir, cap_comm* comm);
@@ -282,6 +283,12 @@ double* cap_dist_R_ptr(cap_dist_plan* plan, int64_t* ld);               /* local
                                                                            below the global diagonal are scratch */
 int cap_dist_get_R(cap_dist_plan* plan, double* out, int64_t ld, void* stream);   /* construct_R: n x local_cols, zero below
                                                                                       the global diagonal              */
+/* Options "complete_inv" = 0 / 1 (+ "split"): the factor call also leaves this rank's block columns of R^-1 - upstream's
+ * R + R^-1 semantics on P > 1 (cholinv.hpp:85-165): ONE all-gather of R, then every rank back-substitutes its own columns
+ * with the diagonal-block inverses it received during the factorization ((n^3/3)/P flops per rank, no further
+ * communication).  complete_inv = 0 leaves Ri[0 : n >> split, n >> split : n] empty (cholinv.hpp:107,147).             */
+int cap_dist_get_Rinv(cap_dist_plan* plan, double* out, int64_t ld, void* stream);   /* construct_Rinv, same layout as get_R */
+double* cap_dist_Rinv_ptr(cap_dist_plan* plan, int64_t* ld);
 /* 0, or the smallest failing pivot (1-based) reported by any rank.  Collective; call it on the stream
  * cap_dist_factor ran on.                                                                              */
 int cap_dist_info(cap_dist_plan* plan, void* stream, int64_t* info);

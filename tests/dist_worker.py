@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--ipc", type=int, default=0, help="1: strip exchange by IPC peer copies instead of the all-gather collective")
     ap.add_argument("--c", type=int, default=1, help="grid depth c (summa: d x d x c, cacqr3d: c x d x c)")
     ap.add_argument("--pr", type=int, default=1, help="gpu2d: process rows Pr of the Pr x Pc block-cyclic grid")
+    ap.add_argument("--ci", type=int, default=-1, help="gpu: complete_inv (0 / 1: the factor call also builds this rank's columns of R^-1)")
+    ap.add_argument("--split", type=int, default=1)
+    ap.add_argument("--golden", default="", help="gpu: name of a tests/golden/cholinv_p8_*.npz dump of the REAL reference to compare with")
     ap.add_argument("--k", type=int, default=0, help="summa: inner dimension")
     ap.add_argument("--chunks", type=int, default=0, help="summa: num_chunks")
     args = ap.parse_args()
@@ -229,8 +232,15 @@ def main():
         from capital_amd import dist_cholesky as dc
         from tests.host_staged import HostStagedComm
         comm = HostStagedComm()
+        gold = None
+        if args.golden:
+            gold = np.load(os.path.join(ROOT, "tests", "golden", args.golden))
+            n, args.ci, args.split = int(gold["n"]), int(gold["complete_inv"]), int(gold["split"])
         a = orc.symmetric_global(n, True)
+        if gold is not None:
+            assert np.array_equal(a, gold["A"])
         cols = dc.global_cols_of_rank(n, nb, size, rank)
+        ri_l = None
         if args.seam:
             # the algorithm seam: cholinv::factor(A, pack, topo) with a multi-rank topo -> same schedule behind the plan handle
             from capital_amd import cholinv
@@ -242,11 +252,13 @@ def main():
             A = matrix(max(cols.size, 1), n, 1, 1)
             if cols.size:
                 A.view()[:, : cols.size].copy_(torch.from_numpy(np.ascontiguousarray(a[:, cols])).cuda())
-            pack = cholinv.info(-1, 1, -2, 'U')
+            pack = cholinv.info(args.ci, args.split, -2, 'U')
             pack.set_option("nb", nb)
             cholinv.factor(A, pack, topo)
             info = pack.last_info()
             rl = cholinv.construct_R(pack, topo).to_numpy()[:, : cols.size]
+            if args.ci >= 0:
+                ri_l = cholinv.construct_Rinv(pack, topo).to_numpy()[:, : cols.size]
             close = lambda: pack._release()
         else:
             ctx = dc.Context(n, nb, comm)
@@ -264,6 +276,8 @@ def main():
                 ctx.set_option("safe", 1)
             if args.ipc:
                 ctx.set_option("ipc", 1)
+            if args.ci >= 0:
+                ctx.set_option("complete_inv", args.ci); ctx.set_option("split", args.split)
             for rep in range(2):                       # plan reuse
                 ctx.factor()
             info = ctx.last_info()
@@ -284,13 +298,38 @@ def main():
             ctx.set_option("profile", 0)
             assert all(b >= 0 for b in busy) and busy[0] > 0 and (size == 1 or busy[3] > 0), list(busy)
             rl = ctx.local_R()
+            if args.ci >= 0:
+                ri_l = ctx.local_Rinv()
             close = ctx.close
         lc_max = max(dc.global_cols_of_rank(n, nb, size, r).size for r in range(size))
         pad = torch.zeros(n, lc_max, dtype=torch.float64); pad[:, : cols.size] = torch.from_numpy(rl)
         outs = [torch.empty_like(pad) for _ in range(size)]
         dist.all_gather(outs, pad)
+        Ri = None
+        if args.ci >= 0:
+            padi = torch.zeros(n, lc_max, dtype=torch.float64); padi[:, : cols.size] = torch.from_numpy(ri_l)
+            outsi = [torch.empty_like(padi) for _ in range(size)]
+            dist.all_gather(outsi, padi)
+            Ri = dc.assemble_global([o.numpy() for o in outsi], n, nb, size)
+        if rank == 0 and Ri is not None:
+            # R^-1 of the distributed factor against the oracle's recursion (same empty root block for complete_inv = 0) and,
+            # when given, against the REAL reference's 8-rank dump of this very configuration
+            r_ref, ri_ref = orc.cholinv(a, args.ci, args.split, -2, 1, 1)
+            assert np.linalg.norm(Ri - ri_ref) / np.linalg.norm(ri_ref) < 1e-12
+            assert np.array_equal(Ri != 0, ri_ref != 0), "R^-1 pattern (triangle + empty root block, cholinv.hpp:147)"
+            if gold is not None:
+                assert np.linalg.norm(Ri - np.triu(gold["Rinv"])) / np.linalg.norm(gold["Rinv"]) < 1e-13
+                assert np.array_equal(Ri != 0, np.triu(gold["Rinv"]) != 0)
+            n1 = n >> args.split
+            Rg = dc.assemble_global([o.numpy() for o in outs], n, nb, size)
+            for (lo, hi) in (((0, n1), (n1, n)) if args.ci == 0 else ((0, n),)):
+                blk = Ri[lo:hi, lo:hi] @ Rg[lo:hi, lo:hi]
+                assert np.linalg.norm(blk - np.eye(hi - lo)) / np.sqrt(hi - lo) < 1e-13
+            print("DISTINV-OK ci=%d split=%d%s" % (args.ci, args.split, " golden=ok" if gold is not None else ""), flush=True)
         if rank == 0:
             R = dc.assemble_global([o.numpy() for o in outs], n, nb, size)
+            if gold is not None:
+                assert np.linalg.norm(R - np.triu(gold["R"])) / np.linalg.norm(gold["R"]) < 1e-14
             assert np.array_equal(np.tril(R, -1), np.zeros_like(R)), "construct_R must zero the part below the global diagonal"
             ref = np.linalg.cholesky(a).T
             err = np.linalg.norm(R - ref) / np.linalg.norm(ref)
