@@ -256,6 +256,10 @@ struct cap_cholinv_plan {
   std::vector<hipEvent_t>* prof_ev; std::vector<double>* prof_flops; int prof_used;
   // multi-GPU plans (comm size > 1): the 1 x P block-cyclic schedule of dist.hip behind the same handle
   cap_dist_plan* dist;
+  // Strip buffers (use_sb): the solved block rows of a strip are written K-contiguously into one of three NB x n buffers
+  // (ld = NB) and every update reads its operands from there; the copy into R - R is only the OUTPUT after that - runs on
+  // its own stream off the panel stream's critical path (it was 64 x 134 MB of copies on it at N = 32768)
+  int use_sb; double* SB; int64_t sb_ld, sb_cols; hipStream_t s_copy; hipEvent_t ev_sbg, ev_copy[3], ev_join_cp; bool sb_ready;
   // R^-1 on top of the blocked factorization (complete_inv >= 0, see InvTree): its own stream, one event per panel
   int inv_fast;         // 1: blocked factorization + inverse tree (default for n >= 2 nb), 0: the plain recursion of cholinv.hpp:85-165
   int inv_overlap;      // 1: tree nodes are enqueued as their inputs become final (overlapped with the sweep), 0: after it
@@ -378,12 +382,34 @@ int panel_solve(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t j0, int64_t
 // factor the nb-wide panel starting at j0: diagonal block (R, Dinv), then the block row solve
 int inverse_after_panel(cap_cholinv_plan* p, int64_t k, int64_t cols_left, hipStream_t s);
 
-int panel_factor(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t j0, int64_t jb, hipStream_t s) {
+// where the solved rows of the strip being factored go (strip-buffer mode): element (Js + r, j) at SB[r + j * ld]
+struct StripCtx { double* SB; int64_t ld, Js; };
+
+int panel_factor(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t j0, int64_t jb, hipStream_t s, const StripCtx* sc = nullptr) {
   // complete_inv >= 0 on the blocked path: the diagonal-block inverse IS the diagonal block of R^-1 (written in place, ld = ldi)
   double* Dinv = p->inv_active ? p->Rinv + j0 + j0 * p->ldi : p->Rinv;
   CAP_TRY(panel_chain(p, R, ldr, j0, jb, Dinv, s));
-  CAP_TRY(panel_solve(p, R, ldr, j0, jb, Dinv, j0 + jb, n, p->work + rec_work_size(p->nb), s));
-  if (p->inv_active) CAP_TRY(inverse_after_panel(p, j0 / p->nb, n - (j0 + jb), s));
+  const int64_t j1 = j0 + jb, m = n - j1;
+  if (!sc) {
+    CAP_TRY(panel_solve(p, R, ldr, j0, jb, Dinv, j1, n, p->work + rec_work_size(p->nb), s));
+    if (p->inv_active) CAP_TRY(inverse_after_panel(p, j0 / p->nb, m, s));
+    return CAP_OK;
+  }
+  // strip-buffer mode: the solve writes straight into the strip buffer; R gets its copy on the copy stream
+  hipStream_t scp = p->s_copy;
+  if (m > 0) {
+    CapRange range("CI::trsm");
+    double* Rpan = R + j0 + j1 * ldr;
+    double* Srow = sc->SB + (j0 - sc->Js) + j1 * sc->ld;
+    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, m, jb, 1.0, Dinv, p->ldi, Rpan, ldr, 0.0, Srow, sc->ld, 0, s, 2 | 16));
+    CAP_HIP(hipEventRecord(p->ev_sbg, s));
+    CAP_HIP(hipStreamWaitEvent(scp, p->ev_sbg, 0));
+    CAP_TRY(cap_copy_rect(Srow, sc->ld, Rpan, ldr, jb, m, scp));
+  } else if (p->inv_active) {
+    CAP_HIP(hipEventRecord(p->ev_sbg, s));
+    CAP_HIP(hipStreamWaitEvent(scp, p->ev_sbg, 0));
+  }
+  if (p->inv_active) CAP_TRY(inverse_after_panel(p, j0 / p->nb, m, scp));     // the tree reads R12 from R: behind the copy
   return CAP_OK;
 }
 
@@ -391,7 +417,8 @@ int panel_factor(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t
 // M == N, A == B: the SYRK on the bulk of the trailing matrix; M < N: the strip of rows updated first so
 // that the panel chain of the step after next can start early (look-ahead depth 2).
 int trailing_update(cap_cholinv_plan* p, int64_t M, int64_t N, int64_t k, const double* A, const double* B, double* C,
-                    int64_t ldr, hipStream_t s) {
+                    int64_t ldr, hipStream_t s, int64_t ldab = 0) {
+  if (ldab == 0) ldab = ldr;              // operands inside R itself (no strip buffer)
   CapRange range("CI::tmu");                    // cholinv.hpp:129-136
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (p->profile && p->prof_ev) {
@@ -403,7 +430,7 @@ int trailing_update(cap_cholinv_plan* p, int64_t M, int64_t N, int64_t k, const 
   }
   // chain-bound tail (N columns left <= occ1_m): one bulk workgroup per CU instead of two, see launch_tn_dma
   const int occ = (p->occ1_m > 0 && N <= p->occ1_m) ? -1 : 0;
-  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, M, N, k, -1.0, A, ldr, B, ldr, 1.0, C, ldr, 1, s, 1 | p->ctag, occ));
+  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, M, N, k, -1.0, A, ldab, B, ldab, 1.0, C, ldr, 1, s, 1 | p->ctag, occ));
   if (e0) {
     CAP_HIP(hipEventRecord(e1, s));
     p->prof_used += 2;
@@ -416,19 +443,45 @@ int trailing_update(cap_cholinv_plan* p, int64_t M, int64_t N, int64_t k, const 
 // Factor the strip R[J0 : J0+rows, J0 : n] (its leading rows x rows block is diagonal), assuming every
 // update from earlier strips has been applied: inner right-looking sweep with nb-wide panels whose
 // trailing update is confined to the strip's own rows.  One stream.
-int factor_strip(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t J0, int64_t rows, hipStream_t s) {
+int factor_strip(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t J0, int64_t rows, hipStream_t s, const StripCtx* sc = nullptr) {
   const int64_t nb = p->nb, Jend = J0 + rows;
   for (int64_t j0 = J0; j0 < Jend; j0 += nb) {
     const int64_t jb = std::min(nb, Jend - j0);
-    CAP_TRY(panel_factor(p, R, ldr, n, j0, jb, s));
+    CAP_TRY(panel_factor(p, R, ldr, n, j0, jb, s, sc));
     const int64_t j1 = j0 + jb, rows_left = Jend - j1, cols = n - j1;
     if (rows_left > 0 && cols > 0) {
-      double* Rpan = R + j0 + j1 * ldr;            // jb x cols block row just solved
-      CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows_left, cols, jb, -1.0, Rpan, ldr, Rpan, ldr, 1.0,
+      // jb x cols block row just solved: inside R, or in the strip buffer
+      const double* Rpan = sc ? sc->SB + (j0 - sc->Js) + j1 * sc->ld : R + j0 + j1 * ldr;
+      const int64_t ldp = sc ? sc->ld : ldr;
+      CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows_left, cols, jb, -1.0, Rpan, ldp, Rpan, ldp, 1.0,
                               R + j1 + j1 * ldr, ldr, 1, s, p->ctag));
     }
   }
   return CAP_OK;
+}
+
+int ensure_sb(cap_cholinv_plan* p, int64_t NB, int64_t n) {
+  if (p->sb_ready && p->sb_ld == NB && p->sb_cols == n) return CAP_OK;
+  if (p->sb_ready) { CAP_HIP(hipDeviceSynchronize()); (void)hipFree(p->SB); p->SB = nullptr; }
+  else {
+    CAP_HIP(hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking));
+    CAP_HIP(hipEventCreateWithFlags(&p->ev_sbg, hipEventDisableTiming));
+    CAP_HIP(hipEventCreateWithFlags(&p->ev_join_cp, hipEventDisableTiming));
+    for (int i = 0; i < 3; i++) CAP_HIP(hipEventCreateWithFlags(&p->ev_copy[i], hipEventDisableTiming));
+  }
+  p->sb_ready = true; p->sb_ld = 0;
+  CAP_HIP(hipMalloc((void**)&p->SB, sizeof(double) * 3 * NB * n));
+  p->sb_ld = NB; p->sb_cols = n;
+  return CAP_OK;
+}
+
+void release_sb(cap_cholinv_plan* p) {
+  if (!p->sb_ready) return;
+  (void)hipStreamSynchronize(p->s_copy); (void)hipStreamDestroy(p->s_copy);
+  (void)hipEventDestroy(p->ev_sbg); (void)hipEventDestroy(p->ev_join_cp);
+  for (int i = 0; i < 3; i++) (void)hipEventDestroy(p->ev_copy[i]);
+  if (p->SB) (void)hipFree(p->SB);
+  p->SB = nullptr; p->sb_ready = false;
 }
 
 // ---- inverse tree on its own stream (see InvTree) ------------------------------------------------------------------------
@@ -650,11 +703,26 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
   CAP_TRY(ensure_bulk_stream(p));
   hipStream_t s1 = p->s_panel;
   hipStream_t s_user = s0;
+  // strip-buffer mode (plan-owned factor, overlapped schedule): see cap_cholinv_plan::use_sb
+  const bool sbm = p->use_sb && p->serial_m == 0 && R == p->R;
+  if (sbm) CAP_TRY(ensure_sb(p, NB, n));
+  auto sctx = [&](int64_t t) { return StripCtx{p->SB + (t % 3) * p->sb_ld * n, p->sb_ld, bnd[(size_t)t]}; };
+  // strip t is factored into buffer t % 3: its previous tenant (strip t - 3) has been read by the bulk update of step t - 3
+  // (finished before the head of step t - 2 that the panel stream has waited for) and by the copy stream (ev_copy)
+  auto strip = [&](int64_t t, hipStream_t s) -> int {
+    if (!sbm) return factor_strip(p, R, ldr, n, bnd[(size_t)t], bnd[(size_t)t + 1] - bnd[(size_t)t], s);
+    if (t >= 3) CAP_HIP(hipStreamWaitEvent(s, p->ev_copy[t % 3], 0));
+    const StripCtx c = sctx(t);
+    CAP_TRY(factor_strip(p, R, ldr, n, bnd[(size_t)t], bnd[(size_t)t + 1] - bnd[(size_t)t], s, &c));
+    CAP_HIP(hipEventRecord(p->ev_copy[t % 3], p->s_copy));
+    return CAP_OK;
+  };
   // fork: the panel stream (and the CU-masked bulk stream) join the caller's stream
   CAP_HIP(hipEventRecord(p->ev_fork, s0));
   CAP_HIP(hipStreamWaitEvent(s1, p->ev_fork, 0));
+  if (sbm) CAP_HIP(hipStreamWaitEvent(p->s_copy, p->ev_fork, 0));
   if (p->bulk_ready) { s0 = p->s_bulk; CAP_HIP(hipStreamWaitEvent(s0, p->ev_fork, 0)); }
-  CAP_TRY(factor_strip(p, R, ldr, n, 0, bnd[1], s1));
+  CAP_TRY(strip(0, s1));
   CAP_HIP(hipEventRecord(p->ev_panel[0], s1));
   // Optional (serial_m > 0, default off): from strip ksw on the chain and the bulk update are NOT overlapped any more.
   // Measured (tools/contend.cpp): the chain's kernels run 8-15x slower next to the bulk kernel - a co-resident wave issuing
@@ -681,29 +749,32 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
       break;
     }
     const int64_t J1 = bnd[k + 1], rows1 = bnd[k + 2] - J1, m2 = m - rows1;
-    double* S = R + J0 + J1 * ldr;                 // strip k right of its diagonal block: rows x m
+    // strip k right of its diagonal block (rows x m): inside R, or in its strip buffer (K-contiguous, ld = NB)
+    const StripCtx ck = sbm ? sctx(k) : StripCtx{nullptr, 0, 0};
+    const double* S = sbm ? ck.SB + J1 * ck.ld : R + J0 + J1 * ldr;
+    const int64_t lds_ = sbm ? ck.ld : ldr;
     // (a) panel stream: bring strip k+1 up to date (K = rows, upper part), then factor it.
     //     needs strip k (same stream) and the HEAD of the bulk update of step k-1 (main stream): the head is the
     //     part of that update that touches strip k+1's rows, so the chain runs one more step ahead of the bulk
     if (k > 0) CAP_HIP(hipStreamWaitEvent(s1, p->ev_update[(k - 1) & 1], 0));
-    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows1, m, rows, -1.0, S, ldr, S, ldr, 1.0, R + J1 + J1 * ldr, ldr, 1, s1, p->ctag));
-    CAP_TRY(factor_strip(p, R, ldr, n, J1, rows1, s1));
+    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows1, m, rows, -1.0, S, lds_, S, lds_, 1.0, R + J1 + J1 * ldr, ldr, 1, s1, p->ctag));
+    CAP_TRY(strip(k + 1, s1));
     CAP_HIP(hipEventRecord(p->ev_panel[(k + 1) & 1], s1));
     // (b) main stream: bulk of the trailing update (rows below strip k+1)
     CAP_HIP(hipStreamWaitEvent(s0, p->ev_panel[k & 1], 0));
     if (m2 > 0) {
-      double* S2 = S + rows1 * ldr;
+      const double* S2 = S + rows1 * lds_;
       const int64_t J2 = J1 + rows1;
       const int64_t rows2 = (k + 3 <= nstrip) ? bnd[k + 3] - bnd[k + 2] : m2;   // height of strip k+2
       if (p->depth2 && rows2 < m2) {
         // head: strip k+2's rows first, then signal the panel stream; rest: everything below
-        CAP_TRY(trailing_update(p, rows2, m2, rows, S2, S2, R + J2 + J2 * ldr, ldr, s0));
+        CAP_TRY(trailing_update(p, rows2, m2, rows, S2, S2, R + J2 + J2 * ldr, ldr, s0, lds_));
         CAP_HIP(hipEventRecord(p->ev_update[k & 1], s0));
         const int64_t m3 = m2 - rows2;
-        double* S3 = S2 + rows2 * ldr;
-        CAP_TRY(trailing_update(p, m3, m3, rows, S3, S3, R + (J2 + rows2) + (J2 + rows2) * ldr, ldr, s0));
+        const double* S3 = S2 + rows2 * lds_;
+        CAP_TRY(trailing_update(p, m3, m3, rows, S3, S3, R + (J2 + rows2) + (J2 + rows2) * ldr, ldr, s0, lds_));
       } else {
-        CAP_TRY(trailing_update(p, m2, m2, rows, S2, S2, R + J2 + J2 * ldr, ldr, s0));
+        CAP_TRY(trailing_update(p, m2, m2, rows, S2, S2, R + J2 + J2 * ldr, ldr, s0, lds_));
         CAP_HIP(hipEventRecord(p->ev_update[k & 1], s0));
       }
     } else {
@@ -711,6 +782,7 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
     }
   }
   // join
+  if (sbm) { CAP_HIP(hipEventRecord(p->ev_join_cp, p->s_copy)); CAP_HIP(hipStreamWaitEvent(s_user, p->ev_join_cp, 0)); }
   CAP_HIP(hipEventRecord(p->ev_join, s1));
   CAP_HIP(hipStreamWaitEvent(s_user, p->ev_join, 0));
   if (s0 != s_user) { CAP_HIP(hipEventRecord(p->ev_join_b, s0)); CAP_HIP(hipStreamWaitEvent(s_user, p->ev_join_b, 0)); }
@@ -808,6 +880,7 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   p->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
   p->depth2 = n >= 24576;     // look-ahead depth 2 pays once a bulk update is long enough to split (+2 % at N = 32768)
   // reference semantics (R and R^-1): blocked factorization + inverse tree; the tree starts once the sweep is chain-bound
+  p->use_sb = getenv("CAP_USE_SB") ? atoi(getenv("CAP_USE_SB")) : 1;
   p->inv_fast = getenv("CAP_INV_FAST") ? atoi(getenv("CAP_INV_FAST")) : 1;
   p->inv_overlap = getenv("CAP_INV_OVERLAP") ? atoi(getenv("CAP_INV_OVERLAP")) : 1;
   p->inv_start_m = getenv("CAP_INV_START_M") ? atoll(getenv("CAP_INV_START_M")) : std::max<int64_t>(16384, n / 2);
@@ -835,6 +908,7 @@ int cap_cholinv_plan_destroy(cap_cholinv_plan* p) {
   }
   release_split(p);
   release_inverse(p);
+  release_sb(p);
   if (p->prof_ev) { for (hipEvent_t e : *p->prof_ev) (void)hipEventDestroy(e); delete p->prof_ev; delete p->prof_flops; }
   delete p;
   return CAP_OK;
@@ -885,6 +959,7 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
   if (k == "inner_la") { p->inner_la = value != 0; return CAP_OK; }
   if (k == "occ1_m") { if (value < 0) return CAP_ERR_ARG; p->occ1_m = value; return CAP_OK; }
   if (k == "fastdiag") { p->fastdiag = value != 0; return CAP_OK; }
+  if (k == "use_sb") { p->use_sb = value != 0; return CAP_OK; }
   if (k == "inv_fast") { p->inv_fast = value != 0; return CAP_OK; }
   if (k == "inv_overlap") { p->inv_overlap = value != 0; return CAP_OK; }
   if (k == "inv_start_m") { if (value < 0) return CAP_ERR_ARG; p->inv_start_m = value; return CAP_OK; }
@@ -923,6 +998,7 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
   if (k == "outer") return p->outer;
   if (k == "tail") return p->tail;
   if (k == "serial_m") return p->serial_m;
+  if (k == "use_sb") return p->use_sb;
   if (k == "inv_fast") return p->inv_fast;
   if (k == "inv_overlap") return p->inv_overlap;
   if (k == "inv_start_m") return p->inv_start_m;

@@ -18,7 +18,17 @@ def _launch(nproc, mode, n, nb, port, extra=()):
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "--mode", mode, "--size", str(n),
            "--nb", str(nb)] + [str(x) for x in extra]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    return subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    if r.returncode != 0:
+        # keep the complete output of a failing multi-rank run (the assertion message only shows its tail)
+        d = os.path.join(ROOT, "gpurun_out")
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "dist_fail_%s_%d_%d.log" % (mode, nproc, port)), "w") as f:
+                f.write(" ".join(cmd) + "\n---- stdout\n" + r.stdout + "\n---- stderr\n" + r.stderr)
+        except OSError:
+            pass
+    return r
 
 
 @pytest.mark.parametrize("nproc,n,nb", [(2, 1024, 128), (3, 1000, 100), (2, 640, 256)])

@@ -113,6 +113,8 @@ def test_matches_oracle(n, ci, split, bc):
     (3072, 1, 1, -3, {"nb": 256, "inv_overlap": 0}),
     (3072, 1, 1, -3, {"nb": 256, "inv_start_m": 0}),            # overlapped mode that never starts early = flush at the end
     (3072, 0, 1, -3, {"nb": 256, "inv_start_m": 1 << 30}),      # tree enqueued from the first panel on
+    (3072, 1, 1, -3, {"nb": 256, "use_sb": 0}),                 # without strip buffers: the tree's events come from the panel stream
+    (1100, 0, 1, -2, {"nb": 128, "use_sb": 0}),
 ])
 def test_inverse_tree_on_blocked_factorization(n, ci, split, bc, opts):
     """complete_inv = 0 / 1 on matrices of several panels: blocked right-looking sweep + inverse tree (cholinv.hip,
@@ -162,7 +164,10 @@ def test_inverse_tree_overlap_modes_are_bitwise_identical():
                                   {"nb": 256, "outer": 256, "inner_la": 1}, {"nb": 128, "outer": 1024, "inner_la": 1},
                                   # one bulk workgroup per CU below / above the threshold
                                   {"nb": 128, "outer": 256, "occ1_m": 0}, {"nb": 128, "outer": 256, "occ1_m": 1024},
-                                  {"nb": 128, "outer": 256, "occ1_m": 4096, "inner_la": 1}])
+                                  {"nb": 128, "outer": 256, "occ1_m": 4096, "inner_la": 1},
+                                  # strip buffers off (block rows solved through the panel scratch and copied back on the panel stream)
+                                  {"nb": 128, "outer": 256, "use_sb": 0}, {"nb": 128, "outer": 512, "tail": 512, "depth2": 1, "use_sb": 0},
+                                  {"nb": 128, "outer": 128, "use_sb": 1}, {"nb": 256, "outer": 512, "tail": 0, "use_sb": 1}])
 def test_schedule_knobs_do_not_change_the_answer(opts):
     from capital_amd import cholinv
     n = 1536
