@@ -120,6 +120,13 @@ SIGNATURES = {
     "cap_mpchol_R32_ptr": (ptr, [ptr, C.POINTER(i64)]),
     "cap_mpchol_set_option": (cint, [ptr, C.c_char_p, i64]),
     "cap_mpchol_profile": (cint, [ptr, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]),
+    "cap_dmp_plan_create": (cint, [C.POINTER(ptr), i64, i64, i64, ptr]),
+    "cap_dmp_plan_destroy": (cint, [ptr]),
+    "cap_dmp_local_cols": (i64, [ptr]),
+    "cap_dmp_factor": (cint, [ptr, ptr, i64, ptr]),
+    "cap_dmp_info": (cint, [ptr, ptr, C.POINTER(i64)]),
+    "cap_dmp_solve": (cint, [ptr, ptr, i64, ptr, i64, ptr, i64, i64, cint, dbl, C.POINTER(cint), C.POINTER(dbl), ptr]),
+    "cap_dmp_R32_ptr": (ptr, [ptr, C.POINTER(i64)]),
     "cap_cacqr_plan_create": (cint, [C.POINTER(ptr), i64, i64, cint, ptr]),
     "cap_cacqr_plan_create_grid": (cint, [C.POINTER(ptr), i64, i64, cint, ptr]),
     "cap_cacqr_local_cols": (i64, [ptr]),

@@ -58,7 +58,7 @@ def build(force=False, verbose=True):
         _, err = p.communicate()
         remarks = [l for l in err.splitlines() if "kernel-resource-usage" in l]
         other = [l for l in err.splitlines() if "kernel-resource-usage" not in l and not re.match(r"^\s*\d*\s*\|", l)
-                 and "remarks generated" not in l]   # (drop the source excerpt clang prints under every remark)
+                 and "remarks generated" not in l and not l.startswith("In file included from")]   # (drop the source excerpt / include trail clang prints with every remark)
         if other:
             print("\n".join(other), file=sys.stderr, flush=True)
         if p.returncode != 0:

@@ -951,6 +951,7 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   g.etri = 3;
   int64_t nsuper = 0;
   for (int sj = 0; sj < g.nsn; sj++) nsuper += stair_cnt(sj, ST, g.tn, g.nsm, p, P, lb0, nb / 128, J0, Pr, pr, rlb0);
+  if (nsuper == 0) return CAP_OK;      // Pr > 1: every local row block may lie below every local column block (nothing to update)
   int64_t slots = nsuper * ST * ST;
   g.chunk = (int)cap_ceil_div(slots, 8);
   return launch_tn_dma<1>(g, g.chunk * 8, stream, persist_wgs);

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "common.h"
+#include "mixed_kernels.h"
 #include "tile_dma.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -43,6 +44,11 @@ struct BfArgs {
   float alpha;
   int tri;                         // 1: only tiles / elements with row <= col (square problems)
   int tm, tn, chunk;
+  // distributed trailing update (dist_mixed.hip; the bf16 twin of GemmArgs::stair / gather in gemm.hip): C = my block-cyclic
+  // block columns (1 x P grid, block width snbT tiles), rows global from block sJ0 on; upper mask along the staircase
+  // row tile <= global tile of my column tile; operand A = the all-gathered bf16 block row, P pieces in (rank, local block) order
+  int stair, sP, sp, snbT, sJ0, slb0;
+  int64_t gpiece; int gstart[8];
 };
 
 // C[M x N] += alpha * A^T B,  A: K x M, B: K x N (both K-contiguous bf16), C fp32 column-major.  M, N % 128 == 0, K % 64 == 0.
@@ -53,7 +59,7 @@ __global__ void __launch_bounds__(256, 2) bf16_tn_kernel(const BfArgs g) {
   const int L = (b & 7) * g.chunk + (b >> 3);
   int ti, tj;
   if ((b >> 3) >= g.chunk) return;
-  if (g.tri && g.tm == g.tn) {
+  if (!g.stair && g.tri && g.tm == g.tn) {
     tj = (int)((__builtin_sqrtf(8.0f * (float)L + 1.0f) - 1.0f) * 0.5f);
     while ((tj + 1) * (tj + 2) / 2 <= L) tj++;
     while (tj * (tj + 1) / 2 > L) tj--;
@@ -62,7 +68,16 @@ __global__ void __launch_bounds__(256, 2) bf16_tn_kernel(const BfArgs g) {
   } else {
     ti = L % g.tm; tj = L / g.tm;
     if (tj >= g.tn) return;
-    if (g.tri && ti > tj) return;                        // strip of a triangular update: only tiles on / above the diagonal
+    if (!g.stair && g.tri && ti > tj) return;            // strip of a triangular update: only tiles on / above the diagonal
+  }
+  int gtj = tj;                                          // global tile column (relative to the row origin) under the staircase view
+  const __bf16* Abase = g.A + (int64_t)ti * TB * g.lda;
+  if (g.stair) {
+    const int J = g.sp + g.sP * (g.slb0 + tj / g.snbT);
+    gtj = (J - g.sJ0) * g.snbT + tj % g.snbT;
+    if (ti > gtj) return;
+    const int I = g.sJ0 + ti / g.snbT, r = I % g.sP, lb = I / g.sP - g.gstart[r];
+    Abase = g.A + (int64_t)r * g.gpiece + ((int64_t)(lb * g.snbT + ti % g.snbT) * TB) * g.lda;
   }
   const int64_t i0 = (int64_t)ti * TB, j0 = (int64_t)tj * TB;
   const int lane = threadIdx.x & 63;
@@ -82,7 +97,7 @@ __global__ void __launch_bounds__(256, 2) bf16_tn_kernel(const BfArgs g) {
 
   const int nk = (int)(g.K / KB);
   // the bf16 panels are addressed as "double" matrices of K / 4 doubles per row: same 128-byte rows, same swizzle
-  DmaBuf dA = dma_buf_make(reinterpret_cast<const double*>(g.A + i0 * g.lda), g.lda / 4);
+  DmaBuf dA = dma_buf_make(reinterpret_cast<const double*>(Abase), g.lda / 4);
   DmaBuf dB = dma_buf_make(reinterpret_cast<const double*>(g.B + j0 * g.ldb), g.ldb / 4);
   // fragment byte offsets: row (block origin + r32), chunk (2 s + kg) ^ ((row >> 1) & 7) = (2 s) ^ t
   const int t = kg ^ ((r32 >> 1) & 7);
@@ -134,7 +149,7 @@ __global__ void __launch_bounds__(256, 2) bf16_tn_kernel(const BfArgs g) {
   }
 
   // epilogue: lane holds C[i0 + wi + 32 i + r32][j0 + wj + 32 j + (e & 3) + 8 (e >> 2) + 4 kg]: 32 consecutive rows per half wave
-  const bool diag = g.tri && ti == tj;
+  const bool diag = g.stair ? (ti == gtj) : (g.tri && ti == tj);
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     const int64_t row = i0 + wi + 32 * i + r32;
@@ -157,47 +172,34 @@ int launch_bf16_tn(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A
   BfArgs g;
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.tri = tri;
   g.tm = (int)(m / TB); g.tn = (int)(n / TB);
+  g.stair = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0;
+  for (int i = 0; i < 8; i++) g.gstart[i] = 0;
   const int64_t tiles = (tri && m == n) ? (int64_t)g.tn * (g.tn + 1) / 2 : (int64_t)g.tm * g.tn;
   g.chunk = (int)cap_ceil_div(tiles, 8);
   hipLaunchKernelGGL(bf16_tn_kernel, dim3((unsigned)(g.chunk * 8)), dim3(256), 4 * TILE_D * sizeof(double), s, g);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
-
-// ---- precision conversions (HBM-bound element kernels) ------------------------------------------------------------
-__global__ void f64_to_f32_upper_kernel(const double* A, int64_t lda, float* R, int64_t ldr, int64_t n) {
-  const int64_t col = blockIdx.y + (int64_t)blockIdx.z * 65535;
-  if (col >= n) return;
-  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x)
-    R[row + col * ldr] = row <= col ? (float)A[row + col * lda] : 0.0f;
-}
-__global__ void f32_to_f64_kernel(const float* S, int64_t lds_, double* D, int64_t ldd, int64_t rows, int64_t cols, int upper_only) {
-  const int64_t col = blockIdx.y + (int64_t)blockIdx.z * 65535;
-  if (col >= cols) return;
-  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < rows; row += (int64_t)gridDim.x * blockDim.x)
-    D[row + col * ldd] = (!upper_only || row <= col) ? (double)S[row + col * lds_] : 0.0;
-}
-// the solved block row: fp64 -> fp32 (into the factor) and bf16 (into the K-contiguous panel of the trailing update)
-__global__ void f64_to_f32_bf16_kernel(const double* S, int64_t lds_, float* R, int64_t ldr, __bf16* P, int64_t ldp, int64_t rows, int64_t cols,
-                                       int upper_only) {
-  const int64_t col = blockIdx.y + (int64_t)blockIdx.z * 65535;
-  if (col >= cols) return;
-  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < rows; row += (int64_t)gridDim.x * blockDim.x) {
-    const double v = (!upper_only || row <= col) ? S[row + col * lds_] : 0.0;
-    R[row + col * ldr] = (float)v;
-    if (P) P[row + col * ldp] = (__bf16)(float)v;
-  }
-}
-__global__ void axpy_cols_kernel(double* X, int64_t ldx, const double* D, int64_t ldd, int64_t rows, int64_t cols) {
-  const int64_t col = blockIdx.y;
-  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < rows; row += (int64_t)gridDim.x * blockDim.x)
-    X[row + col * ldx] += D[row + col * ldd];
-}
-
-dim3 grid2(int64_t rows, int64_t cols) {
-  return dim3((unsigned)std::min<int64_t>(cap_ceil_div(rows, 256), 4096), (unsigned)std::min<int64_t>(cols, 65535), (unsigned)cap_ceil_div(cols, 65535));
-}
 }  // namespace
+
+// Distributed bf16 trailing update on a 1 x P block-column-cyclic fp32 matrix (dist_mixed.hip): C32[m x nloc] -= G^T B restricted
+// to the global upper triangle.  G: gathered bf16 block row (P pieces of `piece` elements, each k x cols_r, ld = k), B: my own
+// columns of it (k x nloc, ld = k), C: my local columns from local block lb0 on, rows global from block J0 on (ldc).
+int cap_bf16_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const void* G16, int64_t piece, const int* gstart, const void* B16,
+                                float* C, int64_t ldc, int P, int p, int nb, int J0, int lb0, hipStream_t s) {
+  if (m <= 0 || nloc <= 0) return CAP_OK;
+  if ((m % TB) || (nloc % TB) || (k % KB) || (nb % TB) || P < 1 || P > 8) return CAP_ERR_UNSUPPORTED;
+  if (128 * k * 2 + k * 2 >= 0xfffffff0LL) return CAP_ERR_UNSUPPORTED;
+  BfArgs g;
+  g.A = (const __bf16*)G16; g.B = (const __bf16*)B16; g.C = C; g.lda = k; g.ldb = k; g.ldc = ldc; g.M = m; g.N = nloc; g.K = k;
+  g.alpha = -1.0f; g.tri = 1; g.tm = (int)(m / TB); g.tn = (int)(nloc / TB);
+  g.stair = 1; g.sP = P; g.sp = p; g.snbT = nb / TB; g.sJ0 = J0; g.slb0 = lb0; g.gpiece = piece;
+  for (int i = 0; i < 8; i++) g.gstart[i] = i < P ? gstart[i] : 0;
+  g.chunk = (int)cap_ceil_div((int64_t)g.tm * g.tn, 8);       // full grid; workgroups below the staircase return at once
+  hipLaunchKernelGGL(bf16_tn_kernel, dim3((unsigned)(g.chunk * 8)), dim3(256), 4 * TILE_D * sizeof(double), s, g);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
 
 struct cap_mpchol_plan {
   int64_t n, nb, nrhs_cap;          // nrhs_cap: internal right-hand-side width (multiple of 128)

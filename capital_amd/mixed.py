@@ -69,3 +69,55 @@ class plan:
             self.close()
         except Exception:
             pass
+
+
+class dist_plan:
+    """Mixed-precision solve on P GPUs (csrc/dist_mixed.hip): 1 x P block-column-cyclic bf16 factorization + distributed fp64
+    refinement.  `comm`: a communicator object with .handle / .rank / .size (dist_cholesky.RcclComm).  The local operand is
+    this rank's block columns of the FULL symmetric matrix as a (local_cols, n) torch tensor (column-major n x local_cols)."""
+
+    def __init__(self, n, comm, nb=0, nrhs_max=128):
+        self.n, self.comm, self.nrhs_max = int(n), comm, int(nrhs_max)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().cap_dmp_plan_create(C.byref(h), self.n, int(nb), self.nrhs_max, comm.handle), "cap_dmp_plan_create")
+        self._h = h
+        self.local_cols = int(_lib.lib().cap_dmp_local_cols(h))
+
+    def factor(self, A_local):
+        _lib.check(_lib.lib().cap_dmp_factor(self._h, A_local.data_ptr(), self.n, cur_stream()), "dmp::factor")
+
+    def last_info(self):
+        v = C.c_int64(0)
+        _lib.lib().cap_dmp_info(self._h, cur_stream(), C.byref(v))
+        return v.value
+
+    def solve(self, A_local, B, max_iter=30, tol=1e-15):
+        """B: `matrix` (n x nrhs), the same on every rank; returns (X matrix, sweeps, relres) - X identical on every rank."""
+        nrhs = B.num_columns_global()
+        X = matrix(nrhs, self.n, 1, 1)
+        it, rr = C.c_int(0), C.c_double(0)
+        _lib.check(_lib.lib().cap_dmp_solve(self._h, A_local.data_ptr(), self.n, B.data_ptr(), B.ld(), X.data_ptr(), X.ld(), nrhs, int(max_iter),
+                                            float(tol), C.byref(it), C.byref(rr), cur_stream()), "dmp::solve")
+        return X, it.value, rr.value
+
+    def R32_local(self):
+        """numpy (n x local_cols) copy of this rank's block columns of the fp32 factor."""
+        import torch
+        ld = C.c_int64(0)
+        p = _lib.lib().cap_dmp_R32_ptr(self._h, C.byref(ld))
+        out = torch.empty(max(self.local_cols, 1), ld.value, dtype=torch.float32, device="cuda")
+        rt = C.CDLL("libamdhip64.so")
+        torch.cuda.synchronize()
+        rt.hipMemcpy(C.c_void_p(out.data_ptr()), C.c_void_p(p), C.c_size_t(max(self.local_cols, 1) * ld.value * 4), C.c_int(3))
+        return out[: self.local_cols, : self.n].cpu().numpy().T.copy()
+
+    def close(self):
+        if self._h:
+            _lib.lib().cap_dmp_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -397,6 +397,23 @@ float* cap_mpchol_R32_ptr(cap_mpchol_plan* plan, int64_t* ld);          /* the f
 int cap_mpchol_set_option(cap_mpchol_plan* plan, const char* key, int64_t value);
 int cap_mpchol_profile(cap_mpchol_plan* plan, int64_t* launches, double* ms_total, double* flops_total, double* bytes_total);
 
+/* The same solve on P GPUs (BASELINE config 5: N = 131072 on 8 MI355X; csrc/dist_mixed.hip): the bf16-MFMA factorization on
+ * the 1 x P block-column-cyclic layout of cap_dist_* - fp64 diagonal blocks and block-row solves, Dinv broadcast, the bf16
+ * panel pieces all-gathered (a quarter of the fp64 schedule's bytes), staircase bf16 update of the local fp32 columns - and
+ * fp64 iterative refinement with a distributed solve: forward / backward block substitution over the block columns (one
+ * nb x nrhs broadcast / all-reduce per block) and the residual from each rank's own columns of the symmetric A.
+ * n % 128 == 0; nb = block width = K of the bf16 update (power of two >= 128, 0 = 1024); Alocal = this rank's block columns
+ * (n rows, cap_dmp_local_cols columns); B and X are n x nrhs and the same on every rank.                                */
+typedef struct cap_dmp_plan cap_dmp_plan;
+int cap_dmp_plan_create(cap_dmp_plan** plan, int64_t n, int64_t nb, int64_t nrhs_max, cap_comm* comm);
+int cap_dmp_plan_destroy(cap_dmp_plan* plan);
+int64_t cap_dmp_local_cols(const cap_dmp_plan* plan);
+int cap_dmp_factor(cap_dmp_plan* plan, const double* Alocal, int64_t lda, void* stream);
+int cap_dmp_info(cap_dmp_plan* plan, void* stream, int64_t* info);
+int cap_dmp_solve(cap_dmp_plan* plan, const double* Alocal, int64_t lda, const double* B, int64_t ldb, double* X, int64_t ldx,
+                  int64_t nrhs, int max_iter, double tol, int* iters, double* relres, void* stream);
+float* cap_dmp_R32_ptr(cap_dmp_plan* plan, int64_t* ld);                /* my block columns of the fp32 factor, ld = padded n */
+
 #ifdef __cplusplus
 }
 #endif
