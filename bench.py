@@ -195,15 +195,18 @@ def cpu_baseline_cacqr(m, n):
 
 def traffic_from_profile(n, args):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
-    (profiles/r02_traffic_bench_n65536.json, produced by tools/prof_round.sh + tools/make_traffic_json.py: FETCH_SIZE and WRITE_SIZE in separate
-    runs, FETCH_SIZE doubled per the gfx950 correction).  Counters cannot be collected inside the timed run; the
-    number is only reported for the exact configuration AND library build it was measured on, else null."""
+    (profiles/rNN_traffic_bench_n65536.json, produced by tools/prof_round.sh + tools/make_traffic_json.py: FETCH_SIZE and WRITE_SIZE in
+    separate runs, FETCH_SIZE doubled per the gfx950 correction).  Counters cannot be collected inside the timed run; the
+    number is only reported for the exact configuration AND library build it was measured on (newest round first), else null."""
+    import glob
+    import hashlib
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic_bench_n65536.json")))
-        if d["config"]["n"] == n and d["config"]["complete_inv"] == args.complete_inv and not (args.nb or args.outer or args.tail >= 0):
-            import hashlib
-            src = b"".join(open(os.path.join(ROOT, "capital_amd", "csrc", f), "rb").read() for f in ("gemm.hip", "tile_dma.h"))
-            if d.get("kernel_src_sha16") == hashlib.sha256(src).hexdigest()[:16]:
+        src = b"".join(open(os.path.join(ROOT, "capital_amd", "csrc", f), "rb").read() for f in ("gemm.hip", "tile_dma.h"))
+        sha = hashlib.sha256(src).hexdigest()[:16]
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_bench_n65536.json")), reverse=True):
+            d = json.load(open(path))
+            if (d["config"]["n"] == n and d["config"]["complete_inv"] == args.complete_inv and not (args.nb or args.outer or args.tail >= 0)
+                    and d.get("kernel_src_sha16") == sha):
                 return d["traffic_bytes_per_launch"]
     except Exception:
         pass

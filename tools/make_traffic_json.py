@@ -1,10 +1,13 @@
-"""profiles/r02_traffic_bench_n65536.json from the PMC passes of tools/prof_round.sh (FETCH_SIZE / WRITE_SIZE of the trailing-update
+"""profiles/r03_traffic_bench_n65536.json (argv[2] overrides the round tag) from the PMC passes of tools/prof_round.sh (FETCH_SIZE / WRITE_SIZE of the trailing-update
 kernel inside `python bench.py`), stamped with the hash of the kernel source it was measured on."""
 import csv, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_round")
 def avg(c):
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(src, "pmc_%s" % c, "bench_counter_collection.csv"))) if r["Counter_Name"] == c]
+    import glob
+    cands = glob.glob(os.path.join(src, "pmc_%s" % c, "**", "*counter_collection.csv"), recursive=True) + \
+        glob.glob(os.path.join(src, "summary", "*pmc_%s_trailing_kernel.csv" % c))
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(cands[0])) if r["Counter_Name"] == c]
     return sum(v) / len(v), len(v)
 f, nf = avg("FETCH_SIZE"); w, nw = avg("WRITE_SIZE")
 out = {"command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-include-regex 'dgemm_tn_dma_kernel<1' -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-check (tools/prof_round.sh, separate passes)",
@@ -14,5 +17,6 @@ out = {"command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-include-rege
        "traffic_bytes_per_launch": (2 * f + w) * 1024.0, "algorithmic_bytes_per_launch": 5.42e9,
        "kernel_src_sha16": hashlib.sha256(b"".join(open(os.path.join(ROOT, "capital_amd", "csrc", f), "rb").read()
                                                     for f in ("gemm.hip", "tile_dma.h"))).hexdigest()[:16]}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_traffic_bench_n65536.json"), "w"), indent=1)
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+json.dump(out, open(os.path.join(ROOT, "profiles", "%s_traffic_bench_n65536.json" % tag), "w"), indent=1)
 print(out["traffic_bytes_per_launch"] / 1e9, "GB per launch,", out["traffic_bytes_per_launch"] / out["algorithmic_bytes_per_launch"], "x algorithmic")
