@@ -57,10 +57,11 @@ def parse():
     ap.add_argument("--inner-la", type=int, default=-1, help="column-split look-ahead 1/0 (-1 = library default: off)")
     ap.add_argument("--serial-m", type=int, default=-1, help="remaining rows below which chain and bulk update are not overlapped (-1 = default)")
     ap.add_argument("--strip", type=int, default=0, help="multi-GPU: block rows per strip (0 = library default)")
-    ap.add_argument("--dist-mode", default="auto", choices=["auto", "safe", "overlap"],
+    ap.add_argument("--dist-mode", default="auto", choices=["auto", "safe", "overlap", "ipc"],
                     help="multi-GPU: safe = one communicator + one communication stream; overlap = small messages on their own "
-                         "communicator/stream; auto = safe first (warm-up + residual check + timing), then overlap under a host "
-                         "watchdog, the better of the two is reported (fallback to the safe figure if overlap makes no progress)")
+                         "communicator/stream; ipc = overlap with the strip exchange as IPC peer copies; auto = safe first (warm-up + "
+                         "residual check + timing), then overlap, then ipc, each under a host watchdog - the best completed mode is "
+                         "reported (fallback to it if a later mode makes no progress)")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "ipc"], help="multi-GPU strip exchange: RCCL all-gather or IPC peer copies")
     ap.add_argument("--grid-rows", type=int, default=1, help="multi-GPU: process rows Pr of the Pr x Pc block-cyclic layout (1 = block columns only)")
     ap.add_argument("--watchdog-s", type=float, default=0.0, help="multi-GPU: seconds without completion before a step counts as hung (0 = auto)")
@@ -503,11 +504,15 @@ def multi_gpu_case(args, torch, L, C, rank, world, dist, emulate, allreduce_sum)
         return ctl_max(time.perf_counter() - t0) / steps
 
     limit = args.watchdog_s or max(60.0, 20.0 * (n / 65536.0) ** 3 * 4.0)
-    modes = ["2d"] if is2d else {"auto": ["safe", "overlap"], "safe": ["safe"], "overlap": ["overlap"]}[args.dist_mode]
+    modes = ["2d"] if is2d else {"auto": ["safe", "overlap", "ipc"], "safe": ["safe"], "overlap": ["overlap"], "ipc": ["ipc"]}[args.dist_mode]
+    if args.exchange == "ipc" and not is2d:
+        modes = [m for m in modes if m != "ipc"] or ["ipc"]         # every mode already runs on the IPC exchange
     results, wd = {}, {}
     for mode in modes:
         if not is2d:
             ctx.set_option("safe", 1 if mode == "safe" else 0)
+            if mode == "ipc":                                          # overlapped schedule, strip exchange by IPC peer copies (SDMA)
+                ctx.set_option("ipc", 1)
         sec = timed_watch(args.steps, max(args.warmup, 1), limit)
         if sec is None:
             wd[mode] = {"hung": True, "limit_s": limit, "progress_rank%d" % rank: progress()}
@@ -516,9 +521,12 @@ def multi_gpu_case(args, torch, L, C, rank, world, dist, emulate, allreduce_sum)
         info = ctx.last_info()
         probe = ctx.probe(allreduce_sum) if not args.no_check else 0.0
         results[mode] = {"sec": sec, "info": int(info), "probe": probe, "tflops": n ** 3 / 3.0 / sec / 1e12}
+        if mode == "ipc" or (args.exchange == "ipc" and not is2d):
+            results[mode]["ipc_active"] = int(ctx.get_option("ipc_active"))    # 0: a peer could not be mapped, the run used RCCL
         if int(info) != 0 or not (probe <= 1e-13):
             break
-    diag["modes"] = {m: {"tflops": r["tflops"], "ms_per_step": r["sec"] * 1e3, "info": r["info"], "probe_residual": r["probe"]} for m, r in results.items()}
+    diag["modes"] = {m: dict({"tflops": r["tflops"], "ms_per_step": r["sec"] * 1e3, "info": r["info"], "probe_residual": r["probe"]},
+                             **({"ipc_active": r["ipc_active"]} if "ipc_active" in r else {})) for m, r in results.items()}
     if wd:
         diag["watchdog"] = wd
     good = {m: r for m, r in results.items() if r["info"] == 0 and r["probe"] <= 1e-13}
@@ -535,8 +543,9 @@ def multi_gpu_case(args, torch, L, C, rank, world, dist, emulate, allreduce_sum)
         _emit_and_exit_on_hang(args, rank, n, world, diag, good[best])
     if is2d:
         diag["launches_per_factor_rank0"] = ctx.launch_counts()
-    if list(results)[-1] != best:        # leave the plan holding the result of the reported mode
+    if list(results)[-1] != best:        # leave the plan holding the result (and the mode, for the profiled call) of the reported mode
         ctx.set_option("safe", 1 if best == "safe" else 0)
+        ctx.set_option("ipc", 1 if (best == "ipc" or args.exchange == "ipc") else 0)
         ctx.factor(); torch.cuda.synchronize()
     return ctx, good[best]["sec"], good[best]["info"], diag
 

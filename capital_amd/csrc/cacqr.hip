@@ -60,13 +60,16 @@ int sweep(cap_cacqr_plan* p, const double* Qin, int64_t ldin, double* Qout, hipS
   // a dense n x n block like NoSerialize::compute_gram (policy.h:22)
   static const bool k256_env = getenv("CAP_CQR256") ? atoi(getenv("CAP_CQR256")) != 0 : true;
   const bool k256 = k256_env && p->gram_work && n == 256 && m % 128 == 0 && !(ldin & 1) && 128 * ldin * 8 < 0xfffffff0LL && !((uintptr_t)Qin & 15);
-  if (k256) {
-    CAP_TRY(cap_gram256_launch(Qin, ldin, m, p->G, n, p->gram_work, s));     // its slab sum also zero-fills below the diagonal
-  } else {
-    CAP_TRY(cap_zero_rect(p->G, n, n, n, s));
-    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n, n, m, 1.0, Qin, ldin, Qin, ldin, 0.0, p->G, n, 1, s));
+  {
+    CapRange range("CQR::gram");                  // cacqr.hpp:83-101
+    if (k256) {
+      CAP_TRY(cap_gram256_launch(Qin, ldin, m, p->G, n, p->gram_work, s));     // its slab sum also zero-fills below the diagonal
+    } else {
+      CAP_TRY(cap_zero_rect(p->G, n, n, n, s));
+      CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, n, n, m, 1.0, Qin, ldin, Qin, ldin, 0.0, p->G, n, 1, s));
+    }
+    CAP_TRY(cap_comm_allreduce_sum(p->comm, p->G, n * n, (void*)s));
   }
-  CAP_TRY(cap_comm_allreduce_sum(p->comm, p->G, n * n, (void*)s));
   // R = chol(G) in place (upper), Gi = R^-1.  The 64-blocked path (n = 256) rewrites every entry of Gi it ever wrote (diagonal
   // blocks with their zero lower parts, the off-diagonal blocks above them) and never touches the blocks below: one zero-fill
   // per plan is enough there
@@ -74,6 +77,7 @@ int sweep(cap_cacqr_plan* p, const double* Qin, int64_t ldin, double* Qout, hipS
   CAP_TRY(cap_rec_cholinv_full(p->G, n, p->Gi, n, n, p->W, p->wcap, p->info_dev, s));
   // Q <- Q * R^-1 (cacqr.hpp:24-25)
   // tag 8: R^-1 is upper triangular -> a column tile only contracts the rows above its diagonal block
+  CapRange range("CQR::formR");                   // cacqr.hpp:106-115 (the TRMM with R^-1)
   if (k256) CAP_TRY(cap_qrapply256_launch(Qin, ldin, p->Gi, Qout, p->ldq, m, s));
   else CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, m, n, n, 1.0, Qin, ldin, p->Gi, n, 0.0, Qout, p->ldq, 0, s, 8));
   return CAP_OK;

@@ -165,115 +165,6 @@ __global__ void __launch_bounds__(256, 2) bf16_tn_kernel(const BfArgs g) {
   }
 }
 
-// 256 x 256 C tile per 256-thread workgroup: 4 waves x (4 x 4 blocks of 32 x 32) = 256 fp32 accumulators per lane, one workgroup
-// per CU (2 stages x 64 KiB of LDS).  Same LDS image, swizzle, DMA and pipeline as bf16_tn_kernel on two 128-row half tiles per
-// operand; per K tile a wave issues 32 ds_read_b128 for 64 MFMAs (the 128-wide tile: 16 for 16), so operand traffic through
-// L2 / LDS per flop halves - the 128-wide kernel is bound by it (465 TF = 0.19 of the bf16 peak in the N = 65536 factorization).
-// M, N % 256 == 0, K % 64 == 0; square upper (tri, tm == tn: triangular enumeration) or full grid with the tile-level skip.
-__global__ void __launch_bounds__(256, 1) bf16_tn256_kernel(const BfArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int b = (int)blockIdx.x;
-  const int L = (b & 7) * g.chunk + (b >> 3);
-  int ti, tj;
-  if ((b >> 3) >= g.chunk) return;
-  if (g.tri && g.tm == g.tn) {
-    tj = (int)((__builtin_sqrtf(8.0f * (float)L + 1.0f) - 1.0f) * 0.5f);
-    while ((tj + 1) * (tj + 2) / 2 <= L) tj++;
-    while (tj * (tj + 1) / 2 > L) tj--;
-    ti = L - tj * (tj + 1) / 2;
-    if (tj >= g.tn) return;
-  } else {
-    ti = L % g.tm; tj = L / g.tm;
-    if (tj >= g.tn) return;
-    if (g.tri && ti > tj) return;
-  }
-  const int64_t i0 = (int64_t)ti * 256, j0 = (int64_t)tj * 256;
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wi = (wid & 1) * 128, wj = (wid >> 1) * 128;
-  const int r32 = lane & 31, kg = lane >> 5;
-  // stage layout: [A rows 0..127][A rows 128..255][B rows 0..127][B rows 128..255], TILE_D doubles (16 KiB) each
-  auto stage = [&](int buf) -> double* { return smem + buf * 4 * TILE_D; };
-
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
-
-  const int nk = (int)(g.K / KB);
-  DmaBuf dA0 = dma_buf_make(reinterpret_cast<const double*>(g.A + i0 * g.lda), g.lda / 4);
-  DmaBuf dA1 = dma_buf_make(reinterpret_cast<const double*>(g.A + (i0 + 128) * g.lda), g.lda / 4);
-  DmaBuf dB0 = dma_buf_make(reinterpret_cast<const double*>(g.B + j0 * g.ldb), g.ldb / 4);
-  DmaBuf dB1 = dma_buf_make(reinterpret_cast<const double*>(g.B + (j0 + 128) * g.ldb), g.ldb / 4);
-  auto dma_a = [&](uint32_t koff, double* st) { dma_tile_buf<0, 4>(dA0, wid, koff, st); dma_tile_buf<0, 4>(dA1, wid, koff, st + TILE_D); };
-  auto dma_b = [&](uint32_t koff, double* st) { dma_tile_buf<0, 4>(dB0, wid, koff, st + 2 * TILE_D); dma_tile_buf<0, 4>(dB1, wid, koff, st + 3 * TILE_D); };
-  const int t = kg ^ ((r32 >> 1) & 7);
-  // the wave's 128 rows lie in ONE half tile of each operand: A half (wid & 1), B half (wid >> 1)
-  const int a_row = (wid & 1) * TILE_D * 8 + r32 * 128, b_row = (2 + (wid >> 1)) * TILE_D * 8 + r32 * 128;
-  // fragments are double buffered per k-step (16 of the 64 k of a tile): 8 ds_read_b128 fly while 16 MFMAs run
-  bf16x8 xa[2][4], xb[2][4];
-  auto read_step = [&](const double* st, int q, bf16x8 (&ya)[4], bf16x8 (&yb)[4]) {
-    const char* ps = reinterpret_cast<const char*>(st);
-    const int off = (((2 * q) ^ t) << 4);
-#pragma unroll
-    for (int blk = 0; blk < 4; blk++) {
-      ya[blk] = *reinterpret_cast<const bf16x8*>(ps + a_row + blk * 32 * 128 + off);
-      yb[blk] = *reinterpret_cast<const bf16x8*>(ps + b_row + blk * 32 * 128 + off);
-    }
-  };
-  auto mma_step = [&](const bf16x8 (&ya)[4], const bf16x8 (&yb)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yb[j], ya[i], acc[i][j], 0, 0, 0);   // swapped: lane = C row
-  };
-
-  if (nk > 0) {
-    dma_a(0u, stage(0)); dma_b(0u, stage(0));
-    __syncthreads();
-    read_step(stage(0), 0, xa[0], xb[0]);
-    { const uint32_t k1 = (nk > 1 ? 1u : 0u) * 128u; dma_a(k1, stage(1)); dma_b(k1, stage(1)); }
-    for (int kt = 0; kt < nk; kt++) {
-      const double* cur = stage(kt & 1);
-      read_step(cur, 1, xa[1], xb[1]); mma_step(xa[0], xb[0]);
-      read_step(cur, 2, xa[0], xb[0]); mma_step(xa[1], xb[1]);
-      read_step(cur, 3, xa[1], xb[1]); mma_step(xa[0], xb[0]);
-      if (kt + 1 < nk) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __syncthreads();                                 // every wave has read the last fragments of `cur`; tile kt+1 has landed
-        const uint32_t kn = (uint32_t)((kt + 2 < nk) ? kt + 2 : nk - 1) * 128u;
-        dma_a(kn, stage(kt & 1)); dma_b(kn, stage(kt & 1));
-        read_step(stage((kt + 1) & 1), 0, xa[0], xb[0]);
-      }
-      mma_step(xa[1], xb[1]);
-    }
-  }
-
-  // epilogue: lane holds C[i0 + wi + 32 i + r32][j0 + wj + 32 j + (e & 3) + 8 (e >> 2) + 4 kg].  Buffer-addressed fp32 atomic adds:
-  // ONE per-lane byte offset, the 256 element positions are scalar offsets (a flat-address epilogue needed 64-bit pointers for
-  // 64 columns at once and spilled)
-  const bool diag = g.tri && ti == tj;
-  __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.C + i0 + j0 * g.ldc), 0, (int)0xffffffffu, 0x00020000);
-  const int ldc4 = (int)(g.ldc * 4);
-  const int row_l = wi + r32, col_l = wj + 4 * kg;
-  const int voff = row_l * 4 + col_l * ldc4;
-#pragma unroll
-  for (int j = 0; j < 4; j++)
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-      const int c = 32 * j + (e & 3) + 8 * (e >> 2);
-      const int soff = c * ldc4;
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-        if (!diag || row_l + 32 * i <= col_l + c)
-          __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(g.alpha * acc[i][j][e], rc, voff + 128 * i, soff, 0);
-    }
-}
-
 int launch_bf16_tn(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A, int64_t lda, const __bf16* B, int64_t ldb, float* C,
                    int64_t ldc, int tri, hipStream_t s) {
   if (m <= 0 || n <= 0 || k <= 0) return CAP_OK;
@@ -283,17 +174,6 @@ int launch_bf16_tn(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.tri = tri;
   g.stair = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0;
   for (int i = 0; i < 8; i++) g.gstart[i] = 0;
-  static const int t256 = getenv("CAP_BF16_T256") ? atoi(getenv("CAP_BF16_T256")) : 1;
-  // (2 = also for launches too small to fill the chip with 256-wide tiles: tests)
-  if (t256 && m % 256 == 0 && n % 256 == 0 && ((int64_t)(m / 256) * (n / 256) >= 128 || t256 == 2) &&
-      256 * lda * 2 + k * 2 < 0xfffffff0LL && 256 * ldb * 2 + k * 2 < 0xfffffff0LL) {
-    g.tm = (int)(m / 256); g.tn = (int)(n / 256);
-    const int64_t tiles2 = (tri && m == n) ? (int64_t)g.tn * (g.tn + 1) / 2 : (int64_t)g.tm * g.tn;
-    g.chunk = (int)cap_ceil_div(tiles2, 8);
-    hipLaunchKernelGGL(bf16_tn256_kernel, dim3((unsigned)(g.chunk * 8)), dim3(256), 8 * TILE_D * sizeof(double), s, g);
-    CAP_HIP(hipGetLastError());
-    return CAP_OK;
-  }
   g.tm = (int)(m / TB); g.tn = (int)(n / TB);
   const int64_t tiles = (tri && m == n) ? (int64_t)g.tn * (g.tn + 1) / 2 : (int64_t)g.tm * g.tn;
   g.chunk = (int)cap_ceil_div(tiles, 8);

@@ -193,6 +193,67 @@ def test_harder_spd_input():
             assert np.linalg.norm(Ri @ R - np.eye(n)) / np.sqrt(n) < 1e-8
 
 
+@pytest.mark.parametrize("kappa", [1e8, 1e10, 1e12])
+def test_ill_conditioned_spd_at_n8192_against_the_oracle(kappa):
+    """A = Q diag(1 .. 1/kappa) Q^T at N = 8192 (16 panels of 512): every block-row solve is "invert the 512^2 diagonal block,
+    then GEMM" like upstream's TRSM-by-inverse (cholinv.hpp:118-121), whose error grows with the conditioning of R_jj.  The
+    bar is therefore the ORACLE's own residual on the same input (the NumPy restatement of upstream's recursion, explicit
+    inverses included) x 10 - not a fixed 1e-13 - for the blocked sweep (complete_inv = -1) and for R + R^-1 (complete_inv = 1)."""
+    from threadpoolctl import threadpool_limits
+    from capital_amd import cholinv
+    n = 8192
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    Qm, _ = torch.linalg.qr(torch.randn(n, n, dtype=torch.float64, device="cuda", generator=g))
+    d = torch.logspace(0.0, -float(np.log10(kappa)), n, dtype=torch.float64, device="cuda")
+    at = (Qm * d) @ Qm.T
+    at = 0.5 * (at + at.T)
+    a = at.cpu().numpy()
+    del Qm
+    with threadpool_limits(limits=32):                       # OpenBLAS on all 256 host threads is slower than on 32
+        r_ref, ri_ref = orc.cholinv(a, 1, 1, -4, 1, 1)       # bcMult -4: 512-wide base cases, the GPU schedule's panel width
+    rt = torch.from_numpy(r_ref).cuda(); rit = torch.from_numpy(ri_ref).cuda()
+    up = torch.triu(torch.ones(n, n, dtype=torch.bool, device="cuda"))
+    na = float(at[up].norm())
+
+    def resid(R):        # test/cholesky/validate.hpp:33-46 with torch's fp64 matmul (none of this library's kernels)
+        return float((torch.triu(R).T @ torch.triu(R) - at)[up].norm()) / na
+
+    def inv_err(R, Ri):
+        return float((torch.triu(Ri) @ torch.triu(R) - torch.eye(n, dtype=torch.float64, device="cuda")).norm()) / np.sqrt(n)
+    res_ref, inv_ref = resid(rt), inv_err(rt, rit)
+    assert res_ref < 1e-10 and np.isfinite(inv_ref)
+    for ci in (-1, 1):
+        _, pack = _factor(n, ci, 1, -4, a=a)
+        assert pack.last_info() == 0
+        R = cholinv.construct_R(pack).view()
+        res = resid(R)
+        assert res <= max(10.0 * res_ref, 5e-16), (ci, kappa, res, res_ref)
+        assert float((R - rt).norm() / rt.norm()) < 1e3 * kappa * 2.2e-16      # forward error of a backward-stable factor: O(kappa eps)
+        if ci == 1:
+            Ri = cholinv.construct_Rinv(pack).view()
+            assert inv_err(R, Ri) <= max(10.0 * inv_ref, 1e-13), (kappa, inv_err(R, Ri), inv_ref)
+        del pack, R
+        torch.cuda.empty_cache()
+
+
+def test_n65536_properties():
+    """The BASELINE metric's own size through the C ABI (the bench checks the same outside pytest): residual of the reference's
+    validator, the independent probe, positive diagonal, strictly-lower part zero."""
+    from capital_amd import cholinv, validate
+    n = 65536
+    A, pack = _factor(n, -1, 1, -5)
+    assert pack.last_info() == 0
+    res = validate.cholesky.residual(A, pack)
+    assert res < RES_TOL, res
+    R = cholinv.construct_R(pack)
+    assert validate.cholesky.probe(A.view(), R.view()) < 1e-13
+    d = torch.diagonal(R.view())
+    assert bool((d > 0).all())
+    assert float(torch.tril(R.view()[-4096:, -4096:], -1).abs().max()) == 0.0
+    del A, pack, R
+    torch.cuda.empty_cache()
+
+
 def test_not_spd_is_reported():
     from capital_amd import cholinv
     n = 300

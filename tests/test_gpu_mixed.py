@@ -81,33 +81,3 @@ def test_matches_the_fp64_path_and_reports_failures():
         assert it == 5 and not (rr <= 1e-14)
     p.close()
 
-
-@pytest.mark.parametrize("t256", [0, 2])
-def test_both_bf16_tile_kernels_give_a_valid_factor(t256):
-    """The 256 x 256-tile bf16 update kernel (default for large trailing matrices) and the 128 x 128 one, forced through
-    CAP_BF16_T256 (read once per process -> a subprocess): same solve accuracy, factors agree to bf16 level."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = """
-import sys, numpy as np
-sys.path.insert(0, %r)
-from oracle import capital_oracle as orc
-from capital_amd import mixed
-from capital_amd.matrix import matrix
-for n in (2048, 3072):
-    a = orc.symmetric_global(n, True)
-    b = np.random.default_rng(n).standard_normal((n, 3))
-    A = matrix(n, n, 1, 1).from_numpy(a); B = matrix(3, n, 1, 1).from_numpy(b)
-    p = mixed.plan(n, 3); p.factor(A)
-    assert p.last_info() == 0
-    r32 = p.R32().cpu().numpy().astype(np.float64)
-    ref = np.linalg.cholesky(a).T
-    e = np.linalg.norm(r32 - ref) / np.linalg.norm(ref)
-    assert np.array_equal(np.tril(r32, -1), np.zeros_like(r32)) and 1e-9 < e < 2e-2, e
-    X, it, rr = p.solve(A, B)
-    assert rr <= 1e-14 and np.linalg.norm(a @ X.to_numpy() - b) / np.linalg.norm(b) < 1e-14
-    p.close()
-print("T256-OK")
-""" % root
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, CAP_BF16_T256=str(t256)))
-    assert r.returncode == 0 and "T256-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

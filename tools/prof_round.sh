@@ -18,6 +18,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-include-regex "dgemm_tn_dma_kernel<1" --output-format csv -d $OUT/pmc_$c -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-check > $OUT/pmc_$c.log 2>&1
   echo "$c rc=$?"
 done
+# named regions (roctx ranges CI::factor_diag / CI::trsm / CI::tmu / CI::inverse_*, CQR::*): marker trace of a small factorization
+timeout 200 rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d $OUT/markers -o bench -- python $R/bench.py --n 16384 --complete-inv 1 --steps 1 --warmup 1 --no-cpu-baseline --no-extra > $OUT/markers.log 2>&1
+for f in $(find $OUT/markers -name "*marker*stats*.csv" -o -name "*marker_api_trace.csv" | head -3); do cp $f $OUT/summary/${TAG}_markers_$(basename $f); done
 for t in b65536:bench_n65536 b32768:bench_n32768 b32768ci0:bench_n32768_complete_inv0 cqr:bench_cacqr_2p21x256 mixed:bench_mixed_n65536; do
   d=${t%%:*}; n=${t##*:}
   f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/summary/${TAG}_${n}_kernel_stats.csv
