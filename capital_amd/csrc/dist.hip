@@ -71,6 +71,8 @@ struct cap_dist_plan {
   // (the data dependencies order them anyway: msg(a), msg(b), exchange(t), msg(a'), ...); the default keeps the small
   // messages on their own communicator + stream
   int safe;
+  // launches / collectives issued by the LAST factor call on this rank (options count_gemm / count_chain / count_copy / count_coll)
+  int64_t cnt_gemm, cnt_chain, cnt_copy, cnt_coll;
   // Strip exchange off the CUs (option "ipc"): every rank maps its peers' gathered-strip buffers (hipIpcGetMemHandle /
   // hipIpcOpenMemHandle, exchanged once through the communicator) and PUSHES its piece into each of them with plain
   // device-to-device copies on one copy stream per peer (SDMA engines, one xGMI link each) - no RCCL kernel competes with
@@ -264,6 +266,7 @@ int update(cap_dist_plan* d, int64_t m, int64_t nloc, int64_t K, const double* G
   // diagonal-block chain of the owner always finds a free slot and shares its SIMDs with one fp64-MFMA wave instead of two
   const int occ = (prof && d->occ1_m > 0 && (double)m * (double)nloc <= (double)d->occ1_m * (double)d->occ1_m) ? -1 : 0;
   CAP_TRY(cap_dist_update_launch(m, nloc, K, G, piece, gstart, B, C, d->ld, d->P, d->p, (int)d->nb, (int)J0, (int)lb0, s, occ));
+  d->cnt_gemm++;
   if (e0) {
     CAP_HIP(hipEventRecord(e1, s));
     d->prof_used += 2;
@@ -382,6 +385,7 @@ int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* 
   d->jitter_state = 0x9E3779B97F4A7C15ull * (uint64_t)(d->p + 1); d->jitter_max_us = 0;
   d->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
   d->profile = 0; d->prof_used = 0; d->bk_used = 0; d->safe = 0;
+  d->cnt_gemm = d->cnt_chain = d->cnt_copy = d->cnt_coll = 0;
   d->complete_inv = -1; d->split = 1; d->Rall = d->Dall = d->Ri = d->Bacc = nullptr;
   d->ipc = getenv("CAP_DIST_IPC") ? atoi(getenv("CAP_DIST_IPC")) : 0; d->ipc_ready = false; d->ipc_failed = false; d->token = nullptr;
   d->ipc_nocu = getenv("CAP_DIST_IPC_NOCU") ? atoi(getenv("CAP_DIST_IPC_NOCU")) : 0;
@@ -468,6 +472,10 @@ int64_t cap_dist_get_option(const cap_dist_plan* d, const char* key) {
   if (k == "jitter_us") return d->jitter_max_us;
   if (k == "safe") return d->safe;
   if (k == "ipc") return d->ipc;
+  if (k == "count_gemm") return d->cnt_gemm;
+  if (k == "count_chain") return d->cnt_chain;
+  if (k == "count_copy") return d->cnt_copy;
+  if (k == "count_coll") return d->cnt_coll;
   if (k == "complete_inv") return d->complete_inv;
   if (k == "split") return d->split;
   if (k == "ipc_active") return (d->ipc && d->ipc_ready) ? 1 : 0;
@@ -499,6 +507,7 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
   const int64_t n = d->n, npad = d->npad, nb = d->nb, nblk = d->nblk, P = d->P, p = d->p, ld = d->ld;
   const int64_t nb2 = nb * nb;
   d->prof_used = 0; d->prof_flops.clear(); d->bk_used = 0;
+  d->cnt_gemm = d->cnt_chain = d->cnt_copy = d->cnt_coll = 0;
   CAP_HIP(hipMemsetAsync(d->info_dev, 0, sizeof(int), s0));
   if (d->lc_valid > 0) CAP_TRY(cap_copy_rect(Aloc, lda, d->R, ld, n, d->lc_valid, s0));
   if (npad != n && d->lc > 0) {
@@ -540,13 +549,13 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
         if (r == 1) {
           // in-strip: D(b) -= S_a(:, blk b)^T S_a(:, blk b); block b is my first column block of S
           const double* Sab = S + (k / P - lbS) * nb * ldS;
-          CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, nb, nb, -1.0, Sab, ldS, Sab, ldS, 1.0, D, ld, 1, s1, 2));
+          CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, nb, nb, -1.0, Sab, ldS, Sab, ldS, 1.0, D, ld, 1, s1, 2)); d->cnt_gemm++;
         }
         {
           CapRange range("CI::factor_diag"); Bucket bk(d, 0, s1);
-          CAP_TRY(cap_rec_cholinv_full(D, ld, Dinv, nb, nb, d->W, d->wcap, d->info_dev, s1, k * nb));
+          CAP_TRY(cap_rec_cholinv_full(D, ld, Dinv, nb, nb, d->W, d->wcap, d->info_dev, s1, k * nb)); d->cnt_chain++;
         }
-        if (r == 1) CAP_TRY(cap_copy_rect(S + (k / P - lbS) * nb * ldS, ldS, mb, nb, nb, nb, s1));   // R(a,b) rides along
+        if (r == 1) { CAP_TRY(cap_copy_rect(S + (k / P - lbS) * nb * ldS, ldS, mb, nb, nb, nb, s1)); d->cnt_copy++; }   // R(a,b) rides along
         CAP_HIP(hipEventRecord(d->ev_fact[k], s1));
         CAP_HIP(hipStreamWaitEvent(sm, d->ev_fact[k], 0));
       } else if (k >= 4) {
@@ -554,12 +563,12 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
       }
       // ---- msg: msg(k) = [ R(k-1,k) | Dinv(k) ] from the owner, on the small-message communicator
       CAP_TRY(jitter(d, sm));
-      { Bucket bk(d, 3, sm); CAP_TRY(cap_comm_bcast(cmsg, mb, 2 * nb2, owner, (void*)sm)); }
+      { Bucket bk(d, 3, sm); CAP_TRY(cap_comm_bcast(cmsg, mb, 2 * nb2, owner, (void*)sm)); d->cnt_coll++; }
       CAP_HIP(hipEventRecord(d->ev_msg[k], sm));
 
       // ---- panel, every rank: block row k of my columns J > k
       CAP_HIP(hipStreamWaitEvent(s1, d->ev_msg[k], 0));
-      if (d->complete_inv >= 0) CAP_TRY(cap_copy_rect(Dinv, nb, d->Dall + k * nb2, nb, nb, nb, s1));   // kept for the inverse (dist_inverse)
+      if (d->complete_inv >= 0) { CAP_TRY(cap_copy_rect(Dinv, nb, d->Dall + k * nb2, nb, nb, nb, s1)); d->cnt_copy++; }   // kept for the inverse (dist_inverse)
       if (r == 0 && t >= 2) CAP_HIP(hipStreamWaitEvent(s1, d->ev_gather[t - 2], 0));   // S[par] was the all-gather source of strip t-2
       const int64_t lbk = lbfirst(p, k, P);
       const int64_t ncols = (d->nloc_blocks - lbk) * nb;
@@ -568,11 +577,14 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
         CAP_TRY(jitter(d, s1));
         double* Rrow = d->R + k * nb + lbk * nb * ld;
         double* Scol = S + (lbk - lbS) * nb * ldS;                // my columns J > k inside the strip buffer
-        if (r == 1)   // in-strip update: R[b, mine] -= R(a,b)^T S_a(:, mine)
+        if (r == 1) {   // in-strip update: R[b, mine] -= R(a,b)^T S_a(:, mine)
           CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, ncols, nb, -1.0, mb, nb, Scol, ldS, 1.0, Rrow, ld, 0, s1, 2));
+          d->cnt_gemm++;
+        }
         // S_k = Dinv(k)^T R[k, mine]  (TRSM by the inverse, cholinv.hpp:118-121), then back into R
         CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, ncols, nb, 1.0, Dinv, nb, Rrow, ld, 0.0, Scol + r * nb, ldS, 0, s1, 2 | 16));
         CAP_TRY(cap_copy_rect(Scol + r * nb, ldS, Rrow, ld, nb, ncols, s1));
+        d->cnt_gemm++; d->cnt_copy++;
       }
       CAP_HIP(hipEventRecord(d->ev_rowdone[k], s1));
     }
@@ -591,6 +603,7 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
     if (t >= 2) CAP_HIP(hipStreamWaitEvent(sc, d->ev_rest[t - 2], 0));   // G[par] was read by the bulk update of strip t-2
     CAP_TRY(jitter(d, sc));
     { Bucket bk(d, 4, sc); CAP_TRY(strip_exchange(d, S + (lbe - lbS) * nb * ldS, par, piece, sc)); }
+    if (d->ipc && d->ipc_ready) { d->cnt_coll += 2; d->cnt_copy += P; } else d->cnt_coll++;
     CAP_HIP(hipEventRecord(d->ev_gather[t], sc));
 
     // ---- panel: HEAD - bring the rows of strip t+1 up to date with strip t (my columns J >= e)

@@ -140,6 +140,11 @@ class Context:
         torch.cuda.synchronize()
         return out[: self.local_cols].cpu().numpy().T.copy()
 
+    def launch_counts(self):
+        """Kernels / collectives this rank issued in the last factor call (the same four counters as Context2D)."""
+        return {"mfma_kernels": self.get_option("count_gemm"), "chains": self.get_option("count_chain"),
+                "copies": self.get_option("count_copy"), "collectives": self.get_option("count_coll")}
+
     def local_Rinv(self):
         """numpy (n x local_cols) copy of this rank's columns of R^-1 (options complete_inv = 0 / 1), construct_Rinv."""
         out = torch.zeros(max(self.local_cols, 1), self.n, dtype=torch.float64, device=self.device)

@@ -304,6 +304,7 @@ def main():
             if args.ci >= 0:
                 ri_l = cholinv.construct_Rinv(pack, topo).to_numpy()[:, : cols.size]
             close = lambda: pack._release()
+            counts = None
         else:
             ctx = dc.Context(n, nb, comm)
             ctx.fill_symmetric(True)
@@ -344,6 +345,7 @@ def main():
             rl = ctx.local_R()
             if args.ci >= 0:
                 ri_l = ctx.local_Rinv()
+            counts = ctx.launch_counts()
             close = ctx.close
         lc_max = max(dc.global_cols_of_rank(n, nb, size, r).size for r in range(size))
         pad = torch.zeros(n, lc_max, dtype=torch.float64); pad[:, : cols.size] = torch.from_numpy(rl)
@@ -381,7 +383,7 @@ def main():
             assert info == 0, info
             assert err < 1e-13, err
             assert res < 1e-14, res
-            print("DIST-OK world=%d n=%d nb=%d err=%.2e residual=%.2e collectives=%s" % (size, n, nb, err, res, comm.calls), flush=True)
+            print("DIST-OK world=%d n=%d nb=%d err=%.2e residual=%.2e collectives=%s launches(rank0)=%s" % (size, n, nb, err, res, comm.calls, counts), flush=True)
         close(); comm.close()
     dist.barrier()
     dist.destroy_process_group()
