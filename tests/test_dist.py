@@ -292,6 +292,33 @@ def test_bench_multi_gpu_code_path_emulated():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc,extra,key", [
+    (4, ("--size", "4096", "--nb", "256", "--grid-rows", "2"), "2x2"),                       # the Pr x Pc plan through bench.py
+    (2, ("--size", "2048", "--nb", "256", "--workload", "mixed"), "mixed"),                   # config 5's method on P ranks
+    (2, ("--size", "4096", "--nb", "256", "--dist-mode", "auto", "--exchange", "rccl"), "auto"),   # safe, overlap and ipc modes in turn
+])
+def test_bench_multi_gpu_variants_emulated(nproc, extra, key):
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(29660 + nproc + len(key)), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "1", "--warmup", "1",
+           "--no-cpu-baseline"] + list(extra)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CAPITAL_BENCH_EMULATE="1", OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == nproc and d["value"] > 0 and d["config"]["info"] == 0
+    if key == "2x2":
+        assert d["config"]["grid"] == "2x2" and d["config"]["n_ranks_seen"] == 4 and d["config"]["launches_per_factor_rank0"]["collectives"] > 0
+    if key == "auto":
+        assert set(d["config"]["modes"]) == {"safe", "overlap", "ipc"} and d["config"]["modes"]["ipc"]["ipc_active"] == 1
+        assert d["config"]["fallback"] is False and d["config"]["mode"] in ("safe", "overlap", "ipc")
+    if key == "mixed":
+        assert d["config"]["residual"] <= 1e-14 and d["config"]["independent_residual"] <= 1e-13
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nproc,c,M,N,K,chunks", [(4, 1, 512, 384, 640, 0), (4, 1, 300, 200, 250, 3), (8, 2, 512, 512, 512, 2),
                                                    (1, 1, 256, 256, 256, 2), (9, 1, 300, 300, 300, 2)])
 def test_summa_gemm_on_process_grids(nproc, c, M, N, K, chunks):
