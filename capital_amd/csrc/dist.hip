@@ -320,10 +320,13 @@ int dist_inverse(cap_dist_plan* d, hipStream_t s) {
     if (lb1 > lbx)
       CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, nb, (lb1 - lbx) * nb, nb, 1.0, Dinv, nb, d->Bacc + i * nb + lbx * nb * npad, npad, 0.0,
                               d->Ri + i * nb + lbx * nb * npad, npad, 0, s, 32));
-    if (i > 0) {
-      const double* Rcol = d->Rall + (i % P) * pe + (i / P) * nb * npad;   // R[0 : i nb, block column i]
-      CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, i * nb, (lb1 - lb0) * nb, nb, -1.0, Rcol, npad, Xi, npad, 1.0, d->Bacc + lb0 * nb * npad, npad,
-                              0, s));
+    // rows above: all of them, or - for the columns right of the root partition - only those below its row boundary (the block
+    // Ri[0:n1, n1:n] stays empty, so its right-hand sides are never formed)
+    const int64_t r0 = (kcut > 0 && i >= kcut) ? kcut * nb : 0;
+    if (i * nb > r0) {
+      const double* Rcol = d->Rall + (i % P) * pe + (i / P) * nb * npad + r0;   // R[r0 : i nb, block column i]
+      CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, i * nb - r0, (lb1 - lb0) * nb, nb, -1.0, Rcol, npad, Xi, npad, 1.0,
+                              d->Bacc + r0 + lb0 * nb * npad, npad, 0, s));
     }
   }
   if (cut && kcut == 0) {
