@@ -299,7 +299,7 @@ int plan_alloc(cap_cholinv_plan* p) {
     CAP_HIP(hipMalloc((void**)&p->Rinv, sizeof(double) * p->ldi * n));
     CAP_HIP(hipMemset(p->Rinv, 0, sizeof(double) * p->ldi * n));
     // plain recursion: (n/2 + 1)^2; blocked factorization + inverse tree: chain scratch + panel scratch + tree scratch
-    // (checked again - and grown if an option changed the panel width - by ensure_inverse_work at factor time)
+    // (checked again - and grown if an option changed the panel width - by factor_with_inverse at factor time)
     p->work_elems = std::max(rec_work_size(n), rec_work_size(1024) + cap_round_up(1024 * n, 2) + (n / 2 + 1024) * (n / 2 + 1024) * 3 / 2);
   } else {
     p->ldi = p->nb;
@@ -933,7 +933,7 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
   }
   if (k == "nb") {
     if (value < 64 || value % 64) return CAP_ERR_ARG;
-    if (p->complete_inv >= 0) {          // workspace is re-checked at factor time (ensure_inverse_work); the tree follows the panels
+    if (p->complete_inv >= 0) {          // workspace is re-checked at factor time (factor_with_inverse); the tree follows the panels
       if (value > 1024) return CAP_ERR_ARG;
       if (value != p->nb) { delete p->itree; p->itree = nullptr; }
       p->nb = value; return CAP_OK;

@@ -257,7 +257,11 @@ int cap_cholinv_info(cap_cholinv_plan* plan, void* stream, int64_t* info);
  * the bulk updates), "tail" (columns left below which strips are nb wide), "depth2" (look-ahead depth 2),
  * "occ1_m" (columns left below which bulk updates run one workgroup per CU so the diagonal-block chain
  * always finds a slot; 0 = never), "inner_la" (column-split look-ahead, off), "reserve" (CU-masked chain
- * stream, off), "serial_m", "fastdiag", "profile".  Multi-GPU plans forward to cap_dist_set_option.        */
+ * stream, off), "serial_m", "fastdiag", "profile", "use_sb" (strip buffers: the solved block rows of a strip are written
+ * K-contiguously into a ring of three buffers every update reads from, R receives a copy off the panel stream; on),
+ * complete_inv >= 0: "inv_fast" (blocked sweep + inverse tree instead of the plain recursion of cholinv.hpp:85-165; on),
+ * "inv_overlap" (tree nodes are enqueued as their inputs become final; on), "inv_start_m" (columns left below which the
+ * tree starts).  Multi-GPU plans forward to cap_dist_set_option.                                                       */
 int cap_cholinv_set_option(cap_cholinv_plan* plan, const char* key, int64_t value);
 int64_t cap_cholinv_get_option(cap_cholinv_plan* plan, const char* key);
 /* Live measurement of the dominant kernel (trailing-update DSYRK) of the LAST factor call, enabled
@@ -293,8 +297,11 @@ double* cap_dist_Rinv_ptr(cap_dist_plan* plan, int64_t* ld);
  * cap_dist_factor ran on.                                                                              */
 int cap_dist_info(cap_dist_plan* plan, void* stream, int64_t* info);
 /* knobs: "strip" (block rows per bulk update, 1|2), "depth2" (split bulk updates), "occ1_m" (bulk updates of at most
- * occ1_m^2 rows x local columns run one workgroup per CU), "profile",
- * "jitter_us" / "jitter_seed" (stress testing: random spin kernels in front of every launch group).    */
+ * occ1_m^2 rows x local columns run one workgroup per CU), "profile", "safe" (one communicator + one communication
+ * stream), "ipc" (strip exchange as IPC peer copies; get "ipc_active" tells whether the peers could be mapped),
+ * "complete_inv" / "split" (R^-1, see cap_dist_get_Rinv), "jitter_us" / "jitter_seed" (stress testing: random spin kernels in
+ * front of every launch group); get only: "count_gemm" / "count_chain" / "count_copy" / "count_coll" = launches and
+ * collectives of the last factor call on this rank.                                                                     */
 int cap_dist_set_option(cap_dist_plan* plan, const char* key, int64_t value);
 int64_t cap_dist_get_option(const cap_dist_plan* plan, const char* key);
 int cap_dist_profile(cap_dist_plan* plan, int64_t* launches, double* ms_total, double* flops_total);
