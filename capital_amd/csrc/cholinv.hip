@@ -239,6 +239,10 @@ struct cap_cholinv_plan {
   // panel stream, so the latency-bound diagonal-block chain is not time-sliced against 512 resident bulk
   // workgroups (hipExtStreamCreateWithCUMask: bit i -> XCD i % 8, tools/cumask_probe.hip)
   hipStream_t s_bulk; hipEvent_t ev_join_b; int64_t reserve; bool bulk_ready;
+  // reserve_m > 0: the masks only apply to the chain-bound tail (at most reserve_m columns left) - the bulk update has slack there,
+  // so the 10 % a masked launch loses (tools/gemm_bench.bin MASK_OFF) costs nothing while the chain runs at its isolated speed;
+  // reserve_m == 0: masks for the whole factorization (measured slower, kept for A/B runs)
+  int64_t reserve_m; bool chain_masked; hipEvent_t ev_bulk_sw;
   // ... and the diagonal-block chain itself (leaf / fused-step / assembly kernels: a handful of workgroups each) runs on a stream
   // masked to exactly those reserved CUs, so none of its waves ever shares a SIMD with fp64-MFMA bulk waves
   hipStream_t s_chain; hipEvent_t ev_chain[2];
@@ -338,6 +342,7 @@ int ensure_bulk_stream(cap_cholinv_plan* p) {
   for (int i = 0; i < 8; i++) mask[i] = ~mask[i];
   CAP_HIP(hipExtStreamCreateWithCUMask(&p->s_chain, 8, mask));
   for (int i = 0; i < 2; i++) CAP_HIP(hipEventCreateWithFlags(&p->ev_chain[i], hipEventDisableTiming));
+  CAP_HIP(hipEventCreateWithFlags(&p->ev_bulk_sw, hipEventDisableTiming));
   p->bulk_ready = true;
   return CAP_OK;
 }
@@ -348,7 +353,7 @@ int panel_chain(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t j0, int64_t
   double* Wrec = p->work;                       // rec scratch
   if (p->fastdiag && jb % 64 == 0 && jb >= 128 && jb <= 1024 && (jb & (jb - 1)) == 0 && p->leaf == CAP_LEAF_MAX) {
     hipStream_t sc = s;
-    if (p->bulk_ready && s != p->s_bulk) {          // (s == s_bulk: the non-overlapped tail, nothing to hide from)
+    if (p->bulk_ready && p->chain_masked && s != p->s_bulk) {          // (s == s_bulk: the non-overlapped tail, nothing to hide from)
       sc = p->s_chain;
       CAP_HIP(hipEventRecord(p->ev_chain[0], s));
       CAP_HIP(hipStreamWaitEvent(sc, p->ev_chain[0], 0));
@@ -721,7 +726,12 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
   CAP_HIP(hipEventRecord(p->ev_fork, s0));
   CAP_HIP(hipStreamWaitEvent(s1, p->ev_fork, 0));
   if (sbm) CAP_HIP(hipStreamWaitEvent(p->s_copy, p->ev_fork, 0));
-  if (p->bulk_ready) { s0 = p->s_bulk; CAP_HIP(hipStreamWaitEvent(s0, p->ev_fork, 0)); }
+  // CU masks (option reserve): whole run (reserve_m == 0), or from the step before the first one with <= reserve_m columns left
+  const bool tail_res = p->bulk_ready && p->reserve_m > 0;
+  int64_t km = nstrip;                       // first step whose trailing matrix is at most reserve_m wide
+  if (tail_res) for (int64_t k = 0; k < nstrip; k++) if (n - bnd[k + 1] <= p->reserve_m) { km = k; break; }
+  p->chain_masked = p->bulk_ready && !tail_res;
+  if (p->bulk_ready && !tail_res) { s0 = p->s_bulk; CAP_HIP(hipStreamWaitEvent(s0, p->ev_fork, 0)); }
   CAP_TRY(strip(0, s1));
   CAP_HIP(hipEventRecord(p->ev_panel[0], s1));
   // Optional (serial_m > 0, default off): from strip ksw on the chain and the bulk update are NOT overlapped any more.
@@ -748,6 +758,12 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
       }
       break;
     }
+    if (tail_res && k + 1 >= km && s0 != p->s_bulk) {   // the bulk moves to the masked stream one step before the chain does
+      CAP_HIP(hipEventRecord(p->ev_bulk_sw, s0));
+      s0 = p->s_bulk;
+      CAP_HIP(hipStreamWaitEvent(s0, p->ev_bulk_sw, 0));
+    }
+    if (tail_res) p->chain_masked = k >= km;
     const int64_t J1 = bnd[k + 1], rows1 = bnd[k + 2] - J1, m2 = m - rows1;
     // strip k right of its diagonal block (rows x m): inside R, or in its strip buffer (K-contiguous, ld = NB)
     const StripCtx ck = sbm ? sctx(k) : StripCtx{nullptr, 0, 0};
@@ -782,6 +798,7 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
     }
   }
   // join
+  p->chain_masked = false;
   if (sbm) { CAP_HIP(hipEventRecord(p->ev_join_cp, p->s_copy)); CAP_HIP(hipStreamWaitEvent(s_user, p->ev_join_cp, 0)); }
   CAP_HIP(hipEventRecord(p->ev_join, s1));
   CAP_HIP(hipStreamWaitEvent(s_user, p->ev_join, 0));
@@ -868,7 +885,9 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   }
   // two-level blocking defaults (tools/sweep.sh on MI355X): K = 2 nb bulk updates while the trailing matrix is
   // large, nb-wide strips for the last n/8 columns where the strip chain could no longer hide
-  p->outer = n >= 8192 ? 2 * p->nb : p->nb; p->tail = n >= 8192 ? n / 8 : 0; p->reserve = 0;
+  p->outer = n >= 8192 ? 2 * p->nb : p->nb; p->tail = n >= 8192 ? n / 8 : 0;
+  p->reserve = getenv("CAP_RESERVE") ? atoll(getenv("CAP_RESERVE")) : 0;
+  p->reserve_m = getenv("CAP_RESERVE_M") ? atoll(getenv("CAP_RESERVE_M")) : 0; p->chain_masked = false;
   // fused 64-blocked diagonal-block path (11 dependent launches per 512 panel instead of 43; N = 8192 alone, first version:
   // 20.8 -> 15.5 ms).  Its workgroups use 84 KiB of LDS so that they fit into ONE slot vacated by a bulk
   // workgroup - a first 135 KiB version needed a fully idle CU and lost 4 % under a concurrent bulk update.
@@ -905,6 +924,7 @@ int cap_cholinv_plan_destroy(cap_cholinv_plan* p) {
   if (p->bulk_ready) {
     (void)hipStreamDestroy(p->s_bulk); (void)hipStreamDestroy(p->s_chain);
     for (int i = 0; i < 2; i++) (void)hipEventDestroy(p->ev_chain[i]);
+    (void)hipEventDestroy(p->ev_bulk_sw);
   }
   release_split(p);
   release_inverse(p);
@@ -969,10 +989,12 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
       (void)hipStreamSynchronize(p->s_bulk); (void)hipStreamDestroy(p->s_bulk);
       (void)hipStreamSynchronize(p->s_chain); (void)hipStreamDestroy(p->s_chain);
       for (int i = 0; i < 2; i++) (void)hipEventDestroy(p->ev_chain[i]);
+      (void)hipEventDestroy(p->ev_bulk_sw);
       p->bulk_ready = false;
     }
     p->reserve = value; return CAP_OK;
   }
+  if (k == "reserve_m") { if (value < 0) return CAP_ERR_ARG; p->reserve_m = value; return CAP_OK; }
   if (k == "profile") {
     p->profile = value != 0;
     if (p->profile && !p->prof_ev) { p->prof_ev = new std::vector<hipEvent_t>(); p->prof_flops = new std::vector<double>(); }
@@ -1005,6 +1027,7 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
   if (k == "depth2") return p->depth2;
   if (k == "fastdiag") return p->fastdiag;
   if (k == "reserve") return p->reserve;
+  if (k == "reserve_m") return p->reserve_m;
   if (k == "inner_la") return p->inner_la;
   if (k == "occ1_m") return p->occ1_m;
   if (k == "n") return p->n;

@@ -19,8 +19,9 @@ int main(int argc, char** argv) {
   long m = atol(argv[1]), n = atol(argv[2]), k = atol(argv[3]);
   int syrk = argc > 4 ? atoi(argv[4]) : 0, reps = argc > 5 ? atoi(argv[5]) : 5;
   double *A, *B, *C;
-  CK(hipMalloc(&A, sizeof(double) * k * m)); CK(hipMalloc(&B, sizeof(double) * k * n)); CK(hipMalloc(&C, sizeof(double) * m * n));
-  fill<<<2048, 256>>>(A, (size_t)k * m, 1); fill<<<2048, 256>>>(B, (size_t)k * n, 2); fill<<<2048, 256>>>(C, (size_t)m * n, 3);
+  const long ld = k + (getenv("LDPAD") ? atol(getenv("LDPAD")) : 0);     // leading dimension of the K-contiguous operands
+  CK(hipMalloc(&A, sizeof(double) * ld * m)); CK(hipMalloc(&B, sizeof(double) * ld * n)); CK(hipMalloc(&C, sizeof(double) * m * n));
+  fill<<<2048, 256>>>(A, (size_t)ld * m, 1); fill<<<2048, 256>>>(B, (size_t)ld * n, 2); fill<<<2048, 256>>>(C, (size_t)m * n, 3);
   CK(hipDeviceSynchronize());
   // MASK_OFF=n: run on a stream whose CU mask has its first n bits (CU i of XCD i % 8) cleared
   hipStream_t st_ = nullptr;
@@ -29,9 +30,10 @@ int main(int argc, char** argv) {
     for (int b = 0; b < atoi(getenv("MASK_OFF")); b++) mk[b / 32] &= ~(1u << (b % 32));
     CK(hipExtStreamCreateWithCUMask(&st_, 8, mk));
   }
+  const double beta = getenv("BETA") ? atof(getenv("BETA")) : 1.0;
   auto run = [&]() {
-    int st = syrk ? cap_dsyrk(CAP_UPPER, CAP_TRANS, n, k, -1.0, A, k, 1.0, C, m, st_)
-                  : cap_dgemm(CAP_TRANS, CAP_NOTRANS, m, n, k, -1.0, A, k, B, k, 1.0, C, m, st_);
+    int st = syrk ? cap_dsyrk(CAP_UPPER, CAP_TRANS, n, k, -1.0, A, ld, beta, C, m, st_)
+                  : cap_dgemm(CAP_TRANS, CAP_NOTRANS, m, n, k, -1.0, A, ld, B, ld, beta, C, m, st_);
     if (st) { printf("status %d\n", st); exit(1); }
   };
   run(); CK(hipDeviceSynchronize());
@@ -41,6 +43,6 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(e1, st_)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
   double fl = syrk ? (double)n * (n + 1) * k : 2.0 * m * n * k;
-  printf("%s m=%ld n=%ld k=%ld: %.3f ms %.2f TFLOP/s\n", syrk ? "syrk" : "gemm", m, n, k, ms, fl / ms * 1e-9);
+  printf("%s m=%ld n=%ld k=%ld ld=%ld: %.3f ms %.2f TFLOP/s\n", syrk ? "syrk" : "gemm", m, n, k, ld, ms, fl / ms * 1e-9);
   return 0;
 }
