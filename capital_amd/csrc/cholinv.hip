@@ -243,6 +243,9 @@ struct cap_cholinv_plan {
   // so the 10 % a masked launch loses (tools/gemm_bench.bin MASK_OFF) costs nothing while the chain runs at its isolated speed;
   // reserve_m == 0: masks for the whole factorization (measured slower, kept for A/B runs)
   int64_t reserve_m; bool chain_masked; hipEvent_t ev_bulk_sw;
+  // factor(A): the A -> R copy is left to right_looking (srcA != nullptr on entry).  fuse_copy: only the first strip's rows are
+  // copied, the updates of step 0 - which together write the whole trailing triangle - read their C input from A instead
+  const double* srcA; int64_t src_lda; int fuse_copy;
   // ... and the diagonal-block chain itself (leaf / fused-step / assembly kernels: a handful of workgroups each) runs on a stream
   // masked to exactly those reserved CUs, so none of its waves ever shares a SIMD with fp64-MFMA bulk waves
   hipStream_t s_chain; hipEvent_t ev_chain[2];
@@ -422,7 +425,7 @@ int panel_factor(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t
 // M == N, A == B: the SYRK on the bulk of the trailing matrix; M < N: the strip of rows updated first so
 // that the panel chain of the step after next can start early (look-ahead depth 2).
 int trailing_update(cap_cholinv_plan* p, int64_t M, int64_t N, int64_t k, const double* A, const double* B, double* C,
-                    int64_t ldr, hipStream_t s, int64_t ldab = 0) {
+                    int64_t ldr, hipStream_t s, int64_t ldab = 0, const double* Cin = nullptr, int64_t ldcin = 0) {
   if (ldab == 0) ldab = ldr;              // operands inside R itself (no strip buffer)
   CapRange range("CI::tmu");                    // cholinv.hpp:129-136
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -435,7 +438,7 @@ int trailing_update(cap_cholinv_plan* p, int64_t M, int64_t N, int64_t k, const 
   }
   // chain-bound tail (N columns left <= occ1_m): one bulk workgroup per CU instead of two, see launch_tn_dma
   const int occ = (p->occ1_m > 0 && N <= p->occ1_m) ? -1 : 0;
-  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, M, N, k, -1.0, A, ldab, B, ldab, 1.0, C, ldr, 1, s, 1 | p->ctag, occ));
+  CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, M, N, k, -1.0, A, ldab, B, ldab, 1.0, C, ldr, 1, s, 1 | p->ctag, occ, Cin, ldcin));
   if (e0) {
     CAP_HIP(hipEventRecord(e1, s));
     p->prof_used += 2;
@@ -692,6 +695,13 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
   const bool la = p->lookahead && nstrip > 2;
   p->prof_used = 0;
   if (p->prof_flops) p->prof_flops->clear();
+  // serialize<uppertri,uppertri>(A -> R), cholinv.hpp:13: only A's upper triangle is consumed.  Fused form: see cap_cholinv_plan::srcA
+  const double* srcA = p->srcA; const int64_t src_lda = p->src_lda;
+  p->srcA = nullptr;
+  const bool split_path = p->inner_la && p->serial_m == 0 && p->reserve == 0 && NB / nb <= 8 && !p->inv_active;
+  const bool fuse = srcA && la && !split_path && p->fuse_copy && n % 128 == 0 && nb % 128 == 0 && !(src_lda & 1) &&
+                    (((uintptr_t)srcA) & 15) == 0 && n - bnd[1] > p->serial_m;
+  if (srcA) CAP_TRY(cap_copy_window(srcA, 0, src_lda, 0, 0, R, 0, ldr, 0, 0, fuse ? bnd[1] : n, n, 1, 0, (void*)s0));
   if (!la) {
     for (int64_t k = 0; k < nstrip; k++) {
       const int64_t J0 = bnd[k], rows = bnd[k + 1] - J0, m = n - bnd[k + 1];
@@ -703,7 +713,7 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
     }
     return CAP_OK;
   }
-  if (p->inner_la && p->serial_m == 0 && p->reserve == 0 && NB / nb <= 8 && !p->inv_active) return right_looking_split(p, R, ldr, n, s0, bnd);
+  if (split_path) return right_looking_split(p, R, ldr, n, s0, bnd);
   CAP_TRY(ensure_streams(p));
   CAP_TRY(ensure_bulk_stream(p));
   hipStream_t s1 = p->s_panel;
@@ -773,7 +783,11 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
     //     needs strip k (same stream) and the HEAD of the bulk update of step k-1 (main stream): the head is the
     //     part of that update that touches strip k+1's rows, so the chain runs one more step ahead of the bulk
     if (k > 0) CAP_HIP(hipStreamWaitEvent(s1, p->ev_update[(k - 1) & 1], 0));
-    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows1, m, rows, -1.0, S, lds_, S, lds_, 1.0, R + J1 + J1 * ldr, ldr, 1, s1, p->ctag));
+    // step 0 of the fused form: C input from A (the three updates of this step cover the trailing triangle exactly once)
+    const bool fz = fuse && k == 0;
+    auto cin = [&](int64_t j) -> const double* { return fz ? srcA + j + j * src_lda : nullptr; };
+    CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows1, m, rows, -1.0, S, lds_, S, lds_, 1.0, R + J1 + J1 * ldr, ldr, 1, s1, p->ctag, 0,
+                            cin(J1), src_lda));
     CAP_TRY(strip(k + 1, s1));
     CAP_HIP(hipEventRecord(p->ev_panel[(k + 1) & 1], s1));
     // (b) main stream: bulk of the trailing update (rows below strip k+1)
@@ -784,13 +798,13 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
       const int64_t rows2 = (k + 3 <= nstrip) ? bnd[k + 3] - bnd[k + 2] : m2;   // height of strip k+2
       if (p->depth2 && rows2 < m2) {
         // head: strip k+2's rows first, then signal the panel stream; rest: everything below
-        CAP_TRY(trailing_update(p, rows2, m2, rows, S2, S2, R + J2 + J2 * ldr, ldr, s0, lds_));
+        CAP_TRY(trailing_update(p, rows2, m2, rows, S2, S2, R + J2 + J2 * ldr, ldr, s0, lds_, cin(J2), src_lda));
         CAP_HIP(hipEventRecord(p->ev_update[k & 1], s0));
         const int64_t m3 = m2 - rows2;
         const double* S3 = S2 + rows2 * lds_;
-        CAP_TRY(trailing_update(p, m3, m3, rows, S3, S3, R + (J2 + rows2) + (J2 + rows2) * ldr, ldr, s0, lds_));
+        CAP_TRY(trailing_update(p, m3, m3, rows, S3, S3, R + (J2 + rows2) + (J2 + rows2) * ldr, ldr, s0, lds_, cin(J2 + rows2), src_lda));
       } else {
-        CAP_TRY(trailing_update(p, m2, m2, rows, S2, S2, R + J2 + J2 * ldr, ldr, s0, lds_));
+        CAP_TRY(trailing_update(p, m2, m2, rows, S2, S2, R + J2 + J2 * ldr, ldr, s0, lds_, cin(J2), src_lda));
         CAP_HIP(hipEventRecord(p->ev_update[k & 1], s0));
       }
     } else {
@@ -888,6 +902,7 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   p->outer = n >= 8192 ? 2 * p->nb : p->nb; p->tail = n >= 8192 ? n / 8 : 0;
   p->reserve = getenv("CAP_RESERVE") ? atoll(getenv("CAP_RESERVE")) : 0;
   p->reserve_m = getenv("CAP_RESERVE_M") ? atoll(getenv("CAP_RESERVE_M")) : 0; p->chain_masked = false;
+  p->srcA = nullptr; p->src_lda = 0; p->fuse_copy = getenv("CAP_FUSE_COPY") ? atoi(getenv("CAP_FUSE_COPY")) : 1;
   // fused 64-blocked diagonal-block path (11 dependent launches per 512 panel instead of 43; N = 8192 alone, first version:
   // 20.8 -> 15.5 ms).  Its workgroups use 84 KiB of LDS so that they fit into ONE slot vacated by a bulk
   // workgroup - a first 135 KiB version needed a fully idle CU and lost 4 % under a concurrent bulk update.
@@ -995,6 +1010,7 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
     p->reserve = value; return CAP_OK;
   }
   if (k == "reserve_m") { if (value < 0) return CAP_ERR_ARG; p->reserve_m = value; return CAP_OK; }
+  if (k == "fuse_copy") { p->fuse_copy = value != 0; return CAP_OK; }
   if (k == "profile") {
     p->profile = value != 0;
     if (p->profile && !p->prof_ev) { p->prof_ev = new std::vector<hipEvent_t>(); p->prof_flops = new std::vector<double>(); }
@@ -1028,6 +1044,7 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
   if (k == "fastdiag") return p->fastdiag;
   if (k == "reserve") return p->reserve;
   if (k == "reserve_m") return p->reserve_m;
+  if (k == "fuse_copy") return p->fuse_copy;
   if (k == "inner_la") return p->inner_la;
   if (k == "occ1_m") return p->occ1_m;
   if (k == "n") return p->n;
@@ -1045,7 +1062,7 @@ int cap_cholinv_factor(cap_cholinv_plan* p, const double* A, int64_t lda, void* 
   const int64_t n = p->n;
   CAP_HIP(hipMemsetAsync(p->info_dev, 0, sizeof(int), s));
   // serialize<uppertri,uppertri>(A -> R), cholinv.hpp:13: only A's upper triangle is consumed
-  CAP_TRY(cap_copy_window(A, 0, lda, 0, 0, p->R, 0, p->ldr, 0, 0, n, n, 1, 0, stream));
+  p->srcA = A; p->src_lda = lda;             // right_looking does the A -> R copy (all of it, or the first strip's rows)
   if (p->complete_inv < 0) return right_looking(p, p->R, p->ldr, n, s);
   // upstream's leaf test at the root (cholinv.hpp:93 with c = d = 1): a root that is itself a base
   // case gets the full inverse whatever complete_inv says (policy.h:199-201 always runs trtri)
@@ -1055,6 +1072,8 @@ int cap_cholinv_factor(cap_cholinv_plan* p, const double* A, int64_t lda, void* 
   const int64_t bc_dim = n / bc;
   const bool root_is_base = (n <= bc_dim) || ((n >> p->split) < p->split);
   if (p->inv_fast && n >= 2 * p->nb && p->leaf == CAP_LEAF_MAX) return factor_with_inverse(p, root_is_base, s);
+  p->srcA = nullptr;
+  CAP_TRY(cap_copy_window(A, 0, lda, 0, 0, p->R, 0, p->ldr, 0, 0, n, n, 1, 0, stream));
   RecCtx c{p->R, p->ldr, p->Rinv, p->ldi, p->work, p->work_elems, p->info_dev, p->leaf, p->split, p->complete_inv, s};
   return rec_cholinv(c, 0, n, !root_is_base, 0);
 }

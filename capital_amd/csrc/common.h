@@ -58,7 +58,7 @@ struct CapRange {
 // tri = 0 full, 1 = only tiles/elements with row <= col (upper), 2 = row >= col (lower).
 int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
                     int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri,
-                    hipStream_t stream, int tag = 0, int persist_wgs = 0);
+                    hipStream_t stream, int tag = 0, int persist_wgs = 0, const double* Cin = nullptr, int64_t ldcin = 0);
 
 // leaf.hip: in-LDS cholinv (potrf + trtri) / trtri of one n <= 64 block
 constexpr int CAP_LEAF_MAX = 64;

@@ -75,6 +75,9 @@ struct GemmArgs {
   int atomic_c;
   int usebuf;       // operand rows of a tile fit a 32-bit byte offset: LDS-DMA through buffer descriptors (scalar offsets)
   int skip;         // launch the block-skipping instantiation (triangular operands, few-tile SYRK)
+  // beta != 0 with the C input read from another matrix (C = alpha op(A) op(B) + beta Cin): the first trailing updates of a
+  // factorization read A and write R, which replaces the n x n copy in front of it.  Cin == C, ldcin == ldc otherwise.
+  const double* Cin; int64_t ldcin;
 };
 
 // global tile index (relative to the row origin) of local column tile tj under the staircase view
@@ -541,7 +544,8 @@ __device__ __forceinline__ void tn_dma_tile(const GemmArgs& g, const int ti, con
             const int64_t col = j0 + wj + 16 * j + kg + 4 * r;
             // diagonal tiles: compare WITHIN-tile offsets (under the staircase view rows and columns have different origins)
             bool ok = !masked.value || (g.tri == 1 ? (row - i0) <= (col - j0) : (row - i0) >= (col - j0));
-            cin[j][r] = ok ? g.C[row + col * g.ldc] : 0.0;
+            // (the NN instantiations sit at 252 VGPRs: they never get a separate C input and must not carry it)
+            cin[j][r] = ok ? (A_MC ? g.C[row + col * g.ldc] : g.Cin[row + col * g.ldcin]) : 0.0;
           }
       }
 #pragma unroll
@@ -810,8 +814,10 @@ double* cap_scratch(int64_t elems, hipStream_t stream) {
 
 int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
                     int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri,
-                    hipStream_t stream, int tag, int persist_wgs) {
+                    hipStream_t stream, int tag, int persist_wgs, const double* Cin, int64_t ldcin) {
   if (m < 0 || n < 0 || k < 0) return CAP_ERR_ARG;
+  if (Cin == C) Cin = nullptr;
+  if (Cin && (ldcin < m || beta == 0.0 || alpha == 0.0 || k == 0)) return CAP_ERR_ARG;
   if (m == 0 || n == 0) return CAP_OK;
   if (ldc < m) return CAP_ERR_ARG;
   if (alpha == 0.0 || k == 0) {
@@ -828,7 +834,7 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   if (transb == CAP_TRANS ? ldb < n : ldb < k) return CAP_ERR_ARG;
 
   // latency-bound little products (diagonal-block recursion): 64 x 64 tiles, no setup cost
-  if (m <= 512 && n <= 512 && k <= 1024 && m * n <= 256 * 256)
+  if (m <= 512 && n <= 512 && k <= 1024 && m * n <= 256 * 256 && !Cin)
     return launch_small(transa, transb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, (tag & 2) ? 1 : 0, stream);
 
   GemmArgs g;
@@ -836,7 +842,8 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.beta = beta; g.tri = tri;
   g.hiprio = (tag & 2) ? 1 : 0; g.bupper = (tag & 8) ? 1 : 0;
   g.aupt = ((tag & 16) && transa == CAP_TRANS) ? 1 : 0; g.aupn = ((tag & 32) && transa != CAP_TRANS) ? 1 : 0;
-  const bool no_atomic = (tag & CAP_TAG_NO_ATOMIC) != 0;
+  const bool no_atomic = (tag & CAP_TAG_NO_ATOMIC) != 0 || Cin != nullptr;
+  g.Cin = Cin ? Cin : C; g.ldcin = Cin ? ldcin : ldc;
   tag &= 1; g.ctr = nullptr;
   g.atomic_c = 0; g.usebuf = 0; g.skip = 0;
   g.stair = 0; g.gather = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0; g.rP = 1; g.rp = 0; g.rlb0 = 0;
@@ -906,6 +913,8 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
 
   int st;
   static const bool use_v1 = getenv("CAP_GEMM_V1") != nullptr;   // A/B switch for profiling
+  // a separate C input is only implemented in the LDS-DMA kernels' load / add / store epilogue
+  if (Cin && !(a_kc && b_kc && !edge && !use_v1 && g.ksplit == 1)) return CAP_ERR_UNSUPPORTED;     // (the NN form has a_kc == false)
   if (a_kc && b_kc && !edge && !use_v1) st = (tag == 1) ? launch_tn_dma<1>(g, (int)grid, stream, persist_wgs) : launch_tn_dma<0>(g, (int)grid, stream, 0);
   else if (!a_kc && b_kc && !edge && !use_v1 && g.ksplit == 1) st = launch_nn_dma(g, (int)grid, stream);
   else if (a_kc && b_kc && tag == 1) st = launch_variant<true, true, 1>(g, edge, (int)grid, stream);
@@ -942,7 +951,7 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   {
     static const int atomic_env = getenv("CAP_ATOMIC_C") ? atoi(getenv("CAP_ATOMIC_C")) : 1;
     g.atomic_c = atomic_env ? 1 : 0;
-    g.usebuf = (128 * k * 8 + k * 8 < 0x7fffffffLL) ? 1 : 0; g.skip = 0;
+    g.usebuf = (128 * k * 8 + k * 8 < 0x7fffffffLL) ? 1 : 0; g.skip = 0; g.Cin = C; g.ldcin = ldc;
   }
   g.stair = 1; g.gather = 1; g.sP = P; g.sp = p; g.snbT = nb / 128; g.sJ0 = J0; g.slb0 = lb0; g.gpiece = piece;
   g.rP = Pr; g.rp = pr; g.rlb0 = rlb0;

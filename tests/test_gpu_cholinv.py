@@ -167,7 +167,12 @@ def test_inverse_tree_overlap_modes_are_bitwise_identical():
                                   {"nb": 128, "outer": 256, "occ1_m": 4096, "inner_la": 1},
                                   # strip buffers off (block rows solved through the panel scratch and copied back on the panel stream)
                                   {"nb": 128, "outer": 256, "use_sb": 0}, {"nb": 128, "outer": 512, "tail": 512, "depth2": 1, "use_sb": 0},
-                                  {"nb": 128, "outer": 128, "use_sb": 1}, {"nb": 256, "outer": 512, "tail": 0, "use_sb": 1}])
+                                  {"nb": 128, "outer": 128, "use_sb": 1}, {"nb": 256, "outer": 512, "tail": 0, "use_sb": 1},
+                                  # A -> R copy: all of it up front / first strip's rows + the step-0 updates reading A
+                                  {"nb": 128, "outer": 256, "fuse_copy": 0}, {"nb": 128, "outer": 256, "depth2": 1, "fuse_copy": 1},
+                                  {"nb": 256, "outer": 256, "use_sb": 0, "fuse_copy": 1},
+                                  # CU masks for the chain-bound tail only
+                                  {"nb": 128, "outer": 256, "reserve": 8, "reserve_m": 768}])
 def test_schedule_knobs_do_not_change_the_answer(opts):
     from capital_amd import cholinv
     n = 1536
@@ -176,6 +181,19 @@ def test_schedule_knobs_do_not_change_the_answer(opts):
     R = cholinv.construct_R(pack).to_numpy()
     assert orc.cholesky_residual(a, R) < RES_TOL
     assert relerr(R, np.linalg.cholesky(a).T) < 1e-13
+
+
+def test_fused_first_step_copy_is_bitwise_identical():
+    """fuse_copy: the step-0 updates read their C input from A and write R (load / add / store) instead of updating a copy with
+    fire-and-forget atomics - the same single rounding per element, so R must not change by one bit; A stays untouched."""
+    from capital_amd import cholinv
+    outs = []
+    for ci, n in ((-1, 2048), (1, 1536)):
+        for f in (0, 1):
+            A, pack = _factor(n, ci, 1, -2, opts={"nb": 128, "outer": 256, "depth2": 1, "fuse_copy": f})
+            outs.append(cholinv.construct_R(pack).to_numpy())
+            assert np.array_equal(A.to_numpy(), orc.symmetric_global(n, True))
+        assert np.array_equal(outs[-1], outs[-2])
 
 
 def test_harder_spd_input():
