@@ -619,13 +619,18 @@ def bench_mixed(args, torch, L, C, rank, world, timed):
     ok = int(info) == 0 and relres == relres and relres <= 1e-14 and indep <= 1e-13 and indep_perturbed > 10 * indep and (x_diff is None or x_diff <= 1e-12)
     # roofline of the dominant kernel (bf16 trailing update), measured live with HIP events on its launch stream
     nl, ms, fl, by = p.profile_update(A)
-    roof = {"bound": "hbm", "kernel": "bf16_tn_kernel (trailing update C32 -= P16^T P16: fp32 C read-modify-write, K/4 flop per byte = 256 at K = 1024 "
-                                      "against a ridge of 312)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+    roof = {"bound": "hbm", "kernel": "bf16_tn_kernel (trailing update C32 -= S16^T S16: fp32 C read-modify-write, K/4 flop per byte)",
+            "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
     if nl:
         gbs, tf16 = by / (ms * 1e-3) / 1e9, fl / (ms * 1e-3) / 1e12
-        roof.update({"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "launches": nl, "avg_launch_ms": ms / nl,
+        intensity, ridge = fl / by, BF16_MFMA_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+        hbm = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+        mfma = {"achieved": tf16, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s (bf16, dense)", "frac": tf16 / BF16_MFMA_PEAK_TF}
+        # the roof that binds is the one the kernel's algorithmic intensity puts it under (K = 2048 strips: 512 flop/B > ridge 312)
+        roof.update(mfma if intensity > ridge else hbm)
+        roof.update({"bound": "mfma" if intensity > ridge else "hbm", "launches": nl, "avg_launch_ms": ms / nl,
                      "algorithmic_bytes_per_launch_avg": by / nl, "algorithmic_flops_per_launch_avg": fl / nl,
-                     "mfma": {"achieved": tf16, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s (bf16, dense)", "frac": tf16 / BF16_MFMA_PEAK_TF}})
+                     "flop_per_byte": intensity, "ridge_flop_per_byte": ridge, "hbm": hbm, "mfma": mfma})
     out = {"metric": "fp64-equivalent Cholesky-solve TFLOP/s (N^3/3 per wall-second of bf16-MFMA factor + fp64 refinement), N=%d" % n,
            "value": tflops if ok else None, "unit": "TFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16 MFMA (fp32 accumulate) factor, f64 refinement",

@@ -45,6 +45,10 @@ struct BfArgs {
   float alpha;
   int tri;                         // 1: only tiles / elements with row <= col (square problems)
   int tm, tn, chunk;
+  // st > 0: tiles are enumerated supertile by supertile (st x st tiles, column-major inside and across; the upper triangle of
+  // supertiles for square tri problems), so the 64 / 32 tiles an XCD runs at a time share 2 st panel slices through its L2
+  // instead of st^2 + 1 (a plain column-major walk: every tile of a column has its own A slice); nsm = supertile rows
+  int st, nsm;
   // distributed trailing update (dist_mixed.hip; the bf16 twin of GemmArgs::stair / gather in gemm.hip): C = my block-cyclic
   // block columns (1 x P grid, block width snbT tiles), rows global from block sJ0 on; upper mask along the staircase
   // row tile <= global tile of my column tile; operand A = the all-gathered bf16 block row, P pieces in (rank, local block) order
@@ -60,7 +64,20 @@ __global__ void __launch_bounds__(256, 2) bf16_tn_kernel(const BfArgs g) {
   const int L = (b & 7) * g.chunk + (b >> 3);
   int ti, tj;
   if ((b >> 3) >= g.chunk) return;
-  if (!g.stair && g.tri && g.tm == g.tn) {
+  if (!g.stair && g.st > 0) {
+    const int per = g.st * g.st, sl = L / per, q = L - sl * per;
+    int si, sj;
+    if (g.tri && g.tm == g.tn) {
+      sj = (int)((__builtin_sqrtf(8.0f * (float)sl + 1.0f) - 1.0f) * 0.5f);
+      while ((sj + 1) * (sj + 2) / 2 <= sl) sj++;
+      while (sj * (sj + 1) / 2 > sl) sj--;
+      si = sl - sj * (sj + 1) / 2;
+    } else {
+      si = sl % g.nsm; sj = sl / g.nsm;
+    }
+    ti = si * g.st + q % g.st; tj = sj * g.st + q / g.st;
+    if (ti >= g.tm || tj >= g.tn || (g.tri && ti > tj)) return;
+  } else if (!g.stair && g.tri && g.tm == g.tn) {
     tj = (int)((__builtin_sqrtf(8.0f * (float)L + 1.0f) - 1.0f) * 0.5f);
     while ((tj + 1) * (tj + 2) / 2 <= L) tj++;
     while (tj * (tj + 1) / 2 > L) tj--;
@@ -174,8 +191,15 @@ int launch_bf16_tn(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.tri = tri;
   g.stair = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0;
   for (int i = 0; i < 8; i++) g.gstart[i] = 0;
+  static const int st_env = getenv("CAP_BF16_ST") ? atoi(getenv("CAP_BF16_ST")) : 8;     // supertile edge (BfArgs::st), 0 = column-major walk
+  g.st = 0; g.nsm = 1;
   g.tm = (int)(m / TB); g.tn = (int)(n / TB);
-  const int64_t tiles = (tri && m == n) ? (int64_t)g.tn * (g.tn + 1) / 2 : (int64_t)g.tm * g.tn;
+  int64_t tiles = (tri && m == n) ? (int64_t)g.tn * (g.tn + 1) / 2 : (int64_t)g.tm * g.tn;
+  if (st_env > 0) {
+    g.st = st_env; g.nsm = (int)cap_ceil_div(g.tm, g.st);
+    const int64_t nsn = cap_ceil_div(g.tn, g.st);
+    tiles = ((tri && m == n) ? nsn * (nsn + 1) / 2 : (int64_t)g.nsm * nsn) * g.st * g.st;
+  }
   g.chunk = (int)cap_ceil_div(tiles, 8);
   hipLaunchKernelGGL(bf16_tn_kernel, dim3((unsigned)(g.chunk * 8)), dim3(256), 4 * TILE_D * sizeof(double), s, g);
   CAP_HIP(hipGetLastError());
@@ -194,7 +218,7 @@ int cap_bf16_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const void* 
   BfArgs g;
   g.A = (const __bf16*)G16; g.B = (const __bf16*)B16; g.C = C; g.lda = k; g.ldb = k; g.ldc = ldc; g.M = m; g.N = nloc; g.K = k;
   g.alpha = -1.0f; g.tri = 1; g.tm = (int)(m / TB); g.tn = (int)(nloc / TB);
-  g.stair = 1; g.sP = P; g.sp = p; g.snbT = nb / TB; g.sJ0 = J0; g.slb0 = lb0; g.gpiece = piece;
+  g.stair = 1; g.sP = P; g.sp = p; g.snbT = nb / TB; g.sJ0 = J0; g.slb0 = lb0; g.gpiece = piece; g.st = 0; g.nsm = 1;
   for (int i = 0; i < 8; i++) g.gstart[i] = i < P ? gstart[i] : 0;
   g.chunk = (int)cap_ceil_div((int64_t)g.tm * g.tn, 8);       // full grid; workgroups below the staircase return at once
   hipLaunchKernelGGL(bf16_tn_kernel, dim3((unsigned)(g.chunk * 8)), dim3(256), 4 * TILE_D * sizeof(double), s, g);
@@ -204,7 +228,9 @@ int cap_bf16_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const void* 
 
 struct cap_mpchol_plan {
   int64_t n, nb, nrhs_cap;          // nrhs_cap: internal right-hand-side width (multiple of 128)
-  float* R32; double* R64; __bf16* P16[2];
+  float* R32; double* R64; __bf16* P16[2]; int64_t strip;
+  // column-split schedule (cap_mpchol_factor): third stream, its events, near-column solve scratch (2 x nb x nb)
+  int split; bool split_ready; hipStream_t s_far; hipEvent_t ev_c, ev_ns, ev_hf, ev_fs[2], ev_far[2], ev_join2; double* Tn;
   hipStream_t s_panel; hipEvent_t ev_rest[2], ev_panel[2], ev_fork, ev_join; bool streams_ready;
   double* D64; double* Dinv; double* T64; double* S64; double* W; int64_t wcap;
   double* Inv; int64_t tb; double* Xt; double* Wt;          // blocked TRSM state
@@ -223,6 +249,8 @@ int cap_mpchol_plan_create(cap_mpchol_plan** plan, int64_t n, int64_t nrhs_max) 
   if (!p) return CAP_ERR_ALLOC;
   memset(p, 0, sizeof(*p));
   p->n = n; p->nb = 1024; p->nrhs_cap = cap_round_up(nrhs_max, 128);
+  p->strip = getenv("CAP_MP_STRIP") ? atoll(getenv("CAP_MP_STRIP")) : 2;
+  p->split = getenv("CAP_MP_SPLIT") ? atoi(getenv("CAP_MP_SPLIT")) : 1;
   // largest power of two <= min(n, 1024) (>= 128 because n % 128 == 0): the fused diagonal-block chain and the bf16 tile
   // kernel (k % 64, m % 128) need it; the last panel of a non-power-of-two n is a shorter multiple of 128
   while (p->nb > n) p->nb /= 2;
@@ -231,7 +259,7 @@ int cap_mpchol_plan_create(cap_mpchol_plan** plan, int64_t n, int64_t nrhs_max) 
   const int64_t nb = p->nb, w = p->nrhs_cap, nblk = cap_ceil_div(n, p->tb);
   hipError_t e = hipMalloc((void**)&p->R32, sizeof(float) * n * n);
   if (e == hipSuccess) e = hipMalloc((void**)&p->R64, sizeof(double) * n * n);
-  for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void**)&p->P16[i], sizeof(__bf16) * nb * n);
+  for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void**)&p->P16[i], sizeof(__bf16) * 2 * nb * n);     // strip buffers, ld = 2 nb
   if (e == hipSuccess) e = hipMalloc((void**)&p->D64, sizeof(double) * (2 * nb * nb + 2 * nb * n + p->wcap));
   if (e == hipSuccess) e = hipMalloc((void**)&p->Inv, sizeof(double) * (nblk * p->tb * p->tb + p->tb * w));
   if (e == hipSuccess) e = hipMalloc((void**)&p->Xw, sizeof(double) * (3 * n * w + 8));
@@ -249,6 +277,11 @@ int cap_mpchol_plan_destroy(cap_mpchol_plan* p) {
   if (p->prof_ev) { for (hipEvent_t e : *p->prof_ev) (void)hipEventDestroy(e); delete p->prof_ev; delete p->prof_flops; delete p->prof_bytes; }
   for (void* q : {(void*)p->R32, (void*)p->R64, (void*)p->P16[0], (void*)p->P16[1], (void*)p->D64, (void*)p->Inv, (void*)p->Xw, (void*)p->info_dev})
     if (q) (void)hipFree(q);
+  if (p->split_ready) {
+    (void)hipStreamDestroy(p->s_far);
+    for (hipEvent_t e : {p->ev_c, p->ev_ns, p->ev_hf, p->ev_fs[0], p->ev_fs[1], p->ev_far[0], p->ev_far[1], p->ev_join2}) (void)hipEventDestroy(e);
+    if (p->Tn) (void)hipFree(p->Tn);
+  }
   if (p->streams_ready) {
     (void)hipStreamDestroy(p->s_panel);
     for (int i = 0; i < 2; i++) { (void)hipEventDestroy(p->ev_rest[i]); (void)hipEventDestroy(p->ev_panel[i]); }
@@ -287,8 +320,132 @@ int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* st
   CAP_HIP(hipEventRecord(p->ev_fork, s0));
   CAP_HIP(hipStreamWaitEvent(s1, p->ev_fork, 0));
 
-  // fp64 panel work of panel k on stream s: diagonal block (R_kk, inverse), block row solve; writes P16[k & 1]
-  auto panel = [&](int64_t k, hipStream_t s) -> int {
+  // Strips of `sp` panels (option "strip", default 2): the bf16 update below a strip contracts K = sp * nb rows at once.  At
+  // K = 1024 a 128 x 128 tile holds 3.4 us of bf16 MFMA work against a cold first DMA and 16 K fp32 atomics: the update ran at
+  // 0.19 of the bf16 peak and 0.23 of HBM, i.e. on per-tile fixed cost; K = 2048 halves the C traffic and the tile count.
+  // Strip buffer (bf16, K-contiguous): element (r, c) = solved row (strip start + r), global column c, at SP[c * ldp + r].
+  const int64_t npan = cap_ceil_div(n, nb), sp = std::max<int64_t>(1, std::min<int64_t>(p->strip, 2)), ldp = 2 * nb;
+  const int64_t nstrip = cap_ceil_div(npan, sp);
+
+  // ---- column-split schedule (option "split", default): the second half of this factorization is bound by the panel stream
+  // (kernel trace, N = 65536: 208 of 247 ms busy - diagonal-block chains 95 ms, fp64 row solves 60 ms, conversions 23 ms, bf16
+  // heads 19 ms - while the big updates need 144 ms).  Only the NEXT diagonal block has to be up to date before its chain can
+  // start, so every block-row solve and every head update is split into the columns of the next panel ("near", panel stream)
+  // and everything to the right ("far", a third stream): the chain of panel k+1 runs next to the far solve / far update of
+  // panel k.  Sums per C element keep their order (head of panel a, head of the strip, rest; one launch each), so the factor
+  // does not depend on the option bit for bit.
+  if (p->split && sp == 2) {
+    if (!p->split_ready) {
+      int lo = 0, hi = 0;
+      CAP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      CAP_HIP(hipStreamCreateWithPriority(&p->s_far, hipStreamNonBlocking, hi));
+      for (hipEvent_t* e : {&p->ev_c, &p->ev_ns, &p->ev_hf, &p->ev_fs[0], &p->ev_fs[1], &p->ev_far[0], &p->ev_far[1], &p->ev_join2})
+        CAP_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+      CAP_HIP(hipMalloc((void**)&p->Tn, sizeof(double) * 2 * nb * nb));
+      p->split_ready = true;
+    }
+    hipStream_t s2 = p->s_far;
+    CAP_HIP(hipStreamWaitEvent(s2, p->ev_fork, 0));
+    double* Tn = p->Tn; double* Sn = p->Tn + nb * nb;
+    bool have_hf = false;
+    // block-row solve of panel k on the columns [c0, c1): X = Dinv_k^T R32[rows k, c0:c1] in fp64 -> fp32 (factor) + bf16 (strip buffer)
+    auto solve_cols = [&](int64_t k, int64_t c0, int64_t c1, double* T, double* S, __bf16* SP, int64_t roff, hipStream_t s) -> int {
+      const int64_t j0 = k * nb, jb = std::min(nb, n - j0), w = c1 - c0;
+      if (w <= 0) return CAP_OK;
+      float* Row32 = p->R32 + j0 + c0 * n;
+      hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, w), dim3(256), 0, s, Row32, n, T, jb, jb, w, 0);
+      CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, w, jb, 1.0, p->Inv + k * nb * nb, nb, T, jb, 0.0, S, jb, 0, s, 2 | 16));
+      hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(jb, w), dim3(256), 0, s, S, jb, Row32, n, SP + roff + c0 * ldp, ldp, jb, w, 0);
+      CAP_HIP(hipGetLastError());
+      return CAP_OK;
+    };
+    auto chain = [&](int64_t k) -> int {
+      const int64_t j0 = k * nb, jb = std::min(nb, n - j0);
+      float* D32 = p->R32 + j0 + j0 * n;
+      double* Dinv = p->Inv + k * nb * nb;
+      hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, jb), dim3(256), 0, s1, D32, n, p->D64, jb, jb, jb, 1);
+      CAP_HIP(hipMemsetAsync(Dinv, 0, sizeof(double) * nb * nb, s1));
+      CAP_TRY(cap_rec_cholinv_full(p->D64, jb, Dinv, nb, jb, p->W, p->wcap, p->info_dev, s1, j0));
+      hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(jb, jb), dim3(256), 0, s1, p->D64, jb, D32, n, (__bf16*)nullptr, (int64_t)0, jb, jb, 1);
+      CAP_HIP(hipGetLastError());
+      return CAP_OK;
+    };
+    for (int64_t t = 0; t < nstrip; t++) {
+      __bf16* SP = p->P16[t & 1];
+      const int64_t ka = 2 * t, kb = std::min(npan, ka + 2) - 1;           // first / last panel of the strip (kb == ka: one panel)
+      for (int64_t k = ka; k <= kb; k++) {
+        const int64_t j1 = std::min(n, (k + 1) * nb), j1n = std::min(n, j1 + nb), roff = (k - ka) * nb;
+        CAP_TRY(chain(k));
+        CAP_HIP(hipEventRecord(p->ev_c, s1));
+        CAP_HIP(hipStreamWaitEvent(s2, p->ev_c, 0));
+        // near solve: the rows of panel k have received every earlier update on the near columns once the last far update is in
+        if (have_hf) CAP_HIP(hipStreamWaitEvent(s1, p->ev_hf, 0));
+        CAP_TRY(solve_cols(k, j1, j1n, Tn, Sn, SP, roff, s1));
+        CAP_HIP(hipEventRecord(p->ev_ns, s1));
+        CAP_TRY(solve_cols(k, j1n, n, p->T64, p->S64, SP, roff, s2));
+        CAP_HIP(hipEventRecord(p->ev_fs[k & 1], s2));
+        if (k < kb) {
+          // head of panel a inside the strip: rows of panel b.  near = its diagonal block, far = the rectangle to the right
+          const int64_t rb = j1n - j1;
+          const __bf16* Pa = SP + roff;                                    // this panel's rows of the strip buffer, column c at c * ldp
+          CAP_TRY(launch_bf16_tn(rb, rb, nb, -1.0f, Pa + j1 * ldp, ldp, Pa + j1 * ldp, ldp, p->R32 + j1 + j1 * n, n, 1, s1));
+          CAP_HIP(hipStreamWaitEvent(s2, p->ev_ns, 0));
+          if (n > j1n) CAP_TRY(launch_bf16_tn(rb, n - j1n, nb, -1.0f, Pa + j1 * ldp, ldp, Pa + j1n * ldp, ldp, p->R32 + j1 + j1n * n, n, 0, s2));
+          CAP_HIP(hipEventRecord(p->ev_hf, s2)); have_hf = true;
+        }
+      }
+      const int64_t Js = std::min(n, (kb + 1) * nb), m = n - Js;
+      CAP_HIP(hipEventRecord(p->ev_panel[t & 1], s1));                      // near solves of the strip are in
+      CAP_HIP(hipEventRecord(p->ev_far[t & 1], s2));                        // ... and the far ones
+      if (m <= 0) break;
+      const int64_t K = Js - ka * nb;                                      // rows of the strip (2 nb: a ragged strip is the last one)
+      const __bf16* S = SP + Js * ldp;
+      const int64_t hb = std::min(2 * nb, m), ra = std::min(nb, m), rbn = hb - ra;    // rows of the next strip / its two panels
+      // head of the strip on the next strip's rows.  near: the diagonal block of its first panel (panel stream: the next chain
+      // waits for nothing else); far: the rest of those rows.  Both wait for rest(t-1), which touched the same rows.
+      if (t > 0) { CAP_HIP(hipStreamWaitEvent(s1, p->ev_rest[(t - 1) & 1], 0)); CAP_HIP(hipStreamWaitEvent(s2, p->ev_rest[(t - 1) & 1], 0)); }
+      if (kb > ka) CAP_HIP(hipStreamWaitEvent(s1, p->ev_fs[ka & 1], 0));    // the first panel's rows at these columns come from its FAR solve
+      CAP_TRY(launch_bf16_tn(ra, ra, K, -1.0f, S, ldp, S, ldp, p->R32 + Js + Js * n, n, 1, s1));
+      CAP_HIP(hipStreamWaitEvent(s2, p->ev_ns, 0));                         // the last panel's rows at the near columns (A operand of rows a')
+      if (m > ra) {
+        CAP_TRY(launch_bf16_tn(ra, m - ra, K, -1.0f, S, ldp, S + ra * ldp, ldp, p->R32 + Js + (Js + ra) * n, n, 0, s2));
+        if (rbn > 0) CAP_TRY(launch_bf16_tn(rbn, m - ra, K, -1.0f, S + ra * ldp, ldp, S + ra * ldp, ldp, p->R32 + (Js + ra) * (n + 1), n, 1, s2));
+      }
+      CAP_HIP(hipEventRecord(p->ev_hf, s2)); have_hf = true;
+      // rest: rows below the next strip, caller's stream
+      CAP_HIP(hipStreamWaitEvent(s0, p->ev_panel[t & 1], 0));
+      CAP_HIP(hipStreamWaitEvent(s0, p->ev_far[t & 1], 0));
+      if (m > hb) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (p->profile && p->prof_ev) {
+          if ((size_t)p->prof_used + 2 > p->prof_ev->size())
+            for (int i = 0; i < 64; i++) { hipEvent_t e; CAP_HIP(hipEventCreate(&e)); p->prof_ev->push_back(e); }
+          e0 = (*p->prof_ev)[p->prof_used]; e1 = (*p->prof_ev)[p->prof_used + 1];
+          CAP_HIP(hipEventRecord(e0, s0));
+        }
+        CAP_TRY(launch_bf16_tn(m - hb, m - hb, K, -1.0f, S + hb * ldp, ldp, S + hb * ldp, ldp, p->R32 + (Js + hb) * (n + 1), n, 1, s0));
+        if (e0) {
+          CAP_HIP(hipEventRecord(e1, s0));
+          p->prof_used += 2;
+          const double mm = (double)(m - hb), elems = 0.5 * mm * (mm + 1.0);
+          p->prof_flops->push_back(2.0 * (double)K * elems);
+          p->prof_bytes->push_back(8.0 * elems + 2.0 * (double)K * mm);
+        }
+      }
+      CAP_HIP(hipEventRecord(p->ev_rest[t & 1], s0));
+    }
+    CAP_HIP(hipEventRecord(p->ev_join2, s2));
+    CAP_HIP(hipStreamWaitEvent(s0, p->ev_join2, 0));
+    CAP_HIP(hipEventRecord(p->ev_join, s1));
+    CAP_HIP(hipStreamWaitEvent(s0, p->ev_join, 0));
+    hipLaunchKernelGGL(f32_to_f64_kernel, grid2(n, n), dim3(256), 0, s0, p->R32, n, p->R64, n, n, n, 1);
+    CAP_HIP(hipGetLastError());
+    p->have_r64 = true;
+    return CAP_OK;
+  }
+
+  // fp64 panel work of panel k on stream s: diagonal block (R_kk, inverse), block row solve; writes rows [roff, roff + jb) of SP
+  auto panel = [&](int64_t k, hipStream_t s, __bf16* SP, int64_t roff) -> int {
     const int64_t j0 = k * nb, jb = std::min(nb, n - j0), j1 = j0 + jb, m = n - j1;
     float* D32 = p->R32 + j0 + j0 * n;
     double* Dinv = p->Inv + k * nb * nb;                  // kept: the diagonal-block inverse of the blocked TRSM
@@ -301,26 +458,41 @@ int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* st
       float* Row32 = p->R32 + j0 + j1 * n;
       hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, m), dim3(256), 0, s, Row32, n, p->T64, jb, jb, m, 0);
       CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, m, jb, 1.0, Dinv, nb, p->T64, jb, 0.0, p->S64, jb, 0, s, 2 | 16));
-      hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(jb, m), dim3(256), 0, s, p->S64, jb, Row32, n, p->P16[k & 1], jb, jb, m, 0);
+      hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(jb, m), dim3(256), 0, s, p->S64, jb, Row32, n, SP + roff + j1 * ldp, ldp, jb, m, 0);
       CAP_HIP(hipGetLastError());
     }
     return CAP_OK;
   };
+  // factor strip t on stream s: its panels one after the other, each followed by the K = nb update of the strip's remaining rows
+  auto strip = [&](int64_t t, hipStream_t s) -> int {
+    __bf16* SP = p->P16[t & 1];
+    const int64_t k0 = t * sp, k1 = std::min(npan, k0 + sp), Jend = std::min(n, k1 * nb);
+    for (int64_t k = k0; k < k1; k++) {
+      CAP_TRY(panel(k, s, SP, (k - k0) * nb));
+      const int64_t j1 = std::min(n, (k + 1) * nb), rows_left = Jend - j1;
+      if (rows_left > 0) {         // rows of the strip below panel k, all columns to their right: K = nb, this panel's rows of SP
+        const __bf16* Pk = SP + (k - k0) * nb + j1 * ldp;
+        CAP_TRY(launch_bf16_tn(rows_left, n - j1, nb, -1.0f, Pk, ldp, Pk, ldp, p->R32 + j1 + j1 * n, n, 1, s));
+      }
+    }
+    return CAP_OK;
+  };
 
-  // update(k): R32[j1:, j1:] -= Pk^T Pk (upper), split into HEAD (the rows of panel k+1, panel stream) and REST (rows
-  // below, caller's stream).  panel(k+1) needs head(k) (same stream) and rest(k-1) (it touched those rows too; waiting for
-  // it before head(k) also keeps the order of the atomic adds - hence the bits - fixed) and frees P16[(k+1) & 1].
-  const int64_t npan = cap_ceil_div(n, nb);
-  CAP_TRY(panel(0, s1));
+  // update(t): R32[Js:, Js:] -= S^T S (upper) with S = the strip's solved rows (K = sp nb), split into HEAD (the rows of strip
+  // t+1, panel stream) and REST (rows below, caller's stream).  strip(t+1) needs head(t) (same stream) and rest(t-1) (it touched
+  // those rows too; waiting for it before head(t) also keeps the order of the atomic adds - hence the bits - fixed) and frees
+  // P16[(t+1) & 1].
+  CAP_TRY(strip(0, s1));
   CAP_HIP(hipEventRecord(p->ev_panel[0], s1));
-  for (int64_t k = 0; k < npan; k++) {
-    const int64_t j0 = k * nb, jb = std::min(nb, n - j0), j1 = j0 + jb, m = n - j1;
+  for (int64_t t = 0; t < nstrip; t++) {
+    const int64_t Js = std::min(n, (t + 1) * sp * nb), m = n - Js;
     if (m <= 0) break;
-    const __bf16* P = p->P16[k & 1];
-    const int64_t hb = std::min(nb, m);                   // rows of the next panel
-    if (k > 0) CAP_HIP(hipStreamWaitEvent(s1, p->ev_rest[(k - 1) & 1], 0));
-    CAP_TRY(launch_bf16_tn(hb, m, jb, -1.0f, P, jb, P, jb, p->R32 + j1 + j1 * n, n, 1, s1));
-    CAP_HIP(hipStreamWaitEvent(s0, p->ev_panel[k & 1], 0));
+    const int64_t K = Js - t * sp * nb;                   // rows of strip t (a multiple of nb: only the last strip can be ragged)
+    const __bf16* S = p->P16[t & 1] + Js * ldp;
+    const int64_t hb = std::min(sp * nb, m);              // rows of the next strip
+    if (t > 0) CAP_HIP(hipStreamWaitEvent(s1, p->ev_rest[(t - 1) & 1], 0));
+    CAP_TRY(launch_bf16_tn(hb, m, K, -1.0f, S, ldp, S, ldp, p->R32 + Js + Js * n, n, 1, s1));
+    CAP_HIP(hipStreamWaitEvent(s0, p->ev_panel[t & 1], 0));
     if (m > hb) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (p->profile && p->prof_ev) {
@@ -329,20 +501,20 @@ int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* st
         e0 = (*p->prof_ev)[p->prof_used]; e1 = (*p->prof_ev)[p->prof_used + 1];
         CAP_HIP(hipEventRecord(e0, s0));
       }
-      CAP_TRY(launch_bf16_tn(m - hb, m - hb, jb, -1.0f, P + hb * jb, jb, P + hb * jb, jb, p->R32 + (j1 + hb) * (n + 1), n, 1, s0));
+      CAP_TRY(launch_bf16_tn(m - hb, m - hb, K, -1.0f, S + hb * ldp, ldp, S + hb * ldp, ldp, p->R32 + (Js + hb) * (n + 1), n, 1, s0));
       if (e0) {
         CAP_HIP(hipEventRecord(e1, s0));
         p->prof_used += 2;
         // algorithmic work of one launch: 2 K flop and 8 B (fp32 read + write) per element of the upper triangle, plus the panel once
         const double mm = (double)(m - hb), elems = 0.5 * mm * (mm + 1.0);
-        p->prof_flops->push_back(2.0 * (double)jb * elems);
-        p->prof_bytes->push_back(8.0 * elems + 2.0 * (double)jb * mm);
+        p->prof_flops->push_back(2.0 * (double)K * elems);
+        p->prof_bytes->push_back(8.0 * elems + 2.0 * (double)K * mm);
       }
     }
-    CAP_HIP(hipEventRecord(p->ev_rest[k & 1], s0));
-    if (k + 1 < npan) {
-      CAP_TRY(panel(k + 1, s1));
-      CAP_HIP(hipEventRecord(p->ev_panel[(k + 1) & 1], s1));
+    CAP_HIP(hipEventRecord(p->ev_rest[t & 1], s0));
+    if (t + 1 < nstrip) {
+      CAP_TRY(strip(t + 1, s1));
+      CAP_HIP(hipEventRecord(p->ev_panel[(t + 1) & 1], s1));
     }
   }
   CAP_HIP(hipEventRecord(p->ev_join, s1));
@@ -364,6 +536,8 @@ int cap_mpchol_set_option(cap_mpchol_plan* p, const char* key, int64_t value) {
     }
     return CAP_OK;
   }
+  if (!strcmp(key, "split")) { p->split = value != 0; return CAP_OK; }     // column-split schedule (near / far columns), see cap_mpchol_factor
+  if (!strcmp(key, "strip")) { if (value < 1 || value > 2) return CAP_ERR_ARG; p->strip = value; return CAP_OK; }   // panels per bf16 update
   return CAP_ERR_ARG;
 }
 

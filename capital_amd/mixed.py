@@ -23,6 +23,10 @@ class plan:
     def factor(self, A):
         _lib.check(_lib.lib().cap_mpchol_factor(self._h, A.data_ptr(), A.ld(), cur_stream()), "mpchol::factor")
 
+    def set_option(self, key, value):
+        """"strip": panels per bf16 trailing update (1 | 2, default 2: K = 2048), "profile"."""
+        _lib.check(_lib.lib().cap_mpchol_set_option(self._h, key.encode(), int(value)), "mpchol::set_option")
+
     def last_info(self):
         v = C.c_int64(0)
         _lib.lib().cap_mpchol_info(self._h, cur_stream(), C.byref(v))

@@ -400,7 +400,7 @@ float* cap_mpchol_R32_ptr(cap_mpchol_plan* plan, int64_t* ld);          /* the f
 /* Live measurement of the bf16 trailing updates (the dominant kernel, bf16_tn_kernel) of the LAST factor call, enabled with
  * cap_mpchol_set_option(plan, "profile", 1): launches, summed duration (ms, HIP events on the launch stream), summed
  * algorithmic flops (2 K per updated element) and bytes (fp32 C read + write, bf16 panel once).  Same protocol as
- * cap_cholinv_profile.                                                                                                     */
+ * cap_cholinv_profile.  Other option: "strip" = panels (1024 rows each) contracted per bf16 update, 1 | 2 (default 2: K = 2048). */
 int cap_mpchol_set_option(cap_mpchol_plan* plan, const char* key, int64_t value);
 int cap_mpchol_profile(cap_mpchol_plan* plan, int64_t* launches, double* ms_total, double* flops_total, double* bytes_total);
 

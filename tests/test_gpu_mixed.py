@@ -47,6 +47,34 @@ def test_solve_reaches_fp64_accuracy(n, kind, nrhs):
     p.close()
 
 
+@pytest.mark.parametrize("n", [3072, 4096, 5248])
+def test_strips_of_two_panels_against_single_panels(n):
+    """"strip" = 2 (default): the bf16 update contracts two panels (K = 2048) at once.  Odd panel counts (3072: the last strip is one
+    panel), even ones, a ragged last panel (5248 = 5 x 1024 + 128): both forms give a usable factor and the same refined solution;
+    "split" = 1 (default) runs the same updates on three streams and must not change a bit."""
+    from capital_amd import mixed
+    from capital_amd.matrix import matrix
+    a = _spd(n, "gram", seed=n); b = np.random.default_rng(n).standard_normal((n, 4))
+    A = matrix(n, n, 1, 1).from_numpy(a); B = matrix(4, n, 1, 1).from_numpy(b)
+    xs, fs = [], []
+    for strip, split in ((1, 0), (2, 0), (2, 1)):
+        p = mixed.plan(n, 4); p.set_option("strip", strip); p.set_option("split", split)
+        p.factor(A)
+        assert p.last_info() == 0
+        fs.append(p.R32().cpu().numpy().astype(np.float64))
+        X, iters, rr = p.solve(A, B)
+        assert rr <= 1e-14 and iters <= 25, (strip, rr, iters)
+        xs.append(X.to_numpy())
+        p.close()
+    ref = np.linalg.cholesky(a).T
+    assert relerr(fs[0], ref) < 2e-2 and relerr(fs[1], ref) < 2e-2
+    assert relerr(fs[0], fs[1]) < 1e-2                                  # same algorithm, different bf16 accumulation grouping
+    assert relerr(xs[0], xs[1]) < 1e-12 * np.linalg.cond(a)
+    assert np.linalg.norm(a @ xs[1] - b) / np.linalg.norm(b) < 1e-14
+    # column-split schedule (near / far columns on two streams): every element still receives the same updates in the same order
+    assert np.array_equal(fs[1], fs[2]) and np.array_equal(xs[1], xs[2])
+
+
 def test_matches_the_fp64_path_and_reports_failures():
     from capital_amd import blas, cholinv, mixed
     from capital_amd.matrix import matrix
