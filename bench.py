@@ -594,15 +594,19 @@ def bench_mixed(args, torch, L, C, rank, world, timed):
     info = p.last_info()
     tf_only = timed(lambda: p.factor(A), 2, 0)
     tflops = n ** 3 / 3.0 / sec / 1e12
-    # check 1: ||A X - B||_F / ||B||_F recomputed with torch's fp64 matmul (rocBLAS), not this library's GEMM.  On the
-    # reference's diagonally dominant input (a_ii ~ N, kappa ~ 1) both residual GEMMs round to the same values element by
-    # element - every dot product is dominated by one O(N) term, the rest sums to far below its ulp - so the two norms agree to
-    # the last digit although the kernels differ; the perturbation below shows the check reacts to X.
+    # check 1: ||A X - B||_F / ||B||_F recomputed with torch's fp64 matmul (rocBLAS), not this library's kernels.  A plain K = N
+    # product sums N / 4 MFMA accumulations in a chain: its own rounding error is ~5e-15 of ||B|| at N = 65536 (rocBLAS and this
+    # library's tile kernel share the MT128x128x16 / MI16x16x4 summation order - their results agreed bit for bit in round 2), so
+    # the same norm is also taken from 1024-column partial products summed by torch's cascade summation (independent_residual_
+    # chunked): that one can see the accuracy the refinement reaches with its compensated residual kernel (gemm.hip, skinny TN).
     r = A.view() @ X.view() - B.view()
-    indep = float(r.norm() / B.view().norm())
-    Xp = X.view().clone(); Xp[0, 0] *= (1.0 + 1e-10)
-    indep_perturbed = float((A.view() @ Xp - B.view()).norm() / B.view().norm())
-    del r, Xp
+    bn = float(B.view().norm())
+    indep = float(r.norm() / bn)
+    parts = torch.stack([A.view()[:, c0:c0 + 1024] @ X.view()[c0:c0 + 1024] for c0 in range(0, n, 1024)])
+    indep_chunked = float((parts.sum(0) - B.view()).norm() / bn)
+    Xp = X.view().clone(); Xp[0, 0] *= (1.0 + 1e-8)
+    indep_perturbed = float((A.view() @ Xp - B.view()).norm() / bn)
+    del r, Xp, parts
     # check 2: the same system through the fp64 path of this library (blocked Cholesky + two blocked TRSMs): a different algorithm
     x_diff = None
     if not args.no_check:
@@ -616,7 +620,8 @@ def bench_mixed(args, torch, L, C, rank, world, timed):
         x_diff = float((X.view() - Xf.view()).norm() / Xf.view().norm())
         del pack, R, Xf
         torch.cuda.empty_cache()
-    ok = int(info) == 0 and relres == relres and relres <= 1e-14 and indep <= 1e-13 and indep_perturbed > 10 * indep and (x_diff is None or x_diff <= 1e-12)
+    ok = (int(info) == 0 and relres == relres and relres <= 1e-14 and indep <= 1e-13 and indep_chunked <= 1e-14 and indep_perturbed > 10 * indep
+          and (x_diff is None or x_diff <= 1e-12))
     # roofline of the dominant kernel (bf16 trailing update), measured live with HIP events on its launch stream
     nl, ms, fl, by = p.profile_update(A)
     roof = {"bound": "hbm", "kernel": "bf16_tn_kernel (trailing update C32 -= S16^T S16: fp32 C read-modify-write, K/4 flop per byte)",
@@ -638,8 +643,10 @@ def bench_mixed(args, torch, L, C, rank, world, timed):
            "config": {"workload": "N=%d mixed-precision Cholesky solve, %d right-hand sides, upstream distribute_symmetric input resident in HBM" % (n, nrhs),
                       "parallelism": "1 GPU", "info": int(info), "refinement_sweeps": int(sweeps), "residual": relres,
                       "residual_kind": "||B - A X||_F/||B||_F (fp64, library kernels)", "independent_residual": indep,
-                      "independent_residual_kind": "same norm with torch fp64 matmul (rocBLAS); after scaling X[0,0] by 1+1e-10 it reads "
-                                                   "independent_residual_perturbed", "independent_residual_perturbed": indep_perturbed,
+                      "independent_residual_kind": "same norm with torch fp64 matmul (rocBLAS, one K = N product: its summation chain rounds at "
+                                                   "~5e-15); _chunked: 1024-column partial products + cascade sum; after scaling X[0,0] by "
+                                                   "1+1e-8 the plain norm reads independent_residual_perturbed",
+                      "independent_residual_chunked": indep_chunked, "independent_residual_perturbed": indep_perturbed,
                       "x_vs_fp64_path": x_diff, "factor_ms": tf_only * 1e3, "factor_fp64_equiv_tflops": n ** 3 / 3.0 / tf_only / 1e12},
            "roofline": roof}
     if not ok:

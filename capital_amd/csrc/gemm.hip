@@ -766,6 +766,137 @@ int launch_small(int transa, int transb, int64_t m, int64_t n, int64_t k, double
 }
 
 // C = beta*C (alpha == 0 or k == 0), honouring the triangle mask
+// ---------------------------------------------------------------------------------------------
+// Skinny products: C[M x N] = alpha op(A) B + beta C with N <= 8 right-hand sides (the refinement sweeps of the mixed-precision
+// solve, TRSM / TRMM with a few columns).  The 128 x 128 tile kernels would pad N to 128 and run 16 x the flops: a block step
+// of the triangular solve became MFMA- and latency-bound although the operation streams op(A) exactly once.  Both kernels read
+// A once, coalesced, with eight independent loads in flight per lane, and are bound by HBM.
+//   TN (A: K x M, K-contiguous): one wave per 16 output rows on v_mfma_f64_16x16x4_f64 - the MFMA is the 64-lane reduction: lane
+//      (lr, kg) feeds column lr of A and right-hand side lr at k = k0 + 2 kg, + 1 (the k permutation of the tile kernels);
+//   NN (A: M x K, M-contiguous): one lane per output row, 8 accumulators, B[k, :] is wave-uniform; the four waves of a workgroup
+//      split K and meet in LDS.
+// ---------------------------------------------------------------------------------------------
+struct SkinnyArgs { const double* A; const double* B; double* C; int64_t lda, ldb, ldc; int64_t M, K; int N; double alpha, beta; };
+
+__global__ void __launch_bounds__(256) dgemm_tn_skinny_kernel(const SkinnyArgs g) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lr = lane & 15, kg = lane >> 4;
+  const int64_t j0 = ((int64_t)blockIdx.x * 4 + wid) * 16;
+  if (j0 >= g.M) return;
+  const double* __restrict__ pa = g.A + (j0 + lr) * g.lda + 2 * kg;
+  const double* __restrict__ pb = g.B + (int64_t)(lr < g.N ? lr : 0) * g.ldb + 2 * kg;
+  const bool bon = lr < g.N;
+  // Blocked, compensated summation: every 64 k start from zero accumulators (chains of 8 MFMAs) and are added to the running
+  // sum with Kahan's correction.  A plain chain of K / 4 MFMA accumulations carries a rounding error of ~sqrt(K / 4) ulp of the
+  // partial sums - 5e-15 of ||b|| in the residual b - A x at K = 65536 (measured; the tile kernels and rocBLAS share that
+  // chain) - and the refinement converges to the fixed point of its residual kernel: this kernel IS the attainable accuracy.
+  d4 sum = {0.0, 0.0, 0.0, 0.0}, comp = {0.0, 0.0, 0.0, 0.0};
+  auto kahan = [&](const d4& t) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const double y = t[r] - comp[r];
+      const double s2 = sum[r] + y;
+      comp[r] = (s2 - sum[r]) - y;
+      sum[r] = s2;
+    }
+  };
+  int64_t k0 = 0;
+  for (; k0 + 64 <= g.K; k0 += 64) {          // 8 x (8 k): sixteen 16-byte loads in flight per lane
+    d2 a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) a[u] = *reinterpret_cast<const d2*>(pa + k0 + 8 * u);
+#pragma unroll
+    for (int u = 0; u < 8; u++) b[u] = bon ? *reinterpret_cast<const d2*>(pb + k0 + 8 * u) : (d2){0.0, 0.0};
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, b[u].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].y, b[u].y, acc1, 0, 0, 0);
+    }
+    kahan(acc0 + acc1);
+  }
+  if (k0 < g.K) {
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (; k0 < g.K; k0 += 8) {
+      const d2 a = *reinterpret_cast<const d2*>(pa + k0);
+      const d2 b = bon ? *reinterpret_cast<const d2*>(pb + k0) : (d2){0.0, 0.0};
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, acc1, 0, 0, 0);
+    }
+    kahan(acc0 + acc1);
+  }
+  if (!bon) return;                           // D layout: row = kg + 4 r (output row), column = lr (right-hand side)
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    double* pc = g.C + j0 + kg + 4 * r + (int64_t)lr * g.ldc;
+    double v = g.alpha * sum[r];
+    if (g.beta != 0.0) v += g.beta * (*pc);
+    *pc = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) dgemm_nn_skinny_kernel(const SkinnyArgs g) {
+  __shared__ double part[4][8][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t kq = ((g.K + 31) / 32) * 8;                       // K quarter, multiple of 8
+  const int64_t kb = wid * kq, ke = (kb + kq < g.K) ? kb + kq : g.K;
+  const double* __restrict__ pa = g.A + row;
+  const double* __restrict__ pb = g.B;
+  double acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) acc[c] = 0.0;
+  int64_t k = kb;
+  for (; k + 8 <= ke; k += 8) {
+    double a[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) a[u] = pa[(k + u) * g.lda];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      if (c < g.N) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc[c] += a[u] * pb[k + u + (int64_t)c * g.ldb];        // wave-uniform operand
+      }
+    }
+  }
+  for (; k < ke; k++) {
+    const double a = pa[k * g.lda];
+#pragma unroll
+    for (int c = 0; c < 8; c++) if (c < g.N) acc[c] += a * pb[k + (int64_t)c * g.ldb];
+  }
+#pragma unroll
+  for (int c = 0; c < 8; c++) part[wid][c][lane] = acc[c];
+  __syncthreads();
+  // thread t: row t & 63, right-hand sides 2 (t >> 6), + 1
+  const int rr = threadIdx.x & 63, c0 = (threadIdx.x >> 6) * 2;
+#pragma unroll
+  for (int c = c0; c < c0 + 2; c++) {
+    if (c < g.N) {
+      double* pc = g.C + (int64_t)blockIdx.x * 64 + rr + (int64_t)c * g.ldc;
+      double v = g.alpha * (part[0][c][rr] + part[1][c][rr] + part[2][c][rr] + part[3][c][rr]);
+      if (g.beta != 0.0) v += g.beta * (*pc);
+      *pc = v;
+    }
+  }
+}
+
+// returns CAP_ERR_UNSUPPORTED when the shape does not qualify (the caller then takes the tile kernels)
+int launch_skinny(int transa, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda, const double* B, int64_t ldb,
+                  double beta, double* C, int64_t ldc, hipStream_t stream) {
+  static const int on = getenv("CAP_SKINNY") ? atoi(getenv("CAP_SKINNY")) : 1;
+  if (!on || n < 1 || n > 8 || m < 64 || k < 8 || (k % 8)) return CAP_ERR_UNSUPPORTED;
+  SkinnyArgs g{A, B, C, lda, ldb, ldc, m, k, (int)n, alpha, beta};
+  if (transa == CAP_TRANS) {
+    if ((m % 16) || (lda & 1) || (ldb & 1) || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15)) return CAP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dgemm_tn_skinny_kernel, dim3((unsigned)cap_ceil_div(m, 64)), dim3(256), 0, stream, g);
+  } else {
+    if (m % 64) return CAP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dgemm_nn_skinny_kernel, dim3((unsigned)(m / 64)), dim3(256), 0, stream, g);
+  }
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
 __global__ void scale_kernel(double* C, int64_t ldc, int64_t m, int64_t n, double beta, int tri) {
   int64_t col = blockIdx.y;
   for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < m; row += (int64_t)gridDim.x * blockDim.x) {
@@ -833,6 +964,11 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   if (transa == CAP_TRANS ? lda < k : lda < m) return CAP_ERR_ARG;
   if (transb == CAP_TRANS ? ldb < n : ldb < k) return CAP_ERR_ARG;
 
+  // a few right-hand sides against a big operand: streaming kernels (no padding of N to a 128-wide tile)
+  if (n <= 8 && tri == 0 && transb != CAP_TRANS && !Cin && m >= 1024) {
+    const int st = launch_skinny(transa, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, stream);
+    if (st != CAP_ERR_UNSUPPORTED) return st;
+  }
   // latency-bound little products (diagonal-block recursion): 64 x 64 tiles, no setup cost
   if (m <= 512 && n <= 512 && k <= 1024 && m * n <= 256 * 256 && !Cin)
     return launch_small(transa, transb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, (tag & 2) ? 1 : 0, stream);

@@ -575,7 +575,9 @@ int cap_mpchol_solve(cap_mpchol_plan* p, const double* A, int64_t lda, const dou
                      int max_iter, double tol, int* iters, double* relres, void* stream) {
   if (!p || !A || !B || !X || lda < p->n || ldb < p->n || ldx < p->n || nrhs <= 0 || nrhs > p->nrhs_cap || !p->have_r64) return CAP_ERR_ARG;
   hipStream_t s = cap_stream(stream);
-  const int64_t n = p->n, w = cap_round_up(nrhs, 128);
+  // working width: up to 8 right-hand sides run on the skinny streaming kernels (gemm.hip: op(A) is read once, no padding to a
+  // 128-wide tile - the residual and every block step of the two substitutions are then bound by HBM, not by 16 x padded flops)
+  const int64_t n = p->n, w = nrhs <= 8 ? 8 : cap_round_up(nrhs, 128);
   auto apply_Ainv = [&](double* V) -> int {      // V <- R^-1 R^-T V  (n x w)
     CAP_TRY(cap_trsm_apply(CAP_LEFT, CAP_TRANS, n, w, p->R64, n, p->Inv, p->tb, V, n, p->Xt, s));
     return cap_trsm_apply(CAP_LEFT, CAP_NOTRANS, n, w, p->R64, n, p->Inv, p->tb, V, n, p->Xt, s);

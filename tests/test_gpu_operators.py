@@ -16,7 +16,9 @@ def _mods():
 
 @pytest.mark.parametrize("ta,tb", [(1, 0), (0, 0), (1, 1), (0, 1)])
 @pytest.mark.parametrize("m,n,k,pad", [(128, 128, 16, 0), (256, 384, 64, 0), (100, 37, 23, 3), (129, 257, 130, 1),
-                                       (1, 1, 1, 0), (64, 200, 7, 0), (384, 128, 512, 0)])
+                                       (1, 1, 1, 0), (64, 200, 7, 0), (384, 128, 512, 0),
+                                       # a few right-hand sides against a big operand: the skinny streaming kernels (ta = 1: MFMA reduction, ta = 0: K split in LDS)
+                                       (2048, 8, 1024, 0), (1088, 3, 4104, 2), (4160, 5, 1000, 0), (1024, 1, 64, 0)])
 def test_gemm_matches_oracle(ta, tb, m, n, k, pad):
     blas, _ = _mods()
     rng = np.random.default_rng(m * 1000 + n * 10 + k + ta * 2 + tb)
