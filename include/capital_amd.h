@@ -51,7 +51,9 @@ int cap_device_info(char* name, int len, int* cus, int64_t* hbm_bytes);
  * ---------------------------------------------------------------------------------- */
 
 /* blas::engine::_gemm  - blas/interface.h:58-60, interface.hpp:43-59 (cblas_dgemm).
- * C[m x n] = alpha * op(A)[m x k] * op(B)[k x n] + beta * C.                          */
+ * C[m x n] = alpha * op(A)[m x k] * op(B)[k x n] + beta * C.
+ * n <= 8 with op(B) = B and m >= 1024 (a few right-hand sides against a big operand: refinement residuals, TRSM block steps)
+ * runs on streaming kernels that read op(A) once; their transposed form sums in 64-k blocks with Kahan's correction.      */
 int cap_dgemm(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha,
               const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
               double* C, int64_t ldc, void* stream);
@@ -261,7 +263,9 @@ int cap_cholinv_info(cap_cholinv_plan* plan, void* stream, int64_t* info);
  * K-contiguously into a ring of three buffers every update reads from, R receives a copy off the panel stream; on),
  * complete_inv >= 0: "inv_fast" (blocked sweep + inverse tree instead of the plain recursion of cholinv.hpp:85-165; on),
  * "inv_overlap" (tree nodes are enqueued as their inputs become final; on), "inv_start_m" (columns left below which the
- * tree starts).  Multi-GPU plans forward to cap_dist_set_option.                                                       */
+ * tree starts), "fuse_copy" (only the first strip's rows of A are copied into R, the updates of step 0 read their C input
+ * from A; on, bit-identical), "reserve_m" (with "reserve": the CU masks only apply once at most reserve_m columns are left;
+ * measured slower, off).  Multi-GPU plans forward to cap_dist_set_option.                                                */
 int cap_cholinv_set_option(cap_cholinv_plan* plan, const char* key, int64_t value);
 int64_t cap_cholinv_get_option(cap_cholinv_plan* plan, const char* key);
 /* Live measurement of the dominant kernel (trailing-update DSYRK) of the LAST factor call, enabled
@@ -400,7 +404,9 @@ float* cap_mpchol_R32_ptr(cap_mpchol_plan* plan, int64_t* ld);          /* the f
 /* Live measurement of the bf16 trailing updates (the dominant kernel, bf16_tn_kernel) of the LAST factor call, enabled with
  * cap_mpchol_set_option(plan, "profile", 1): launches, summed duration (ms, HIP events on the launch stream), summed
  * algorithmic flops (2 K per updated element) and bytes (fp32 C read + write, bf16 panel once).  Same protocol as
- * cap_cholinv_profile.  Other option: "strip" = panels (1024 rows each) contracted per bf16 update, 1 | 2 (default 2: K = 2048). */
+ * cap_cholinv_profile.  Other options: "strip" = panels (1024 rows each) contracted per bf16 update, 1 | 2 (default 2: K = 2048);
+ * "split" = column-split schedule (near columns of every block-row solve / head update on the panel stream, the far ones on a
+ * third stream; default 1, bit-identical to 0).                                                                           */
 int cap_mpchol_set_option(cap_mpchol_plan* plan, const char* key, int64_t value);
 int cap_mpchol_profile(cap_mpchol_plan* plan, int64_t* launches, double* ms_total, double* flops_total, double* bytes_total);
 

@@ -13,7 +13,7 @@ f, nf = avg("FETCH_SIZE"); w, nw = avg("WRITE_SIZE")
 out = {"command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-include-regex 'dgemm_tn_dma_kernel<1' -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-check (tools/prof_round.sh, separate passes)",
        "config": {"n": 65536, "complete_inv": -1}, "kernel": "dgemm_tn_dma_kernel<1, false, 0, true, false>", "dispatches": nf,
        "FETCH_SIZE_KB_per_launch_reported": f, "WRITE_SIZE_KB_per_launch": w,
-       "fetch_correction": "x2 (gfx950 rocprofv3 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE is used as reported (it matches the algorithmic C-tile bytes 1:1)",
+       "fetch_correction": "x2 (gfx950 rocprofv3 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section; calibrated on this kernel's own LDS-DMA pattern with tools/exp_fetchcal.sh: a product whose B operand can only be fetched once reads 0.571 GB reported for 1.074 GB true, TCC_EA0_RDREQ x 128 B = 1.141 GB); WRITE_SIZE is used as reported (it matches the algorithmic C-tile bytes 1:1)",
        "traffic_bytes_per_launch": (2 * f + w) * 1024.0, "algorithmic_bytes_per_launch": 5.42e9,
        "kernel_src_sha16": hashlib.sha256(b"".join(open(os.path.join(ROOT, "capital_amd", "csrc", f), "rb").read()
                                                     for f in ("gemm.hip", "tile_dma.h"))).hexdigest()[:16]}
