@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the kernel variant this script switches on (CAP_KPHASE / CAP_KSTAG in tn_dma_tile, gemm.hip) was measured from a working-tree patch and
+# removed again because it made things worse (profiles/r03_experiments.log section 8 describes it); the script is kept for the record.
 # k-phase alignment of the bulk update (CAP_KPHASE): timing stand-alone and in the factorization, L2-miss traffic (FETCH_SIZE)
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the kernel variant this script switches on (CAP_KPHASE / CAP_KSTAG in tn_dma_tile, gemm.hip) was measured from a working-tree patch and
+# removed again because it made things worse (profiles/r03_experiments.log section 8 describes it); the script is kept for the record.
 # k stagger of the tiles sharing a panel slice (CAP_KSTAG = K tiles per step): time and fabric read requests (x 128 B)
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the strip-buffer padding (CAP_SB_PAD) part needs a removed working-tree patch; the LDPAD / gemm_bench part runs as is.
 # leading dimension of the K-contiguous panel operands (row stride 8 KiB at ld = 1024: every row of a K tile in the same L2 channel?)
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
