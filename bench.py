@@ -372,18 +372,32 @@ def bench_cholesky(args, torch, L, C, rank, world, dist, emulate, timed, allredu
         del A, pack
         torch.cuda.empty_cache()
         extra = []
-        for (nn, ci, label) in ((32768, -1, "BASELINE configs[1]: N=32768 blocked Cholesky"),
-                                (32768, 0, "reference semantics (cholinv.hpp:85-165): R and R^-1, complete_inv=0, N=32768"),
-                                (32768, 1, "reference semantics: R and the full R^-1, complete_inv=1, N=32768")):
-            A2, p2, s2 = single_gpu_case(nn, ci, 3, 1, opts=False)
+        for (nn, ci, steps2, label) in (
+                (32768, -1, 3, "BASELINE configs[1]: N=32768 blocked Cholesky"),
+                (32768, 0, 3, "reference semantics (cholinv.hpp:85-165): R and R^-1, complete_inv=0, N=32768"),
+                (32768, 1, 3, "reference semantics: R and the full R^-1, complete_inv=1, N=32768"),
+                (65536, 0, 2, "reference semantics at the headline size (what bench/cholesky/cholinv.cpp:39-53 runs): R and R^-1, "
+                              "complete_inv=0, N=65536")):
+            A2, p2, s2 = single_gpu_case(nn, ci, steps2, 1, opts=False)
             i2 = p2.last_info()
             r2 = validate.cholesky.residual(A2, p2) if not args.no_check else None
             tf = nn ** 3 / 3.0 / s2 / 1e12
             e = {"workload": label, "n": nn, "complete_inv": ci, "value": tf, "unit": "TFLOP/s (N^3/3)", "ms_per_step": s2 * 1e3,
-                 "pct_of_fp64_mfma_peak": 100.0 * tf / FP64_MFMA_PEAK_TF, "info": int(i2), "residual": r2}
+                 "steps": steps2, "pct_of_fp64_mfma_peak": 100.0 * tf / FP64_MFMA_PEAK_TF, "info": int(i2), "residual": r2}
             if ci >= 0:   # true flops: N^3/3 (factor) + 2 (N/2)^3/3 (the two diagonal blocks of R^-1, split = 1) or + N^3/3 (all of R^-1)
                 true_tf = (nn ** 3 / 3.0 + (nn ** 3 / 12.0 if ci == 0 else nn ** 3 / 3.0)) / s2 / 1e12
                 e["true_flops_tflops"] = true_tf; e["true_flops_frac_of_peak"] = true_tf / FP64_MFMA_PEAK_TF
+                if not args.no_check:
+                    # the OTHER half of the reference's output: R^-1 checked where it is timed (torch fp64 matmul, per filled block) +
+                    # the structure of the root block (exactly empty for complete_inv = 0, cholinv.hpp:147; filled for 1)
+                    torch.cuda.empty_cache()
+                    R2 = cholinv.construct_R(p2); Ri2 = cholinv.construct_Rinv(p2)
+                    pr, nz = validate.cholesky.rinv_probe(R2.view(), Ri2.view(), ci, 1)
+                    del R2, Ri2
+                    e["rinv_probe"] = pr; e["rinv_root_block_nonzeros"] = nz
+                    e["rinv_probe_kind"] = ("max over the filled diagonal blocks of ||R (R^-1 X) - X||_F/||X||_F, 8 vectors, torch fp64 matmul; "
+                                            "root block Rinv[0:n/2, n/2:n] must be exactly zero for complete_inv=0, non-zero for 1")
+                    ok = ok and validate.cholesky.rinv_ok(pr, nz, ci, nn, 1)
             extra.append(e)
             ok = ok and int(i2) == 0 and (r2 is None or r2 <= RES_TOL)
             del A2, p2

@@ -305,9 +305,17 @@ int plan_alloc(cap_cholinv_plan* p) {
     p->ldi = cap_round_up(n, 2);
     CAP_HIP(hipMalloc((void**)&p->Rinv, sizeof(double) * p->ldi * n));
     CAP_HIP(hipMemset(p->Rinv, 0, sizeof(double) * p->ldi * n));
-    // plain recursion: (n/2 + 1)^2; blocked factorization + inverse tree: chain scratch + panel scratch + tree scratch
-    // (checked again - and grown if an option changed the panel width - by factor_with_inverse at factor time)
-    p->work_elems = std::max(rec_work_size(n), rec_work_size(1024) + cap_round_up(1024 * n, 2) + (n / 2 + 1024) * (n / 2 + 1024) * 3 / 2);
+    // blocked factorization + inverse tree (the path cap_cholinv_factor takes for n >= 2 nb): chain scratch + panel scratch + the
+    // tree's scratch for THIS plan's panels and root partition; otherwise the plain recursion's (n/2 + 1)^2.  Both paths check
+    // the size again at factor time and grow the buffer if an option (nb, inv_fast, leaf) moved the plan to the other one.
+    if (p->inv_fast && n >= 2 * p->nb && p->leaf == CAP_LEAF_MAX) {
+      const int64_t n1 = n >> p->split;
+      const bool on_panel = n1 > 0 && n1 < n && n1 % p->nb == 0;
+      const InvTree t = inv_tree_build(panel_bounds(n, p->nb), on_panel ? (int)(n1 / p->nb) : -1, on_panel && p->complete_inv == 0);
+      p->work_elems = rec_work_size(p->nb) + cap_round_up(p->nb * n, 2) + t.scratch;
+    } else {
+      p->work_elems = rec_work_size(n);
+    }
   } else {
     p->ldi = p->nb;
     CAP_HIP(hipMalloc((void**)&p->Rinv, sizeof(double) * p->nb * p->nb));
@@ -845,7 +853,7 @@ int factor_with_inverse(cap_cholinv_plan* p, bool root_is_base, hipStream_t s) {
   if (base + p->itree->scratch > p->work_elems) {
     CAP_HIP(hipDeviceSynchronize());
     (void)hipFree(p->work); p->work = nullptr;
-    p->work_elems = std::max(rec_work_size(n), base + p->itree->scratch);
+    p->work_elems = base + p->itree->scratch;
     CAP_HIP(hipMalloc((void**)&p->work, sizeof(double) * p->work_elems));
   }
   p->inv_W = p->work + base;
@@ -1073,6 +1081,12 @@ int cap_cholinv_factor(cap_cholinv_plan* p, const double* A, int64_t lda, void* 
   const bool root_is_base = (n <= bc_dim) || ((n >> p->split) < p->split);
   if (p->inv_fast && n >= 2 * p->nb && p->leaf == CAP_LEAF_MAX) return factor_with_inverse(p, root_is_base, s);
   p->srcA = nullptr;
+  if (p->work_elems < rec_work_size(n)) {       // the plan was sized for the blocked path (plan_alloc) and an option left it
+    CAP_HIP(hipDeviceSynchronize());
+    (void)hipFree(p->work); p->work = nullptr;
+    p->work_elems = rec_work_size(n);
+    CAP_HIP(hipMalloc((void**)&p->work, sizeof(double) * p->work_elems));
+  }
   CAP_TRY(cap_copy_window(A, 0, lda, 0, 0, p->R, 0, p->ldr, 0, 0, n, n, 1, 0, stream));
   RecCtx c{p->R, p->ldr, p->Rinv, p->ldi, p->work, p->work_elems, p->info_dev, p->leaf, p->split, p->complete_inv, s};
   return rec_cholinv(c, 0, n, !root_is_base, 0);

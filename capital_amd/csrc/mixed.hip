@@ -167,16 +167,20 @@ __global__ void __launch_bounds__(256, 2) bf16_tn_kernel(const BfArgs g) {
   }
 
   // epilogue: lane holds C[i0 + wi + 32 i + r32][j0 + wj + 32 j + (e & 3) + 8 (e >> 2) + 4 kg]: 32 consecutive rows per half wave
+  // the diagonal mask compares WITHIN-tile offsets: under the staircase view a diagonal tile (ti == gtj) sits at a local column
+  // tile tj != ti, so absolute offsets would drop the whole tile (the fp64 twin tn_dma_tile in gemm.hip does the same)
   const bool diag = g.stair ? (ti == gtj) : (g.tri && ti == tj);
 #pragma unroll
   for (int i = 0; i < 2; i++) {
-    const int64_t row = i0 + wi + 32 * i + r32;
+    const int lrow = wi + 32 * i + r32;
+    const int64_t row = i0 + lrow;
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int e = 0; e < 16; e++) {
-        const int64_t col = j0 + wj + 32 * j + (e & 3) + 8 * (e >> 2) + 4 * kg;
-        if (!diag || row <= col)
+        const int lcol = wj + 32 * j + (e & 3) + 8 * (e >> 2) + 4 * kg;
+        const int64_t col = j0 + lcol;
+        if (!diag || lrow <= lcol)
           __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)(g.C + row + col * g.ldc), g.alpha * acc[i][j][e]);
       }
   }

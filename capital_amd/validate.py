@@ -49,6 +49,44 @@ class cholesky:
         return math.sqrt(e) / math.sqrt(c)
 
 
+    @staticmethod
+    def rinv_probe(R, Rinv, complete_inv, split=1, nvec=8, seed=11):
+        """Independent check of the explicit inverse (cholinv.hpp:144-159) - torch fp64 matmul, none of this library's kernels.
+
+        R, Rinv: [n, n] device views (upper triangular, zero below the diagonal).  Returns (probe, root_nonzeros):
+          probe = max over the FILLED diagonal blocks B of ||R_BB (Rinv_BB X) - X||_F / ||X||_F for nvec pseudo-random vectors:
+                  complete_inv = 1 -> the whole matrix; complete_inv = 0 -> the two blocks [0, n1) and [n1, n), n1 = n >> split
+                  (the inverse of a block-triangular matrix has the blocks' inverses on its diagonal, so each block is checked
+                  against R's own diagonal block);
+          root_nonzeros = count of non-zero entries of Rinv[0:n1, n1:n]: must be exactly 0 for complete_inv = 0 (the block
+                  upstream leaves empty, cholinv.hpp:147) and > 0 for complete_inv = 1."""
+        n = R.shape[0]
+        n1 = n >> split
+        blocks = ((0, n),) if (complete_inv == 1 or n1 <= 0 or n1 >= n) else ((0, n1), (n1, n))
+        g = torch.Generator(device="cpu"); g.manual_seed(seed)
+        X = (torch.rand(n, nvec, dtype=torch.float64, generator=g) - 0.5).to(R.device)
+        worst = 0.0
+        for lo, hi in blocks:
+            Xb = X[lo:hi]
+            Z = R[lo:hi, lo:hi] @ (Rinv[lo:hi, lo:hi] @ Xb)
+            worst = max(worst, float((Z - Xb).norm() / Xb.norm()))
+        root_nz = 0
+        if 0 < n1 < n:
+            for c0 in range(n1, n, 4096):                  # column chunks: the comparison's bool temporary stays small
+                root_nz += int(torch.count_nonzero(Rinv[0:n1, c0:min(n, c0 + 4096)]))
+        return worst, root_nz
+
+    @staticmethod
+    def rinv_ok(probe, root_nz, complete_inv, n, split=1, tol=1e-13):
+        """the gate bench.py and the tests apply to rinv_probe's result"""
+        n1 = n >> split
+        if not (probe == probe and probe <= tol):
+            return False
+        if 0 < n1 < n:
+            return root_nz == 0 if complete_inv == 0 else root_nz > 0
+        return True
+
+
 class qr:
     @staticmethod
     def _sumsq(t, ld, m, n, sub_identity=False):

@@ -155,6 +155,15 @@ def test_inverse_tree_overlap_modes_are_bitwise_identical():
         assert np.array_equal(r, outs[0][0]) and np.array_equal(ri, outs[0][1])
 
 
+_KNOB_R = {}
+
+
+def _knob_oracle_R(n):
+    if n not in _KNOB_R:
+        _KNOB_R[n] = orc.cholinv(orc.symmetric_global(n, True), 1, 1, -2, 1, 1)[0]
+    return _KNOB_R[n]
+
+
 @pytest.mark.parametrize("opts", [{"lookahead": 0}, {"lookahead": 1, "nb": 128}, {"nb": 256}, {"nb": 512, "leaf": 32}, {"leaf": 16},
                                   {"nb": 128, "outer": 512, "tail": 256}, {"nb": 128, "outer": 256, "depth2": 1},
                                   {"nb": 128, "outer": 256, "tail": 512, "depth2": 1}, {"nb": 256, "reserve": 8}, {"nb": 512, "fastdiag": 1}, {"nb": 256, "fastdiag": 1, "lookahead": 0},
@@ -174,13 +183,14 @@ def test_inverse_tree_overlap_modes_are_bitwise_identical():
                                   # CU masks for the chain-bound tail only
                                   {"nb": 128, "outer": 256, "reserve": 8, "reserve_m": 768}])
 def test_schedule_knobs_do_not_change_the_answer(opts):
+    """every schedule knob against the ORACLE's factor (the restated recursion of cholinv.hpp:85-165, computed once)"""
     from capital_amd import cholinv
     n = 1536
     a = orc.symmetric_global(n, True)
     _, pack = _factor(n, -1, 1, -2, opts=opts)
     R = cholinv.construct_R(pack).to_numpy()
     assert orc.cholesky_residual(a, R) < RES_TOL
-    assert relerr(R, np.linalg.cholesky(a).T) < 1e-13
+    assert relerr(R, _knob_oracle_R(n)) < 1e-13
 
 
 def test_fused_first_step_copy_is_bitwise_identical():
@@ -331,3 +341,55 @@ def test_large_result_against_independent_arithmetic(n, ci):
         X = torch.rand(n, 8, dtype=torch.float64, generator=g).cuda()
         Y = R.view() @ (Ri.view() @ X)
         assert float((Y - X).norm() / X.norm()) < 1e-13
+
+
+@pytest.mark.parametrize("n,ci,opts", [(32768, 0, {}), (32768, 1, {}),
+                                       # the overlapped tree with >= 32 panels: never started early / started with the first panel
+                                       (16384, 1, {"inv_start_m": 0}), (16384, 1, {"inv_start_m": 1 << 30}),
+                                       (16384, 0, {"inv_start_m": 1 << 30}), (16384, 1, {"inv_overlap": 0})])
+def test_rinv_is_validated_at_the_sizes_it_is_timed_on(n, ci, opts):
+    """Half of the reference's output is R^-1 (cholinv.hpp:144-159): at the sizes bench.py quotes reference semantics on, check
+    it with arithmetic that is not this library's (torch fp64 matmul): ||R (R^-1 X) - X|| / ||X|| per filled diagonal block, and
+    the structure of the root block (exactly empty for complete_inv = 0, cholinv.hpp:147; filled for 1).  A missing event edge
+    in the overlapped inverse tree that only bites with many panels shows up here."""
+    from capital_amd import cholinv, validate
+    A, pack = _factor(n, ci, 1, -5, opts=opts)
+    assert pack.last_info() == 0
+    assert pack.get_option("inv_fast") == 1 and n // pack.get_option("nb") >= 32
+    assert validate.cholesky.residual(A, pack) < RES_TOL
+    R = cholinv.construct_R(pack); Ri = cholinv.construct_Rinv(pack)
+    probe, root_nz = validate.cholesky.rinv_probe(R.view(), Ri.view(), ci, 1)
+    assert probe <= 1e-13, probe
+    assert validate.cholesky.rinv_ok(probe, root_nz, ci, n, 1), (probe, root_nz)
+    if ci == 1:
+        assert root_nz >= 0.999 * (n // 2) * (n // 2)              # a dense block: Rinv12 is filled, not just touched
+    # strictly-lower part of R^-1 stays zero, its diagonal is 1 / diag(R)
+    assert float(torch.tril(Ri.view()[:4096, :4096], -1).abs().max()) == 0.0
+    d = torch.diagonal(R.view()) * torch.diagonal(Ri.view())
+    assert float((d - 1.0).abs().max()) < 1e-14
+    # second factor call on the same plan: bit-identical R^-1 (the tree's products are beta = 0, fixed order)
+    cholinv.factor(A, pack, None)
+    Ri2 = cholinv.construct_Rinv(pack)
+    assert torch.equal(Ri2.view(), Ri.view())
+    del A, pack, R, Ri, Ri2
+    torch.cuda.empty_cache()
+
+
+def test_workspace_follows_the_path_taken():
+    """The plan's workspace is sized for the path factor() takes (blocked sweep + tree, or the plain recursion) and grows when an
+    option moves the plan to the other one - both orders give the oracle's factors."""
+    from capital_amd import cholinv
+    n = 2048
+    a = orc.symmetric_global(n, True)
+    r_ref, ri_ref = orc.cholinv(a, 1, 1, -2, 1, 1)
+    A, pack = _factor(n, 1, 1, -2)                   # blocked path first ...
+    Ri = cholinv.construct_Rinv(pack).to_numpy()
+    pack.set_option("inv_fast", 0)                   # ... then the recursion on the same plan (needs (n/2 + 1)^2 scratch)
+    cholinv.factor(A, pack, None)
+    assert pack.last_info() == 0
+    assert relerr(cholinv.construct_Rinv(pack).to_numpy(), ri_ref) < 1e-12
+    assert relerr(Ri, ri_ref) < 1e-12
+    pack.set_option("inv_fast", 1); pack.set_option("nb", 128)      # back, with narrower panels (a deeper tree)
+    cholinv.factor(A, pack, None)
+    assert relerr(cholinv.construct_Rinv(pack).to_numpy(), ri_ref) < 1e-12
+    assert relerr(cholinv.construct_R(pack).to_numpy(), r_ref) < 1e-13
