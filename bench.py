@@ -88,11 +88,17 @@ def _largest_cube(limit):
 
 
 def cpu_baseline(cpu_n, budget_s=90.0):
-    """Reference CPU/MPI path on the host cores (protocol bench/cholesky/cholinv.cpp:44-60), bounded to about `budget_s`
-    seconds: the REAL reference (oracle/_ref) on the largest cube of MPI ranks the host holds (up to 64 = its 4 x 4 x 4 grid;
-    upstream needs c == d), MKL 1 thread per rank, bcMult sweep at N = cpu_n, then N = 2 cpu_n with the best knobs if the
-    budget allows, plus the one-rank all-cores variant (MKL_THREADING_LAYER=GNU).  The best TFLOP/s (N^3/3) is reported
-    with the cores that produced it; every run is listed in `runs`."""
+    """Reference CPU/MPI path on the host cores (protocol bench/cholesky/cholinv.cpp:44-60), bounded to about `budget_s` seconds.
+
+    The REAL reference (oracle/_ref), MKL 1 thread per rank.  What the budget is spent on (round-3 measurements on the GPU box's
+    256-core EPYC: upstream's own 2 x 2 x 2 grid wins; 64 ranks and one rank x 128 MKL threads are 2-4x SLOWER):
+      c1     BASELINE configs[0], the plumbing case: 1 rank, N = 2048, bcMult = 0, the bench's default policy; its residual is
+             the number SURVEY App. A pins (1.70e-16);
+      8 ranks, bcMult in {-3, -2} at N = cpu_n / 2, then the better of the two at N = cpu_n (about 7 s per factor at 16384;
+             a run = generation + warm-up + timed factor + the validator's own SUMMA product, i.e. several factor times);
+      one documented run each of the 64-rank (4 x 4 x 4) grid and of 1 rank x all cores inside MKL (GNU threading layer), at
+             N = cpu_n / 4 so that they stay cheap - scaling evidence, never the reported value unless they win.
+    `value` is the figure of the LARGEST N that completed (TFLOP/s on N^3/3, best knobs at that N); every run is in `runs`."""
     exe = os.path.join(ROOT, "oracle", "_ref", "cholinv_ref")
     mpiexec = "/opt/conda/bin/mpiexec"
     ncores = os.cpu_count() or 1
@@ -106,13 +112,13 @@ def cpu_baseline(cpu_n, budget_s=90.0):
     t_start = time.time()
     runs = []
 
-    def run_ref(ranks, nn, bc, threads, timeout):
+    def run_ref(ranks, nn, bc, threads, timeout, policy=1, keep=True):
         env = dict(os.environ, MKL_NUM_THREADS=str(threads), OMP_NUM_THREADS=str(threads))
         if threads > 1:
             env["MKL_THREADING_LAYER"] = "GNU"        # the default Intel-OpenMP layer gives wrong answers here
         t0 = time.time()
         try:
-            out = subprocess.run([mpiexec, "-n", str(ranks), exe, str(nn), "0", "1", str(bc), "0", "0", "1", "-", "1"],
+            out = subprocess.run([mpiexec, "-n", str(ranks), exe, str(nn), "0", "1", str(bc), "0", "0", str(policy), "-", "1"],
                                  env=env, capture_output=True, text=True, timeout=max(5.0, timeout)).stdout
         except Exception:
             return None
@@ -123,40 +129,46 @@ def cpu_baseline(cpu_n, budget_s=90.0):
         r = {"ranks": ranks, "threads_per_rank": threads, "cores": ranks * threads, "n": nn, "bcMult": bc, "seconds": t,
              "tflops": nn ** 3 / 3.0 / t / 1e12, "residual": res, "wall_s": time.time() - t0}
         if res < 1e-14:
-            runs.append(r)
+            if keep:
+                runs.append(r)
             return r
         return None
 
     if os.path.exists(exe) and os.path.exists(mpiexec):
         left = lambda: budget_s - (time.time() - t_start)
-        cap = lambda: min(left(), 0.3 * budget_s)      # no single candidate may eat the budget
-        big = _largest_cube(min(ncores, 64))
         half_n = max(1024, cpu_n // 2)
-        threads = min(ncores, 128)
-        # Candidates on the half-size sample (1/8 of the flops), known-good first: upstream's own 2 x 2 x 2 grid, the largest
-        # cube the host holds (up to 4 x 4 x 4 = 64 ranks; measured on the GPU box's 256-core EPYC: 64 ranks are SLOWER than 8 -
-        # 11 s per factor at N = 16384), 27 ranks, and one rank with all cores inside MKL (GNU threading layer).  Then the best
-        # configuration once more at N = cpu_n if its predicted wall time (8x) fits.  A run = generation + warm-up + timed
-        # factor + the validator's own SUMMA product, i.e. several factor times.
-        cands = [(8, -3, 1), (8, -2, 1), (big, -2, 1), (1, 0, threads), (1, -2, threads), (27, -2, 1), (big, -3, 1)]
-        seen = set()
-        for ranks, bc, th in cands:
-            if (ranks, bc, th) in seen or ranks * (1 if th > 1 else 1) > ncores or (th == 1 and ranks < 8) or (th > 1 and threads <= 1) or left() < 8:
-                continue
-            seen.add((ranks, bc, th))
-            run_ref(ranks, half_n, bc, th, cap())
+        # configs[0]: the reference's own CPU-runnable case (1 rank, N = 2048, bcMult = 0, Serialize + NoReplication = the bench default)
+        c1r = run_ref(1, 2048, 0, 1, 20.0, policy=0, keep=False)
+        c1 = ({"n": 2048, "ranks": 1, "bcMult": 0, "seconds": c1r["seconds"], "tflops": c1r["tflops"], "residual": c1r["residual"],
+               "what": "BASELINE configs[0]: N=2048 fp64 cholinv, 1 MPI rank, reference CPU BLAS path (MKL, 1 thread)"} if c1r else None)
+        if ncores >= 8:
+            for bc in (-3, -2):
+                if left() > 10:
+                    run_ref(8, half_n, bc, 1, min(left(), 0.25 * budget_s))
+            small = [r for r in runs if r["ranks"] == 8]
+            if small:
+                b = max(small, key=lambda r: r["tflops"])
+                if left() > 8.5 * b["wall_s"] + 12:      # 8x the flops; keep room for the two documented runs below
+                    run_ref(8, cpu_n, b["bcMult"], 1, left() - 10)
+        quarter_n = max(1024, cpu_n // 4)
+        if ncores >= 64 and left() > 8:
+            run_ref(64, quarter_n, -2, 1, min(left() - 2, 20.0))
+        if ncores >= 16 and left() > 6:
+            run_ref(1, quarter_n, -2, min(ncores, 128), min(left() - 1, 20.0))
+        if not runs and left() > 5:      # fewer than 8 cores: whatever the host has
+            run_ref(1, min(cpu_n, 4096), -2, 1, left())
         if runs:
-            b = max(runs, key=lambda r: r["tflops"])
-            if left() > 8.0 * b["wall_s"] + 5:
-                run_ref(b["ranks"], cpu_n, b["bcMult"], b["threads_per_rank"], left())
-        if runs:
-            b = max(runs, key=lambda r: r["tflops"])
-            return {"value": b["tflops"], "unit": "TFLOP/s", "cores": b["cores"], "kind": "reference", "host": host,
-                    "sample": "N=%d (bounded sample of the N=65536 workload): upstream cholinv on %d MPI rank(s) x %d MKL thread(s), "
-                              "Serialize+ReplicateCommComp, bcMult=%d, complete_inv=0, %.3f s/factor, residual %.2e; best of %d runs "
-                              "in %.0f s (all listed in `runs`)" % (b["n"], b["ranks"], b["threads_per_rank"], b["bcMult"], b["seconds"],
-                                                                   b["residual"], len(runs), time.time() - t_start),
-                    "runs": runs}
+            nmax = max(r["n"] for r in runs)
+            b = max((r for r in runs if r["n"] == nmax), key=lambda r: r["tflops"])
+            out = {"value": b["tflops"], "unit": "TFLOP/s", "cores": b["cores"], "kind": "reference", "host": host,
+                   "sample": "N=%d (bounded sample of the N=65536 workload; the largest N of %d runs in %.0f s, all listed in `runs`): upstream "
+                             "cholinv on %d MPI rank(s) x %d MKL thread(s), Serialize+ReplicateCommComp, bcMult=%d, complete_inv=0, %.3f s/factor, "
+                             "residual %.2e" % (b["n"], len(runs), time.time() - t_start, b["ranks"], b["threads_per_rank"], b["bcMult"],
+                                                b["seconds"], b["residual"]),
+                   "runs": runs}
+            if c1:
+                out["c1"] = c1
+            return out
     # fallback: the NumPy/LAPACK port of the same factorization on all host cores
     import numpy as np
     from oracle import capital_oracle as orc

@@ -174,10 +174,14 @@ def test_2d_block_cyclic_schedule_on_one_gpu(nproc, pr, n, nb):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nproc,n,nb", [(2, 1024, 128), (4, 2048, 256), (3, 1536, 128), (1, 1024, 256), (8, 8192, 512), (4, 1280, 256), (2, 1152, 256)])
-def test_distributed_mixed_precision_solve(nproc, n, nb):
+@pytest.mark.parametrize("hard", [0, 1])
+def test_distributed_mixed_precision_solve(nproc, n, nb, hard):
     """BASELINE config 5's method on P ranks sharing cuda:0: bf16-MFMA factorization on block columns (bf16 panels all-gathered,
-    staircase bf16 update) + distributed fp64 refinement; X against numpy's fp64 solve, the fp32 factor against the fp64 one."""
-    r = _launch(nproc, "mixed", n, nb, 29801 + nproc)
+    staircase bf16 update) + distributed fp64 refinement; X against numpy's fp64 solve, the fp32 factor against the fp64 one and
+    against the one-rank factor of the same arithmetic (fp32 rounding level); hard = an input that is not diagonally dominant."""
+    if hard and nproc not in (2, 3, 4):
+        pytest.skip("the non-dominant input is run on three grids")
+    r = _launch(nproc, "mixed", n, nb, 29801 + nproc + 20 * hard, ("--hard", hard))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "DMP-OK" in r.stdout, r.stdout[-2000:]
 
