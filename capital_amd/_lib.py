@@ -68,6 +68,14 @@ SIGNATURES = {
     "cap_comm_bcast": (cint, [ptr, ptr, i64, cint, ptr]),
     "cap_comm_allgather": (cint, [ptr, ptr, ptr, i64, ptr]),
     "cap_comm_barrier": (cint, [ptr, ptr]),
+    "cap_comm_alltoallv": (cint, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr]),
+    "cap_comm_exchange": (cint, [ptr, ptr, ptr, i64, cint, ptr]),
+    "cap_comm_set_alltoallv_callback": (cint, [ptr, ptr]),
+    "cap_redist_plan_create": (cint, [C.POINTER(ptr), i64, i64, ptr, cint, cint]),
+    "cap_redist_plan_destroy": (cint, [ptr]),
+    "cap_redist_get": (i64, [ptr, cint]),
+    "cap_redistribute_cyclic_to_bc": (cint, [ptr, ptr, i64, ptr, i64, ptr]),
+    "cap_redistribute_bc_to_cyclic": (cint, [ptr, ptr, i64, ptr, i64, ptr]),
     "cap_cholinv_plan_create": (cint, [C.POINTER(ptr), i64, cint, i64, i64, C.c_char, ptr]),
     "cap_cholinv_plan_destroy": (cint, [ptr]),
     "cap_cholinv_factor": (cint, [ptr, ptr, i64, ptr]),

@@ -45,7 +45,8 @@ class info:
         _lib.check(L.cap_cholinv_plan_create(C.byref(h), n, self.complete_inv, self.split, self.bc_mult_dim,
                                              self.dir.encode()[0:1], comm), "cap_cholinv_plan_create")
         self._plan, self._n, self._comm = h, n, comm
-        for k, v in self.options.items():
+        order = sorted(self.options.items(), key=lambda kv: kv[0] == "cyclic_c")      # the layout follows the block width: "nb" first
+        for k, v in order:
             _lib.check(L.cap_cholinv_set_option(self._plan, k.encode(), v), "set_option")
 
     def _release(self):
@@ -73,10 +74,18 @@ def factor(A, args, CommInfo=None):
     if args.split <= 0:
         raise _lib.CapitalError("split must be > 0 (cholinv.hpp:9)")
     if CommInfo is not None and getattr(CommInfo, "size", 1) != 1:
-        # multi-GPU: A is a `block_cyclic_columns` piece (this rank's block columns, all n rows) and CommInfo.world the
-        # communicator; the 1 x P schedule of csrc/dist.hip runs behind the same plan handle (complete_inv = 0 / 1 add R^-1)
+        # multi-GPU: the 1 x P schedule of csrc/dist.hip runs behind the same plan handle (complete_inv = 0 / 1 add R^-1).
+        #  * A created on the d x d grid of a topo::square bundle (matrix(n, n, d, d), bench/cholesky/cholinv.cpp:34-35): the
+        #    REFERENCE's layout - A is this rank's element-cyclic piece, construct_R / construct_Rinv return pieces of the same
+        #    shape on every rank (option "cyclic_c": distributed redistribution in front of / behind the plan, csrc/redist.hip);
+        #  * A on a 1 x 1 grid: this rank's block columns (all n rows), construct_* return block columns.
         n = A.num_rows_global()
+        d = getattr(CommInfo, "d", 1)
+        args._cyclic = (d > 1 and A._pgridX == d and A._pgridY == d)
+        args.options["cyclic_c"] = int(getattr(CommInfo, "c", 1)) if args._cyclic else 0
+        args._grid_d = d
         args._ensure(n, getattr(CommInfo, "world", None))
+        args.set_option("cyclic_c", args.options["cyclic_c"])          # (a reused plan follows the layout of THIS call's A)
         _lib.check(_lib.lib().cap_cholinv_factor(args._plan, A.data_ptr(), A.ld(), cur_stream()), "cholinv::factor")
         return
     n = A.num_rows_global()
@@ -88,7 +97,9 @@ def factor(A, args, CommInfo=None):
 
 def _construct(args, which):
     n = args._n
-    if args._comm is not None and _lib.lib().cap_comm_size(args._comm) > 1:
+    if args._comm is not None and _lib.lib().cap_comm_size(args._comm) > 1 and getattr(args, "_cyclic", False):
+        out = matrix(n, n, args._grid_d, args._grid_d, rect)      # my element-cyclic piece, like upstream's construct_R
+    elif args._comm is not None and _lib.lib().cap_comm_size(args._comm) > 1:
         lc = int(_lib.lib().cap_cholinv_get_option(args._plan, b"local_cols"))
         out = matrix(max(lc, 1), n, 1, 1, rect)      # my block-cyclic columns (n x local_cols)
     else:

@@ -263,6 +263,10 @@ struct cap_cholinv_plan {
   std::vector<hipEvent_t>* prof_ev; std::vector<double>* prof_flops; int prof_used;
   // multi-GPU plans (comm size > 1): the 1 x P block-cyclic schedule of dist.hip behind the same handle
   cap_dist_plan* dist;
+  // option "cyclic_c" = c: the caller speaks the REFERENCE's layout (element-cyclic pieces on topo::square's d x d x c grid,
+  // matrix.hpp:8-11) end to end - factor() redistributes the piece into this rank's block columns (redist.hip), get_R / get_Rinv
+  // redistribute the result back into a piece on every rank of every layer (construct_R / construct_Rinv, cholinv.hpp:30-46)
+  cap_redist_plan* redist; int cyc_c; double* bcA; double* bcOut; int64_t bc_cols;
   // Strip buffers (use_sb): the solved block rows of a strip are written K-contiguously into one of three NB x n buffers
   // (ld = NB) and every update reads its operands from there; the copy into R - R is only the OUTPUT after that - runs on
   // its own stream off the panel stream's critical path (it was 64 x 134 MB of copies on it at N = 32768)
@@ -277,6 +281,34 @@ struct cap_cholinv_plan {
 };
 
 namespace {
+
+// upstream's leaf test at the root (cholinv.hpp:93 with c = d = 1): a root that is itself a base case gets the full inverse
+// whatever complete_inv says (policy.h:199-201 always runs trtri)
+bool root_is_base_case(int64_t n, int64_t split, int64_t bc_mult_dim) {
+  int64_t bc = 1;
+  if (bc_mult_dim < 0) for (int64_t i = 0; i < -bc_mult_dim && bc < n; i++) bc *= 2;
+  bc = std::max<int64_t>(1, std::min<int64_t>(n, bc));
+  const int64_t bc_dim = n / bc;
+  return (n <= bc_dim) || ((n >> split) < split);
+}
+
+// (re)build the reference-layout front end of a multi-GPU plan: redistribution plan + the two block-column staging arrays
+int setup_cyclic(cap_cholinv_plan* p, int c) {
+  if (p->redist) { (void)cap_redist_plan_destroy(p->redist); p->redist = nullptr; }
+  if (p->bcA) { (void)hipFree(p->bcA); p->bcA = nullptr; }
+  if (p->bcOut) { (void)hipFree(p->bcOut); p->bcOut = nullptr; }
+  p->cyc_c = 0;
+  if (c <= 0) return CAP_OK;
+  CAP_TRY(cap_redist_plan_create(&p->redist, p->n, cap_dist_get_option(p->dist, "nb"), p->comm, c, 1));
+  p->bc_cols = cap_dist_local_cols(p->dist);
+  const size_t bytes = sizeof(double) * (size_t)p->n * (size_t)std::max<int64_t>(p->bc_cols, 1);
+  if (hipMalloc((void**)&p->bcA, bytes) != hipSuccess || hipMalloc((void**)&p->bcOut, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return CAP_ERR_ALLOC;       // (the caller's plan stays usable on the block-column layout; destroy frees what was allocated)
+  }
+  p->cyc_c = c;
+  return CAP_OK;
+}
 
 int64_t default_nb(int64_t n, int64_t bc_mult_dim) {
   // Panel width of the GPU schedule.  The sweet spot on MI355X is 512 (256 for small matrices): wider panels
@@ -900,8 +932,10 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
     // A is this rank's block-cyclic column set (cap_bc_num_local_cols columns, all n rows); see dist.hip
     int st = cap_dist_plan_create(&p->dist, n, std::max<int64_t>(128, (p->nb / 128) * 128), comm);
     if (st != CAP_OK) { delete p; return st; }
-    (void)cap_dist_set_option(p->dist, "complete_inv", complete_inv);
-    (void)cap_dist_set_option(p->dist, "split", split);
+    // the single-GPU rule applies on P > 1 too: a root that is itself a base case gets the full inverse (cholinv.hpp:93)
+    st = cap_dist_set_option(p->dist, "complete_inv", (complete_inv == 0 && root_is_base_case(n, split, bc_mult_dim)) ? 1 : complete_inv);
+    if (st == CAP_OK) st = cap_dist_set_option(p->dist, "split", split);
+    if (st != CAP_OK) { (void)cap_dist_plan_destroy(p->dist); delete p; return st; }
     *plan = p;
     return CAP_OK;
   }
@@ -934,6 +968,9 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
 
 int cap_cholinv_plan_destroy(cap_cholinv_plan* p) {
   if (!p) return CAP_OK;
+  if (p->redist) (void)cap_redist_plan_destroy(p->redist);
+  if (p->bcA) (void)hipFree(p->bcA);
+  if (p->bcOut) (void)hipFree(p->bcOut);
   if (p->dist) (void)cap_dist_plan_destroy(p->dist);
   if (p->R) (void)hipFree(p->R);
   if (p->Rinv) (void)hipFree(p->Rinv);
@@ -968,9 +1005,15 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
       CAP_TRY(cap_dist_plan_create(&nd, p->n, value, p->comm));
       (void)cap_dist_plan_destroy(p->dist);
       p->dist = nd; p->nb = value;
-      (void)cap_dist_set_option(p->dist, "complete_inv", p->complete_inv);
-      (void)cap_dist_set_option(p->dist, "split", p->split);
+      CAP_TRY(cap_dist_set_option(p->dist, "complete_inv", (p->complete_inv == 0 && root_is_base_case(p->n, p->split, p->bc_mult_dim)) ? 1 : p->complete_inv));
+      CAP_TRY(cap_dist_set_option(p->dist, "split", p->split));
+      if (p->cyc_c) CAP_TRY(setup_cyclic(p, p->cyc_c));       // the redistribution follows the block width
       return CAP_OK;
+    }
+    if (k == "cyclic_c") {     // 0: block-column pieces (default); c >= 1: element-cyclic pieces on the d x d x c grid
+      if (value < 0) return CAP_ERR_ARG;
+      if (value == p->cyc_c) return CAP_OK;
+      return setup_cyclic(p, (int)value);
     }
     return cap_dist_set_option(p->dist, key, value);
   }
@@ -1035,6 +1078,8 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
     if (k == "split") return p->split;
     if (k == "bc_mult_dim") return p->bc_mult_dim;
     if (k == "local_cols") return cap_dist_local_cols(p->dist);
+    if (k == "cyclic_c") return p->cyc_c;
+    if (k == "piece") return p->redist ? cap_redist_get(p->redist, 0) : 0;        // edge of the element-cyclic piece
     return cap_dist_get_option(p->dist, key);
   }
   if (k == "local_cols") return p->n;
@@ -1064,6 +1109,10 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
 
 int cap_cholinv_factor(cap_cholinv_plan* p, const double* A, int64_t lda, void* stream) {
   if (!p) return CAP_ERR_ARG;
+  if (p->dist && p->redist) {       // A = my element-cyclic piece (ceil(n/d) x ceil(n/d), lda)
+    CAP_TRY(cap_redistribute_cyclic_to_bc(p->redist, A, lda, p->bcA, p->n, stream));
+    return cap_dist_factor(p->dist, p->bcA, p->n, stream);
+  }
   if (p->dist) return cap_dist_factor(p->dist, A, lda, stream);
   if (!A || lda < p->n) return CAP_ERR_ARG;
   hipStream_t s = cap_stream(stream);
@@ -1072,13 +1121,7 @@ int cap_cholinv_factor(cap_cholinv_plan* p, const double* A, int64_t lda, void* 
   // serialize<uppertri,uppertri>(A -> R), cholinv.hpp:13: only A's upper triangle is consumed
   p->srcA = A; p->src_lda = lda;             // right_looking does the A -> R copy (all of it, or the first strip's rows)
   if (p->complete_inv < 0) return right_looking(p, p->R, p->ldr, n, s);
-  // upstream's leaf test at the root (cholinv.hpp:93 with c = d = 1): a root that is itself a base
-  // case gets the full inverse whatever complete_inv says (policy.h:199-201 always runs trtri)
-  int64_t bc = 1;
-  if (p->bc_mult_dim < 0) for (int64_t i = 0; i < -p->bc_mult_dim && bc < n; i++) bc *= 2;
-  bc = std::max<int64_t>(1, std::min<int64_t>(n, bc));
-  const int64_t bc_dim = n / bc;
-  const bool root_is_base = (n <= bc_dim) || ((n >> p->split) < p->split);
+  const bool root_is_base = root_is_base_case(n, p->split, p->bc_mult_dim);
   if (p->inv_fast && n >= 2 * p->nb && p->leaf == CAP_LEAF_MAX) return factor_with_inverse(p, root_is_base, s);
   p->srcA = nullptr;
   if (p->work_elems < rec_work_size(n)) {       // the plan was sized for the blocked path (plan_alloc) and an option left it
@@ -1093,12 +1136,21 @@ int cap_cholinv_factor(cap_cholinv_plan* p, const double* A, int64_t lda, void* 
 }
 
 int cap_cholinv_get_R(cap_cholinv_plan* p, double* out, int64_t ld, void* stream) {
+  if (p && p->dist && p->redist) {                                     // my element-cyclic piece (construct_R, cholinv.hpp:30-37)
+    CAP_TRY(cap_dist_get_R(p->dist, p->bcOut, p->n, stream));
+    return cap_redistribute_bc_to_cyclic(p->redist, p->bcOut, p->n, out, ld, stream);
+  }
   if (p && p->dist) return cap_dist_get_R(p->dist, out, ld, stream);   // my block-cyclic columns
   if (!p || !out || ld < p->n) return CAP_ERR_ARG;
   return cap_copy_window(p->R, 0, p->ldr, 0, 0, out, 0, ld, 0, 0, p->n, p->n, 1, 1, stream);
 }
 
 int cap_cholinv_get_Rinv(cap_cholinv_plan* p, double* out, int64_t ld, void* stream) {
+  if (p && p->dist && p->redist) {
+    if (p->complete_inv < 0) return CAP_ERR_UNSUPPORTED;
+    CAP_TRY(cap_dist_get_Rinv(p->dist, p->bcOut, p->n, stream));
+    return cap_redistribute_bc_to_cyclic(p->redist, p->bcOut, p->n, out, ld, stream);
+  }
   if (p && p->dist) return p->complete_inv < 0 ? CAP_ERR_UNSUPPORTED : cap_dist_get_Rinv(p->dist, out, ld, stream);   // my block-cyclic columns
   if (!p || !out || ld < p->n) return CAP_ERR_ARG;
   if (p->complete_inv < 0) return CAP_ERR_UNSUPPORTED;   // this mode never builds R^-1

@@ -28,6 +28,7 @@ struct cap_comm {
   int rank, size;
   bool self;
   cap_allgather_fn cb_allgather; cap_bcast_fn cb_bcast; cap_allreduce_fn cb_allreduce; void* cb_ctx;
+  cap_alltoallv_fn cb_alltoallv;    // optional (host-staged communicators): cap_comm_set_alltoallv_callback
   double* token;      // 1-double device scratch (barrier)
 };
 
@@ -46,7 +47,7 @@ cap_comm* new_comm(int rank, int size) {
   cap_comm* c = new (std::nothrow) cap_comm();
   if (!c) return nullptr;
   c->rank = rank; c->size = size; c->self = false; c->nccl = nullptr;
-  c->cb_allgather = nullptr; c->cb_bcast = nullptr; c->cb_allreduce = nullptr; c->cb_ctx = nullptr;
+  c->cb_allgather = nullptr; c->cb_bcast = nullptr; c->cb_allreduce = nullptr; c->cb_ctx = nullptr; c->cb_alltoallv = nullptr;
   c->token = nullptr;
   return c;
 }
@@ -130,6 +131,7 @@ int cap_comm_dup(cap_comm* comm, cap_comm** out) {
     cap_comm* c = new_comm(comm->rank, comm->size);
     if (!c) return CAP_ERR_ALLOC;
     c->cb_allgather = comm->cb_allgather; c->cb_bcast = comm->cb_bcast; c->cb_allreduce = comm->cb_allreduce; c->cb_ctx = comm->cb_ctx;
+    c->cb_alltoallv = comm->cb_alltoallv;
     *out = c;
     return CAP_OK;
   }
@@ -200,6 +202,64 @@ int cap_comm_allgather(cap_comm* c, const double* send, double* recv, int64_t co
   if (count_per_rank == 0) return CAP_OK;
   if (c->cb_allgather) return c->cb_allgather(c->cb_ctx, send, recv, count_per_rank, stream) ? CAP_ERR_COMM : CAP_OK;
   CAP_NCCL(ncclAllGather(send, recv, (size_t)count_per_rank, ncclDouble, c->nccl, cap_stream(stream)));
+  return CAP_OK;
+}
+
+// Personalised all-to-all (the data movement behind util::block_to_cyclic_* / cyclic_to_local, util.hpp:56-230, and the
+// transpose-partner exchange util::transpose, util.hpp:232-247 - upstream builds both from MPI_Allgather / MPI_Sendrecv_replace):
+// rank r receives sendcounts_q[r] doubles from every q.  counts / displacements are HOST arrays of `size` int64 (elements).
+// RCCL: one group of ncclSend / ncclRecv pairs (each pair rides its own xGMI link on the fully connected node); the piece a
+// rank sends to itself is a device copy.
+int cap_comm_alltoallv(cap_comm* c, const double* send, const int64_t* sendcounts, const int64_t* sdispls, double* recv,
+                       const int64_t* recvcounts, const int64_t* rdispls, void* stream) {
+  if (!sendcounts || !sdispls || !recvcounts || !rdispls) return CAP_ERR_ARG;
+  const int size = c ? c->size : 1, rank = c ? c->rank : 0;
+  if (sendcounts[rank] != recvcounts[rank]) return CAP_ERR_ARG;
+  if (sendcounts[rank] > 0)
+    CAP_HIP(hipMemcpyAsync(recv + rdispls[rank], send + sdispls[rank], sizeof(double) * sendcounts[rank], hipMemcpyDeviceToDevice, cap_stream(stream)));
+  if (!c || c->self || size == 1) return CAP_OK;
+  if (c->cb_allgather) {
+    if (!c->cb_alltoallv) return CAP_ERR_UNSUPPORTED;
+    return c->cb_alltoallv(c->cb_ctx, send, sendcounts, sdispls, recv, recvcounts, rdispls, stream) ? CAP_ERR_COMM : CAP_OK;
+  }
+  CAP_NCCL(ncclGroupStart());
+  for (int r = 0; r < size; r++) {
+    if (r == rank) continue;
+    if (sendcounts[r] > 0) CAP_NCCL(ncclSend(send + sdispls[r], (size_t)sendcounts[r], ncclDouble, r, c->nccl, cap_stream(stream)));
+    if (recvcounts[r] > 0) CAP_NCCL(ncclRecv(recv + rdispls[r], (size_t)recvcounts[r], ncclDouble, r, c->nccl, cap_stream(stream)));
+  }
+  CAP_NCCL(ncclGroupEnd());
+  return CAP_OK;
+}
+
+// host-staged communicators only: the caller's implementation of cap_comm_alltoallv (the piece a rank sends to itself has
+// already been copied when the callback runs; it must skip it)
+int cap_comm_set_alltoallv_callback(cap_comm* c, cap_alltoallv_fn fn) {
+  if (!c || !c->cb_allgather) return CAP_ERR_ARG;
+  c->cb_alltoallv = fn;
+  return CAP_OK;
+}
+
+// MPI_Sendrecv_replace with one partner (util::transpose, util.hpp:232-247): `count` doubles of `buf` are swapped with the
+// same range on rank `partner` (partner == my rank: nothing to do).  `tmp`: device scratch of `count` doubles.
+int cap_comm_exchange(cap_comm* c, double* buf, double* tmp, int64_t count, int partner, void* stream) {
+  const int size = c ? c->size : 1, rank = c ? c->rank : 0;
+  if (partner < 0 || partner >= size || count < 0) return CAP_ERR_ARG;
+  if (partner == rank || count == 0) return CAP_OK;
+  if (!tmp) return CAP_ERR_ARG;
+  if (c->cb_allgather) {
+    if (!c->cb_alltoallv) return CAP_ERR_UNSUPPORTED;
+    int64_t sc[64], sd[64], rc[64], rd[64];
+    if (size > 64) return CAP_ERR_UNSUPPORTED;
+    for (int r = 0; r < size; r++) { sc[r] = rc[r] = (r == partner) ? count : 0; sd[r] = rd[r] = 0; }
+    if (c->cb_alltoallv(c->cb_ctx, buf, sc, sd, tmp, rc, rd, stream)) return CAP_ERR_COMM;
+  } else {
+    CAP_NCCL(ncclGroupStart());
+    CAP_NCCL(ncclSend(buf, (size_t)count, ncclDouble, partner, c->nccl, cap_stream(stream)));
+    CAP_NCCL(ncclRecv(tmp, (size_t)count, ncclDouble, partner, c->nccl, cap_stream(stream)));
+    CAP_NCCL(ncclGroupEnd());
+  }
+  CAP_HIP(hipMemcpyAsync(buf, tmp, sizeof(double) * count, hipMemcpyDeviceToDevice, cap_stream(stream)));
   return CAP_OK;
 }
 

@@ -201,6 +201,18 @@ int cap_comm_reduce_sum(cap_comm* comm, double* buf, int64_t count, int root, vo
 int cap_comm_bcast(cap_comm* comm, double* buf, int64_t count, int root, void* stream);
 int cap_comm_allgather(cap_comm* comm, const double* send, double* recv, int64_t count_per_rank, void* stream);
 int cap_comm_barrier(cap_comm* comm, void* stream);
+/* Personalised all-to-all (what upstream assembles from MPI_Allgather + util::block_to_cyclic_* / cyclic_to_local,
+ * util.hpp:56-230): rank r receives the `sendcounts[r]` doubles every rank addressed to it.  counts / displacements are HOST
+ * arrays of cap_comm_size int64 (in doubles); grouped ncclSend / ncclRecv, the self piece is a device copy.
+ * cap_comm_exchange = MPI_Sendrecv_replace with one partner (util::transpose, util.hpp:232-247): swaps `count` doubles of
+ * `buf` with rank `partner` (tmp: device scratch of `count` doubles; partner == own rank: no-op).                       */
+int cap_comm_alltoallv(cap_comm* comm, const double* send, const int64_t* sendcounts, const int64_t* sdispls, double* recv,
+                       const int64_t* recvcounts, const int64_t* rdispls, void* stream);
+int cap_comm_exchange(cap_comm* comm, double* buf, double* tmp, int64_t count, int partner, void* stream);
+/* host-staged communicators (tests): the caller's all-to-all; 0 = success.  The self piece is copied by the library. */
+typedef int (*cap_alltoallv_fn)(void* ctx, const double* send, const int64_t* sendcounts, const int64_t* sdispls, double* recv,
+                                const int64_t* recvcounts, const int64_t* rdispls, void* stream);
+int cap_comm_set_alltoallv_callback(cap_comm* comm, cap_alltoallv_fn fn);
 
 /* Grid bundles: topo::square (kind 0, d x d x c, topology.h:67-143) and topo::rect (kind 1, c x d x c,
  * topology.h:16-65) - the row / column / depth / slice (/ column_contig / column_alt / cube)
@@ -220,6 +232,25 @@ cap_comm* cap_topo_comm(cap_topo* topo, int which);
 /* field: 0 rank, 1 size, 2 c, 3 d, 4 x, 5 y, 6 z, 7 layout, 8 num_chunks, 9 kind */
 int cap_topo_get(const cap_topo* topo, int field);
 
+/* Distributed redistribution between the reference's element-cyclic pieces and the block-cyclic layouts of the multi-GPU
+ * plans (csrc/redist.hip) - how a caller holding upstream-style pieces on P ranks reaches cap_dist_* / cap_dist2d_* / cap_dmp_*
+ * and gets R / R^-1 back the way construct_R / construct_Rinv return them (cholinv.hpp:30-46).
+ *   cyclic side: rank = z + c x + c d y of topo::square's d x d x c grid (topology.h:75-83) holds piece (x, y): global rows
+ *                y, y + d, ..., columns x, x + d, ... (ceil(n / d) each, zero padded; matrix.hpp:8-11), replicated over z;
+ *   block-cyclic side: block (I, J) of nb x nb on process (I mod Pr, J mod Pc), rank = pr Pc + pc, local block (I div Pr,
+ *                J div Pc), compact local array (valid rows x valid columns); Pr = 1: the block columns of cap_dist_*.
+ * One all-to-all over `world` (cap_comm_alltoallv) + one gather / scatter launch per peer; the index sets are derived on both
+ * sides from (n, nb, d, Pr, Pc).  cyclic_to_bc: destination t reads from layer z = t mod c (the replicas share the work);
+ * bc_to_cyclic: every rank of every layer receives its piece.  Collective, asynchronous on `stream`.
+ * cap_redist_get: 0 cyclic piece edge, 1 / 2 valid local rows / columns of my block-cyclic piece, 3 d, 4 c, 5 x, 6 y, 7 z,
+ * 8 Pr, 9 Pc, 10 pr, 11 pc, 12 / 13 doubles sent in direction cyclic->bc / bc->cyclic, 14 / 15 doubles received.        */
+typedef struct cap_redist_plan cap_redist_plan;
+int cap_redist_plan_create(cap_redist_plan** plan, int64_t n, int64_t nb, cap_comm* world, int c, int Pr);
+int cap_redist_plan_destroy(cap_redist_plan* plan);
+int64_t cap_redist_get(const cap_redist_plan* plan, int which);
+int cap_redistribute_cyclic_to_bc(cap_redist_plan* plan, const double* piece, int64_t ldp, double* bc_local, int64_t ldb, void* stream);
+int cap_redistribute_bc_to_cyclic(cap_redist_plan* plan, const double* bc_local, int64_t ldb, double* piece, int64_t ldp, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Algorithm seam (replaces src/alg/cholesky/cholinv, src/alg/qr/cacqr)
  * ---------------------------------------------------------------------------------- */
@@ -237,7 +268,12 @@ int cap_topo_get(const cap_topo* topo, int field);
  * comm of size P > 1: the multi-GPU schedule of cap_dist_* behind the same handle - A, get_R / get_Rinv and
  * the *_ptr accessors then refer to THIS RANK's block-cyclic columns (global block column J, width nb, on
  * rank J % P; cap_bc_num_local_cols columns, all n rows; option "nb" sets the width); complete_inv = 0 / 1
- * also build R^-1 there (cap_dist_get_Rinv).                                                          */
+ * also build R^-1 there (cap_dist_get_Rinv).
+ * Option "cyclic_c" = c (multi-GPU plans; c = depth of topo::square's d x d x c grid, comm size = c d d): the plan speaks the
+ * REFERENCE's layout end to end - factor's A is this rank's element-cyclic piece (ceil(n/d) x ceil(n/d), matrix.hpp:8-11),
+ * get_R / get_Rinv write this rank's piece of R / R^-1 (what construct_R / construct_Rinv return on every rank of every layer,
+ * cholinv.hpp:30-46; zero below the GLOBAL diagonal, i.e. already util::remove_triangle'd) - through the distributed
+ * redistribution of cap_redistribute_* (one all-to-all each way).  get "piece" = the piece edge.                          */
 typedef struct cap_cholinv_plan cap_cholinv_plan;
 int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv, int64_t split,
                             int64_t bc_mult_dim, char dir, cap_comm* comm);

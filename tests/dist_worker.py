@@ -111,6 +111,117 @@ def main():
             assert probe < 1e-13, probe
             print("DIST2D-OK world=%d grid=%dx%d n=%d nb=%d err=%.2e residual=%.2e probe=%.2e launches(rank0)=%s" % (size, ctx.Pr, ctx.Pc, n, nb, err, res, probe, counts), flush=True)
         ctx.close(); row.close(); col.close(); comm.close()
+    elif args.mode == "redist":
+        # distributed redistribution element-cyclic (d x d x c) <-> block-cyclic (Pr x Pc), csrc/redist.hip: every rank on cuda:0,
+        # all-to-all through the host-staged communicator (gloo point-to-point)
+        torch.cuda.set_device(0)
+        from capital_amd import dist_cholesky as dc, redist, topo as tp
+        from capital_amd.matrix import matrix
+        from tests.host_staged import HostStagedComm
+        comm = HostStagedComm()
+        co = tp.square_coords(rank, size, args.c)
+        d, x, y, z = co["d"], co["x"], co["y"], co["z"]
+        a = np.random.default_rng(5).standard_normal((n, n))           # NOT symmetric: a transposed index shows
+        rp = redist.plan(n, nb, comm, args.c, args.pr)
+        assert (rp.d, rp.x, rp.y, rp.z) == (d, x, y, z) and rp.Pr == args.pr and rp.Pc == size // args.pr
+        rows = dc.global_index_2d(n, nb, rp.Pr, rp.pr); cols = dc.global_index_2d(n, nb, rp.Pc, rp.pc)
+        assert rows.size == rp.bc_rows and cols.size == rp.bc_cols
+        # every layer holds the same piece upstream; here layer z adds 1000 z so that the test sees WHICH replica supplied a rank
+        P0 = matrix(n, n, d, d).from_numpy(orc.cyclic_local(a, x, y, d, d) + 1000.0 * z)
+        bc = rp.new_bc()
+        for rep in range(2):                                            # plan reuse
+            bc.fill_(float("nan"))
+            rp.cyclic_to_bc(P0, bc)
+        torch.cuda.synchronize()
+        if rows.size and cols.size:
+            got = bc[: cols.size, : rows.size].cpu().numpy().T
+            assert np.array_equal(got, a[np.ix_(rows, cols)] + 1000.0 * (rank % args.c)), "cyclic -> block-cyclic"
+        # back: every rank of every layer receives its piece (of the layer-0 values: strip the marker first)
+        if rows.size and cols.size:
+            bc[: cols.size, : rows.size] -= 1000.0 * (rank % args.c)
+        P1 = matrix(n, n, d, d); P1.data().fill_(float("nan"))
+        rp.bc_to_cyclic(bc, P1)
+        torch.cuda.synchronize()
+        want = orc.cyclic_local(a, x, y, d, d)
+        assert np.array_equal(P1.to_numpy(), want), "block-cyclic -> cyclic (incl. the zero padding of a ragged n)"
+        tot = torch.tensor([float(rp.sent[0]), float(rp.received[0]), float(rp.sent[1]), float(rp.received[1])]); dist.all_reduce(tot)
+        assert tot[0] == tot[1] and tot[2] == tot[3]
+        if rank == 0:
+            print("REDIST-OK world=%d grid=%dx%dx%d -> %dx%d n=%d nb=%d moved=%s collectives=%s" % (size, d, d, args.c, rp.Pr, rp.Pc, n, nb, tot.tolist(), comm.calls), flush=True)
+        rp.close(); comm.close()
+    elif args.mode in ("cyclic", "cyclic2d"):
+        # the reference's layout end to end: element-cyclic pieces on topo::square's d x d x c grid in, pieces of R / R^-1 out
+        #   cyclic   : cholinv::factor(A, pack, topo) / construct_R / construct_Rinv (option "cyclic_c" behind the plan handle, 1 x P)
+        #   cyclic2d : redistribute -> the Pr x Pc plan (csrc/dist2d.hip) -> redistribute back (R only: that plan builds no inverse)
+        # compared piece by piece with the REAL reference's 8-rank dump (--golden) or with the oracle's factors cut into pieces
+        torch.cuda.set_device(0)
+        from capital_amd import cholinv, dist_cholesky as dc, redist, topo as tp
+        from capital_amd.matrix import matrix
+        from tests.host_staged import HostStagedComm, grid_groups
+        gold = None
+        if args.golden:
+            gold = np.load(os.path.join(ROOT, "tests", "golden", args.golden))
+            n, args.ci, args.split, args.c = int(gold["n"]), int(gold["complete_inv"]), int(gold["split"]), int(gold["c"])
+        T = tp.square(args.c, 0, 0, comm_factory=HostStagedComm)
+        d = T.d
+        a = orc.symmetric_global(n, True)
+        A = matrix(n, n, d, d)
+        A.distribute_symmetric(T.x, T.y, d, d, rank // T.c, True)         # bench/cholesky/cholinv.cpp:35
+        assert np.array_equal(A.to_numpy(), orc.cyclic_local(a, T.x, T.y, d, d))
+        ri_p = None
+        if args.mode == "cyclic":
+            pack = cholinv.info(args.ci, args.split, -2, 'U')
+            pack.set_option("nb", nb)
+            for rep in range(2):
+                cholinv.factor(A, pack, T)
+            info = pack.last_info()
+            Rm = cholinv.construct_R(pack, T)
+            assert (Rm.num_rows_local(), Rm.num_columns_local()) == (A.num_rows_local(), A.num_columns_local())
+            r_p = Rm.to_numpy()
+            if args.ci >= 0:
+                ri_p = cholinv.construct_Rinv(pack, T).to_numpy()
+            assert pack.get_option("cyclic_c") == T.c and pack.get_option("piece") == A.num_rows_local()
+            close = pack._release
+        else:
+            row, col = grid_groups(args.pr)
+            rp = redist.plan(n, nb, T, T.c, args.pr)
+            ctx = dc.Context2D(n, nb, T._comm_obj, args.pr, row, col)
+            assert (ctx.local_rows, ctx.local_cols) == (rp.bc_rows, rp.bc_cols)
+            rp.cyclic_to_bc(A, ctx.A)
+            ctx.factor()
+            info = ctx.last_info()
+            Rm = matrix(n, n, d, d)
+            rp.bc_to_cyclic(ctx.local_R_device(), Rm)
+            r_p = Rm.to_numpy()
+            close = lambda: (ctx.close(), rp.close(), row.close(), col.close())
+        assert info == 0, info
+        # which slots of my piece are globally on / above the diagonal (util::remove_triangle's mask, util.hpp:266-318)
+        pl = A.num_rows_local()
+        gi = np.arange(pl)[:, None] * d + T.y; gj = np.arange(pl)[None, :] * d + T.x
+        upper = (gi <= gj) & (gi < n) & (gj < n)
+        if gold is not None:
+            pieces = gold["pieces"][rank]                                  # (A, R, Rinv) as the reference left them on THIS rank
+            assert tuple(gold["rank_coords"][rank]) == (rank, T.x, T.y, T.z)
+            ref_r, ref_ri = pieces[1], pieces[2]
+            assert np.array_equal(pieces[0], A.to_numpy())
+        else:
+            rr, rri = orc.cholinv(a, max(args.ci, 0), args.split, -2, 1, 1)
+            ref_r, ref_ri = orc.cyclic_local(rr, T.x, T.y, d, d), orc.cyclic_local(rri, T.x, T.y, d, d)
+        err = np.linalg.norm((r_p - ref_r)[upper]) / max(np.linalg.norm(ref_r[upper]), 1e-300)
+        assert err < 1e-13, ("R piece", rank, err)
+        assert not r_p[~upper].any(), "entries of my piece below the global diagonal (and the padding) must be zero"
+        erri = 0.0
+        if ri_p is not None:
+            erri = np.linalg.norm((ri_p - ref_ri)[upper]) / max(np.linalg.norm(ref_ri[upper]), 1e-300)
+            assert erri < 1e-12, ("Rinv piece", rank, erri)
+            assert not ri_p[~upper].any()
+            assert np.array_equal(ri_p[upper] != 0, ref_ri[upper] != 0), "same empty root block (cholinv.hpp:147), piece by piece"
+        errs = [None] * size
+        dist.all_gather_object(errs, (float(err), float(erri)))
+        if rank == 0:
+            print("CYCLIC-OK mode=%s world=%d grid=%dx%dx%d n=%d nb=%d ci=%d max_err_R=%.2e max_err_Rinv=%.2e%s" % (
+                args.mode, size, d, d, T.c, n, nb, args.ci, max(e[0] for e in errs), max(e[1] for e in errs), " golden=ok" if gold is not None else ""), flush=True)
+        close(); T.close()
     elif args.mode == "mixed":
         # mixed-precision solve on P ranks (csrc/dist_mixed.hip): bf16 factorization on block columns + distributed fp64 refinement
         torch.cuda.set_device(0)

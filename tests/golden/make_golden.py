@@ -51,11 +51,13 @@ def cholinv_multirank_dump_case(name, n, ci, split, bc, pol=1, ranks=8):
         kv = _kv(out)
         mats = [np.zeros((n, n)) for _ in range(3)]
         layers = {}
+        per_rank, coords = [], []
         for r in range(ranks):
             raw = open("%s.%d" % (dump, r), "rb").read()
             rank, x, y, z, d, c, rl, cl = (int(v) for v in np.frombuffer(raw[:64], dtype=np.int64))
             body = np.frombuffer(raw[64:], dtype=np.float64).reshape(3, cl, rl)      # column-major local pieces
             pieces = [body[k].T for k in range(3)]
+            per_rank.append(np.stack(pieces)); coords.append((rank, x, y, z))
             layers.setdefault((x, y), []).append(pieces)
             if z == 0:
                 nr, nc = len(range(y, n, d)), len(range(x, n, d))                     # ragged N: the padded tail is dropped
@@ -66,9 +68,11 @@ def cholinv_multirank_dump_case(name, n, ci, split, bc, pol=1, ranks=8):
                 assert np.array_equal(ps[0][0], other[0])
                 assert np.allclose(ps[0][1], other[1], rtol=0, atol=1e-13)
     a, r, ri = mats
+    # pieces[rank] = (A, R, Rinv) exactly as construct_R / construct_Rinv left them on that rank (ceil(n/d) x ceil(n/d), [row, col]):
+    # the local upper triangle only - on ranks with y > x the local diagonal holds globally sub-diagonal slots
     np.savez_compressed(os.path.join(HERE, name + ".npz"), A=a, R=r, Rinv=ri, n=n, complete_inv=ci, split=split,
                         bc_mult_dim=bc, policy=pol, ranks=ranks, c=c, d=d, ref_residual=float(kv["residual"]),
-                        ref_stdout=out.strip())
+                        ref_stdout=out.strip(), pieces=np.stack(per_rank), rank_coords=np.array(coords, dtype=np.int64))
     print(name, out.strip())
 
 

@@ -25,6 +25,8 @@ class HostStagedComm:
     _AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
     _BC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
     _AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+    _A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64),
+                       C.POINTER(C.c_int64), C.c_void_p)
 
     def __init__(self, group=None):
         dist = _dist()
@@ -32,7 +34,7 @@ class HostStagedComm:
             raise _lib.CapitalError("HostStagedComm needs torch.distributed initialised with the gloo backend")
         self.group = group
         self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
-        self.calls = {"allgather": 0, "bcast": 0, "allreduce": 0}
+        self.calls = {"allgather": 0, "bcast": 0, "allreduce": 0, "alltoallv": 0}
 
         def sync(stream):
             if stream:
@@ -80,11 +82,40 @@ class HostStagedComm:
                 print("HostStagedComm allreduce failed:", e, flush=True)
                 return 1
 
-        self._cbs = (self._AG(ag), self._BC(bc), self._AR(ar))   # keep alive
+        def a2a(ctx, send, sc, sd, recv, rc, rd, stream):
+            # personalised all-to-all as gloo point-to-point pairs (the self piece was already copied by the library)
+            try:
+                sync(stream)
+                g = (lambda r: dist.get_global_rank(self.group, r)) if self.group is not None else (lambda r: r)
+                reqs, rbufs = [], []
+                for r in range(self.size):
+                    if r == self.rank:
+                        continue
+                    if rc[r] > 0:
+                        t = torch.empty(rc[r], dtype=torch.float64)
+                        rbufs.append((r, t))
+                        reqs.append(dist.irecv(t, src=g(r), group=self.group))
+                for r in range(self.size):
+                    if r == self.rank or sc[r] <= 0:
+                        continue
+                    t = _DevView(int(send) + 8 * sd[r], sc[r]).to_host()
+                    reqs.append(dist.isend(t, dst=g(r), group=self.group))
+                for q in reqs:
+                    q.wait()
+                for r, t in rbufs:
+                    _DevView(int(recv) + 8 * rd[r], rc[r]).from_host(t)
+                self.calls["alltoallv"] += 1
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("HostStagedComm alltoallv failed:", e, flush=True)
+                return 1
+
+        self._cbs = (self._AG(ag), self._BC(bc), self._AR(ar), self._A2A(a2a))   # keep alive
         h = C.c_void_p()
         _lib.check(_lib.lib().cap_comm_create_callbacks(C.byref(h), self.rank, self.size,
                                                         C.cast(self._cbs[0], C.c_void_p), C.cast(self._cbs[1], C.c_void_p),
                                                         C.cast(self._cbs[2], C.c_void_p), None), "cap_comm_create_callbacks")
+        _lib.check(_lib.lib().cap_comm_set_alltoallv_callback(h, C.cast(self._cbs[3], C.c_void_p)), "cap_comm_set_alltoallv_callback")
         self.handle = h
 
     def close(self):

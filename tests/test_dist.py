@@ -345,3 +345,44 @@ def test_cacqr_3d_and_tunable_grid(nproc, c, m, n):
     assert "CACQR3D-OK" in r.stdout, r.stdout[-2000:]
     if m == 256:
         assert "golden=ok" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,c,pr,n,nb", [
+    (8, 2, 1, 1024, 128),        # the reference's 2 x 2 x 2 grid -> 1 x 8 block columns
+    (8, 2, 2, 1024, 128),        # ... -> 2 x 4 block-cyclic (cap_dist2d_*)
+    (4, 1, 1, 1000, 128),        # 2 x 2 x 1, ragged n (padded pieces, partial last block)
+    (4, 1, 2, 777, 256),         # -> 2 x 2, odd n
+    (9, 1, 3, 1100, 128),        # 3 x 3 x 1 -> 3 x 3
+    (8, 2, 1, 250, 128),         # fewer blocks than ranks: most ranks hold nothing on the block-cyclic side
+    (1, 1, 1, 512, 128),
+])
+def test_distributed_redistribution_cyclic_block_cyclic(nproc, c, pr, n, nb):
+    """Element-cyclic d x d x c pieces <-> Pr x Pc block-cyclic pieces by ONE all-to-all (csrc/redist.hip): both directions
+    bit-exact against NumPy index arithmetic; the replicas share the supply (destination t reads layer t mod c)."""
+    r = _launch(nproc, "redist", n, nb, 29821 + nproc + pr, ("--c", c, "--pr", pr))
+    assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    assert "REDIST-OK" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,pr", [("cyclic", 1), ("cyclic2d", 2)])
+@pytest.mark.parametrize("name", ["cholinv_p8_n128_ci1_s1_bc-2.npz", "cholinv_p8_n192_ci0_s1_bc-3.npz", "cholinv_p8_n250_ci1_s1_bc-2.npz"])
+def test_reference_layout_end_to_end_against_the_8rank_piece_dumps(mode, pr, name):
+    """A caller holding the reference's element-cyclic pieces on 8 ranks (2 x 2 x 2): factor, construct_R, construct_Rinv speak
+    that layout end to end (1 x 8 behind cholinv::factor; 2 x 4 through redistribute + cap_dist2d) - every rank's piece is
+    compared with the piece the REAL reference left on the same rank."""
+    r = _launch(8, mode, 128, 128, 29841 + pr, ("--golden", name, "--pr", pr))
+    assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    assert "CYCLIC-OK" in r.stdout and "golden=ok" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,c,mode,pr,n,nb,ci", [
+    (8, 2, "cyclic", 1, 2048, 128, 1), (8, 2, "cyclic", 1, 2048, 256, 0), (4, 1, "cyclic", 1, 1000, 128, 1),
+    (8, 2, "cyclic2d", 2, 2048, 128, -1), (4, 1, "cyclic2d", 2, 1000, 128, -1), (8, 2, "cyclic", 1, 4096, 512, -1),
+])
+def test_reference_layout_end_to_end_against_the_oracle(nproc, c, mode, pr, n, nb, ci):
+    r = _launch(nproc, mode, n, nb, 29851 + nproc + pr, ("--c", c, "--pr", pr, "--ci", ci))
+    assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    assert "CYCLIC-OK" in r.stdout, r.stdout[-2000:]
