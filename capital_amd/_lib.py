@@ -120,6 +120,9 @@ SIGNATURES = {
     "cap_summa_plan_destroy": (cint, [ptr]),
     "cap_summa_local_dims": (None, [ptr, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
     "cap_summa_dgemm": (cint, [ptr, dbl, ptr, i64, ptr, i64, dbl, ptr, i64, ptr]),
+    "cap_util_transpose": (cint, [ptr, ptr, ptr, i64, ptr]),
+    "cap_summa_dtrmm": (cint, [ptr, cint, cint, cint, cint, dbl, ptr, i64, cint, ptr, i64, ptr]),
+    "cap_summa_dsyrk": (cint, [ptr, cint, cint, dbl, ptr, i64, dbl, ptr, i64, cint, ptr]),
     "cap_mpchol_plan_create": (cint, [C.POINTER(ptr), i64, i64]),
     "cap_mpchol_plan_destroy": (cint, [ptr]),
     "cap_mpchol_factor": (cint, [ptr, ptr, i64, ptr]),

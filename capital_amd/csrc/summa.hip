@@ -29,6 +29,8 @@ struct cap_summa_plan {
   int64_t m, n, k, ml, nl, kl;          // global / local (ceil) dimensions
   int num_chunks;
   double* bufA[2]; double* bufB[2]; double* acc;
+  double* triA[2]; double* triB[2];     // unpack targets of packed-upper triangular slots (TRMM overload), allocated on first use
+  double* xch[2];                       // the transpose-partner copy of the SYRK overload + its exchange scratch
   hipStream_t s_row, s_col;
   std::vector<hipEvent_t> ev_a, ev_b, ev_free;   // [buf], [buf * num_chunks + chunk], [buf]
   hipEvent_t ev_start, ev_join_r, ev_join_c;
@@ -61,7 +63,7 @@ int cap_summa_plan_create(cap_summa_plan** plan, cap_topo* topo, int64_t m, int6
   p->ml = cap_ceil_div(m, p->d); p->nl = cap_ceil_div(n, p->d); p->kl = cap_ceil_div(k, p->d);
   p->num_chunks = std::max(1, num_chunks);
   if (p->num_chunks > p->nl) p->num_chunks = (int)p->nl;
-  for (int i = 0; i < 2; i++) p->bufA[i] = p->bufB[i] = nullptr;
+  for (int i = 0; i < 2; i++) p->bufA[i] = p->bufB[i] = p->triA[i] = p->triB[i] = p->xch[i] = nullptr;
   p->acc = nullptr; p->s_row = p->s_col = nullptr;
   hipError_t e = hipSuccess;
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
@@ -88,7 +90,8 @@ int cap_summa_plan_create(cap_summa_plan** plan, cap_topo* topo, int64_t m, int6
 
 int cap_summa_plan_destroy(cap_summa_plan* p) {
   if (!p) return CAP_OK;
-  for (int i = 0; i < 2; i++) { if (p->bufA[i]) (void)hipFree(p->bufA[i]); if (p->bufB[i]) (void)hipFree(p->bufB[i]); }
+  for (int i = 0; i < 2; i++)
+    for (double* q : {p->bufA[i], p->bufB[i], p->triA[i], p->triB[i], p->xch[i]}) if (q) (void)hipFree(q);
   if (p->acc) (void)hipFree(p->acc);
   for (auto* v : {&p->ev_a, &p->ev_b, &p->ev_free}) for (auto ev : *v) if (ev) (void)hipEventDestroy(ev);
   if (p->ev_start) { (void)hipEventDestroy(p->ev_start); (void)hipEventDestroy(p->ev_join_r); (void)hipEventDestroy(p->ev_join_c); }
@@ -103,56 +106,188 @@ void cap_summa_local_dims(const cap_summa_plan* p, int64_t* ml, int64_t* nl, int
   if (ml) *ml = p->ml; if (nl) *nl = p->nl; if (kl) *kl = p->kl;
 }
 
+// ---- the SUMMA carrier shared by the three overloads (summa.hpp:6-161) ------------------------------------------------------
+// One slot pair per inner process index kp: the A slot travels along my process row (root x == kp), the B slot down my
+// process column (root y == kp); acc (+)= alpha op(Aslot) op(Bslot).  How a slot's piece is staged on its root:
+//   SLOT_RECT    the ra x ca piece as it is
+//   SLOT_TRI     a square piece holding an upper triangle (rect storage): upper part copied, strictly-lower part zero-filled
+//   SLOT_PACKED  the same triangle in upstream's packed-upper storage (structure.h:39): the PACKED image is broadcast
+//                (n (n + 1) / 2 doubles, as upstream does, summa.hpp:185) and unpacked behind the broadcast on every rank
+// A triangular piece (kp, y) of a globally upper-triangular T has zeros exactly where local row > local column (and on the
+// local diagonal when y > kp - stored zeros), so the local product is a GEMM whose K ranges stop at the triangle (tags
+// 8 / 16 / 32 of cap_gemm_launch) - what upstream gets from calling cblas_dtrmm on the piece (summa.hpp:66,73).
+enum { SLOT_RECT = 0, SLOT_TRI = 1, SLOT_PACKED = 2 };
+struct Slot { const double* src; int64_t ld; int mode; int64_t rows, cols; };   // stored dims of the piece
+
+static int summa_core(cap_summa_plan* p, int opa, int opb, const Slot& A, const Slot& B, int64_t M, int64_t N, int64_t K, double alpha,
+                      int tag, int chunked, hipStream_t s0) {
+  hipStream_t sr = p->s_row, sc = p->s_col;
+  const int nch = chunked ? p->num_chunks : 1;
+  CAP_HIP(hipEventRecord(p->ev_start, s0));
+  CAP_HIP(hipStreamWaitEvent(sr, p->ev_start, 0));
+  CAP_HIP(hipStreamWaitEvent(sc, p->ev_start, 0));
+  std::vector<int> steps;
+  for (int kp = p->z; kp < p->d; kp += p->c) steps.push_back(kp);
+  // stage + broadcast one slot; returns the buffer the GEMM reads (the unpack target for packed triangles)
+  auto move = [&](const Slot& S, bool is_root, double* buf, double* tribuf, cap_comm* comm, int root, hipStream_t s, int chunks, hipEvent_t* evs,
+                  const double** out) -> int {
+    if (S.mode == SLOT_PACKED) {
+      const int64_t np = S.rows * (S.rows + 1) / 2;
+      if (is_root) CAP_HIP(hipMemcpyAsync(buf, S.src, sizeof(double) * np, hipMemcpyDeviceToDevice, s));
+      CAP_TRY(cap_comm_bcast(comm, buf, np, root, (void*)s));
+      CAP_TRY(cap_copy_window(buf, 1, 0, 0, 0, tribuf, 0, S.rows, 0, 0, S.rows, S.rows, 1, 1, (void*)s));
+      CAP_HIP(hipEventRecord(evs[0], s));
+      *out = tribuf;
+      return CAP_OK;
+    }
+    if (is_root) {
+      if (S.mode == SLOT_TRI) CAP_TRY(cap_copy_window(S.src, 0, S.ld, 0, 0, buf, 0, S.rows, 0, 0, S.rows, S.rows, 1, 1, (void*)s));
+      else CAP_TRY(cap_copy_rect(S.src, S.ld, buf, S.rows, S.rows, S.cols, s));
+    }
+    for (int ch = 0; ch < chunks; ch++) {
+      const int64_t c0 = S.cols * ch / chunks, c1 = S.cols * (ch + 1) / chunks;
+      CAP_TRY(cap_comm_bcast(comm, buf + c0 * S.rows, S.rows * (c1 - c0), root, (void*)s));
+      CAP_HIP(hipEventRecord(evs[ch], s));
+    }
+    *out = buf;
+    return CAP_OK;
+  };
+  for (size_t si = 0; si < steps.size(); si++) {
+    const int kp = steps[si], buf = (int)(si & 1);
+    if (si >= 2) { CAP_HIP(hipStreamWaitEvent(sr, p->ev_free[buf], 0)); CAP_HIP(hipStreamWaitEvent(sc, p->ev_free[buf], 0)); }
+    const double *Ab = nullptr, *Bb = nullptr;
+    CAP_TRY(move(A, p->x == kp, p->bufA[buf], p->triA[buf], p->row, kp, sr, 1, &p->ev_a[buf], &Ab));
+    CAP_TRY(move(B, p->y == kp, p->bufB[buf], p->triB[buf], p->column, kp, sc, nch, &p->ev_b[(size_t)buf * p->num_chunks], &Bb));
+    CAP_HIP(hipStreamWaitEvent(s0, p->ev_a[buf], 0));
+    for (int ch = 0; ch < nch; ch++) {
+      const int64_t c0 = N * ch / nch, c1 = N * (ch + 1) / nch;          // chunked: opb == NoTrans, B slot K x N (ld = K)
+      CAP_HIP(hipStreamWaitEvent(s0, p->ev_b[(size_t)buf * p->num_chunks + ch], 0));
+      CAP_TRY(cap_gemm_launch(opa, opb, M, c1 - c0, K, alpha, Ab, A.rows, Bb + c0 * B.rows, B.rows, si == 0 ? 0.0 : 1.0, p->acc + c0 * M, M, 0, s0, tag));
+    }
+    CAP_HIP(hipEventRecord(p->ev_free[buf], s0));
+  }
+  // ---- depth: sum the layers' partial products (collect, summa.hpp:223-253)
+  if (p->c > 1) CAP_TRY(cap_comm_allreduce_sum(p->depth, p->acc, M * N, (void*)s0));
+  return CAP_OK;
+}
+
+static int summa_join(cap_summa_plan* p, hipStream_t s0) {
+  CAP_HIP(hipEventRecord(p->ev_join_r, p->s_row));
+  CAP_HIP(hipEventRecord(p->ev_join_c, p->s_col));
+  CAP_HIP(hipStreamWaitEvent(s0, p->ev_join_r, 0));
+  CAP_HIP(hipStreamWaitEvent(s0, p->ev_join_c, 0));
+  return CAP_OK;
+}
+
+static int ensure_tri(cap_summa_plan* p, int64_t na, int64_t nb_) {
+  for (int i = 0; i < 2; i++) {
+    if (na > 0 && !p->triA[i]) CAP_HIP(hipMalloc((void**)&p->triA[i], sizeof(double) * na * na));
+    if (nb_ > 0 && !p->triB[i]) CAP_HIP(hipMalloc((void**)&p->triB[i], sizeof(double) * nb_ * nb_));
+  }
+  return CAP_OK;
+}
+
 // C_local = alpha * (A B)_local + beta * C_local.  A_local: ml x kl (lda), B_local: kl x nl (ldb), C_local: ml x nl (ldc),
 // all column-major element-cyclic pieces with zero padding (matrix.hpp:8-11).  NoTrans x NoTrans, like the reference's
 // driver (bench/matmult/summa_gemm.cpp:38); the transposed forms need a partner exchange upstream does outside SUMMA.
 int cap_summa_dgemm(cap_summa_plan* p, double alpha, const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
                     double* C, int64_t ldc, void* stream) {
   if (!p || !A || !B || !C || lda < p->ml || ldb < p->kl || ldc < p->ml) return CAP_ERR_ARG;
-  hipStream_t s0 = cap_stream(stream), sr = p->s_row, sc = p->s_col;
+  hipStream_t s0 = cap_stream(stream);
   const int64_t ml = p->ml, nl = p->nl, kl = p->kl;
-  const int nch = p->num_chunks;
-  CAP_HIP(hipEventRecord(p->ev_start, s0));
-  CAP_HIP(hipStreamWaitEvent(sr, p->ev_start, 0));
-  CAP_HIP(hipStreamWaitEvent(sc, p->ev_start, 0));
-  std::vector<int> steps;
-  for (int kp = p->z; kp < p->d; kp += p->c) steps.push_back(kp);
-  for (size_t si = 0; si < steps.size(); si++) {
-    const int kp = steps[si], buf = (int)(si & 1);
-    // ---- row stream: A's piece of process column kp to everybody in my process row (summa.hpp:185)
-    if (si >= 2) CAP_HIP(hipStreamWaitEvent(sr, p->ev_free[buf], 0));       // the GEMMs of step si-2 have read bufA[buf]
-    if (p->x == kp) CAP_TRY(cap_copy_rect(A, lda, p->bufA[buf], ml, ml, kl, sr));
-    CAP_TRY(cap_comm_bcast(p->row, p->bufA[buf], ml * kl, kp, (void*)sr));
-    CAP_HIP(hipEventRecord(p->ev_a[buf], sr));
-    // ---- column stream: B's piece of process row kp down my process column, in column chunks (summa.hpp:193, 201-214)
-    if (si >= 2) CAP_HIP(hipStreamWaitEvent(sc, p->ev_free[buf], 0));
-    if (p->y == kp) CAP_TRY(cap_copy_rect(B, ldb, p->bufB[buf], kl, kl, nl, sc));
-    for (int ch = 0; ch < nch; ch++) {
-      const int64_t c0 = nl * ch / nch, c1 = nl * (ch + 1) / nch;
-      CAP_TRY(cap_comm_bcast(p->column, p->bufB[buf] + c0 * kl, kl * (c1 - c0), kp, (void*)sc));
-      CAP_HIP(hipEventRecord(p->ev_b[buf * nch + ch], sc));
-    }
-    // ---- caller's stream: acc(:, chunk) (+)= A_piece * B_piece(:, chunk) as the chunks land
-    CAP_HIP(hipStreamWaitEvent(s0, p->ev_a[buf], 0));
-    for (int ch = 0; ch < nch; ch++) {
-      const int64_t c0 = nl * ch / nch, c1 = nl * (ch + 1) / nch;
-      CAP_HIP(hipStreamWaitEvent(s0, p->ev_b[buf * nch + ch], 0));
-      CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, ml, c1 - c0, kl, alpha, p->bufA[buf], ml, p->bufB[buf] + c0 * kl, kl,
-                              si == 0 ? 0.0 : 1.0, p->acc + c0 * ml, ml, 0, s0));
-    }
-    CAP_HIP(hipEventRecord(p->ev_free[buf], s0));
-  }
-  // ---- depth: sum the layers' partial products (summa.hpp:236), then C = beta C + acc (summa.hpp:32-35)
-  if (p->c > 1) CAP_TRY(cap_comm_allreduce_sum(p->depth, p->acc, ml * nl, (void*)s0));
   if (nl > 65535) return CAP_ERR_UNSUPPORTED;
+  CAP_TRY(summa_core(p, CAP_NOTRANS, CAP_NOTRANS, Slot{A, lda, SLOT_RECT, ml, kl}, Slot{B, ldb, SLOT_RECT, kl, nl}, ml, nl, kl, alpha, 0, 1, s0));
+  // C = beta C + acc (summa.hpp:32-35)
   hipLaunchKernelGGL(combine_kernel, dim3((unsigned)std::min<int64_t>(cap_ceil_div(ml, 256), 1024), (unsigned)nl), dim3(256), 0, s0, C, ldc,
                      p->acc, ml, ml, nl, beta);
   CAP_HIP(hipGetLastError());
-  CAP_HIP(hipEventRecord(p->ev_join_r, sr));
-  CAP_HIP(hipEventRecord(p->ev_join_c, sc));
-  CAP_HIP(hipStreamWaitEvent(s0, p->ev_join_r, 0));
-  CAP_HIP(hipStreamWaitEvent(s0, p->ev_join_c, 0));
-  return CAP_OK;
+  return summa_join(p, s0);
+}
+
+// util::transpose (util.hpp:232-247): swap my piece with the transpose partner (x, y, z) <-> (y, x, z) of topo::square - the
+// received piece is NOT transposed (it is the partner's piece as stored).  count doubles of `buf`; tmp: scratch of `count`.
+int cap_util_transpose(cap_topo* topo, double* buf, double* tmp, int64_t count, void* stream) {
+  if (!topo || cap_topo_get(topo, 9) != 0) return CAP_ERR_ARG;
+  const int c = cap_topo_get(topo, 2), d = cap_topo_get(topo, 3), x = cap_topo_get(topo, 4), y = cap_topo_get(topo, 5), z = cap_topo_get(topo, 6);
+  const int partner = x * c * d + y * c + z;             // layout 0: rank = z + c x + c d y with x and y swapped
+  return cap_comm_exchange(cap_topo_comm(topo, 0), buf, tmp, count, partner, stream);
+}
+
+// matmult::summa::invoke, TRMM overload (summa.hpp:46-83): B <- alpha op(T) B (side LEFT, T m x m) or alpha B op(T) (RIGHT,
+// T n x n) on element-cyclic pieces, in place in B like upstream.  The plan is created with (m, n, k = m) for LEFT and
+// (m, n, k = n) for RIGHT.  T_local: my piece of the globally upper-triangular T - rect storage (t_packed = 0: only its upper
+// triangle is referenced) or upstream's packed-upper storage (t_packed = 1, ldt ignored).  trans == CAP_TRANS: T_local must be
+// the piece AFTER util::transpose (cap_util_transpose), exactly as upstream's call site prepares it (cholinv.hpp:114-120).
+int cap_summa_dtrmm(cap_summa_plan* p, int side, int uplo, int trans, int diag, double alpha, const double* T, int64_t ldt, int t_packed,
+                    double* B, int64_t ldb, void* stream) {
+  if (!p || !T || !B || ldb < p->ml) return CAP_ERR_ARG;
+  if (uplo != CAP_UPPER || diag != CAP_NONUNIT) return CAP_ERR_UNSUPPORTED;       // every upstream call site
+  hipStream_t s0 = cap_stream(stream);
+  const int64_t ml = p->ml, nl = p->nl, kl = p->kl;
+  const bool left = side == CAP_LEFT;
+  if ((left && kl != ml) || (!left && kl != nl) || (!t_packed && ldt < kl) || nl > 65535) return CAP_ERR_ARG;
+  const int tmode = t_packed ? SLOT_PACKED : SLOT_TRI;
+  CAP_TRY(ensure_tri(p, left && t_packed ? kl : 0, !left && t_packed ? kl : 0));
+  if (left) {
+    // acc[ly, lx] = sum over kp, lk of  op(Tpiece)[ly, lk] B(x, kp)[lk, lx];  NoTrans: Tpiece = T(kp, y); Trans: the exchanged piece
+    // on (kp, y) is T(y, kp) = T[lk d + kp, ly d + y], used transposed
+    CAP_TRY(summa_core(p, trans, CAP_NOTRANS, Slot{T, ldt, tmode, kl, kl}, Slot{B, ldb, SLOT_RECT, kl, nl}, ml, nl, kl, alpha,
+                       trans == CAP_TRANS ? 16 : 32, 1, s0));
+  } else {
+    // acc[ly, lx] = sum B(kp, y)[ly, lk] op(Tpiece)[lk, lx];  NoTrans: Tpiece = T(x, kp); Trans: the exchanged piece on (x, kp) is T(kp, x)
+    CAP_TRY(summa_core(p, CAP_NOTRANS, trans, Slot{B, ldb, SLOT_RECT, ml, kl}, Slot{T, ldt, tmode, kl, kl}, ml, nl, kl, alpha,
+                       trans == CAP_TRANS ? 0 : 8, 0, s0));
+  }
+  hipLaunchKernelGGL(combine_kernel, dim3((unsigned)std::min<int64_t>(cap_ceil_div(ml, 256), 1024), (unsigned)nl), dim3(256), 0, s0, B, ldb,
+                     p->acc, ml, ml, nl, 0.0);
+  CAP_HIP(hipGetLastError());
+  return summa_join(p, s0);
+}
+
+namespace {
+// C (rect, full local square - what upstream leaves for a rect C, summa.hpp:146-151 - or packed upper: local upper triangle)
+__global__ void combine_packed_kernel(double* Cp, const double* acc, int64_t n, double beta) {
+  const int64_t col = blockIdx.y;
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row <= col; row += (int64_t)gridDim.x * blockDim.x) {
+    double* q = Cp + col * (col + 1) / 2 + row;
+    const double a = acc[row + col * n];
+    *q = beta == 0.0 ? a : beta * (*q) + a;
+  }
+}
+}  // namespace
+
+// matmult::summa::invoke, SYRK overload (summa.hpp:85-161): C <- alpha A^T A + beta C (trans == CAP_TRANS, A k x n: the form
+// cholinv.hpp:128-133 uses) or alpha A A^T + beta C (NoTrans, A n x k) on element-cyclic pieces.  Like upstream it is a GEMM of
+// A's piece with the piece of the TRANSPOSE PARTNER (a copy of A exchanged through util::transpose, summa.hpp:91-92) - a rank's
+// block of the symmetric result is not symmetric itself.  Plan: (m = n, n = n, k).  C_local: nl x nl rect (c_packed = 0: the
+// whole local square is written) or packed upper (c_packed = 1: the local upper triangle).
+int cap_summa_dsyrk(cap_summa_plan* p, int uplo, int trans, double alpha, const double* A, int64_t lda, double beta, double* C,
+                    int64_t ldc, int c_packed, void* stream) {
+  if (!p || !A || !C || p->ml != p->nl || (!c_packed && ldc < p->nl)) return CAP_ERR_ARG;
+  if (uplo != CAP_UPPER) return CAP_ERR_UNSUPPORTED;
+  hipStream_t s0 = cap_stream(stream);
+  const int64_t nl = p->nl, kl = p->kl;
+  if (nl > 65535) return CAP_ERR_UNSUPPORTED;
+  const bool tr = trans == CAP_TRANS;
+  const int64_t ra = tr ? kl : nl, ca = tr ? nl : kl;      // stored dims of A's piece
+  if (lda < ra) return CAP_ERR_ARG;
+  // the exchanged copy (upstream: MatrixSrcType B = A; util::transpose(B), summa.hpp:91)
+  if (!p->xch[0]) for (int i = 0; i < 2; i++) CAP_HIP(hipMalloc((void**)&p->xch[i], sizeof(double) * nl * kl));
+  CAP_TRY(cap_copy_rect(A, lda, p->xch[0], ra, ra, ca, s0));
+  CAP_TRY(cap_util_transpose(p->topo, p->xch[0], p->xch[1], ra * ca, stream));
+  if (tr) {
+    // acc[ly, lx] = sum_k A[k, gy] A[k, gx]:  A slot = exchanged piece on (kp, y) = A(y, kp) = A[lk d + kp, ly d + y] used transposed;
+    //                                       B slot = A(x, kp) = A[lk d + kp, lx d + x]
+    CAP_TRY(summa_core(p, CAP_TRANS, CAP_NOTRANS, Slot{p->xch[0], kl, SLOT_RECT, kl, nl}, Slot{A, lda, SLOT_RECT, kl, nl}, nl, nl, kl, alpha, 0, 1, s0));
+  } else {
+    // acc[ly, lx] = sum_k A[gy, k] A[gx, k]:  A slot = A(kp, y) = A[ly d + y, lk d + kp];  B slot = exchanged piece on (x, kp) = A(kp, x) =
+    //                                       A[lx d + x, lk d + kp] used transposed
+    CAP_TRY(summa_core(p, CAP_NOTRANS, CAP_TRANS, Slot{A, lda, SLOT_RECT, nl, kl}, Slot{p->xch[0], nl, SLOT_RECT, nl, kl}, nl, nl, kl, alpha, 0, 0, s0));
+  }
+  if (c_packed) hipLaunchKernelGGL(combine_packed_kernel, dim3((unsigned)std::min<int64_t>(cap_ceil_div(nl, 256), 1024), (unsigned)nl), dim3(256), 0, s0, C, p->acc, nl, beta);
+  else hipLaunchKernelGGL(combine_kernel, dim3((unsigned)std::min<int64_t>(cap_ceil_div(nl, 256), 1024), (unsigned)nl), dim3(256), 0, s0, C, ldc, p->acc, nl, nl, nl, beta);
+  CAP_HIP(hipGetLastError());
+  return summa_join(p, s0);
 }
 
 }  // extern "C"

@@ -398,6 +398,25 @@ int cap_summa_plan_destroy(cap_summa_plan* plan);
 void cap_summa_local_dims(const cap_summa_plan* plan, int64_t* ml, int64_t* nl, int64_t* kl);
 int cap_summa_dgemm(cap_summa_plan* plan, double alpha, const double* A_local, int64_t lda, const double* B_local,
                     int64_t ldb, double beta, double* C_local, int64_t ldc, void* stream);
+/* util::transpose (util.hpp:232-247): MPI_Sendrecv_replace with the transpose partner (x, y, z) <-> (y, x, z) of topo::square.
+ * `count` doubles of `buf` are swapped (the received piece is the partner's piece as stored, NOT transposed); tmp: device
+ * scratch of `count` doubles.                                                                                            */
+int cap_util_transpose(cap_topo* topo, double* buf, double* tmp, int64_t count, void* stream);
+/* matmult::summa::invoke, TRMM overload (summa.hpp:46-83; call sites cholinv.hpp:114-120,148-154): in place
+ * B <- alpha op(T) B (side LEFT, T m x m; plan created with (m, n, k = m)) or alpha B op(T) (RIGHT, T n x n; plan (m, n, k = n))
+ * on element-cyclic pieces.  T_local = my piece of the globally upper-triangular T: rect storage (t_packed = 0, only its upper
+ * triangle is referenced) or upstream's packed-upper storage (t_packed = 1: column x at x (x + 1) / 2, structure.h:39; the
+ * packed image is what travels).  trans = CAP_TRANS: T_local must be the piece AFTER cap_util_transpose, exactly as upstream's
+ * call site prepares it.  uplo = UPPER, diag = NONUNIT only (every upstream call site); local products run on the MFMA GEMM
+ * with K ranges cut at the triangle.                                                                                     */
+int cap_summa_dtrmm(cap_summa_plan* plan, int side, int uplo, int trans, int diag, double alpha, const double* T_local, int64_t ldt,
+                    int t_packed, double* B_local, int64_t ldb, void* stream);
+/* matmult::summa::invoke, SYRK overload (summa.hpp:85-161; call site cholinv.hpp:128-133): C <- alpha A^T A + beta C (trans =
+ * CAP_TRANS, A k x n) or alpha A A^T + beta C (NoTrans, A n x k); plan created with (m = n, n = n, k).  Like upstream a GEMM of
+ * A's piece with the transpose partner's piece (internal copy + cap_util_transpose, summa.hpp:91-92).  C_local: nl x nl rect
+ * (c_packed = 0: the whole local square is written, as upstream does for a rect C) or packed upper (c_packed = 1).        */
+int cap_summa_dsyrk(cap_summa_plan* plan, int uplo, int trans, double alpha, const double* A_local, int64_t lda, double beta,
+                    double* C_local, int64_t ldc, int c_packed, void* stream);
 
 /* qr::cacqr<...>::info + factor, 1D path - cacqr.h:18-49, cacqr.hpp:5-29,172-193,217-248.
  * A is the local row-cyclic piece (m_local x n, column-major); R (n x n) is replicated;

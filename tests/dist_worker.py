@@ -126,8 +126,8 @@ def main():
         assert (rp.d, rp.x, rp.y, rp.z) == (d, x, y, z) and rp.Pr == args.pr and rp.Pc == size // args.pr
         rows = dc.global_index_2d(n, nb, rp.Pr, rp.pr); cols = dc.global_index_2d(n, nb, rp.Pc, rp.pc)
         assert rows.size == rp.bc_rows and cols.size == rp.bc_cols
-        # every layer holds the same piece upstream; here layer z adds 1000 z so that the test sees WHICH replica supplied a rank
-        P0 = matrix(n, n, d, d).from_numpy(orc.cyclic_local(a, x, y, d, d) + 1000.0 * z)
+        # every layer holds the same piece upstream; here layer z scales it by 2^z (exact) so that the test sees WHICH replica supplied a rank
+        P0 = matrix(n, n, d, d).from_numpy(orc.cyclic_local(a, x, y, d, d) * 2.0 ** z)
         bc = rp.new_bc()
         for rep in range(2):                                            # plan reuse
             bc.fill_(float("nan"))
@@ -135,10 +135,10 @@ def main():
         torch.cuda.synchronize()
         if rows.size and cols.size:
             got = bc[: cols.size, : rows.size].cpu().numpy().T
-            assert np.array_equal(got, a[np.ix_(rows, cols)] + 1000.0 * (rank % args.c)), "cyclic -> block-cyclic"
+            assert np.array_equal(got, a[np.ix_(rows, cols)] * 2.0 ** (rank % args.c)), "cyclic -> block-cyclic"
         # back: every rank of every layer receives its piece (of the layer-0 values: strip the marker first)
         if rows.size and cols.size:
-            bc[: cols.size, : rows.size] -= 1000.0 * (rank % args.c)
+            bc[: cols.size, : rows.size] *= 0.5 ** (rank % args.c)
         P1 = matrix(n, n, d, d); P1.data().fill_(float("nan"))
         rp.bc_to_cyclic(bc, P1)
         torch.cuda.synchronize()
@@ -328,6 +328,119 @@ def main():
                 assert np.array_equal(po[: len(range(y, M, d)), : len(range(x, N, d))], og[y::d, x::d])
             assert err < 1e-13, err
             print("SUMMA-OK world=%d d=%d c=%d M=%d N=%d K=%d chunks=%d err=%.2e" % (size, d, T.c, M, N, K, args.chunks, err), flush=True)
+        summa.release(T); T.close()
+    elif args.mode == "summa_tri":
+        # matmult::summa TRMM / SYRK overloads on the d x d x c grid (summa.hpp:46-161) + util::transpose, element-cyclic pieces on
+        # every rank; against the oracle's trmm / syrk; with --golden: one level of cholinv's recursion (cholinv.hpp:107-159)
+        # composed from them on the pieces of the REAL reference's 8-rank dump
+        torch.cuda.set_device(0)
+        import ctypes as C
+        from capital_amd import _lib, blas, summa, topo as tp
+        from capital_amd.matrix import matrix, serialize
+        from tests.host_staged import HostStagedComm
+        gold = np.load(os.path.join(ROOT, "tests", "golden", args.golden)) if args.golden else None
+        T = tp.square(int(gold["c"]) if gold is not None else args.c, 0, args.chunks, comm_factory=HostStagedComm)
+        d, x, y = T.d, T.x, T.y
+        CM, L_, R_, U_, NT, TR, NU = (blas.Order.AblasColumnMajor, blas.Side.AblasLeft, blas.Side.AblasRight, blas.UpLo.AblasUpper,
+                                      blas.Transpose.AblasNoTrans, blas.Transpose.AblasTrans, blas.Diag.AblasNonUnit)
+
+        def piece(g):                      # my element-cyclic piece of a global (rows x cols) array as a `matrix`
+            return matrix(g.shape[1], g.shape[0], d, d).from_numpy(orc.cyclic_local(g, x, y, d, d))
+
+        def close(m, g, tol=1e-13):        # my piece of the result against the global reference
+            want = orc.cyclic_local(g, x, y, d, d)
+            err = np.linalg.norm(m.to_numpy() - want) / max(np.linalg.norm(g) / d, 1e-300)
+            assert err < tol, (rank, err)
+            return err
+        worst = 0.0
+        if gold is None:
+            M, N = args.n, args.nb                                    # --size = m, --nb = n
+            rng = np.random.default_rng(11)
+            tm = np.triu(rng.standard_normal((M, M))) + 2.0 * np.eye(M)      # upper triangular, globally
+            tn = np.triu(rng.standard_normal((N, N))) + 2.0 * np.eye(N)
+            b = rng.standard_normal((M, N))
+            for (side, trans, t) in ((L_, NT, tm), (L_, TR, tm), (R_, NT, tn), (R_, TR, tn)):
+                Tm, Bm = piece(t), piece(b)
+                if trans == TR:
+                    summa.transpose(Tm, T)                            # upstream's call-site preparation (cholinv.hpp:115)
+                    px, py = y, x
+                    assert np.array_equal(Tm.to_numpy(), orc.cyclic_local(t, px, py, d, d)), "util::transpose: I now hold my partner's piece"
+                for rep in range(2):                                  # in place: the second call multiplies once more
+                    summa.invoke(Tm, Bm, T, blas.ArgPack_trmm(CM, side, U_, trans, NU, 0.75))
+                ref = b
+                for rep in range(2):
+                    ref = orc.trmm(t, ref, side == L_, True, trans == TR, 0.75)
+                worst = max(worst, close(Bm, ref))
+            # packed-upper storage of T through the C ABI (what upstream's uppertri matrices hold): same result as the rect piece
+            Tm, Bm = piece(tm), piece(b)
+            pl = Tm.num_rows_local()
+            packed = torch.zeros(pl * (pl + 1) // 2, dtype=torch.float64, device="cuda")
+            serialize(Tm.data(), packed, (0, pl, 0, pl), (0, 0), tri_only=True, src_ld=Tm.ld(), dst_packed=True)
+            Lh = _lib.lib()
+            _lib.check(Lh.cap_summa_dtrmm(summa._plan(T, M, N, M), int(L_), int(U_), int(NT), int(NU), -1.25, packed.data_ptr(), 0, 1,
+                                          Bm.data_ptr(), Bm.ld(), torch.cuda.current_stream().cuda_stream), "cap_summa_dtrmm(packed)")
+            worst = max(worst, close(Bm, orc.trmm(tm, b, True, True, False, -1.25)))
+            # SYRK: both transposes, beta != 0 and beta == 0, rect C (whole local square) and packed C (local upper triangle)
+            K = args.k or (M // 2 + 3)
+            a_t = rng.standard_normal((K, N)); a_n = rng.standard_normal((N, K)); c0 = rng.standard_normal((N, N)); c0 = c0 + c0.T
+            for (trans, a) in ((TR, a_t), (NT, a_n)):
+                for beta in (1.0, 0.0, -0.5):
+                    Am, Cm = piece(a), piece(c0)
+                    summa.invoke(Am, Cm, T, blas.ArgPack_syrk(CM, U_, trans, -1.0, beta))
+                    g = (a.T @ a) if trans == TR else (a @ a.T)
+                    worst = max(worst, close(Cm, -1.0 * g + beta * c0))
+                    assert np.array_equal(Am.to_numpy(), orc.cyclic_local(a, x, y, d, d)), "A is read-only"
+            Am, Cm = piece(a_t), piece(c0)
+            nl = Cm.num_rows_local()
+            cp = torch.zeros(nl * (nl + 1) // 2, dtype=torch.float64, device="cuda")
+            serialize(Cm.data(), cp, (0, nl, 0, nl), (0, 0), tri_only=True, src_ld=Cm.ld(), dst_packed=True)
+            _lib.check(Lh.cap_summa_dsyrk(summa._plan(T, N, N, K), int(U_), int(TR), -1.0, Am.data_ptr(), Am.ld(), 1.0, cp.data_ptr(), 0, 1,
+                                          torch.cuda.current_stream().cuda_stream), "cap_summa_dsyrk(packed)")
+            torch.cuda.synchronize()
+            want = orc.cyclic_local(c0 - a_t.T @ a_t, x, y, d, d)
+            got = orc.unpack_upper(cp.cpu().numpy(), nl)
+            assert np.linalg.norm(np.triu(got - want)) / np.linalg.norm(want) < 1e-13
+            tag = "m=%d n=%d k=%d" % (M, N, K)
+        else:
+            # one level of the recursion on the reference's own pieces: local n1 = pl >> split leading rows / columns of a piece are
+            # the piece of the leading global block (element-cyclic), so sub-blocks of pieces are pieces of sub-blocks
+            n, split = int(gold["n"]), int(gold["split"])
+            assert tuple(gold["rank_coords"][rank]) == (rank, T.x, T.y, T.z)
+            Ap, Rp, Rip = (np.array(v) for v in gold["pieces"][rank])
+            pl = Ap.shape[0]; n1 = pl >> split; n2 = pl - n1
+            # the dump keeps construct_R's raw local upper triangle: apply util::remove_triangle's mask (validate.hpp:11)
+            gi = np.arange(pl)[:, None] * d + y; gj = np.arange(pl)[None, :] * d + x
+            up = gi <= gj
+            Rp = np.where(up, Rp, 0.0); Rip = np.where(up, Rip, 0.0)
+
+            def mat(a):                    # a local block as a `matrix` on the d x d grid
+                return matrix(a.shape[1] * d, a.shape[0] * d, d, d).from_numpy(np.ascontiguousarray(a))
+            # (1) CI::trsm  R12 = Ri11^T A12   (cholinv.hpp:114-120)
+            Ri11 = mat(Rip[:n1, :n1]); summa.transpose(Ri11, T)
+            B12 = mat(Ap[:n1, n1:])
+            summa.invoke(Ri11, B12, T, blas.ArgPack_trmm(CM, L_, U_, TR, NU, 1.0))
+            e1 = np.linalg.norm(B12.to_numpy() - Rp[:n1, n1:]) / np.linalg.norm(Rp[:n1, n1:])
+            # (2) CI::tmu   A22 <- A22 - R12^T R12   (cholinv.hpp:128-133) == R22^T R22 of the dump (global product, cut into my piece)
+            C22 = mat(Ap[n1:, n1:])
+            summa.invoke(mat(Rp[:n1, n1:]), C22, T, blas.ArgPack_syrk(CM, U_, TR, -1.0, 1.0))
+            rg = np.triu(gold["R"]); g1 = n1 * d
+            s22 = rg[g1:, g1:].T @ rg[g1:, g1:]
+            want = orc.cyclic_local(s22, x, y, d, d)
+            e2 = np.linalg.norm((C22.to_numpy() - want)[up[n1:, n1:]]) / np.linalg.norm(want)
+            # (3) CI::tmu   Ri12 = -Ri11 R12 Ri22   (cholinv.hpp:148-154): TRMM left NoTrans, then right NoTrans with alpha = -1
+            e3 = 0.0
+            if int(gold["complete_inv"]) == 1:
+                W = mat(Rp[:n1, n1:])
+                summa.invoke(mat(Rip[:n1, :n1]), W, T, blas.ArgPack_trmm(CM, L_, U_, NT, NU, 1.0))
+                summa.invoke(mat(Rip[n1:, n1:]), W, T, blas.ArgPack_trmm(CM, R_, U_, NT, NU, -1.0))
+                e3 = np.linalg.norm(W.to_numpy() - Rip[:n1, n1:]) / np.linalg.norm(Rip[:n1, n1:])
+            assert e1 < 1e-13 and e2 < 1e-13 and e3 < 1e-12, (rank, e1, e2, e3)
+            worst = max(e1, e2, e3)
+            tag = "golden=ok n=%d" % n
+        errs = [None] * size
+        dist.all_gather_object(errs, float(worst))
+        if rank == 0:
+            print("SUMMATRI-OK world=%d grid=%dx%dx%d %s max_err=%.2e" % (size, d, d, T.c, tag, max(errs)), flush=True)
         summa.release(T); T.close()
     elif args.mode == "cacqr3d":
         # qr::cacqr on the c x d x c grid (bench/qr/cacqr.cpp:28-41): rows cyclic over d, columns over c, replicated over the layers

@@ -386,3 +386,25 @@ def test_reference_layout_end_to_end_against_the_oracle(nproc, c, mode, pr, n, n
     r = _launch(nproc, mode, n, nb, 29851 + nproc + pr, ("--c", c, "--pr", pr, "--ci", ci))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "CYCLIC-OK" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,c,M,N,K,chunks", [(4, 1, 384, 256, 200, 0), (8, 2, 512, 384, 0, 2), (9, 1, 300, 210, 150, 0), (4, 1, 301, 203, 97, 3),
+                                                   (1, 1, 256, 128, 64, 0)])
+def test_summa_trmm_and_syrk_overloads_on_process_grids(nproc, c, M, N, K, chunks):
+    """matmult::summa's TRMM (Left / Right x NoTrans / Trans, rect and packed-upper T) and SYRK (Trans / NoTrans, beta, rect and
+    packed C) overloads on d x d x c grids sharing one GPU, util::transpose partner exchange included - against the oracle."""
+    r = _launch(nproc, "summa_tri", M, N, 29871 + nproc + c, ("--c", c, "--k", K, "--chunks", chunks))
+    assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    assert "SUMMATRI-OK" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cholinv_p8_n128_ci1_s1_bc-2.npz", "cholinv_p8_n192_ci0_s1_bc-3.npz", "cholinv_p8_n250_ci1_s1_bc-2.npz"])
+def test_reference_recursion_composed_from_the_distributed_operators(name):
+    """One level of cholinv's recursion (CI::trsm, CI::tmu, the inverse completion - cholinv.hpp:107-159) composed from
+    util::transpose + the distributed TRMM / SYRK on the pieces the REAL reference left on its 8 ranks: R12, the Schur
+    complement and Rinv12 come out as the reference's own pieces."""
+    r = _launch(8, "summa_tri", 128, 128, 29891, ("--golden", name))
+    assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    assert "SUMMATRI-OK" in r.stdout and "golden=ok" in r.stdout, r.stdout[-2000:]
