@@ -101,6 +101,7 @@ SIGNATURES = {
     "cap_dist_profile": (cint, [ptr, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]),
     "cap_dist_profile_streams": (cint, [ptr, C.POINTER(dbl)]),
     "cap_dist_progress": (cint, [ptr, C.POINTER(i64)]),
+    "cap_dist_profile_inverse": (cint, [ptr, C.POINTER(dbl)]),
     "cap_fill_symmetric_bc": (cint, [ptr, i64, i64, i64, cint, cint, cint, ptr]),
     "cap_bc_owner": (cint, [i64, cint]),
     "cap_bc_local_block": (i64, [i64, cint]),

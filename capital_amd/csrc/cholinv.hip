@@ -921,8 +921,8 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   if (dir != 'U') return CAP_ERR_UNSUPPORTED;                      // assert(args.dir == 'U'), cholinv.hpp:9
   if (complete_inv < -1 || complete_inv > 1) return CAP_ERR_ARG;
   const bool multi = comm && cap_comm_size(comm) > 1;
-  // multi-GPU: the blocked Cholesky of dist.hip; complete_inv = 0 / 1 add R^-1 by one all-gather of R + a local block
-  // substitution per rank (dist.hip, dist_inverse) - upstream's R + R^-1 semantics on P > 1
+  // multi-GPU: the blocked Cholesky of dist.hip; complete_inv = 0 / 1 add R^-1 by the streamed column-broadcast product of
+  // dist.hip (inverse_step) - upstream's R + R^-1 semantics on P > 1
   cap_cholinv_plan* p = new (std::nothrow) cap_cholinv_plan();
   if (!p) return CAP_ERR_ALLOC;
   memset(p, 0, sizeof(*p));

@@ -79,12 +79,14 @@ struct cap_dist_plan {
   // the bulk update for CU slots (the reference pipelines the same move with MPI_Ibcast, summa.hpp:185-214).  Two 8-byte
   // all-reduces per strip carry the synchronisation: "every rank's buffer is free" before the pushes, "every push has
   // landed" after them.  RCCL stays the default and the fallback (option off, or if mapping a peer fails).
-  // R^-1 on the distributed factor (complete_inv = 0 / 1, the reference's semantics on P > 1): see dist_inverse
+  // R^-1 on the distributed factor (complete_inv = 0 / 1, the reference's semantics on P > 1): see inverse_step
   int complete_inv; int64_t split;
-  double* Rall;                  // all-gathered R: P pieces of npad x nmax0 (rank r's block columns), ld = npad
-  double* Dall;                  // every diagonal-block inverse (nblk x nb x nb), saved from the msg broadcasts
-  double* Ri;                    // my block columns of R^-1 (npad x nmax0, ld = npad)
-  double* Bacc;                  // right-hand-side accumulator of the block substitution (same shape)
+  double* Dall;                  // the diagonal-block inverses of MY block columns' steps (nblk x nb x nb slots), saved from the msg broadcasts
+  double* Ri;                    // my block columns of R^-1 (npad x lc, ld = npad): the partial product X_k while the sweep runs
+  double* Cb[2];                 // ring of two broadcast buffers for a finished block column of R^-1 (npad x nb each)
+  cap_comm* comm3;               // the inverse's broadcasts (owned duplicate): they run on their own stream next to the sweep's collectives
+  hipStream_t s_inv; hipEvent_t ev_join_i;
+  hipEvent_t ev_t0, ev_sweep_end, ev_inv_end;    // profile mode (timing): start of the call, the sweep's join, end of the inverse
   int ipc; bool ipc_ready; bool ipc_failed;
   double* peerG[8][2]; hipStream_t s_peer[8]; hipEvent_t ev_x0, ev_xr[8]; double* token; int ipc_nocu;
 };
@@ -282,60 +284,90 @@ int update(cap_dist_plan* d, int64_t m, int64_t nloc, int64_t K, const double* G
   }
   return CAP_OK;
 }
-// R^-1 of the distributed factor (complete_inv = 0 / 1 with P > 1: the reference's `factor` leaves both R and R^-1 on its
-// grid, cholinv.hpp:85-165 + the distributed TRMM of summa.hpp:46-83).  On the 1 x P layout every block column of R^-1 only
-// depends on R and on ITSELF:  R X = E_J  =>  X[i, J] = Dinv(i) (E[i, J] - sum_{i < k <= J} R[i, k] X[k, J]),  so after ONE
-// all-gather of R (the same volume as the factorization's strip exchanges) every rank back-substitutes its own block columns
-// with no further communication: block rows bottom-up,
-//     X[i, Js] = Dinv(i) Bacc[i, Js]            (Js = my blocks J >= i; Bacc[i, i] = I, i.e. X[i, i] = Dinv(i))
-//     Bacc[0:i, Js] -= R[0:i, i] X[i, Js]       (one MFMA GEMM, M = i nb, K = nb)
-// exactly (n^3 / 3) / P flops per rank.  Dinv(i) are the diagonal-block inverses every rank already received in msg(i).
-// complete_inv == 0: the root block Ri[0:n1, n1:n] (n1 = n >> split, cholinv.hpp:107,147) stays empty - the columns J >= n1
-// stop their substitution at block row n1 / nb (n1 on a block boundary), or the block is cleared afterwards (n1 inside a block).
-int dist_inverse(cap_dist_plan* d, hipStream_t s) {
-  CapRange range("CI::inverse");
-  const int64_t nb = d->nb, nblk = d->nblk, npad = d->npad, P = d->P, p = d->p, nb2 = nb * nb;
-  const int64_t pe = npad * d->nmax0;
-  // 1. replicate R: piece r = rank r's block columns (padded to nmax0 columns)
-  CAP_TRY(cap_comm_allgather(d->comm, d->R, d->Rall, pe, (void*)s));
-  if (d->nloc_blocks == 0) return CAP_OK;
-  CAP_HIP(hipMemsetAsync(d->Ri, 0, sizeof(double) * pe, s));
-  CAP_HIP(hipMemsetAsync(d->Bacc, 0, sizeof(double) * pe, s));
+// R^-1 of the distributed factor (complete_inv = 0 / 1 with P > 1: the reference's `factor` leaves both R and R^-1 on its grid,
+// cholinv.hpp:85-165 + the distributed TRMM of summa.hpp:46-83) - STREAMED with the sweep, no replicated R.
+//   R = E_{nblk-1} ... E_1 E_0,  E_k = identity with block row k replaced by block row k of R, so
+//   R^-1 = E_0^-1 E_1^-1 ... E_{nblk-1}^-1,  E_k^-1 = identity with block row k replaced by [ Dinv(k) | -Dinv(k) R[k, k+1:] ],
+// and the partial products X_k = E_0^-1 ... E_k^-1 can be built LEFT TO RIGHT, i.e. in the order the sweep finishes block rows:
+//   step k   owner(k):  X[0:k+1, k] <- X[0:k+1, k] Dinv(k)            (block column k of R^-1 is final: rows 0 .. k)
+//            broadcast of that column ((k + 1) nb x nb doubles, the volume of HALF an all-gather of R over the whole run)
+//            every rank: X[0:k+1, Js] -= X[0:k+1, k] R[k, Js]          (Js = my block columns J > k; R[k, Js] is my OWN piece of the
+//                                                                      solved block row: no other rank's part of R is ever needed)
+// Each rank holds its block columns of R and of R^-1 plus two n x nb broadcast buffers: per-rank memory O(n^2 / P + nb n) where the
+// previous form replicated R (32 GiB per rank at N = 65536).  Exactly (n^3 / 3) / P flops per rank, one MFMA GEMM per step, enqueued on
+// its own stream behind "block row k is solved" - the inverse runs inside the factorization wherever that is chain- or
+// communication-bound (cap_dist_profile_inverse reports how much of it was left after the sweep's join).
+// complete_inv == 0: the root block Ri[0:n1, n1:n] (n1 = n >> split, cholinv.hpp:107,147) stays empty - columns J >= n1 / nb take no
+// updates from block rows k < n1 / nb and are only finished from row n1 on (n1 on a block boundary), or the block is cleared
+// afterwards (n1 inside a block).
+__global__ void identity_blocks_bc_kernel(double* X, int64_t ld, int64_t nb, int P, int p, int64_t lc) {
+  const int64_t l = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (l >= lc) return;
+  const int64_t g = ((l / nb) * P + p) * nb + l % nb;        // global (= row) index of local column l
+  X[g + l * ld] = 1.0;
+}
+
+struct InvCut { bool cut; int64_t kcut, n1; };
+inline InvCut inv_cut(const cap_dist_plan* d) {
   const int64_t n1 = d->n >> d->split;
   const bool cut = d->complete_inv == 0 && n1 > 0 && n1 < d->n;
-  const int64_t kcut = (cut && n1 % nb == 0) ? n1 / nb : 0;          // block boundary of the root partition (0: none)
-  for (int64_t i = nblk - 1; i >= 0; i--) {
-    // my local blocks with J >= i ... and, above the root partition's row boundary, only those with J < kcut
-    const int64_t lb0 = lbfirst(p, i - 1, P);
-    int64_t lb1 = d->nloc_blocks;
-    if (kcut > 0 && i < kcut) lb1 = lbfirst(p, kcut - 1, P);
-    if (lb1 <= lb0) continue;
-    const double* Dinv = d->Dall + i * nb2;
-    double* Xi = d->Ri + i * nb + lb0 * nb * npad;                   // block row i of my columns from local block lb0 on
-    int64_t lbx = lb0;
-    if (lb0 * P + p == i) {                                          // I own block column i: X[i, i] = Dinv(i)
-      CAP_TRY(cap_copy_rect(Dinv, nb, Xi, npad, nb, nb, s));
-      lbx = lb0 + 1;
-    }
-    if (lb1 > lbx)
-      CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, nb, (lb1 - lbx) * nb, nb, 1.0, Dinv, nb, d->Bacc + i * nb + lbx * nb * npad, npad, 0.0,
-                              d->Ri + i * nb + lbx * nb * npad, npad, 0, s, 32));
-    // rows above: all of them, or - for the columns right of the root partition - only those below its row boundary (the block
-    // Ri[0:n1, n1:n] stays empty, so its right-hand sides are never formed)
-    const int64_t r0 = (kcut > 0 && i >= kcut) ? kcut * nb : 0;
-    if (i * nb > r0) {
-      const double* Rcol = d->Rall + (i % P) * pe + (i / P) * nb * npad + r0;   // R[r0 : i nb, block column i]
-      CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, i * nb - r0, (lb1 - lb0) * nb, nb, -1.0, Rcol, npad, Xi, npad, 1.0,
-                              d->Bacc + r0 + lb0 * nb * npad, npad, 0, s));
-    }
+  return InvCut{cut, (cut && n1 % d->nb == 0) ? n1 / d->nb : 0, n1};
+}
+
+// step k of the product above on stream s (broadcast on communicator c); see Bucket kind 6
+int inverse_step(cap_dist_plan* d, int64_t k, hipStream_t s, cap_comm* c) {
+  CapRange range("CI::inverse");
+  Bucket bk(d, 6, s);
+  const int64_t nb = d->nb, npad = d->npad, P = d->P, p = d->p, nb2 = nb * nb;
+  const InvCut ic = inv_cut(d);
+  const int64_t rows0 = (ic.kcut > 0 && k >= ic.kcut) ? ic.kcut * nb : 0;     // columns right of the root partition start at its row
+  const int64_t rows = (k + 1) * nb - rows0;
+  const int owner = (int)(k % P);
+  double* Cbuf = d->Cb[k & 1];
+  CAP_TRY(jitter(d, s));
+  if (p == owner) {
+    double* Xk = d->Ri + rows0 + (k / P) * nb * npad;
+    // (X_{k-1}[:, k]) Dinv(k): Dinv upper triangular -> K range of a column tile stops at its diagonal (tag 8)
+    CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, rows, nb, nb, 1.0, Xk, npad, d->Dall + k * nb2, nb, 0.0, Cbuf, rows, 0, s, 8));
+    CAP_TRY(cap_copy_rect(Cbuf, rows, Xk, npad, rows, nb, s));
+    d->cnt_gemm++; d->cnt_copy++;
   }
-  if (cut && kcut == 0) {
+  CAP_TRY(cap_comm_bcast(c, Cbuf, rows * nb, owner, (void*)s)); d->cnt_coll++;
+  const int64_t lb0 = lbfirst(p, k, P);
+  int64_t lb1 = d->nloc_blocks;
+  if (ic.kcut > 0 && k < ic.kcut) lb1 = lbfirst(p, ic.kcut - 1, P);          // left of the root partition only
+  if (lb1 > lb0) {
+    CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, rows, (lb1 - lb0) * nb, nb, -1.0, Cbuf, rows, d->R + k * nb + lb0 * nb * d->ld, d->ld, 1.0,
+                            d->Ri + rows0 + lb0 * nb * npad, npad, 0, s));
+    d->cnt_gemm++;
+  }
+  return CAP_OK;
+}
+
+int inverse_finish(cap_dist_plan* d, hipStream_t s) {
+  const InvCut ic = inv_cut(d);
+  if (ic.cut && ic.kcut == 0) {
     // root partition inside a block: clear Ri[0:n1, columns >= n1] of my columns
     for (int64_t lb = 0; lb < d->nloc_blocks; lb++) {
-      const int64_t c0 = (lb * P + p) * nb;
-      const int64_t from = std::max<int64_t>(c0, n1), to = c0 + nb;
-      if (from < to) CAP_TRY(cap_zero_rect(d->Ri + (lb * nb + (from - c0)) * npad, npad, n1, to - from, s));
+      const int64_t c0 = (lb * d->P + d->p) * d->nb;
+      const int64_t from = std::max<int64_t>(c0, ic.n1), to = c0 + d->nb;
+      if (from < to) CAP_TRY(cap_zero_rect(d->Ri + (lb * d->nb + (from - c0)) * d->npad, d->npad, ic.n1, to - from, s));
     }
+  }
+  return CAP_OK;
+}
+
+// buffers of the streamed inverse; called when the option is set, so an allocation failure is reported BEFORE any rank enters a collective
+int ensure_inverse_buffers(cap_dist_plan* d) {
+  if (d->Ri) return CAP_OK;
+  const int64_t cols = std::max<int64_t>(d->lc, d->nb);
+  hipError_t e = hipMalloc((void**)&d->Ri, sizeof(double) * d->npad * cols);
+  if (e == hipSuccess) e = hipMalloc((void**)&d->Dall, sizeof(double) * d->nblk * d->nb * d->nb);
+  for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void**)&d->Cb[i], sizeof(double) * d->npad * d->nb);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    for (double** q : {&d->Ri, &d->Dall, &d->Cb[0], &d->Cb[1]}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+    return CAP_ERR_ALLOC;
   }
   return CAP_OK;
 }
@@ -389,7 +421,8 @@ int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* 
   d->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
   d->profile = 0; d->prof_used = 0; d->bk_used = 0; d->safe = 0;
   d->cnt_gemm = d->cnt_chain = d->cnt_copy = d->cnt_coll = 0;
-  d->complete_inv = -1; d->split = 1; d->Rall = d->Dall = d->Ri = d->Bacc = nullptr;
+  d->complete_inv = -1; d->split = 1; d->Dall = d->Ri = nullptr; d->Cb[0] = d->Cb[1] = nullptr; d->comm3 = nullptr;
+  d->s_inv = nullptr; d->ev_join_i = nullptr; d->ev_t0 = d->ev_sweep_end = d->ev_inv_end = nullptr;
   d->ipc = getenv("CAP_DIST_IPC") ? atoi(getenv("CAP_DIST_IPC")) : 0; d->ipc_ready = false; d->ipc_failed = false; d->token = nullptr;
   d->ipc_nocu = getenv("CAP_DIST_IPC_NOCU") ? atoi(getenv("CAP_DIST_IPC_NOCU")) : 0;
   for (int r = 0; r < 8; r++) { d->peerG[r][0] = d->peerG[r][1] = nullptr; d->s_peer[r] = nullptr; d->ev_xr[r] = nullptr; }
@@ -399,7 +432,7 @@ int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* 
     int st = cap_comm_dup(comm, &d->comm2);
     if (st != CAP_OK) { delete d; return st; }
   }
-  hipError_t e = hipMalloc((void**)&d->R, sizeof(double) * std::max<int64_t>(d->npad * std::max(d->lc, d->nmax0), 2));   // nmax0 columns: the all-gather of R (dist_inverse) sends equal pieces
+  hipError_t e = hipMalloc((void**)&d->R, sizeof(double) * std::max<int64_t>(d->npad * d->lc, 2));
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
     // S: one extra block column - a rank that owns the strip's last block sends from one block further in, and the
     // equal-sized padded pieces are as wide as the widest rank's remainder
@@ -427,7 +460,10 @@ int cap_dist_plan_destroy(cap_dist_plan* d) {
   if (d->W) (void)hipFree(d->W);
   if (d->info_dev) (void)hipFree(d->info_dev);
   if (d->info_red) (void)hipFree(d->info_red);
-  for (double* q : {d->Rall, d->Dall, d->Ri, d->Bacc}) if (q) (void)hipFree(q);
+  for (double* q : {d->Dall, d->Ri, d->Cb[0], d->Cb[1]}) if (q) (void)hipFree(q);
+  if (d->s_inv) { (void)hipStreamSynchronize(d->s_inv); (void)hipStreamDestroy(d->s_inv); }
+  for (hipEvent_t e : {d->ev_join_i, d->ev_t0, d->ev_sweep_end, d->ev_inv_end}) if (e) (void)hipEventDestroy(e);
+  if (d->comm3) cap_comm_destroy(d->comm3);
   if (!d->ev_msg.empty()) {
     for (auto* v : {&d->ev_fact, &d->ev_msg, &d->ev_rowdone, &d->ev_solved, &d->ev_gather, &d->ev_head2, &d->ev_rest})
       for (auto e : *v) (void)hipEventDestroy(e);
@@ -460,7 +496,12 @@ int cap_dist_set_option(cap_dist_plan* d, const char* key, int64_t value) {
   if (k == "profile") { d->profile = value != 0; return CAP_OK; }
   if (k == "safe") { d->safe = value != 0; return CAP_OK; }
   if (k == "ipc") { d->ipc = value != 0; return CAP_OK; }
-  if (k == "complete_inv") { if (value < -1 || value > 1) return CAP_ERR_ARG; d->complete_inv = (int)value; return CAP_OK; }
+  if (k == "complete_inv") {
+    if (value < -1 || value > 1) return CAP_ERR_ARG;
+    if (value >= 0) CAP_TRY(ensure_inverse_buffers(d));       // O(n^2 / P + nb n) doubles; a failure is reported here, not inside factor
+    d->complete_inv = (int)value;
+    return CAP_OK;
+  }
   if (k == "split") { if (value <= 0) return CAP_ERR_ARG; d->split = value; return CAP_OK; }
   if (k == "ipc_nocu") { d->ipc_nocu = value != 0; return CAP_OK; }
   return CAP_ERR_ARG;
@@ -497,16 +538,25 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
   if (!d || (d->lc_valid > 0 && (!Aloc || lda < d->n))) return CAP_ERR_ARG;
   CAP_TRY(ensure_events(d));
   if (d->ipc) CAP_TRY(ensure_ipc(d, cap_stream(stream)));
-  if (d->complete_inv >= 0 && !d->Ri) {
-    const int64_t pe = d->npad * d->nmax0;
-    hipError_t e = hipMalloc((void**)&d->Rall, sizeof(double) * pe * d->P);
-    if (e == hipSuccess) e = hipMalloc((void**)&d->Dall, sizeof(double) * d->nblk * d->nb * d->nb);
-    if (e == hipSuccess) e = hipMalloc((void**)&d->Ri, sizeof(double) * pe);
-    if (e == hipSuccess) e = hipMalloc((void**)&d->Bacc, sizeof(double) * pe);
-    if (e != hipSuccess) return CAP_ERR_ALLOC;
+  const bool inv = d->complete_inv >= 0;
+  if (inv) {
+    CAP_TRY(ensure_inverse_buffers(d));
+    if (!d->s_inv) {
+      int lo = 0, hi = 0;
+      CAP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      CAP_HIP(hipStreamCreateWithPriority(&d->s_inv, hipStreamNonBlocking, lo));      // below the panel stream: it fills the gaps
+      CAP_HIP(hipEventCreateWithFlags(&d->ev_join_i, hipEventDisableTiming));
+      CAP_HIP(hipEventCreate(&d->ev_t0)); CAP_HIP(hipEventCreate(&d->ev_sweep_end)); CAP_HIP(hipEventCreate(&d->ev_inv_end));
+      if (d->comm2) CAP_TRY(cap_comm_dup(d->comm, &d->comm3));
+    }
   }
   hipStream_t s0 = cap_stream(stream), s1 = d->s_panel, sc = d->s_comm, sm = d->safe ? d->s_comm : d->s_msg;
   cap_comm* cmsg = (d->safe || !d->comm2) ? d->comm : d->comm2;
+  // the inverse's steps: overlapped (own stream + own communicator, enqueued as the block rows finish) or - safe mode: ONE
+  // communicator, collectives in program order - after the sweep on the caller's stream
+  const bool inv_overlap = inv && !d->safe;
+  hipStream_t si = inv_overlap ? d->s_inv : s0;
+  cap_comm* cinv = (inv_overlap && d->comm3) ? d->comm3 : d->comm;
   const int64_t n = d->n, npad = d->npad, nb = d->nb, nblk = d->nblk, P = d->P, p = d->p, ld = d->ld;
   const int64_t nb2 = nb * nb;
   d->prof_used = 0; d->prof_flops.clear(); d->bk_used = 0;
@@ -523,10 +573,20 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
                          d->R, ld, n, npad, nb, (int)P, (int)p, (int64_t)0, d->lc_valid, npad, d->lc - d->lc_valid);
     CAP_HIP(hipGetLastError());
   }
+  if (inv) {
+    // X_{-1} = I on my block columns
+    if (d->profile) CAP_HIP(hipEventRecord(d->ev_t0, s0));
+    CAP_HIP(hipMemsetAsync(d->Ri, 0, sizeof(double) * d->npad * std::max<int64_t>(d->lc, 1), s0));
+    if (d->lc > 0) {
+      hipLaunchKernelGGL(identity_blocks_bc_kernel, dim3((unsigned)cap_ceil_div(d->lc, 256)), dim3(256), 0, s0, d->Ri, npad, nb, (int)P, (int)p, d->lc);
+      CAP_HIP(hipGetLastError());
+    }
+  }
   CAP_HIP(hipEventRecord(d->ev_init, s0));
   CAP_HIP(hipStreamWaitEvent(s1, d->ev_init, 0));
   CAP_HIP(hipStreamWaitEvent(sc, d->ev_init, 0));
   CAP_HIP(hipStreamWaitEvent(sm, d->ev_init, 0));
+  if (inv_overlap) CAP_HIP(hipStreamWaitEvent(si, d->ev_init, 0));
 
   // strips: sb[t] = first block row, sq[t] = block rows (d->strip, the last one may be shorter)
   std::vector<int64_t> sb, sq;
@@ -571,7 +631,7 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
 
       // ---- panel, every rank: block row k of my columns J > k
       CAP_HIP(hipStreamWaitEvent(s1, d->ev_msg[k], 0));
-      if (d->complete_inv >= 0) { CAP_TRY(cap_copy_rect(Dinv, nb, d->Dall + k * nb2, nb, nb, nb, s1)); d->cnt_copy++; }   // kept for the inverse (dist_inverse)
+      if (inv && p == owner) { CAP_TRY(cap_copy_rect(Dinv, nb, d->Dall + k * nb2, nb, nb, nb, s1)); d->cnt_copy++; }   // kept for step k of the inverse
       if (r == 0 && t >= 2) CAP_HIP(hipStreamWaitEvent(s1, d->ev_gather[t - 2], 0));   // S[par] was the all-gather source of strip t-2
       const int64_t lbk = lbfirst(p, k, P);
       const int64_t ncols = (d->nloc_blocks - lbk) * nb;
@@ -590,6 +650,10 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
         d->cnt_gemm++; d->cnt_copy++;
       }
       CAP_HIP(hipEventRecord(d->ev_rowdone[k], s1));
+      if (inv_overlap) {       // block row k is final: step k of the streamed inverse (its own stream, next to everything below)
+        CAP_HIP(hipStreamWaitEvent(si, d->ev_rowdone[k], 0));
+        CAP_TRY(inverse_step(d, k, si, cinv));
+      }
     }
     CAP_HIP(hipEventRecord(d->ev_solved[t], s1));
     if (e >= nblk) continue;
@@ -650,7 +714,17 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
   CAP_HIP(hipStreamWaitEvent(s0, d->ev_join_p, 0));
   CAP_HIP(hipStreamWaitEvent(s0, d->ev_join_c, 0));
   CAP_HIP(hipStreamWaitEvent(s0, d->ev_join_m, 0));
-  if (d->complete_inv >= 0) CAP_TRY(dist_inverse(d, s0));
+  if (inv) {
+    if (d->profile) CAP_HIP(hipEventRecord(d->ev_sweep_end, s0));
+    if (inv_overlap) {
+      CAP_HIP(hipEventRecord(d->ev_join_i, si));
+      CAP_HIP(hipStreamWaitEvent(s0, d->ev_join_i, 0));
+    } else {
+      for (int64_t k = 0; k < nblk; k++) CAP_TRY(inverse_step(d, k, s0, cinv));
+    }
+    CAP_TRY(inverse_finish(d, s0));
+    if (d->profile) CAP_HIP(hipEventRecord(d->ev_inv_end, s0));
+  }
   return CAP_OK;
 }
 
@@ -727,6 +801,27 @@ int cap_dist_profile_streams(cap_dist_plan* d, double* out6) {
     CAP_HIP(hipEventElapsedTime(&ms, d->prof_ev[(size_t)i], d->prof_ev[(size_t)i + 1]));
     out6[5] += ms;
   }
+  return CAP_OK;
+}
+
+// profile mode, complete_inv >= 0: out3 = busy ms of the inverse's launch groups (summed), ms between the sweep's join and the end of
+// the inverse (what the overlap did NOT hide; the whole inverse in safe mode), ms of the whole factor call.  Synchronises.
+int cap_dist_profile_inverse(cap_dist_plan* d, double* out3) {
+  if (!d || !out3) return CAP_ERR_ARG;
+  out3[0] = out3[1] = out3[2] = 0.0;
+  if (d->complete_inv < 0 || !d->ev_inv_end || !d->profile) return CAP_OK;
+  for (int i = 0; i + 1 < d->bk_used; i += 2) {
+    if (d->bk_kind[(size_t)i] != 6) continue;
+    CAP_HIP(hipEventSynchronize(d->bk_ev[(size_t)i + 1]));
+    float ms = 0;
+    CAP_HIP(hipEventElapsedTime(&ms, d->bk_ev[(size_t)i], d->bk_ev[(size_t)i + 1]));
+    out3[0] += ms;
+  }
+  CAP_HIP(hipEventSynchronize(d->ev_inv_end));
+  float a = 0, b = 0;
+  CAP_HIP(hipEventElapsedTime(&a, d->ev_sweep_end, d->ev_inv_end));
+  CAP_HIP(hipEventElapsedTime(&b, d->ev_t0, d->ev_inv_end));
+  out3[1] = a; out3[2] = b;
   return CAP_OK;
 }
 

@@ -328,9 +328,13 @@ double* cap_dist_R_ptr(cap_dist_plan* plan, int64_t* ld);               /* local
 int cap_dist_get_R(cap_dist_plan* plan, double* out, int64_t ld, void* stream);   /* construct_R: n x local_cols, zero below
                                                                                       the global diagonal              */
 /* Options "complete_inv" = 0 / 1 (+ "split"): the factor call also leaves this rank's block columns of R^-1 - upstream's
- * R + R^-1 semantics on P > 1 (cholinv.hpp:85-165): ONE all-gather of R, then every rank back-substitutes its own columns
- * with the diagonal-block inverses it received during the factorization ((n^3/3)/P flops per rank, no further
- * communication).  complete_inv = 0 leaves Ri[0 : n >> split, n >> split : n] empty (cholinv.hpp:107,147).             */
+ * R + R^-1 semantics on P > 1 (cholinv.hpp:85-165) - STREAMED with the sweep: as soon as block row k is solved, the owner of
+ * block column k finishes that column of R^-1 (X[0:k+1, k] Dinv(k)), broadcasts it ((k+1) nb x nb doubles) and every rank
+ * updates its own block columns J > k with its OWN piece of the solved row (X[0:k+1, J] -= X[0:k+1, k] R[k, J]) - one MFMA GEMM
+ * per step on the plan's inverse stream, (n^3/3)/P flops per rank, half the bytes of an all-gather of R, no replicated R:
+ * per-rank memory is the local columns of R and R^-1 plus two n x nb buffers (allocated when the option is set, so a failure is
+ * reported before any collective).  "safe" = 1 runs the steps after the sweep on the one communicator.
+ * complete_inv = 0 leaves Ri[0 : n >> split, n >> split : n] empty (cholinv.hpp:107,147).                              */
 int cap_dist_get_Rinv(cap_dist_plan* plan, double* out, int64_t ld, void* stream);   /* construct_Rinv, same layout as get_R */
 double* cap_dist_Rinv_ptr(cap_dist_plan* plan, int64_t* ld);
 /* 0, or the smallest failing pivot (1-based) reported by any rank.  Collective; call it on the stream
@@ -348,6 +352,9 @@ int cap_dist_profile(cap_dist_plan* plan, int64_t* launches, double* ms_total, d
 /* profile mode, per stream role: out6 = busy ms of the diagonal-block chains, block-row solves, HEAD updates (panel stream),
  * message broadcasts, strip exchanges (communication streams) and bulk updates (caller's stream) of the LAST factor call. */
 int cap_dist_profile_streams(cap_dist_plan* plan, double* out6);
+/* profile mode, complete_inv >= 0: out3 = busy ms of the streamed inverse's launch groups, ms of it left after the sweep's join
+ * (what the overlap did not hide), ms of the whole factor call.                                                          */
+int cap_dist_profile_inverse(cap_dist_plan* plan, double* out3);
 /* Non-blocking progress of the factor call in flight (host watchdog of bench.py): out9 = leading complete events among
  * fact, msg, rowdone (per block row), solved, gather, head2, rest (per strip), then the block-row and strip counts.
  * Option "safe" = 1 runs the same schedule with ONE communicator and ONE communication stream (collectives in program order). */

@@ -129,6 +129,10 @@ def test_multirank_schedule_under_random_stream_delays(nproc, n, nb, jitter):
     (8, 4096, 512, ("--ci", 1)),
     (2, 2048, 256, ("--ci", 1, "--seam", 1)),                     # through cholinv::factor / construct_Rinv with a multi-rank topo
     (1, 1024, 128, ("--ci", 0)),
+    # the streamed inverse under random per-stream delays (its steps run on their own stream behind "block row k is solved"), with the
+    # IPC strip exchange, and with more steps
+    (4, 2048, 128, ("--ci", 1, "--jitter", 300)), (3, 1536, 128, ("--ci", 0, "--jitter", 200)), (4, 2048, 128, ("--ci", 1, "--ipc", 1)),
+    (2, 4096, 128, ("--ci", 1)), (8, 8192, 512, ("--ci", 0, "--safe", 1)),
 ])
 def test_distributed_inverse_matches_oracle(nproc, n, nb, extra):
     r = _launch(nproc, "gpu", n, nb, 29761 + nproc, extra)
