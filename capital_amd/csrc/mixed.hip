@@ -209,7 +209,245 @@ int launch_bf16_tn(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
+
+// =====================================================================================================================================
+// bf16 update, second generation (round 4): what the round-3 measurements asked for (profiles/r03_bf16_update_pmc.txt: matrix pipe busy
+// 40 %, waves waiting 52 % of their cycles; K = 1024 -> 2048 showed a fixed cost of 0.45 K-1024-loops per 128 x 128 tile).
+//   * 256 x 128 C tile per 512-thread workgroup: 48 KiB of operands per 64-deep K tile for 4.2 MFLOP (87 flop/B through L2, 64 before)
+//   * wave specialisation: waves 0-3 compute (128 x 64 each: 8 accumulators of 32 x 32), waves 4-7 only move data (LDS-DMA).
+//     The two roles never share a memory counter: the loaders' vmcnt counts DMA pieces only (12 per wave and stage, waited for with a
+//     COUNTED s_waitcnt - loads return in order), the compute waves' vmcnt counts their fire-and-forget fp32 atomics only and is never
+//     waited for.  (One wave doing both cannot use a counted wait: loads and atomics complete out of order with respect to each other.)
+//   * three-deep LDS ring of 48 KiB stages (144 of 160 KiB, one workgroup per CU): stage g + 2 is requested when stage g is handed
+//     over - a prefetch distance of two K tiles (~2000 cycles of MFMA work) against the ~1-2 us the L2 misses take under load
+//   * ONE raw s_barrier per K tile; fragments one k-step ahead in registers; the last k-step of a stage runs behind the barrier
+//     and covers the first fragment reads of the next stage
+//   * tile loop: a workgroup walks `tpw` supertile steps (a chunk of up to tpw tiles); the ring runs on across tile boundaries, the
+//     accumulators' 128 atomics per lane are issued behind the next tile's first fragment reads and drain while it computes.
+//     Round 3's kernels paid prologue DMA + epilogue drain per tile with the whole chip in lockstep (every tile takes the same time, so
+//     all 512 resident tiles reached their read-modify-write of C - 32 MB, an HBM-bound burst - together while the matrix pipes idled).
+//   * XCD-aware order: the 32 workgroups an XCD runs side by side work on the 4 x 8 tiles of one 1024 x 1024 supertile (4 A slices +
+//     8 B slices per K tile for 32 tiles), supertiles round-robin over the XCDs, upper-triangular enumeration for the symmetric update.
+struct Bf2Args {
+  const __bf16* A; const __bf16* B; float* C;
+  int64_t lda, ldb, ldc;                 // elements
+  int tm, tn, nk;                        // 256-row tiles, 128-column tiles, K / 64
+  int tri;                               // square problem, same origin for rows and columns: tiles / elements with row <= col only
+  int nsi, nsuper, tpw;                  // supertile rows (rectangular walk), supertiles in all, supertile steps per workgroup
+  float alpha;
+};
+constexpr int V2_STAGE = 49152, V2_AIMG = 32768;      // bytes: A image 256 rows x 128 B, B image 128 rows x 128 B
+
+// step i of workgroup (xcd, slot, round): which tile, if any
+__device__ __forceinline__ bool v2_tile_at(const Bf2Args& g, int xcd, int slot, int round, int i, int& ti, int& tj) {
+  const int q = xcd + 8 * (round * g.tpw + i);
+  if (i >= g.tpw || q >= g.nsuper) return false;
+  int si, sj;
+  if (g.tri) {
+    sj = (int)((__builtin_sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+    while ((sj + 1) * (sj + 2) / 2 <= q) sj++;
+    while (sj * (sj + 1) / 2 > q) sj--;
+    si = q - sj * (sj + 1) / 2;
+  } else {
+    si = q % g.nsi; sj = q / g.nsi;
+  }
+  ti = 4 * si + (slot & 3); tj = 8 * sj + (slot >> 2);
+  return ti < g.tm && tj < g.tn && !(g.tri && tj < 2 * ti);      // (tj < 2 ti: every row of the tile lies below its columns)
+}
+__device__ __forceinline__ int v2_next(const Bf2Args& g, int xcd, int slot, int round, int i, int& ti, int& tj) {
+  while (i < g.tpw && !v2_tile_at(g, xcd, slot, round, i, ti, tj)) i++;
+  return i;
+}
+
+__global__ void __launch_bounds__(512, 2) bf16_tn_v2_kernel(const Bf2Args g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  char* lds = reinterpret_cast<char*>(smem);
+  const int b = (int)blockIdx.x, xcd = b & 7, ell = b >> 3, slot = ell & 31, round = ell >> 5;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // my tiles: count them (every wave runs the same scalar walk: no LDS list, the loaders must not read LDS inside their loop)
+  int nt = 0;
+  { int ti, tj; for (int i = 0; i < g.tpw; i++) nt += v2_tile_at(g, xcd, slot, round, i, ti, tj) ? 1 : 0; }
+  if (nt == 0) return;
+  const int G = nt * g.nk;                         // stages (K tiles) of this workgroup
+
+  if (wid >= 4) {
+    // ------------------------------------------------------------------ loaders: 12 LDS-DMA pieces (1 KiB each) per wave and stage
+    const int lw = wid - 4;
+    DmaBuf dA = dma_buf_make(reinterpret_cast<const double*>(g.A), g.lda / 4);
+    DmaBuf dB = dma_buf_make(reinterpret_cast<const double*>(g.B), g.ldb / 4);
+    int li, lti = 0, ltj = 0, lkt = 0, issued = 0, sl = 0;      // issue cursor: step, tile, K tile; stages issued; ring slot of the next stage
+    li = v2_next(g, xcd, slot, round, 0, lti, ltj);
+    auto retarget = [&]() {
+      dA.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (int64_t)lti * 256 * g.lda), 0, (int)0xffffffffu, 0x00020000);
+      dB.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.B + (int64_t)ltj * 128 * g.ldb), 0, (int)0xffffffffu, 0x00020000);
+    };
+    retarget();
+    auto issue = [&]() {
+      char* st = lds + sl * V2_STAGE;
+      const uint32_t kb = (uint32_t)lkt * 128u;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t g8 = (uint32_t)(lw * 8 + q);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dA.rsrc, (__attribute__((address_space(3))) void*)(st + g8 * 1024), 16,
+                                                 (int)((q & 1) ? dA.voff_odd : dA.voff_even), (int)(g8 * dA.rowgrp + kb), 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t g8 = (uint32_t)(lw * 4 + q);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dB.rsrc, (__attribute__((address_space(3))) void*)(st + V2_AIMG + g8 * 1024), 16,
+                                                 (int)((q & 1) ? dB.voff_odd : dB.voff_even), (int)(g8 * dB.rowgrp + kb), 0, 0);
+      }
+      issued++; sl = sl == 2 ? 0 : sl + 1;
+      if (++lkt == g.nk) { lkt = 0; li = v2_next(g, xcd, slot, round, li + 1, lti, ltj); if (li < g.tpw) retarget(); }
+    };
+    issue();
+    if (G > 1) issue();
+    for (int gs = 0; gs < G; gs++) {
+      // stage gs has landed once at most the pieces of stage gs + 1 (12 of mine) are outstanding
+      if (issued > gs + 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");                   // B(gs): stage gs is visible; the readers have left slot (gs - 1) % 3
+      if (issued < G) issue();                                   // stage gs + 2 into that slot
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute waves: 128 x 64 of the tile each
+  const int wi = (wid & 1) * 128, wj = (wid >> 1) * 64;
+  const int r32 = lane & 31, kg = lane >> 5;
+  const int t = kg ^ ((r32 >> 1) & 7);
+  const int a_off = (wi + r32) * 128, b_off = V2_AIMG + (wj + r32) * 128;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+  bf16x8 fa0[4], fa1[4], fb0[2], fb1[2];
+  auto rd = [&](const char* st, int ks, bf16x8 (&xa)[4], bf16x8 (&xb)[2]) {
+    const int off = ((2 * ks) ^ t) << 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) xa[i] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 32 * 128 + off);
+#pragma unroll
+    for (int j = 0; j < 2; j++) xb[j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 32 * 128 + off);
+  };
+  auto mma = [&](const bf16x8 (&xa)[4], const bf16x8 (&xb)[2]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[j], xa[i], acc[i][j], 0, 0, 0);   // swapped: lane = C row
+  };
+  int ci, cti = 0, ctj = 0, ckt = 0, sl = 0;
+  ci = v2_next(g, xcd, slot, round, 0, cti, ctj);
+  asm volatile("s_barrier" ::: "memory");                       // B(0)
+  rd(lds, 0, fa0, fb0);
+  for (int gs = 0; gs < G; gs++) {
+    const char* st = lds + sl * V2_STAGE;
+    rd(st, 1, fa1, fb1); mma(fa0, fb0);
+    rd(st, 2, fa0, fb0); mma(fa1, fb1);
+    rd(st, 3, fa1, fb1); mma(fa0, fb0);
+    sl = sl == 2 ? 0 : sl + 1;
+    if (gs + 1 < G) {
+      // every fragment read of this stage has returned before the loaders may refill its slot
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // B(gs + 1)
+      rd(lds + sl * V2_STAGE, 0, fa0, fb0);
+    }
+    mma(fa1, fb1);
+    if (++ckt == g.nk) {
+      // tile done: fire-and-forget atomics (lane = 32 consecutive rows of a column per half wave -> whole 128-B lines), then on to
+      // the next tile; the first fragments of its stage 0 are already on their way
+      const int64_t i0 = (int64_t)cti * 256, j0 = (int64_t)ctj * 128;
+      const int dd = g.tri ? (int)(j0 - i0) : 1 << 30;           // columns lead the rows by dd: mask row <= col  <=>  lrow <= lcol + dd
+      const bool diag = g.tri && dd < 256;                       // wave-uniform: only the two tiles per tile row that touch the diagonal
+      float* Cl = g.C + (i0 + wi + r32) + (j0 + wj + 4 * kg) * g.ldc;      // this lane's first element
+      if (!diag) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+              __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)(Cl + 32 * i + (int64_t)(32 * j + (e & 3) + 8 * (e >> 2)) * g.ldc),
+                                                      g.alpha * acc[i][j][e]);
+              acc[i][j][e] = 0.0f;
+            }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int lrow = wi + 32 * i + r32;
+#pragma unroll
+          for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+              const int lcol = wj + 32 * j + (e & 3) + 8 * (e >> 2) + 4 * kg;
+              if (lrow <= lcol + dd)
+                __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)(Cl + 32 * i + (int64_t)(32 * j + (e & 3) + 8 * (e >> 2)) * g.ldc),
+                                                        g.alpha * acc[i][j][e]);
+              acc[i][j][e] = 0.0f;
+            }
+        }
+      }
+      ckt = 0;
+      ci = v2_next(g, xcd, slot, round, ci + 1, cti, ctj);
+    }
+  }
+}
+
+// process-wide choice of the update kernel: 0 = round-3 kernel only, 1 = second-generation kernel wherever it applies (default),
+// tpw = supertile steps per workgroup
+static int g_bf16_variant = getenv("CAP_BF16_V2") ? atoi(getenv("CAP_BF16_V2")) : 1;
+static int g_bf16_tpw = getenv("CAP_BF16_TPW") ? atoi(getenv("CAP_BF16_TPW")) : 8;
+static int64_t g_bf16_min_tiles = getenv("CAP_BF16_V2_MIN") ? atoll(getenv("CAP_BF16_V2_MIN")) : 1024;
+
+int launch_bf16_v2(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A, int64_t lda, const __bf16* B, int64_t ldb, float* C, int64_t ldc,
+                   int tri, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    CAP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_tn_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * V2_STAGE));
+    attr_set = true;
+  }
+  Bf2Args g;
+  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha; g.tri = tri ? 1 : 0;
+  g.tm = (int)(m / 256); g.tn = (int)(n / 128); g.nk = (int)(k / 64);
+  const int64_t nsi = cap_ceil_div(g.tm, 4), nsj = cap_ceil_div(g.tn, 8);
+  g.nsi = (int)nsi;
+  g.nsuper = (int)(tri ? nsj * (nsj + 1) / 2 : nsi * nsj);
+  const int64_t per_xcd = cap_ceil_div(g.nsuper, 8);
+  g.tpw = (int)std::max<int64_t>(1, std::min<int64_t>(g_bf16_tpw, per_xcd));
+  const int64_t rounds = cap_ceil_div(per_xcd, g.tpw);
+  hipLaunchKernelGGL(bf16_tn_v2_kernel, dim3((unsigned)(256 * rounds)), dim3(512), 3 * V2_STAGE, s, g);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+// dispatcher of the single-GPU updates: the second-generation kernel needs whole 256 x 128 tiles and enough of them to fill the chip
+int launch_bf16_update(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A, int64_t lda, const __bf16* B, int64_t ldb, float* C,
+                       int64_t ldc, int tri, hipStream_t s) {
+  if (m <= 0 || n <= 0 || k <= 0) return CAP_OK;
+  const bool ok2 = g_bf16_variant == 1 && m % 256 == 0 && n % 128 == 0 && k % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && (!tri || m == n) &&
+                   (m / 256) * (n / 128) / (tri ? 2 : 1) >= g_bf16_min_tiles &&
+                   256 * lda * 2 + k * 2 < 0xfffffff0LL && 128 * ldb * 2 + k * 2 < 0xfffffff0LL;
+  if (ok2) return launch_bf16_v2(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
+  return launch_bf16_tn(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
+}
 }  // namespace
+
+// Testing / benchmarking entry of the bf16 update (tests/test_gpu_mixed.py, tools/bf16_bench.py): C32[m x n] += alpha A^T B with A: k x m,
+// B: k x n bf16 (K-contiguous, lda / ldb elements), upper triangle only when tri.  variant 0 = round-3 kernel, 1 = second generation
+// (CAP_ERR_UNSUPPORTED where it does not apply), -1 = the dispatcher the factorization uses.  tpw > 0 overrides the chunk length.
+extern "C" int cap_bf16_update(int variant, int64_t m, int64_t n, int64_t k, float alpha, const void* A16, int64_t lda, const void* B16, int64_t ldb,
+                               float* C, int64_t ldc, int tri, int tpw, void* stream) {
+  if (!A16 || !B16 || !C || m < 0 || n < 0 || k < 0) return CAP_ERR_ARG;
+  if (tpw > 0) g_bf16_tpw = tpw;
+  const __bf16* A = (const __bf16*)A16; const __bf16* B = (const __bf16*)B16;
+  hipStream_t s = cap_stream(stream);
+  if (variant < 0) return launch_bf16_update(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
+  if (variant == 0) return launch_bf16_tn(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
+  if (m % 256 || n % 128 || k % 64 || lda % 8 || ldb % 8 || (tri && m != n) || m == 0 || n == 0 || k == 0) return CAP_ERR_UNSUPPORTED;
+  return launch_bf16_v2(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
+}
 
 // Distributed bf16 trailing update on a 1 x P block-column-cyclic fp32 matrix (dist_mixed.hip): C32[m x nloc] -= G^T B restricted
 // to the global upper triangle.  G: gathered bf16 block row (P pieces of `piece` elements, each k x cols_r, ld = k), B: my own
@@ -427,7 +665,7 @@ int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* st
           e0 = (*p->prof_ev)[p->prof_used]; e1 = (*p->prof_ev)[p->prof_used + 1];
           CAP_HIP(hipEventRecord(e0, s0));
         }
-        CAP_TRY(launch_bf16_tn(m - hb, m - hb, K, -1.0f, S + hb * ldp, ldp, S + hb * ldp, ldp, p->R32 + (Js + hb) * (n + 1), n, 1, s0));
+        CAP_TRY(launch_bf16_update(m - hb, m - hb, K, -1.0f, S + hb * ldp, ldp, S + hb * ldp, ldp, p->R32 + (Js + hb) * (n + 1), n, 1, s0));
         if (e0) {
           CAP_HIP(hipEventRecord(e1, s0));
           p->prof_used += 2;
@@ -505,7 +743,7 @@ int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* st
         e0 = (*p->prof_ev)[p->prof_used]; e1 = (*p->prof_ev)[p->prof_used + 1];
         CAP_HIP(hipEventRecord(e0, s0));
       }
-      CAP_TRY(launch_bf16_tn(m - hb, m - hb, K, -1.0f, S + hb * ldp, ldp, S + hb * ldp, ldp, p->R32 + (Js + hb) * (n + 1), n, 1, s0));
+      CAP_TRY(launch_bf16_update(m - hb, m - hb, K, -1.0f, S + hb * ldp, ldp, S + hb * ldp, ldp, p->R32 + (Js + hb) * (n + 1), n, 1, s0));
       if (e0) {
         CAP_HIP(hipEventRecord(e1, s0));
         p->prof_used += 2;
@@ -541,6 +779,10 @@ int cap_mpchol_set_option(cap_mpchol_plan* p, const char* key, int64_t value) {
     return CAP_OK;
   }
   if (!strcmp(key, "split")) { p->split = value != 0; return CAP_OK; }     // column-split schedule (near / far columns), see cap_mpchol_factor
+  // process-wide A/B switches of the bf16 update (see launch_bf16_update): which kernel, chunk length, smallest launch for the new one
+  if (!strcmp(key, "update_kernel")) { if (value < 0 || value > 1) return CAP_ERR_ARG; g_bf16_variant = (int)value; return CAP_OK; }
+  if (!strcmp(key, "update_tpw")) { if (value < 1 || value > 64) return CAP_ERR_ARG; g_bf16_tpw = (int)value; return CAP_OK; }
+  if (!strcmp(key, "update_min_tiles")) { if (value < 0) return CAP_ERR_ARG; g_bf16_min_tiles = value; return CAP_OK; }
   if (!strcmp(key, "strip")) { if (value < 1 || value > 2) return CAP_ERR_ARG; p->strip = value; return CAP_OK; }   // panels per bf16 update
   return CAP_ERR_ARG;
 }

@@ -470,6 +470,14 @@ float* cap_mpchol_R32_ptr(cap_mpchol_plan* plan, int64_t* ld);          /* the f
  * "split" = column-split schedule (near columns of every block-row solve / head update on the panel stream, the far ones on a
  * third stream; default 1, bit-identical to 0).                                                                           */
 int cap_mpchol_set_option(cap_mpchol_plan* plan, const char* key, int64_t value);
+/* The bf16 trailing update by itself (tests, tools/bf16_bench.py): C32[m x n] += alpha A^T B, A: k x m, B: k x n bf16, both
+ * K-contiguous (lda / ldb in elements), fp32 atomics into C; tri = 1: square problem, elements with row <= col only.
+ * variant 0 = the 128 x 128-tile kernel, 1 = the wave-specialised 256 x 128-tile kernel with the three-deep LDS ring and the tile
+ * loop (m % 256 == n % 128 == k % 64 == 0, else CAP_ERR_UNSUPPORTED), -1 = the dispatcher the factorization uses (options
+ * "update_kernel" 0 | 1, "update_tpw" = supertile steps per workgroup, "update_min_tiles" of cap_mpchol_set_option; process-wide).
+ * tpw > 0 overrides the chunk length.                                                                                     */
+int cap_bf16_update(int variant, int64_t m, int64_t n, int64_t k, float alpha, const void* A16, int64_t lda, const void* B16,
+                    int64_t ldb, float* C, int64_t ldc, int tri, int tpw, void* stream);
 int cap_mpchol_profile(cap_mpchol_plan* plan, int64_t* launches, double* ms_total, double* flops_total, double* bytes_total);
 
 /* The same solve on P GPUs (BASELINE config 5: N = 131072 on 8 MI355X; csrc/dist_mixed.hip): the bf16-MFMA factorization on

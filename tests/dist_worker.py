@@ -591,13 +591,13 @@ def main():
             ctx.set_option("profile", 1); ctx.factor(); torch.cuda.synchronize()
             busy = (ctypes.c_double * 6)()
             _lib.check(_lib.lib().cap_dist_profile_streams(ctx.plan, busy))
-            ctx.set_option("profile", 0)
-            assert all(b >= 0 for b in busy) and (busy[0] > 0 or ctx.local_cols == 0) and (size == 1 or busy[3] > 0), list(busy)
             if args.ci >= 0:
                 # the streamed inverse reports its own busy time, what was left of it after the sweep's join, and the call's wall time
                 inv3 = (ctypes.c_double * 3)()
                 _lib.check(_lib.lib().cap_dist_profile_inverse(ctx.plan, inv3))
                 assert inv3[0] > 0 and 0 <= inv3[1] <= inv3[2], list(inv3)
+            ctx.set_option("profile", 0)
+            assert all(b >= 0 for b in busy) and (busy[0] > 0 or ctx.local_cols == 0) and (size == 1 or busy[3] > 0), list(busy)
             rl = ctx.local_R()
             if args.ci >= 0:
                 ri_l = ctx.local_Rinv()

@@ -109,3 +109,79 @@ def test_matches_the_fp64_path_and_reports_failures():
         assert it == 5 and not (rr <= 1e-14)
     p.close()
 
+
+
+def _bf16_update(variant, a16, b16, c32, alpha, tri, tpw=0):
+    """C32 += alpha A^T B through the C ABI (cap_bf16_update); a16: [m, k], b16: [n, k] bf16 (K-contiguous), c32: [n, m] fp32 buffer of C^T."""
+    from capital_amd import _lib
+    m, k = a16.shape; n = b16.shape[0]
+    st = _lib.lib().cap_bf16_update(variant, m, n, k, float(alpha), a16.data_ptr(), a16.stride(0), b16.data_ptr(), b16.stride(0), c32.data_ptr(),
+                                    c32.stride(0), int(tri), int(tpw), torch.cuda.current_stream().cuda_stream)
+    return st
+
+
+@pytest.mark.parametrize("m,n,k,tri,tpw", [(256, 128, 64, 0, 0), (512, 256, 128, 0, 1), (1024, 1024, 192, 1, 0), (2048, 2048, 512, 1, 3), (2304, 2304, 64, 1, 2),
+                                           (2048, 1152, 1024, 0, 8), (4096, 4096, 2048, 1, 8), (3072, 3072, 256, 1, 1), (1280, 4224, 320, 0, 5)])
+def test_bf16_update_kernels_against_torch(m, n, k, tri, tpw):
+    """Both generations of the bf16 trailing-update kernel (csrc/mixed.hip) against torch's fp32 matmul of the same bf16 operands:
+    every tile shape of the walk (supertile edges, diagonal tiles of the symmetric update, chunks of 1 .. 8 steps per workgroup,
+    K tiles 1 .. 32 so that the three-deep LDS ring wraps, fills and drains), untouched strictly-lower part, padded leading dimensions.
+    Not symmetric data: a transposed fragment or a swapped operand shows."""
+    g = torch.Generator(device="cuda"); g.manual_seed(m + n + k)
+    lda = k + 64                                                  # padded K stride (multiple of 8)
+    abuf = torch.randn(m, lda, device="cuda", generator=g).to(torch.bfloat16); a16 = abuf[:, :k]
+    if tri:
+        b16 = a16
+    else:
+        bbuf = torch.randn(n, lda, device="cuda", generator=g).to(torch.bfloat16); b16 = bbuf[:, :k]
+    c0 = torch.randn(n, m + 32, device="cuda", generator=g)      # C^T buffer: [col, row], ldc = m + 32
+    ref = c0[:, :m].t().double() - 0.5 * (a16.double() @ b16.double().t())        # [m, n]
+    mask = torch.triu(torch.ones(m, n, dtype=torch.bool, device="cuda")) if tri else torch.ones(m, n, dtype=torch.bool, device="cuda")
+    scale = float(ref.abs().max())
+    outs = []
+    for variant in (0, 1):
+        c = c0.clone()
+        st = _bf16_update(variant, a16, b16, c, -0.5, tri, tpw)
+        if variant == 0 and st != 0:
+            assert m % 128 or n % 128 or k % 64, st           # the 128-tile kernel only refuses shapes outside its granularity
+            continue
+        assert st == 0, st
+        torch.cuda.synchronize()
+        got = c[:, :m].t().double()
+        err = float((got - ref)[mask].abs().max()) / scale
+        assert err < 2e-6 * max(1.0, (k / 64) ** 0.5), (variant, err)                   # fp32 accumulation of exact bf16 products
+        if tri:
+            assert torch.equal(c[:, :m].t()[~mask], c0[:, :m].t()[~mask]), "entries below the diagonal must not be touched"
+        assert torch.equal(c[:, m:], c0[:, m:]), "padding of the leading dimension must not be touched"
+        outs.append(got)
+    if len(outs) == 2:
+        assert float((outs[0] - outs[1])[mask].abs().max()) / scale < 4e-6 * max(1.0, (k / 64) ** 0.5)
+
+
+def test_bf16_update_dispatcher_and_refusals():
+    """variant 1 refuses shapes outside whole 256 x 128 x 64 tiles (the dispatcher then takes the 128-tile kernel); the factorization
+    gives the same factor (to fp32 rounding of a different summation order) with either kernel forced for every big update."""
+    from capital_amd import mixed
+    from capital_amd.matrix import matrix
+    a16 = torch.randn(384, 64, device="cuda").to(torch.bfloat16)
+    c = torch.zeros(384, 384, device="cuda")
+    assert _bf16_update(1, a16, a16, c, 1.0, 1) != 0             # m = 384 is no multiple of 256
+    assert _bf16_update(-1, a16, a16, c, 1.0, 1) == 0
+    torch.cuda.synchronize()
+    want = torch.triu(a16.float() @ a16.float().t())
+    assert float((torch.triu(c.t()) - want).abs().max()) < 1e-4
+    n = 6144
+    a = _spd(n, "gram", seed=3)
+    A = matrix(n, n, 1, 1).from_numpy(a)
+    fs = []
+    for kern in (0, 1):
+        p = mixed.plan(n, 4)
+        p.set_option("update_kernel", kern); p.set_option("update_min_tiles", 0)
+        p.factor(A)
+        assert p.last_info() == 0
+        fs.append(p.R32().cpu().numpy().astype(np.float64))
+        p.set_option("update_kernel", 1); p.set_option("update_min_tiles", 1024)
+        p.close()
+    ref = np.linalg.cholesky(a).T
+    assert relerr(fs[0], ref) < 2e-2 and relerr(fs[1], ref) < 2e-2
+    assert relerr(fs[1], fs[0]) < 1e-3            # same bf16 panels up to rare rounding flips; fp32 sums in a different order
