@@ -149,13 +149,13 @@ def test_bf16_update_kernels_against_torch(m, n, k, tri, tpw):
         torch.cuda.synchronize()
         got = c[:, :m].t().double()
         err = float((got - ref)[mask].abs().max()) / scale
-        assert err < 2e-6 * max(1.0, (k / 64) ** 0.5), (variant, err)                   # fp32 accumulation of exact bf16 products
+        assert err < 2e-5, (variant, err)                   # fp32 accumulation of exact bf16 products
         if tri:
             assert torch.equal(c[:, :m].t()[~mask], c0[:, :m].t()[~mask]), "entries below the diagonal must not be touched"
         assert torch.equal(c[:, m:], c0[:, m:]), "padding of the leading dimension must not be touched"
         outs.append(got)
     if len(outs) == 2:
-        assert float((outs[0] - outs[1])[mask].abs().max()) / scale < 4e-6 * max(1.0, (k / 64) ** 0.5)
+        assert float((outs[0] - outs[1])[mask].abs().max()) / scale < 4e-5
 
 
 def test_bf16_update_dispatcher_and_refusals():
