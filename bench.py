@@ -63,7 +63,10 @@ def parse():
                          "residual check + timing), then overlap, then ipc, each under a host watchdog - the best completed mode is "
                          "reported (fallback to it if a later mode makes no progress)")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "ipc"], help="multi-GPU strip exchange: RCCL all-gather or IPC peer copies")
-    ap.add_argument("--grid-rows", type=int, default=1, help="multi-GPU: process rows Pr of the Pr x Pc block-cyclic layout (1 = block columns only)")
+    ap.add_argument("--grid-rows", default="auto",
+                    help="multi-GPU: process rows Pr of the Pr x Pc block-cyclic layout (1 = block columns only); auto (default) = the 1 x P modes "
+                         "first, then - where P = 2 x Pc with 2 | Pc (4, 8 GPUs) - the 2 x (P/2) layout, all under the same watchdog in ONE "
+                         "invocation: every layout / mode is listed in config.modes, the best completed one is reported")
     ap.add_argument("--watchdog-s", type=float, default=0.0, help="multi-GPU: seconds without completion before a step counts as hung (0 = auto)")
     ap.add_argument("--complete-inv", type=int, default=-1,
                     help="-1 blocked Cholesky (headline), 0/1 reference cholinv semantics (R and R^-1)")
@@ -251,26 +254,59 @@ def main():
     L = _lib.lib()     # fails loudly if the HIP library is missing
     import ctypes as C
 
-    def barrier():
-        torch.cuda.synchronize()
+    # N > 1: the control plane (barriers, max over ranks) runs over a gloo group on the HOST and GPU completion is POLLED, so a
+    # collective that never completes (first contact with multi-rank RCCL) cannot block the bench: after `watchdog_s` without
+    # completion every rank reports, rank 0 prints a JSON line with value null + the error, and the processes leave without
+    # touching the GPU again.  Used by every multi-GPU workload that has no mode ladder of its own (CholeskyQR2, mixed precision).
+    ctl = dist.new_group(backend="gloo") if (dist is not None and not emulate) else None
+
+    def ctl_max(x):
+        if dist is None:
+            return float(x)
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
+        return float(t.item())
+
+    def wait_gpu(limit_s):
+        if dist is None:
+            torch.cuda.synchronize()
+            return True
+        ev = torch.cuda.Event(); ev.record()
+        t0 = time.perf_counter()
+        while not ev.query():
+            if time.perf_counter() - t0 > limit_s:
+                return False
+            time.sleep(2e-4)
+        return True
+
+    def hang_exit(what):
+        print("[bench rank %d] %s made no progress within the watchdog limit" % (rank, what), file=sys.stderr, flush=True)
+        if rank == 0:
+            print(json.dumps({"metric": args.workload, "value": None, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "higher_is_better": True, "error": "%s made no progress within %.0f s (host watchdog): a collective did not "
+                              "complete" % (what, watchdog_limit), "fallback": True}), flush=True)
+        sys.stdout.flush(); sys.stderr.flush()
+        time.sleep(1.0)
+        os._exit(1)
+
+    watchdog_limit = args.watchdog_s or 120.0
+
+    def barrier(what="step"):
+        if ctl_max(0.0 if wait_gpu(watchdog_limit) else 1.0):
+            hang_exit(what)
         if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.barrier(group=ctl)
 
     def timed(run, steps, warmup):
         for _ in range(warmup):
             run()
-        barrier()
+        barrier("warm-up")
         t0 = time.perf_counter()
         for _ in range(steps):
             run()
-        barrier()
+        barrier("timed region")
         dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if emulate else "cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt / steps
+        return ctl_max(dt) / steps
 
     def allreduce_sum(t):
         if dist is None:
@@ -466,29 +502,36 @@ def multi_gpu_case(args, torch, L, C, rank, world, dist, emulate, allreduce_sum)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
         return float(t.item())
 
-    is2d = args.grid_rows > 1
-    row = col = None
-    if emulate:
-        from tests.host_staged import HostStagedComm, grid_groups
-        comm = HostStagedComm()
-        if is2d:
-            row, col = grid_groups(args.grid_rows, HostStagedComm)
-    else:
-        comm = dist_cholesky.RcclComm()
-    ctx = dist_cholesky.setup(n, nb=args.nb or 0, comm=comm, grid_rows=args.grid_rows, row=row, col=col)
-    if not is2d:
-        if args.strip:
-            ctx.set_option("strip", args.strip)
-        if args.depth2 >= 0:
-            ctx.set_option("depth2", args.depth2)
-        if args.exchange == "ipc":
-            ctx.set_option("ipc", 1)
+    auto_grid = str(args.grid_rows) == "auto"
+    layouts = [1] if auto_grid else [int(args.grid_rows)]
+    if auto_grid and world >= 4 and world % 2 == 0 and (world // 2) % 2 == 0:
+        layouts.append(2)                # 2 x 2, 2 x 4: the north star's 2D block-cyclic layout, measured next to 1 x P in the same run
+
+    def make_ctx(gr):
+        row = col = None
+        if emulate:
+            from tests.host_staged import HostStagedComm, grid_groups
+            c = HostStagedComm()
+            if gr > 1:
+                row, col = grid_groups(gr, HostStagedComm)
+        else:
+            c = dist_cholesky.RcclComm()
+        cx = dist_cholesky.setup(n, nb=args.nb or 0, comm=c, grid_rows=gr, row=row, col=col)
+        if gr == 1:
+            if args.strip:
+                cx.set_option("strip", args.strip)
+            if args.depth2 >= 0:
+                cx.set_option("depth2", args.depth2)
+            if args.exchange == "ipc":
+                cx.set_option("ipc", 1)
+        return c, cx
+
+    comm, ctx = make_ctx(layouts[0])
     nr, rk, dev = C.c_int(0), C.c_int(0), C.c_int(0)
     _lib.check(L.cap_comm_query(comm.handle, C.byref(nr), C.byref(rk), C.byref(dev)))
     diag = {"n_ranks_seen": nr.value, "rank_seen": rk.value, "device": dev.value, "librccl": _librccl_path(),
             "comm_backend": {0: "self", 1: "rccl", 2: "host-staged (emulation)"}[int(L.cap_comm_backend(comm.handle))],
-            "exchange": args.exchange, "grid": "%dx%d" % (ctx.grid_rows, world // ctx.grid_rows),
-            "parallelism": "%dx%d block-cyclic (nb=%d), RCCL over xGMI" % (ctx.grid_rows, world // ctx.grid_rows, ctx.nb)}
+            "exchange": args.exchange}
     seen = ctl_max(-nr.value)            # every rank must see the same communicator size
     if int(-seen) != world or nr.value != world:
         diag["error"] = "communicator reports %d ranks, launcher %d" % (nr.value, world)
@@ -503,26 +546,26 @@ def multi_gpu_case(args, torch, L, C, rank, world, dist, emulate, allreduce_sum)
             time.sleep(2e-4)
         return True
 
-    def progress():
+    def progress(cx, is2d):
         if is2d:
             return {}
         out9 = (ctypes.c_int64 * 9)()
-        L.cap_dist_progress(ctx.plan, out9)
+        L.cap_dist_progress(cx.plan, out9)
         v = list(out9)
         return {"fact": v[0], "msg": v[1], "rowdone": v[2], "solved": v[3], "gather": v[4], "head2": v[5], "rest": v[6],
                 "block_rows": v[7], "strips": v[8]}
 
-    def timed_watch(steps, warmup, limit_s):
+    def timed_watch(cx, steps, warmup, limit_s):
         """barrier + sync | K factor calls | sync + barrier, max over ranks - with the syncs polled; None when a rank hangs."""
         for _ in range(warmup):
-            ctx.factor()
+            cx.factor()
         hung = ctl_max(0.0 if wait_gpu(limit_s * max(warmup, 1)) else 1.0)
         if hung:
             return None
         ctl_barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            ctx.factor()
+            cx.factor()
         okw = wait_gpu(limit_s * steps)
         if ctl_max(0.0 if okw else 1.0):
             return None
@@ -531,50 +574,75 @@ def multi_gpu_case(args, torch, L, C, rank, world, dist, emulate, allreduce_sum)
         return ctl_max(time.perf_counter() - t0) / steps
 
     limit = args.watchdog_s or max(60.0, 20.0 * (n / 65536.0) ** 3 * 4.0)
-    modes = ["2d"] if is2d else {"auto": ["safe", "overlap", "ipc"], "safe": ["safe"], "overlap": ["overlap"], "ipc": ["ipc"]}[args.dist_mode]
-    if args.exchange == "ipc" and not is2d:
-        modes = [m for m in modes if m != "ipc"] or ["ipc"]         # every mode already runs on the IPC exchange
-    results, wd = {}, {}
-    for mode in modes:
-        if not is2d:
-            ctx.set_option("safe", 1 if mode == "safe" else 0)
-            if mode == "ipc":                                          # overlapped schedule, strip exchange by IPC peer copies (SDMA)
-                ctx.set_option("ipc", 1)
-        sec = timed_watch(args.steps, max(args.warmup, 1), limit)
-        if sec is None:
-            wd[mode] = {"hung": True, "limit_s": limit, "progress_rank%d" % rank: progress()}
-            print("[bench rank %d] %s mode made no progress within %.0f s: %s" % (rank, mode, limit, json.dumps(wd[mode])), file=sys.stderr, flush=True)
-            break                        # the GPU queues are stuck: nothing further can run in this process
-        info = ctx.last_info()
-        probe = ctx.probe(allreduce_sum) if not args.no_check else 0.0
-        results[mode] = {"sec": sec, "info": int(info), "probe": probe, "tflops": n ** 3 / 3.0 / sec / 1e12}
-        if mode == "ipc" or (args.exchange == "ipc" and not is2d):
-            results[mode]["ipc_active"] = int(ctx.get_option("ipc_active"))    # 0: a peer could not be mapped, the run used RCCL
-        if int(info) != 0 or not (probe <= 1e-13):
+    results, wd, ctxs = {}, {}, {}
+    stop = False
+    for gr in layouts:
+        is2d = gr > 1
+        if gr != layouts[0]:
+            _, ctx = make_ctx(gr)
+        if is2d:
+            modes = ["2d"]
+        else:
+            modes = {"auto": ["safe", "overlap", "ipc"], "safe": ["safe"], "overlap": ["overlap"], "ipc": ["ipc"]}[args.dist_mode]
+            if args.exchange == "ipc":
+                modes = [m for m in modes if m != "ipc"] or ["ipc"]         # every mode already runs on the IPC exchange
+        for mode in modes:
+            key = mode if not is2d else "%dx%d" % (gr, world // gr)
+            if not is2d:
+                ctx.set_option("safe", 1 if mode == "safe" else 0)
+                if mode == "ipc":                                          # overlapped schedule, strip exchange by IPC peer copies (SDMA)
+                    ctx.set_option("ipc", 1)
+            sec = timed_watch(ctx, args.steps, max(args.warmup, 1), limit)
+            if sec is None:
+                wd[key] = {"hung": True, "limit_s": limit, "progress_rank%d" % rank: progress(ctx, is2d)}
+                print("[bench rank %d] %s made no progress within %.0f s: %s" % (rank, key, limit, json.dumps(wd[key])), file=sys.stderr, flush=True)
+                stop = True
+                break                        # the GPU queues are stuck: nothing further can run in this process
+            info = ctx.last_info()
+            probe = ctx.probe(allreduce_sum) if not args.no_check else 0.0
+            results[key] = {"sec": sec, "info": int(info), "probe": probe, "tflops": n ** 3 / 3.0 / sec / 1e12,
+                            "layout": "%dx%d block-cyclic (nb=%d)" % (gr, world // gr, ctx.nb)}
+            ctxs[key] = (ctx, mode, is2d)
+            if not is2d and (mode == "ipc" or args.exchange == "ipc"):
+                results[key]["ipc_active"] = int(ctx.get_option("ipc_active"))    # 0: a peer could not be mapped, the run used RCCL
+            if is2d:
+                results[key]["launches_per_factor_rank0"] = ctx.launch_counts()
+            if int(info) != 0 or not (probe <= 1e-13):
+                stop = True
+                break
+        if stop:
             break
-    diag["modes"] = {m: dict({"tflops": r["tflops"], "ms_per_step": r["sec"] * 1e3, "info": r["info"], "probe_residual": r["probe"]},
-                             **({"ipc_active": r["ipc_active"]} if "ipc_active" in r else {})) for m, r in results.items()}
+    diag["modes"] = {m: dict({"tflops": r["tflops"], "ms_per_step": r["sec"] * 1e3, "info": r["info"], "probe_residual": r["probe"], "layout": r["layout"]},
+                             **{k: r[k] for k in ("ipc_active", "launches_per_factor_rank0") if k in r}) for m, r in results.items()}
     if wd:
         diag["watchdog"] = wd
     good = {m: r for m, r in results.items() if r["info"] == 0 and r["probe"] <= 1e-13}
+    first_gr = layouts[0]
+    diag["parallelism"] = "%dx%d block-cyclic (nb=%d), RCCL over xGMI" % (first_gr, world // first_gr, ctx.nb)
+    diag["grid"] = "%dx%d" % (first_gr, world // first_gr)
     if not good:
         if wd:
             _emit_and_exit_on_hang(args, rank, n, world, diag, None)
         return ctx, None, (list(results.values())[0]["info"] if results else -1), diag
     best = min(good, key=lambda m: good[m]["sec"])
+    bctx, bmode, b2d = ctxs[best]
     diag["mode"] = best
     diag["fallback"] = bool(wd)
+    diag["parallelism"] = good[best]["layout"] + ", RCCL over xGMI"
+    diag["grid"] = good[best]["layout"].split()[0]
     if wd:
         # a mode hung: its kernels still occupy the queues, so nothing more can be measured or checked in this process -
         # report the mode that completed, and leave without touching the GPU again
         _emit_and_exit_on_hang(args, rank, n, world, diag, good[best])
-    if is2d:
-        diag["launches_per_factor_rank0"] = ctx.launch_counts()
-    if list(results)[-1] != best:        # leave the plan holding the result (and the mode, for the profiled call) of the reported mode
-        ctx.set_option("safe", 1 if best == "safe" else 0)
-        ctx.set_option("ipc", 1 if (best == "ipc" or args.exchange == "ipc") else 0)
-        ctx.factor(); torch.cuda.synchronize()
-    return ctx, good[best]["sec"], good[best]["info"], diag
+    if b2d:
+        diag["launches_per_factor_rank0"] = good[best]["launches_per_factor_rank0"]
+    if list(results)[-1] != best and not b2d:        # leave the plan holding the result (and the mode, for the profiled call) of the reported mode
+        bctx.set_option("safe", 1 if bmode == "safe" else 0)
+        bctx.set_option("ipc", 1 if (bmode == "ipc" or args.exchange == "ipc") else 0)
+        bctx.factor(); torch.cuda.synchronize()
+    elif list(results)[-1] != best:
+        bctx.factor(); torch.cuda.synchronize()
+    return bctx, good[best]["sec"], good[best]["info"], diag
 
 
 def _emit_and_exit_on_hang(args, rank, n, world, diag, res):

@@ -304,6 +304,8 @@ def test_bench_multi_gpu_code_path_emulated():
     (4, ("--size", "4096", "--nb", "256", "--grid-rows", "2"), "2x2"),                       # the Pr x Pc plan through bench.py
     (2, ("--size", "2048", "--nb", "256", "--workload", "mixed"), "mixed"),                   # config 5's method on P ranks
     (2, ("--size", "4096", "--nb", "256", "--dist-mode", "auto", "--exchange", "rccl"), "auto"),   # safe, overlap and ipc modes in turn
+    (4, ("--size", "4096", "--nb", "256"), "layouts"),                                       # default --grid-rows auto: 1 x 4 modes, then 2 x 2
+    (2, ("--workload", "cacqr", "--qr-rows", "8192", "--qr-cols", "64"), "cacqr"),            # CholeskyQR2 under the polled watchdog
 ])
 def test_bench_multi_gpu_variants_emulated(nproc, extra, key):
     import json
@@ -317,6 +319,12 @@ def test_bench_multi_gpu_variants_emulated(nproc, extra, key):
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == nproc and d["value"] > 0 and d["config"]["info"] == 0
+    if key == "layouts":
+        assert set(d["config"]["modes"]) == {"safe", "overlap", "ipc", "2x2"}, d["config"]["modes"]
+        assert all(m["info"] == 0 and m["probe_residual"] <= 1e-13 for m in d["config"]["modes"].values())
+        assert d["config"]["mode"] in d["config"]["modes"] and d["config"]["fallback"] is False
+    if key == "cacqr":
+        assert d["scaling"] == "weak" and d["config"]["residual"] <= 1e-13
     if key == "2x2":
         assert d["config"]["grid"] == "2x2" and d["config"]["n_ranks_seen"] == 4 and d["config"]["launches_per_factor_rank0"]["collectives"] > 0
     if key == "auto":
