@@ -114,6 +114,8 @@ SIGNATURES = {
     "cap_dist2d_get_R": (cint, [ptr, ptr, i64, ptr]),
     "cap_dist2d_info": (cint, [ptr, ptr, C.POINTER(i64)]),
     "cap_dist2d_set_option": (cint, [ptr, C.c_char_p, i64]),
+    "cap_dist2d_get_Rinv": (cint, [ptr, ptr, i64, ptr]),
+    "cap_dist2d_Rinv_ptr": (ptr, [ptr, C.POINTER(i64)]),
     "cap_bc2d_local_extent": (i64, [i64, i64, cint, cint, cint, cint, cint]),
     "cap_bc2d_rows_le": (cint, [cint, cint, cint, cint, cint, cint]),
     "cap_fill_symmetric_bc2d": (cint, [ptr, i64, i64, i64, cint, cint, cint, cint, cint, ptr]),

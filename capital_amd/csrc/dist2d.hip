@@ -5,23 +5,28 @@
 // (I / Pr, J / Pc); rank = pr * Pc + pc; the local array is column-major (local rows x local columns).  N is padded to a
 // multiple of nb with an identity tail (policy.h:196 `span`).  Pr must divide Pc (1 x P, 2 x 2, 2 x 4, 4 x 4 ...).
 //
-// Right-looking step k (block row k; owner process row prk = k % Pr, owner column pck = k % Pc) - the roles of upstream's
+// Schedule (round 4: the same two-level blocking and look-ahead as the 1 x P plan of dist.hip): strips of `strip` = 2 block rows
+// (a, b = a + 1), one K = 2 nb update per strip.  Owner process row prk = k % Pr, owner column pck = k % Pc; the roles of upstream's
 // SUMMA collectives (summa.hpp:163-253: row broadcast, column broadcast, base-case gather policy.h:160-305) with RCCL:
-//   1. (prk, pck)            factor + invert the diagonal block (the fused 64-blocked chain of leaf.hip)
-//   2. process row prk       ncclBroadcast of Dinv(k) along the row communicator                                [nb^2]
-//   3. process row prk       S_k = Dinv^T R[k, my columns J > k]                                               (1 GEMM)
-//   4. every process column  ncclBroadcast of S_k's piece down the column communicator (root prk): the B operand
-//                            S_k[:, J = pc mod Pc]                                                             [nb x n / Pc]
-//   5. every process row     the A operand S_k[:, I = pr mod Pr]: those blocks sit, after 4., on the columns pc' = pr mod Pr,
-//                            + Pr, ... of my own process row - each of these Pc / Pr contributors broadcasts its piece along
-//                            the row communicator (the "transpose" exchange of a symmetric update, util.hpp:232-247)
-//                                                                                                              [nb x n / Pr]
-//   6. every process         C[I, J] -= S_k[:, I]^T S_k[:, J] on its local blocks k < I <= J: the staircase MFMA update of
-//                            gemm.hip, generalised to row-cyclic C (GemmArgs::rP); HEAD = the block row k + 1 first (panel
-//                            stream, feeds the next diagonal block), bulk = the rows below on the caller's stream.
-// Per step a process receives nb x (n / Pc + n / Pr) doubles instead of the 1 x P layout's nb x n - but it issues
-// 2 + Pc / Pr collectives on two communicator families instead of 1 broadcast + 1/2 all-gather (DESIGN.md section 5 compares the
-// measured launch counts).  Look-ahead depth 1: the panel of step k + 1 overlaps with the bulk update of step k.
+//   per block row k of the strip (panel stream + the message stream):
+//     1. (prk, pck)            [row b: D(b) -= S_a(:, b)^T S_a(:, b) first]  factor + invert the diagonal block (fused 64-blocked chain)
+//     2. process row prk       msg(k) = [ R(a, b) | Dinv(k) ] along the row communicator                            [2 nb^2]
+//     3. process row prk       [row b: R[b, J] -= R(a, b)^T S_a(:, J)]   S_k = Dinv^T R[k, my columns J > k]          (1-2 GEMMs)
+//     4. every process column  S_k's piece down the column communicator (root prk) into the strip buffer (K-contiguous, ld = 2 nb):
+//                              the B operand, and what row b's in-strip update and the inverse read                  [nb x n / Pc]
+//   per strip:
+//     5. every process row     the A operand S[:, I = pr mod Pr]: those blocks sit, after 4., on the columns pc' = pr mod Pr, + Pr, ... of
+//                              my own process row - each of these Pc / Pr contributors broadcasts its strip piece along the row
+//                              communicator (the "transpose" exchange of a symmetric update, util.hpp:232-247)    [2 nb x n / Pr]
+//     6. every process         C[I, J] -= S[:, I]^T S[:, J] on its local blocks b < I <= J, K = 2 nb: the staircase MFMA update of gemm.hip,
+//                              generalised to row-cyclic C (GemmArgs::rP); HEAD = the rows of strip t + 1 (panel stream), bulk = the rows
+//                              below on the caller's stream, itself split into the rows of strip t + 2 (signals the panel stream:
+//                              look-ahead depth 2) + the rest.
+// Per strip a process receives 2 nb x (n / Pc + n / Pr) doubles instead of the 1 x P layout's 2 nb x n, for 4 + Pc / Pr collectives
+// (two messages, two column broadcasts, Pc / Pr row broadcasts) against 2 + 1 (DESIGN.md section 5 compares measured launch counts).
+// Options: "strip" (1 | 2), "depth2", "occ1_m", "complete_inv" / "split" (R^-1 streamed with the sweep like dist.hip: per block row
+// one more nb^2 broadcast down the owner's process column and one row broadcast of the finished block column of R^-1), "ipc" (both
+// operand moves as IPC peer copies on SDMA engines instead of RCCL broadcasts).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -39,20 +44,32 @@ struct cap_dist2d_plan {
   int64_t n, npad, nb, nblk;
   int Pr, Pc, pr, pc, P, rank;
   cap_comm *world, *row, *col; bool owns_row, owns_col;
+  cap_comm* row2;                // the small messages of a process row travel on their own communicator + stream (owned duplicate)
   int64_t nlr, nlc;              // local row / column blocks
   int64_t lr_valid, lc_valid;    // local rows / columns that exist in the n x n matrix
   double* R; int64_t ld;         // (nlr nb) x (nlc nb)
-  double* B[2];                  // B operand / my solved piece of block row k: nb x (nlc nb), ld = nb
-  double* A[2];                  // A operand: Pc / Pr pieces of nb x apiece_cols
-  double* Dinv[2];               // nb x nb
+  double* Bt[2];                 // solved block row k, my columns J > k, contiguous (ld = nb): payload of the column broadcast; ring over block rows
+  double* S[2];                  // strip buffer: the strip's solved rows at my columns J > a, K-contiguous (ld = q nb); ring over strips
+  double* A[2];                  // A operand: Pc / Pr pieces of (q nb) x maxcols; ring over strips
+  double* msg[4];                // [ R(a, b) | Dinv(k) ], ring over block rows
   double* W; int64_t wcap;
-  int64_t apiece;                // doubles per A piece (nb x max local columns of any process column)
+  int64_t maxcols, apiece;       // widest local column count of any process column; doubles per A piece
   int* info_dev; double* info_red;
-  hipStream_t s_panel, s_comm;
-  std::vector<hipEvent_t> ev_fact, ev_msg, ev_solved, ev_gather, ev_head, ev_bulk;
-  hipEvent_t ev_init, ev_join_p, ev_join_c;
+  hipStream_t s_panel, s_comm, s_msg;
+  std::vector<hipEvent_t> ev_fact, ev_msg, ev_rowdone, ev_colb, ev_inv;      // per block row
+  std::vector<hipEvent_t> ev_gather, ev_head, ev_head2, ev_rest;              // per strip
+  hipEvent_t ev_init, ev_join_p, ev_join_c, ev_join_m, ev_join_i;
+  int strip, depth2, safe;
   int64_t occ1_m;
   int64_t cnt_gemm, cnt_chain, cnt_copy, cnt_coll;      // launches / collectives of the LAST factor call (this rank)
+  // R^-1 streamed with the sweep (complete_inv = 0 / 1): see inverse_step2d
+  int complete_inv; int64_t split;
+  double* Ri;                    // my piece of R^-1 (same shape as R): the partial product X_k while the sweep runs
+  double* Dall;                  // Dinv(k) of the diagonal blocks I own (nblk slots)
+  double* Dc[2];                 // Dinv(k) on the owner's process column (nb x nb), ring
+  double* Xc[2];                 // the finished block column k of R^-1 at my rows ((nlr nb) x nb), ring
+  cap_comm *row3, *col3;         // the inverse's broadcasts (owned duplicates)
+  hipStream_t s_inv;
 };
 
 namespace {
@@ -123,15 +140,93 @@ int ensure_events2(cap_dist2d_plan* d) {
     return CAP_OK;
   };
   const size_t cnt = (size_t)d->nblk + 2;
-  CAP_TRY(mk(d->ev_fact, cnt)); CAP_TRY(mk(d->ev_msg, cnt)); CAP_TRY(mk(d->ev_solved, cnt));
-  CAP_TRY(mk(d->ev_gather, cnt)); CAP_TRY(mk(d->ev_head, cnt)); CAP_TRY(mk(d->ev_bulk, cnt));
-  CAP_HIP(hipEventCreateWithFlags(&d->ev_init, hipEventDisableTiming));
-  CAP_HIP(hipEventCreateWithFlags(&d->ev_join_p, hipEventDisableTiming));
-  CAP_HIP(hipEventCreateWithFlags(&d->ev_join_c, hipEventDisableTiming));
+  CAP_TRY(mk(d->ev_fact, cnt)); CAP_TRY(mk(d->ev_msg, cnt)); CAP_TRY(mk(d->ev_rowdone, cnt)); CAP_TRY(mk(d->ev_colb, cnt)); CAP_TRY(mk(d->ev_inv, cnt));
+  CAP_TRY(mk(d->ev_gather, cnt)); CAP_TRY(mk(d->ev_head, cnt)); CAP_TRY(mk(d->ev_head2, cnt)); CAP_TRY(mk(d->ev_rest, cnt));
+  for (hipEvent_t* e : {&d->ev_init, &d->ev_join_p, &d->ev_join_c, &d->ev_join_m, &d->ev_join_i}) CAP_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
   int lo = 0, hi = 0;
   CAP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
   CAP_HIP(hipStreamCreateWithPriority(&d->s_panel, hipStreamNonBlocking, hi));
   CAP_HIP(hipStreamCreateWithPriority(&d->s_comm, hipStreamNonBlocking, hi));
+  CAP_HIP(hipStreamCreateWithPriority(&d->s_msg, hipStreamNonBlocking, hi));
+  CAP_HIP(hipStreamCreateWithPriority(&d->s_inv, hipStreamNonBlocking, lo));
+  return CAP_OK;
+}
+
+// X_{-1} = I on my piece: local column l (global g) carries a 1 at global row g if that row is mine
+__global__ void identity_2d_kernel(double* X, int64_t ld, int64_t nb, int Pr, int Pc, int pr, int pc, int64_t lcols) {
+  const int64_t l = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (l >= lcols) return;
+  const int64_t J = (l / nb) * Pc + pc;
+  if ((int)(J % Pr) != pr) return;
+  X[(J / Pr) * nb + l % nb + l * ld] = 1.0;
+}
+// complete_inv == 0 with the root partition inside a block: clear Ri[global rows < n1, global columns >= n1]
+__global__ void zero_root_2d_kernel(double* X, int64_t ld, int64_t nb, int Pr, int Pc, int pr, int pc, int64_t lrows, int64_t lcols, int64_t n1) {
+  const int64_t lrow = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t lcol = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (lrow >= lrows || lcol >= lcols) return;
+  const int64_t grow = ((lrow / nb) * Pr + pr) * nb + lrow % nb, gcol = ((lcol / nb) * Pc + pc) * nb + lcol % nb;
+  if (grow < n1 && gcol >= n1) X[lrow + lcol * ld] = 0.0;
+}
+
+struct Cut2 { bool cut; int64_t kcut, n1; };
+inline Cut2 inv_cut2(const cap_dist2d_plan* d) {
+  const int64_t n1 = d->n >> d->split;
+  const bool cut = d->complete_inv == 0 && n1 > 0 && n1 < d->n;
+  return Cut2{cut, (cut && n1 % d->nb == 0) ? n1 / d->nb : 0, n1};
+}
+
+// Step k of the streamed inverse on the Pr x Pc grid (the left-to-right product of dist.hip's inverse_step): block column k of R^-1
+// lives on process column pck with its rows spread over the process rows.
+//   a. Dinv(k) down process column pck (root prk)                                                              [nb^2]
+//   b. process column pck: X[my rows <= k, k] <- X[my rows <= k, k] Dinv(k)        (the column is final)
+//   c. that piece along every process row (root pck)                                                           [(k + 1) nb / Pr x nb]
+//   d. every process: X[my rows <= k, my J > k] -= X[my rows <= k, k] R[k, my J]   (R[k, my J] = the solved row in my strip buffer)
+// Srow: block row k at my columns J > k inside the strip buffer (ld = ldS, column origin = local block lbk).
+int inverse_step2d(cap_dist2d_plan* d, int64_t k, const double* Srow, int64_t ldS, hipStream_t s, cap_comm* crow, cap_comm* ccol) {
+  CapRange range("CI::inverse");
+  const int64_t nb = d->nb, nb2 = nb * nb, ld = d->ld;
+  const int Pr = d->Pr, Pc = d->Pc, pr = d->pr, pc = d->pc;
+  const int prk = (int)(k % Pr), pck = (int)(k % Pc);
+  const Cut2 ic = inv_cut2(d);
+  const int64_t r0 = (ic.kcut > 0 && k >= ic.kcut) ? lbfirst2(pr, ic.kcut - 1, Pr) : 0;      // my first active row block
+  const int64_t r1 = lbfirst2(pr, k, Pr);                                                    // my row blocks I <= k
+  const int64_t rows = (r1 - r0) * nb;
+  double* Dk = d->Dc[k & 1]; double* Xk = d->Xc[k & 1];
+  if (pc == pck) {
+    if (pr == prk) CAP_TRY(cap_copy_rect(d->Dall + k * nb2, nb, Dk, nb, nb, nb, s));
+    if (Pr > 1) { CAP_TRY(cap_comm_bcast(ccol, Dk, nb2, prk, (void*)s)); d->cnt_coll++; }
+    if (rows > 0) {
+      double* Xcol = d->Ri + r0 * nb + (k / Pc) * nb * ld;
+      CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, rows, nb, nb, 1.0, Xcol, ld, Dk, nb, 0.0, Xk, rows, 0, s, 8));
+      CAP_TRY(cap_copy_rect(Xk, rows, Xcol, ld, rows, nb, s));
+      d->cnt_gemm++; d->cnt_copy++;
+    }
+  }
+  if (rows > 0 && Pc > 1) { CAP_TRY(cap_comm_bcast(crow, Xk, rows * nb, pck, (void*)s)); d->cnt_coll++; }
+  const int64_t lb0 = lbfirst2(pc, k, Pc);
+  int64_t lb1 = d->nlc;
+  if (ic.kcut > 0 && k < ic.kcut) lb1 = lbfirst2(pc, ic.kcut - 1, Pc);
+  if (rows > 0 && lb1 > lb0) {
+    CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, rows, (lb1 - lb0) * nb, nb, -1.0, Xk, rows, Srow, ldS, 1.0, d->Ri + r0 * nb + lb0 * nb * ld, ld, 0, s));
+    d->cnt_gemm++;
+  }
+  return CAP_OK;
+}
+
+int ensure_inverse2d(cap_dist2d_plan* d) {
+  if (d->Ri) return CAP_OK;
+  hipError_t e = hipMalloc((void**)&d->Ri, sizeof(double) * std::max<int64_t>(d->ld * d->nlc * d->nb, 2));
+  if (e == hipSuccess) e = hipMalloc((void**)&d->Dall, sizeof(double) * d->nblk * d->nb * d->nb);
+  for (int i = 0; i < 2 && e == hipSuccess; i++) {
+    e = hipMalloc((void**)&d->Dc[i], sizeof(double) * d->nb * d->nb);
+    if (e == hipSuccess) e = hipMalloc((void**)&d->Xc[i], sizeof(double) * std::max<int64_t>(d->nlr, 1) * d->nb * d->nb);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    for (double** q : {&d->Ri, &d->Dall, &d->Dc[0], &d->Dc[1], &d->Xc[0], &d->Xc[1]}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+    return CAP_ERR_ALLOC;
+  }
   return CAP_OK;
 }
 }  // namespace
@@ -166,16 +261,19 @@ int cap_dist2d_plan_create(cap_dist2d_plan** plan, int64_t n, int64_t nb, cap_co
   if (P % Pr) return CAP_ERR_ARG;
   const int Pc = P / Pr;
   if (Pc % Pr) return CAP_ERR_UNSUPPORTED;                 // the A-operand contributors are whole process columns only if Pr | Pc
-  if (Pc > 8) return CAP_ERR_UNSUPPORTED;                  // the update kernel carries 8 piece offsets
+  if (Pc > 8 || 4 % Pr) return CAP_ERR_UNSUPPORTED;       // the update kernel carries 8 piece offsets; the message ring of 4 needs Pr | 4
   cap_dist2d_plan* d = new (std::nothrow) cap_dist2d_plan();
   if (!d) return CAP_ERR_ALLOC;
   d->n = n; d->nb = nb; d->nblk = cap_ceil_div(n, nb); d->npad = d->nblk * nb;
   d->Pr = Pr; d->Pc = Pc; d->P = P; d->rank = rank; d->pr = rank / Pc; d->pc = rank % Pc;
-  d->world = world; d->row = row; d->col = col; d->owns_row = d->owns_col = false;
+  d->world = world; d->row = row; d->col = col; d->owns_row = d->owns_col = false; d->row2 = d->row3 = d->col3 = nullptr;
   d->R = nullptr; d->W = nullptr; d->info_dev = nullptr; d->info_red = nullptr;
-  for (int i = 0; i < 2; i++) d->B[i] = d->A[i] = d->Dinv[i] = nullptr;
-  d->s_panel = d->s_comm = nullptr;
+  for (int i = 0; i < 2; i++) d->Bt[i] = d->S[i] = d->A[i] = d->Dc[i] = d->Xc[i] = nullptr;
+  for (int i = 0; i < 4; i++) d->msg[i] = nullptr;
+  d->Ri = d->Dall = nullptr;
+  d->s_panel = d->s_comm = d->s_msg = d->s_inv = nullptr;
   d->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
+  d->strip = d->nblk >= 8 ? 2 : 1; d->depth2 = 1; d->safe = 0; d->complete_inv = -1; d->split = 1;
   d->cnt_gemm = d->cnt_chain = d->cnt_copy = d->cnt_coll = 0;
   if (!d->row && P > 1) {
     int st = cap_comm_split(world, d->pr, d->pc, &d->row);
@@ -191,19 +289,28 @@ int cap_dist2d_plan_create(cap_dist2d_plan** plan, int64_t n, int64_t nb, cap_co
     cap_dist2d_plan_destroy(d);
     return CAP_ERR_ARG;
   }
+  if (P > 1) {      // the small messages and the inverse's broadcasts run next to the operand moves: their own communicators
+    int st = cap_comm_dup(d->row, &d->row2);
+    if (st == CAP_OK) st = cap_comm_dup(d->row, &d->row3);
+    if (st == CAP_OK) st = cap_comm_dup(d->col, &d->col3);
+    if (st != CAP_OK) { cap_dist2d_plan_destroy(d); return st; }
+  }
   d->nlr = nblocks_of2(d->pr, d->nblk, Pr); d->nlc = nblocks_of2(d->pc, d->nblk, Pc);
   d->lr_valid = valid_extent(n, nb, Pr, d->pr); d->lc_valid = valid_extent(n, nb, Pc, d->pc);
   d->ld = std::max<int64_t>(d->nlr * nb, 2);
-  const int64_t maxcols = nblocks_of2(0, d->nblk, Pc) * nb;        // process column 0 owns the most blocks
-  d->apiece = nb * maxcols;
+  d->maxcols = nblocks_of2(0, d->nblk, Pc) * nb;           // process column 0 owns the most blocks
+  d->apiece = 2 * nb * d->maxcols;
   d->wcap = cap_rec_work_size(nb);
   hipError_t e = hipMalloc((void**)&d->R, sizeof(double) * std::max<int64_t>(d->ld * d->nlc * nb, 2));
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
-    e = hipMalloc((void**)&d->B[i], sizeof(double) * nb * (maxcols + nb));
-    if (e == hipSuccess) e = hipMemset(d->B[i], 0, sizeof(double) * nb * (maxcols + nb));
+    e = hipMalloc((void**)&d->Bt[i], sizeof(double) * nb * (d->maxcols + nb));
+    if (e == hipSuccess) e = hipMalloc((void**)&d->S[i], sizeof(double) * 2 * nb * (d->maxcols + nb));
+    if (e == hipSuccess) e = hipMemset(d->S[i], 0, sizeof(double) * 2 * nb * (d->maxcols + nb));
     if (e == hipSuccess) e = hipMalloc((void**)&d->A[i], sizeof(double) * d->apiece * (Pc / Pr));
-    if (e == hipSuccess) e = hipMalloc((void**)&d->Dinv[i], sizeof(double) * nb * nb);
-    if (e == hipSuccess) e = hipMemset(d->Dinv[i], 0, sizeof(double) * nb * nb);
+  }
+  for (int i = 0; i < 4 && e == hipSuccess; i++) {
+    e = hipMalloc((void**)&d->msg[i], sizeof(double) * 2 * nb * nb);
+    if (e == hipSuccess) e = hipMemset(d->msg[i], 0, sizeof(double) * 2 * nb * nb);
   }
   if (e == hipSuccess) e = hipMalloc((void**)&d->W, sizeof(double) * d->wcap);
   if (e == hipSuccess) e = hipMalloc((void**)&d->info_dev, sizeof(int));
@@ -215,17 +322,17 @@ int cap_dist2d_plan_create(cap_dist2d_plan** plan, int64_t n, int64_t nb, cap_co
 
 int cap_dist2d_plan_destroy(cap_dist2d_plan* d) {
   if (!d) return CAP_OK;
-  if (d->R) (void)hipFree(d->R);
-  for (int i = 0; i < 2; i++) { if (d->B[i]) (void)hipFree(d->B[i]); if (d->A[i]) (void)hipFree(d->A[i]); if (d->Dinv[i]) (void)hipFree(d->Dinv[i]); }
-  if (d->W) (void)hipFree(d->W);
+  for (double* q : {d->R, d->Bt[0], d->Bt[1], d->S[0], d->S[1], d->A[0], d->A[1], d->msg[0], d->msg[1], d->msg[2], d->msg[3], d->W, d->info_red, d->Ri,
+                    d->Dall, d->Dc[0], d->Dc[1], d->Xc[0], d->Xc[1]})
+    if (q) (void)hipFree(q);
   if (d->info_dev) (void)hipFree(d->info_dev);
-  if (d->info_red) (void)hipFree(d->info_red);
   if (!d->ev_msg.empty()) {
-    for (auto* v : {&d->ev_fact, &d->ev_msg, &d->ev_solved, &d->ev_gather, &d->ev_head, &d->ev_bulk})
+    for (auto* v : {&d->ev_fact, &d->ev_msg, &d->ev_rowdone, &d->ev_colb, &d->ev_inv, &d->ev_gather, &d->ev_head, &d->ev_head2, &d->ev_rest})
       for (auto e : *v) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(d->ev_init); (void)hipEventDestroy(d->ev_join_p); (void)hipEventDestroy(d->ev_join_c);
-    (void)hipStreamDestroy(d->s_panel); (void)hipStreamDestroy(d->s_comm);
+    for (hipEvent_t e : {d->ev_init, d->ev_join_p, d->ev_join_c, d->ev_join_m, d->ev_join_i}) (void)hipEventDestroy(e);
+    for (hipStream_t st : {d->s_panel, d->s_comm, d->s_msg, d->s_inv}) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   }
+  for (cap_comm* c : {d->row2, d->row3, d->col3}) if (c) cap_comm_destroy(c);
   if (d->owns_row && d->row) cap_comm_destroy(d->row);
   if (d->owns_col && d->col) cap_comm_destroy(d->col);
   delete d;
@@ -245,14 +352,22 @@ int64_t cap_dist2d_get(const cap_dist2d_plan* d, int which) {
 }
 
 double* cap_dist2d_R_ptr(cap_dist2d_plan* d, int64_t* ld) { if (!d) return nullptr; if (ld) *ld = d->ld; return d->R; }
+double* cap_dist2d_Rinv_ptr(cap_dist2d_plan* d, int64_t* ld) { if (!d || !d->Ri) return nullptr; if (ld) *ld = d->ld; return d->Ri; }
 
 // Alocal: this process's valid local piece (cap_bc2d_local_extent rows x columns, column-major, lda >= rows), read-only
 int cap_dist2d_factor(cap_dist2d_plan* d, const double* Aloc, int64_t lda, void* stream) {
   if (!d) return CAP_ERR_ARG;
   if (d->lr_valid > 0 && d->lc_valid > 0 && (!Aloc || lda < d->lr_valid)) return CAP_ERR_ARG;
   CAP_TRY(ensure_events2(d));
+  const bool inv = d->complete_inv >= 0;
+  if (inv) CAP_TRY(ensure_inverse2d(d));
   CapRange frange("CI::factor");
-  hipStream_t s0 = cap_stream(stream), s1 = d->s_panel, sc = d->s_comm;
+  hipStream_t s0 = cap_stream(stream), s1 = d->s_panel, sc = d->s_comm, sm = d->safe ? d->s_comm : d->s_msg;
+  cap_comm* rmsg = (d->safe || !d->row2) ? d->row : d->row2;
+  const bool inv_overlap = inv && !d->safe;
+  hipStream_t si = inv_overlap ? d->s_inv : s0;
+  cap_comm* rinv = (inv_overlap && d->row3) ? d->row3 : d->row;
+  cap_comm* cinv = (inv_overlap && d->col3) ? d->col3 : d->col;
   const int64_t nb = d->nb, nblk = d->nblk, ld = d->ld, nb2 = nb * nb;
   const int Pr = d->Pr, Pc = d->Pc, pr = d->pr, pc = d->pc, ncon = Pc / Pr;
   d->cnt_gemm = d->cnt_chain = d->cnt_copy = d->cnt_coll = 0;
@@ -263,96 +378,183 @@ int cap_dist2d_factor(cap_dist2d_plan* d, const double* Aloc, int64_t lda, void*
     CAP_HIP(hipGetLastError());
     d->cnt_copy++;
   }
-  CAP_HIP(hipEventRecord(d->ev_init, s0));
-  CAP_HIP(hipStreamWaitEvent(s1, d->ev_init, 0));
-  CAP_HIP(hipStreamWaitEvent(sc, d->ev_init, 0));
-
-  for (int64_t k = 0; k < nblk; k++) {
-    const int par = (int)(k & 1);
-    const int prk = (int)(k % Pr), pck = (int)(k % Pc);
-    const bool in_row = pr == prk, owner = in_row && pc == pck;
-    double* Dinv = d->Dinv[par]; double* Bk = d->B[par]; double* Ak = d->A[par];
-    const int64_t lbk = lbfirst2(pc, k, Pc);                    // my local column blocks with J <= k
-    const int64_t ncols = (d->nlc - lbk) * nb;                  // my columns J > k
-    // ---- 1. diagonal block (needs every earlier update of block row k: HEAD(k-1) is on this stream, bulk(k-2) by event)
-    if (k >= 2) CAP_HIP(hipStreamWaitEvent(s1, d->ev_bulk[k - 2], 0));
-    if (owner) {
-      CapRange range("CI::factor_diag");
-      double* D = d->R + (k / Pr) * nb + (k / Pc) * nb * ld;
-      CAP_TRY(cap_rec_cholinv_full(D, ld, Dinv, nb, nb, d->W, d->wcap, d->info_dev, s1, k * nb));
-      d->cnt_chain++;
-      CAP_HIP(hipEventRecord(d->ev_fact[k], s1));
+  if (inv) {
+    CAP_HIP(hipMemsetAsync(d->Ri, 0, sizeof(double) * std::max<int64_t>(ld * d->nlc * nb, 2), s0));
+    if (d->nlr > 0 && d->nlc > 0) {
+      hipLaunchKernelGGL(identity_2d_kernel, dim3((unsigned)cap_ceil_div(d->nlc * nb, 256)), dim3(256), 0, s0, d->Ri, ld, nb, Pr, Pc, pr, pc, d->nlc * nb);
+      CAP_HIP(hipGetLastError());
     }
-    // ---- 2. Dinv(k) along process row prk
-    if (in_row) {
-      if (owner) CAP_HIP(hipStreamWaitEvent(sc, d->ev_fact[k], 0));
-      else if (k >= 2) CAP_HIP(hipStreamWaitEvent(sc, d->ev_solved[k - 2], 0));     // the broadcast overwrites the inverse step k-2 solved with
-      if (Pc > 1) { CAP_TRY(cap_comm_bcast(d->row, Dinv, nb2, pck, (void*)sc)); d->cnt_coll++; }
-      CAP_HIP(hipEventRecord(d->ev_msg[k], sc));
-      // ---- 3. my part of block row k
-      CAP_HIP(hipStreamWaitEvent(s1, d->ev_msg[k], 0));
+  }
+  CAP_HIP(hipEventRecord(d->ev_init, s0));
+  for (hipStream_t st : {s1, sc, sm}) CAP_HIP(hipStreamWaitEvent(st, d->ev_init, 0));
+  if (inv_overlap) CAP_HIP(hipStreamWaitEvent(si, d->ev_init, 0));
+
+  // strips: sb[t] = first block row, sq[t] = block rows (d->strip, the last one may be shorter)
+  std::vector<int64_t> sb, sq;
+  for (int64_t k = 0; k < nblk; k += d->strip) { sb.push_back(k); sq.push_back(std::min<int64_t>(d->strip, nblk - k)); }
+  const int64_t nstrips = (int64_t)sb.size();
+
+  for (int64_t t = 0; t < nstrips; t++) {
+    const int par = (int)(t & 1);
+    const int64_t a = sb[t], q = sq[t], b = a + q - 1, e = b + 1;
+    const int64_t ldS = q * nb;
+    const int64_t lbS = lbfirst2(pc, a, Pc);                      // my first local column block with J > a: column origin of S[par]
+    double* S = d->S[par]; double* Ak = d->A[par];
+    // S[par] / A[par] were read by the HEAD (panel stream), the bulk update (caller's stream) and the inverse of strip t - 2
+    if (t >= 2) {
+      CAP_HIP(hipStreamWaitEvent(sc, d->ev_head[t - 2], 0));
+      CAP_HIP(hipStreamWaitEvent(sc, d->ev_rest[t - 2], 0));
+      if (inv_overlap) CAP_HIP(hipStreamWaitEvent(sc, d->ev_inv[sb[t - 2] + sq[t - 2] - 1], 0));
+    }
+    for (int64_t r = 0; r < q; r++) {
+      const int64_t k = a + r;
+      const int prk = (int)(k % Pr), pck = (int)(k % Pc);
+      const bool in_row = pr == prk, owner = in_row && pc == pck;
+      double* mb = d->msg[k & 3]; double* Dinv = mb + nb2; double* Bt = d->Bt[k & 1];
+      const int64_t lbk = lbfirst2(pc, k, Pc);                    // my local column blocks with J <= k
+      const int64_t ncols = (d->nlc - lbk) * nb;                  // my columns J > k
+      const int64_t rlk = k / Pr;                                 // local row block of block row k on process row prk
+      // ---- 1. diagonal block on its owner (every earlier update of block row k is in: HEAD(t-1) ran on this stream behind the
+      //         head of bulk(t-2), which covered the rows of strip t)
+      if (owner) {
+        double* D = d->R + rlk * nb + (k / Pc) * nb * ld;
+        if (r == 1) {
+          // in-strip: D(b) -= S_a(:, b)^T S_a(:, b); S_a's column block b came down my process column
+          CAP_HIP(hipStreamWaitEvent(s1, d->ev_colb[a], 0));
+          const double* Sab = S + (k / Pc - lbS) * nb * ldS;
+          CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, nb, nb, -1.0, Sab, ldS, Sab, ldS, 1.0, D, ld, 1, s1, 2)); d->cnt_gemm++;
+        }
+        {
+          CapRange range("CI::factor_diag");
+          CAP_TRY(cap_rec_cholinv_full(D, ld, Dinv, nb, nb, d->W, d->wcap, d->info_dev, s1, k * nb)); d->cnt_chain++;
+        }
+        if (r == 1) { CAP_TRY(cap_copy_rect(S + (k / Pc - lbS) * nb * ldS, ldS, mb, nb, nb, nb, s1)); d->cnt_copy++; }     // R(a, b) rides along
+        if (inv) { CAP_TRY(cap_copy_rect(Dinv, nb, d->Dall + k * nb2, nb, nb, nb, s1)); d->cnt_copy++; }
+        CAP_HIP(hipEventRecord(d->ev_fact[k], s1));
+        CAP_HIP(hipStreamWaitEvent(sm, d->ev_fact[k], 0));
+      } else if (in_row && k >= 4) {
+        CAP_HIP(hipStreamWaitEvent(sm, d->ev_rowdone[k - 4], 0));  // the broadcast overwrites the message block row k - 4 was solved with
+      }
+      // ---- 2. msg(k) = [ R(a, b) | Dinv(k) ] along process row prk
+      if (in_row) {
+        if (Pc > 1) { CAP_TRY(cap_comm_bcast(rmsg, mb, 2 * nb2, pck, (void*)sm)); d->cnt_coll++; }
+        CAP_HIP(hipEventRecord(d->ev_msg[k], sm));
+        // ---- 3. my part of block row k
+        CAP_HIP(hipStreamWaitEvent(s1, d->ev_msg[k], 0));
+        if (k >= 2) CAP_HIP(hipStreamWaitEvent(s1, d->ev_colb[k - 2], 0));          // Bt[k & 1] was the payload of block row k - 2
+        if (ncols > 0) {
+          CapRange range("CI::trsm");
+          double* Rrow = d->R + rlk * nb + lbk * nb * ld;
+          if (r == 1) {   // in-strip update: R[b, mine] -= R(a, b)^T S_a(:, mine)
+            CAP_HIP(hipStreamWaitEvent(s1, d->ev_colb[a], 0));
+            CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, ncols, nb, -1.0, mb, nb, S + (lbk - lbS) * nb * ldS, ldS, 1.0, Rrow, ld, 0, s1, 2));
+            d->cnt_gemm++;
+          }
+          CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, ncols, nb, 1.0, Dinv, nb, Rrow, ld, 0.0, Bt, nb, 0, s1, 2 | 16));
+          CAP_TRY(cap_copy_rect(Bt, nb, Rrow, ld, nb, ncols, s1));
+          d->cnt_gemm++; d->cnt_copy++;
+        }
+      }
+      CAP_HIP(hipEventRecord(d->ev_rowdone[k], s1));
+      // ---- 4. S_k's piece down my process column (root: process row prk), then into the strip buffer (rows r nb .., ld = q nb)
+      CAP_HIP(hipStreamWaitEvent(sc, d->ev_rowdone[k], 0));
       if (ncols > 0) {
-        CapRange range("CI::trsm");
-        double* Rrow = d->R + (k / Pr) * nb + lbk * nb * ld;
-        CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, ncols, nb, 1.0, Dinv, nb, Rrow, ld, 0.0, Bk, nb, 0, s1, 2 | 16));
-        CAP_TRY(cap_copy_rect(Bk, nb, Rrow, ld, nb, ncols, s1));
-        d->cnt_gemm++; d->cnt_copy++;
+        if (Pr > 1) { CAP_TRY(cap_comm_bcast(d->col, Bt, nb * ncols, prk, (void*)sc)); d->cnt_coll++; }
+        CAP_TRY(cap_copy_rect(Bt, nb, S + r * nb + (lbk - lbS) * nb * ldS, ldS, nb, ncols, sc)); d->cnt_copy++;
+      }
+      CAP_HIP(hipEventRecord(d->ev_colb[k], sc));
+      if (inv_overlap) {       // block row k is final and in my strip buffer: step k of the streamed inverse on its own stream
+        CAP_HIP(hipStreamWaitEvent(si, d->ev_colb[k], 0));
+        CAP_TRY(inverse_step2d(d, k, S + r * nb + (lbk - lbS) * nb * ldS, ldS, si, rinv, cinv));
+        CAP_HIP(hipEventRecord(d->ev_inv[k], si));
       }
     }
-    CAP_HIP(hipEventRecord(d->ev_solved[k], s1));
-    if (k + 1 >= nblk) continue;                                 // last block row: nothing below it
+    if (e >= nblk) continue;                                     // last strip: nothing below it
 
-    // ---- 4. B operand: S_k[:, my columns J > k] down my process column (root: process row prk)
-    CAP_HIP(hipStreamWaitEvent(sc, d->ev_solved[k], 0));         // root: the piece is solved; others: s1 has passed HEAD(k-2), the last reader of Bk on it
-    if (k >= 2) CAP_HIP(hipStreamWaitEvent(sc, d->ev_bulk[k - 2], 0));   // bulk(k-2) read Bk / Ak
-    if (Pr > 1 && ncols > 0) { CAP_TRY(cap_comm_bcast(d->col, Bk, nb * ncols, prk, (void*)sc)); d->cnt_coll++; }
-    // ---- 5. A operand: blocks I = pr mod Pr of S_k, held (after 4.) by the columns pc' = pr mod Pr + m Pr of my process row
+    // ---- 5. A operand: blocks I = pr mod Pr of the strip, held (after 4.) by the columns pc' = pr mod Pr + m Pr of my process row
+    const int64_t lbe = lbfirst2(pc, b, Pc);                      // my first local column block with J >= e
     int gstart[8];
     for (int m = 0; m < 8; m++) gstart[m] = 0;
-    for (int m = 0; m < ncon; m++) {
-      const int pcs = pr % Pr + m * Pr;                          // contributor's column coordinate
-      const int64_t lbs = lbfirst2(pcs, k, Pc), cs = (nblocks_of2(pcs, nblk, Pc) - lbs) * nb;
-      gstart[m] = (int)lbs;
-      if (cs <= 0) continue;
-      double* slot = Ak + (int64_t)m * d->apiece;
-      if (pcs == pc) { CAP_TRY(cap_copy_rect(Bk, nb, slot, nb, nb, cs, sc)); d->cnt_copy++; }
-      if (Pc > 1) { CAP_TRY(cap_comm_bcast(d->row, slot, nb * cs, pcs, (void*)sc)); d->cnt_coll++; }
-    }
-    CAP_HIP(hipEventRecord(d->ev_gather[k], sc));
-
-    // ---- 6. updates with step k: local blocks k < I <= J
-    const int64_t lbc1 = lbfirst2(pc, k, Pc);                    // first local column block with J >= k + 1
-    const int64_t ncols1 = (d->nlc - lbc1) * nb;
-    // HEAD: block row k + 1 (on its process row), panel stream - the next diagonal block and block row depend on it
-    CAP_HIP(hipStreamWaitEvent(s1, d->ev_gather[k], 0));
-    if (k >= 1) CAP_HIP(hipStreamWaitEvent(s1, d->ev_bulk[k - 1], 0));      // bulk(k-1) also updates block row k + 1
-    if ((int)((k + 1) % Pr) == pr && ncols1 > 0) {
-      CapRange range("CI::tmu");
-      const int64_t rl = (k + 1) / Pr;
-      CAP_TRY(cap_dist_update_launch(nb, ncols1, nb, Ak, d->apiece, gstart, Bk + (lbc1 - lbk) * nb * nb, d->R + rl * nb + lbc1 * nb * ld, ld, Pc, pc,
-                                     (int)nb, (int)(k + 1), (int)lbc1, s1, 0, Pr, pr, (int)rl));
-      d->cnt_gemm++;
-    }
-    CAP_HIP(hipEventRecord(d->ev_head[k], s1));
-    // bulk: local block rows I >= k + 2, columns J >= k + 2, caller's stream
-    CAP_HIP(hipStreamWaitEvent(s0, d->ev_gather[k], 0));
-    if (k + 2 < nblk) {
-      const int64_t rl2 = lbfirst2(pr, k + 1, Pr), lbc2 = lbfirst2(pc, k + 1, Pc);
-      const int64_t mrows = (d->nlr - rl2) * nb, ncols2 = (d->nlc - lbc2) * nb;
-      if (mrows > 0 && ncols2 > 0) {
-        CapRange range("CI::tmu");
-        const int occ = (d->occ1_m > 0 && (double)mrows * (double)ncols2 <= (double)d->occ1_m * (double)d->occ1_m) ? -1 : 0;
-        CAP_TRY(cap_dist_update_launch(mrows, ncols2, nb, Ak, d->apiece, gstart, Bk + (lbc2 - lbk) * nb * nb, d->R + rl2 * nb + lbc2 * nb * ld, ld, Pc,
-                                       pc, (int)nb, (int)(k + 2), (int)lbc2, s0, occ, Pr, pr, (int)rl2));
-        d->cnt_gemm++;
+    const double* G = Ak; int64_t gpiece = d->apiece;
+    if (Pc == 1) {                                               // one process: the strip buffer IS the A operand
+      gstart[0] = (int)lbe; G = S + (lbe - lbS) * nb * ldS; gpiece = 0;
+    } else {
+      for (int m = 0; m < ncon; m++) {
+        const int pcs = pr % Pr + m * Pr;                        // contributor's column coordinate
+        const int64_t lbs = lbfirst2(pcs, b, Pc), cs = (nblocks_of2(pcs, nblk, Pc) - lbs) * nb;
+        gstart[m] = (int)lbs;
+        if (cs <= 0) continue;
+        double* slot = Ak + (int64_t)m * d->apiece;
+        if (pcs == pc) { CAP_TRY(cap_copy_rect(S + (lbe - lbS) * nb * ldS, ldS, slot, ldS, ldS, cs, sc)); d->cnt_copy++; }
+        CAP_TRY(cap_comm_bcast(d->row, slot, ldS * cs, pcs, (void*)sc)); d->cnt_coll++;
       }
     }
-    CAP_HIP(hipEventRecord(d->ev_bulk[k], s0));
+    CAP_HIP(hipEventRecord(d->ev_gather[t], sc));
+
+    // ---- 6. updates with strip t, K = q nb: local blocks b < I <= J
+    const int64_t q1 = sq[t + 1], e2 = e + q1;
+    auto upd = [&](int64_t I0, int64_t I1, hipStream_t s, int occ) -> int {     // my row blocks with I0 <= I < I1 (I1 < 0: all below I0)
+      const int64_t rl0 = lbfirst2(pr, I0 - 1, Pr), rl1 = I1 < 0 ? d->nlr : lbfirst2(pr, I1 - 1, Pr);
+      const int64_t lbc = lbfirst2(pc, I0 - 1, Pc), mrows = (rl1 - rl0) * nb, nc = (d->nlc - lbc) * nb;
+      if (mrows <= 0 || nc <= 0) return CAP_OK;
+      CapRange range("CI::tmu");
+      if (occ < 0) occ = (d->occ1_m > 0 && (double)mrows * (double)nc <= (double)d->occ1_m * (double)d->occ1_m) ? -1 : 0;
+      CAP_TRY(cap_dist_update_launch(mrows, nc, ldS, G, gpiece, gstart, S + (lbc - lbS) * nb * ldS, d->R + rl0 * nb + lbc * nb * ld, ld, Pc, pc, (int)nb,
+                                     (int)I0, (int)lbc, s, occ, Pr, pr, (int)rl0));
+      d->cnt_gemm++;
+      return CAP_OK;
+    };
+    // HEAD: the rows of strip t + 1 (panel stream: its diagonal blocks and block rows depend on it)
+    CAP_HIP(hipStreamWaitEvent(s1, d->ev_gather[t], 0));
+    if (t >= 1) CAP_HIP(hipStreamWaitEvent(s1, d->ev_head2[t - 1], 0));     // strip t - 1's bulk update has passed these rows
+    CAP_TRY(upd(e, e2, s1, 0));
+    CAP_HIP(hipEventRecord(d->ev_head[t], s1));
+    // bulk: rows below strip t + 1, caller's stream; split so that the rows of strip t + 2 release the panel stream early
+    CAP_HIP(hipStreamWaitEvent(s0, d->ev_gather[t], 0));
+    if (e2 < nblk) {
+      const int64_t q2 = (t + 2 < nstrips) ? sq[t + 2] : 0, e3 = e2 + q2;
+      if (d->depth2 && q2 > 0 && e3 < nblk) {
+        CAP_TRY(upd(e2, e3, s0, -1));
+        CAP_HIP(hipEventRecord(d->ev_head2[t], s0));
+        CAP_TRY(upd(e3, -1, s0, -1));
+      } else {
+        CAP_TRY(upd(e2, -1, s0, -1));
+        CAP_HIP(hipEventRecord(d->ev_head2[t], s0));
+      }
+    } else {
+      CAP_HIP(hipEventRecord(d->ev_head2[t], s0));
+    }
+    CAP_HIP(hipEventRecord(d->ev_rest[t], s0));
   }
   CAP_HIP(hipEventRecord(d->ev_join_p, s1));
   CAP_HIP(hipEventRecord(d->ev_join_c, sc));
-  CAP_HIP(hipStreamWaitEvent(s0, d->ev_join_p, 0));
-  CAP_HIP(hipStreamWaitEvent(s0, d->ev_join_c, 0));
+  CAP_HIP(hipEventRecord(d->ev_join_m, sm));
+  for (hipEvent_t ev : {d->ev_join_p, d->ev_join_c, d->ev_join_m}) CAP_HIP(hipStreamWaitEvent(s0, ev, 0));
+  if (inv) {
+    if (inv_overlap) {
+      CAP_HIP(hipEventRecord(d->ev_join_i, si));
+      CAP_HIP(hipStreamWaitEvent(s0, d->ev_join_i, 0));
+    } else {
+      // safe mode: the steps after the sweep, in program order on the one communicator family; block row k is read back from R
+      // (row k lives on process row prk only: one more column broadcast per step into the payload buffer)
+      for (int64_t k = 0; k < nblk; k++) {
+        const int prk = (int)(k % Pr);
+        const int64_t lbk = lbfirst2(pc, k, Pc), ncols = (d->nlc - lbk) * nb;
+        double* Bt = d->Bt[k & 1];
+        if (ncols > 0) {
+          if (pr == prk) CAP_TRY(cap_copy_rect(d->R + (k / Pr) * nb + lbk * nb * ld, ld, Bt, nb, nb, ncols, s0));
+          if (Pr > 1) { CAP_TRY(cap_comm_bcast(d->col, Bt, nb * ncols, prk, (void*)s0)); d->cnt_coll++; }
+        }
+        CAP_TRY(inverse_step2d(d, k, Bt, nb, s0, rinv, cinv));
+      }
+    }
+    const Cut2 ic = inv_cut2(d);
+    if (ic.cut && ic.kcut == 0 && d->nlr > 0 && d->nlc > 0) {
+      hipLaunchKernelGGL(zero_root_2d_kernel, grid_cols(d->nlr * nb, d->nlc * nb), dim3(256), 0, s0, d->Ri, ld, nb, Pr, Pc, pr, pc, d->nlr * nb,
+                         d->nlc * nb, ic.n1);
+      CAP_HIP(hipGetLastError());
+    }
+  }
   return CAP_OK;
 }
 
@@ -384,9 +586,31 @@ int cap_dist2d_info(cap_dist2d_plan* d, void* stream, int64_t* info) {
   return best == 0 ? CAP_OK : CAP_ERR_NOT_SPD;
 }
 
+// construct_Rinv (cholinv.hpp:39-46) for this layout (options complete_inv = 0 / 1)
+int cap_dist2d_get_Rinv(cap_dist2d_plan* d, double* out, int64_t ldo, void* stream) {
+  if (!d) return CAP_ERR_ARG;
+  if (d->complete_inv < 0 || !d->Ri) return CAP_ERR_UNSUPPORTED;
+  if (d->lr_valid == 0 || d->lc_valid == 0) return CAP_OK;
+  if (!out || ldo < d->lr_valid) return CAP_ERR_ARG;
+  hipLaunchKernelGGL(export_upper_2d_kernel, grid_cols(d->lr_valid, d->lc_valid), dim3(256), 0, cap_stream(stream), d->Ri, d->ld, out, ldo, d->nb,
+                     d->Pr, d->Pc, d->pr, d->pc, d->lr_valid, d->lc_valid);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
 int cap_dist2d_set_option(cap_dist2d_plan* d, const char* key, int64_t value) {
   if (!d || !key) return CAP_ERR_ARG;
   if (!strcmp(key, "occ1_m")) { if (value < 0) return CAP_ERR_ARG; d->occ1_m = value; return CAP_OK; }
+  if (!strcmp(key, "strip")) { if (value < 1 || value > 2) return CAP_ERR_ARG; d->strip = (int)value; return CAP_OK; }
+  if (!strcmp(key, "depth2")) { d->depth2 = value != 0; return CAP_OK; }
+  if (!strcmp(key, "safe")) { d->safe = value != 0; return CAP_OK; }
+  if (!strcmp(key, "complete_inv")) {
+    if (value < -1 || value > 1) return CAP_ERR_ARG;
+    if (value >= 0) CAP_TRY(ensure_inverse2d(d));
+    d->complete_inv = (int)value;
+    return CAP_OK;
+  }
+  if (!strcmp(key, "split")) { if (value <= 0) return CAP_ERR_ARG; d->split = value; return CAP_OK; }
   return CAP_ERR_ARG;
 }
 

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -259,6 +260,13 @@ __device__ __forceinline__ int v2_next(const Bf2Args& g, int xcd, int slot, int 
   return i;
 }
 
+// SCHED 1: the fragment reads of k-step s + 1 are all issued before the MFMAs of k-step s (sched_barrier: hipcc otherwise sinks them
+//          behind the MFMAs that free their registers, 2 - 3 MFMAs ahead of their use - one compute wave per SIMD has nobody to cover that)
+// DBG (timing surgery, wrong results, CAP_EXPERIMENTS builds only): 1 no atomics, 2 no DMA after the ring is primed, 4 no MFMAs
+// PFI > 0: the loaders also pull the C tile through L2 (LDS-DMA into a 1 KiB dummy slot) during the last PFI K tiles of a tile, so that the
+//          atomics that follow find their lines in L2 (measured: the atomics of a launch alone take as long as K = 2048 of MFMA work,
+//          at a third of the HBM rate - every one of them is an L2 miss)
+template <int SCHED, int DBG, int PFI>
 __global__ void __launch_bounds__(512, 2) bf16_tn_v2_kernel(const Bf2Args g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   char* lds = reinterpret_cast<char*>(smem);
@@ -278,14 +286,28 @@ __global__ void __launch_bounds__(512, 2) bf16_tn_v2_kernel(const Bf2Args g) {
     DmaBuf dB = dma_buf_make(reinterpret_cast<const double*>(g.B), g.ldb / 4);
     int li, lti = 0, ltj = 0, lkt = 0, issued = 0, sl = 0;      // issue cursor: step, tile, K tile; stages issued; ring slot of the next stage
     li = v2_next(g, xcd, slot, round, 0, lti, ltj);
+    constexpr int NPF = PFI > 0 ? 32 / PFI : 0;                // C columns (1 KiB each: 256 rows) per loader wave and K tile
+    __amdgpu_buffer_rsrc_t rC = dA.rsrc;
+    const bool pf_on = PFI > 0 && g.nk >= PFI;
+    int pf_last = 0;
     auto retarget = [&]() {
       dA.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (int64_t)lti * 256 * g.lda), 0, (int)0xffffffffu, 0x00020000);
       dB.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.B + (int64_t)ltj * 128 * g.ldb), 0, (int)0xffffffffu, 0x00020000);
+      if (PFI > 0) rC = __builtin_amdgcn_make_buffer_rsrc((void*)(g.C + (int64_t)lti * 256 + (int64_t)ltj * 128 * g.ldc), 0, (int)0xffffffffu, 0x00020000);
     };
     retarget();
     auto issue = [&]() {
       char* st = lds + sl * V2_STAGE;
       const uint32_t kb = (uint32_t)lkt * 128u;
+      pf_last = 0;
+      if (PFI > 0 && pf_on && lkt >= g.nk - PFI) {                // C columns [32 lw + NPF (lkt - (nk - PFI)), + NPF) of this tile, BEFORE the stage's pieces
+        const uint32_t c0 = (uint32_t)(lw * 32 + NPF * (lkt - (g.nk - PFI)));
+#pragma unroll
+        for (int q = 0; q < NPF; q++)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rC, (__attribute__((address_space(3))) void*)(lds + 3 * V2_STAGE), 16, lane * 16,
+                                                   (int)((c0 + q) * (uint32_t)(g.ldc * 4)), 0, 0);
+        pf_last = 1;
+      }
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         const uint32_t g8 = (uint32_t)(lw * 8 + q);
@@ -305,11 +327,18 @@ __global__ void __launch_bounds__(512, 2) bf16_tn_v2_kernel(const Bf2Args g) {
     if (G > 1) issue();
     for (int gs = 0; gs < G; gs++) {
       // stage gs has landed once at most the pieces of stage gs + 1 (12 of mine) are outstanding
-      if (issued > gs + 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (everything issued behind stage gs's last piece: the C prefetches + 12 pieces of the most recent issue)
+      if (issued > gs + 1) {
+        if (PFI > 0 && pf_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 + NPF) : "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_barrier" ::: "memory");                   // B(gs): stage gs is visible; the readers have left slot (gs - 1) % 3
-      if (issued < G) issue();                                   // stage gs + 2 into that slot
+      if (issued < G) {                                          // stage gs + 2 into that slot
+        if ((DBG & 2) && issued >= 3) issued++;
+        else issue();
+      }
     }
+    asm volatile("s_barrier" ::: "memory");                       // B(G): pairs with the compute waves' barrier behind their last stage
     return;
   }
 
@@ -334,10 +363,19 @@ __global__ void __launch_bounds__(512, 2) bf16_tn_v2_kernel(const Bf2Args g) {
     for (int j = 0; j < 2; j++) xb[j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 32 * 128 + off);
   };
   auto mma = [&](const bf16x8 (&xa)[4], const bf16x8 (&xb)[2]) {
+    if (SCHED) __builtin_amdgcn_sched_barrier(0);
+    if (DBG & 4) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+      for (int i = 0; i < 4; i++) asm volatile("" :: "v"(xa[i]));
 #pragma unroll
-      for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[j], xa[i], acc[i][j], 0, 0, 0);   // swapped: lane = C row
+      for (int j = 0; j < 2; j++) asm volatile("" :: "v"(xb[j]));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[j], xa[i], acc[i][j], 0, 0, 0);   // swapped: lane = C row
+    }
+    if (SCHED) __builtin_amdgcn_sched_barrier(0);
   };
   int ci, cti = 0, ctj = 0, ckt = 0, sl = 0;
   ci = v2_next(g, xcd, slot, round, 0, cti, ctj);
@@ -349,9 +387,14 @@ __global__ void __launch_bounds__(512, 2) bf16_tn_v2_kernel(const Bf2Args g) {
     rd(st, 2, fa0, fb0); mma(fa1, fb1);
     rd(st, 3, fa1, fb1); mma(fa0, fb0);
     sl = sl == 2 ? 0 : sl + 1;
-    if (gs + 1 < G) {
-      // every fragment read of this stage has returned before the loaders may refill its slot
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // B(gs + 1)
+    {
+      // every fragment read of this stage has returned before the loaders may refill its slot.  The barrier is UNCONDITIONAL (the
+      // loaders run one extra one after their last stage; behind the last stage these reads fetch stale bytes nobody uses): with a
+      // barrier-free path joining here hipcc would re-wait for the fragments of k-step 3 - i.e. for the reads just issued
+      // (the wait is the BUILTIN so that hipcc's own counter model knows the fragments of k-step 3 have landed - behind an asm wait
+      //  it re-waits for them after the barrier, i.e. for the next stage's first reads, in front of the MFMAs meant to cover those)
+      __builtin_amdgcn_s_waitcnt(0xc07f);                                  // lgkmcnt(0)
+      asm volatile("s_barrier" ::: "memory");                              // B(gs + 1)
       rd(lds + sl * V2_STAGE, 0, fa0, fb0);
     }
     mma(fa1, fb1);
@@ -362,7 +405,14 @@ __global__ void __launch_bounds__(512, 2) bf16_tn_v2_kernel(const Bf2Args g) {
       const int dd = g.tri ? (int)(j0 - i0) : 1 << 30;           // columns lead the rows by dd: mask row <= col  <=>  lrow <= lcol + dd
       const bool diag = g.tri && dd < 256;                       // wave-uniform: only the two tiles per tile row that touch the diagonal
       float* Cl = g.C + (i0 + wi + r32) + (j0 + wj + 4 * kg) * g.ldc;      // this lane's first element
-      if (!diag) {
+      if (DBG & 1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) { asm volatile("" :: "v"(acc[i][j][e])); acc[i][j][e] = 0.0f; }
+      } else if (!diag) {
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -397,17 +447,32 @@ __global__ void __launch_bounds__(512, 2) bf16_tn_v2_kernel(const Bf2Args g) {
 
 // process-wide choice of the update kernel: 0 = round-3 kernel only, 1 = second-generation kernel wherever it applies (default),
 // tpw = supertile steps per workgroup
-static int g_bf16_variant = getenv("CAP_BF16_V2") ? atoi(getenv("CAP_BF16_V2")) : 1;
+// Default 0: measured inside the N = 65536 factorization (profiles/r04_experiments.log) the new kernel's updates run at 700-720 TF
+// against 630 for the old one, but its workgroups hold 145 KiB of LDS for a whole chunk, the diagonal-block chain finds no CU to
+// start on, and the factorization - bound by that chain (panel stream) at every strip - gets 5 % SLOWER (211 vs 199 ms).  Stand-alone
+// (update-bound callers, K >= 2048) it is the faster kernel: 855 vs 770 TF at K = 2048, 1017 vs 894 at K = 4096.
+static int g_bf16_variant = getenv("CAP_BF16_V2") ? atoi(getenv("CAP_BF16_V2")) : 0;
 static int g_bf16_tpw = getenv("CAP_BF16_TPW") ? atoi(getenv("CAP_BF16_TPW")) : 8;
 static int64_t g_bf16_min_tiles = getenv("CAP_BF16_V2_MIN") ? atoll(getenv("CAP_BF16_V2_MIN")) : 1024;
 
-int launch_bf16_v2(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A, int64_t lda, const __bf16* B, int64_t ldb, float* C, int64_t ldc,
-                   int tri, hipStream_t s) {
+static int g_bf16_sched = getenv("CAP_BF16_SCHED") ? atoi(getenv("CAP_BF16_SCHED")) : 1;
+static int g_bf16_dbg = 0;              // timing surgery (CAP_EXPERIMENTS builds): set through cap_bf16_update(variant = 100 + DBG)
+
+template <int SCHED, int DBG, int PFI = 0>
+int launch_bf16_v2_t(const Bf2Args& g, unsigned grid, hipStream_t s) {
   static bool attr_set = false;
+  constexpr int LDS_BYTES = 3 * V2_STAGE + 1024;            // ring + the dummy slot of the C prefetch
   if (!attr_set) {
-    CAP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_tn_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * V2_STAGE));
+    CAP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_tn_v2_kernel<SCHED, DBG, PFI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
   }
+  hipLaunchKernelGGL((bf16_tn_v2_kernel<SCHED, DBG, PFI>), dim3(grid), dim3(512), LDS_BYTES, s, g);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+int launch_bf16_v2(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A, int64_t lda, const __bf16* B, int64_t ldb, float* C, int64_t ldc,
+                   int tri, hipStream_t s) {
   Bf2Args g;
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha; g.tri = tri ? 1 : 0;
   g.tm = (int)(m / 256); g.tn = (int)(n / 128); g.nk = (int)(k / 64);
@@ -417,9 +482,22 @@ int launch_bf16_v2(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A
   const int64_t per_xcd = cap_ceil_div(g.nsuper, 8);
   g.tpw = (int)std::max<int64_t>(1, std::min<int64_t>(g_bf16_tpw, per_xcd));
   const int64_t rounds = cap_ceil_div(per_xcd, g.tpw);
-  hipLaunchKernelGGL(bf16_tn_v2_kernel, dim3((unsigned)(256 * rounds)), dim3(512), 3 * V2_STAGE, s, g);
-  CAP_HIP(hipGetLastError());
-  return CAP_OK;
+  const unsigned grid = (unsigned)(256 * rounds);
+  if constexpr (CAP_EXPERIMENTS) {
+    switch (g_bf16_dbg) {
+      case 1: return launch_bf16_v2_t<1, 1>(g, grid, s);
+      case 2: return launch_bf16_v2_t<1, 2>(g, grid, s);
+      case 3: return launch_bf16_v2_t<1, 3>(g, grid, s);
+      case 4: return launch_bf16_v2_t<1, 4>(g, grid, s);
+      case 6: return launch_bf16_v2_t<1, 6>(g, grid, s);
+      case 16: return launch_bf16_v2_t<1, 0, 2>(g, grid, s);       // C prefetch over the last 2 / 4 / 8 K tiles
+      case 17: return launch_bf16_v2_t<1, 0, 4>(g, grid, s);
+      case 18: return launch_bf16_v2_t<1, 0, 8>(g, grid, s);
+      case 20: return launch_bf16_v2_t<1, 4, 4>(g, grid, s);       // ... without the MFMAs
+      default: break;
+    }
+  }
+  return g_bf16_sched ? launch_bf16_v2_t<1, 0>(g, grid, s) : launch_bf16_v2_t<0, 0>(g, grid, s);
 }
 
 // dispatcher of the single-GPU updates: the second-generation kernel needs whole 256 x 128 tiles and enough of them to fill the chip
@@ -446,7 +524,13 @@ extern "C" int cap_bf16_update(int variant, int64_t m, int64_t n, int64_t k, flo
   if (variant < 0) return launch_bf16_update(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
   if (variant == 0) return launch_bf16_tn(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
   if (m % 256 || n % 128 || k % 64 || lda % 8 || ldb % 8 || (tri && m != n) || m == 0 || n == 0 || k == 0) return CAP_ERR_UNSUPPORTED;
-  return launch_bf16_v2(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
+  // variant 1: the production schedule; 2: without the forced read-ahead; 100 + DBG: timing surgery (experiment builds only)
+  g_bf16_sched = variant == 2 ? 0 : 1;
+  g_bf16_dbg = variant >= 100 ? variant - 100 : 0;
+  if (g_bf16_dbg && !CAP_EXPERIMENTS) return CAP_ERR_UNSUPPORTED;
+  const int st = launch_bf16_v2(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
+  g_bf16_sched = 1; g_bf16_dbg = 0;
+  return st;
 }
 
 // Distributed bf16 trailing update on a 1 x P block-column-cyclic fp32 matrix (dist_mixed.hip): C32[m x nloc] -= G^T B restricted
@@ -473,6 +557,13 @@ struct cap_mpchol_plan {
   float* R32; double* R64; __bf16* P16[2]; int64_t strip;
   // column-split schedule (cap_mpchol_factor): third stream, its events, near-column solve scratch (2 x nb x nb)
   int split; bool split_ready; hipStream_t s_far; hipEvent_t ev_c, ev_ns, ev_hf, ev_fs[2], ev_far[2], ev_join2; double* Tn;
+  // option "reserve" = r > 0: r CUs (bit i of the mask -> XCD i % 8) are kept free of everything but the diagonal-block chains:
+  // the updates run on a stream masked OFF those CUs, the panel / far streams too, the chain's latency-bound launches (leaf, fused
+  // 64-steps, inverse merges: <= 15 workgroups of 84 KiB LDS each) on a stream masked to exactly those CUs - they start at once and
+  // never share a SIMD with bf16-MFMA waves (measured under contention: 91 us per fused step against 30 us alone, 88 of a 198 ms factor)
+  int reserve; hipStream_t s_bulk, s_chain; hipEvent_t ev_user, ev_bulk_done, ev_ch[2]; bool res_ready;
+  // block-row solve on the bf16 pipe (option "solve3", default on): split operands, see mixed_kernels.h
+  int solve3; __bf16* A3[2]; __bf16* B3far; __bf16* B3near;
   hipStream_t s_panel; hipEvent_t ev_rest[2], ev_panel[2], ev_fork, ev_join; bool streams_ready;
   double* D64; double* Dinv; double* T64; double* S64; double* W; int64_t wcap;
   double* Inv; int64_t tb; double* Xt; double* Wt;          // blocked TRSM state
@@ -481,6 +572,56 @@ struct cap_mpchol_plan {
   // live profile of the bf16 trailing updates on the caller's stream (HIP events; cap_mpchol_profile)
   int profile; std::vector<hipEvent_t>* prof_ev; std::vector<double>* prof_flops; std::vector<double>* prof_bytes; int prof_used;
 };
+
+namespace {
+// a helper stream of the factorization: high priority on the whole chip, or - reserve mode - masked off the chain's CUs
+int mp_make_stream(cap_mpchol_plan* p, hipStream_t* out) {
+  if (p->reserve > 0) {
+    uint32_t mask[8];
+    for (int i = 0; i < 8; i++) mask[i] = 0xffffffffu;
+    for (int b = 0; b < p->reserve && b < 128; b++) mask[b / 32] &= ~(1u << (b % 32));
+    CAP_HIP(hipExtStreamCreateWithCUMask(out, 8, mask));
+    return CAP_OK;
+  }
+  int lo = 0, hi = 0;
+  CAP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  CAP_HIP(hipStreamCreateWithPriority(out, hipStreamNonBlocking, hi));
+  return CAP_OK;
+}
+int mp_ensure_reserved(cap_mpchol_plan* p) {
+  if (p->res_ready || p->reserve <= 0) return CAP_OK;
+  CAP_TRY(mp_make_stream(p, &p->s_bulk));
+  uint32_t mask[8];
+  for (int i = 0; i < 8; i++) mask[i] = 0u;
+  for (int b = 0; b < p->reserve && b < 128; b++) mask[b / 32] |= 1u << (b % 32);
+  CAP_HIP(hipExtStreamCreateWithCUMask(&p->s_chain, 8, mask));
+  for (hipEvent_t* e : {&p->ev_user, &p->ev_bulk_done, &p->ev_ch[0], &p->ev_ch[1]}) CAP_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  p->res_ready = true;
+  return CAP_OK;
+}
+void mp_release_streams(cap_mpchol_plan* p) {
+  if (p->split_ready) {
+    (void)hipStreamSynchronize(p->s_far); (void)hipStreamDestroy(p->s_far);
+    for (hipEvent_t e : {p->ev_c, p->ev_ns, p->ev_hf, p->ev_fs[0], p->ev_fs[1], p->ev_far[0], p->ev_far[1], p->ev_join2}) (void)hipEventDestroy(e);
+    if (p->Tn) (void)hipFree(p->Tn);
+    p->Tn = nullptr; p->split_ready = false;
+  }
+  if (p->streams_ready) {
+    (void)hipStreamSynchronize(p->s_panel); (void)hipStreamDestroy(p->s_panel);
+    for (int i = 0; i < 2; i++) { (void)hipEventDestroy(p->ev_rest[i]); (void)hipEventDestroy(p->ev_panel[i]); }
+    (void)hipEventDestroy(p->ev_fork); (void)hipEventDestroy(p->ev_join);
+    p->streams_ready = false;
+  }
+  if (p->res_ready) {
+    (void)hipStreamSynchronize(p->s_bulk); (void)hipStreamDestroy(p->s_bulk);
+    (void)hipStreamSynchronize(p->s_chain); (void)hipStreamDestroy(p->s_chain);
+    for (hipEvent_t e : {p->ev_user, p->ev_bulk_done, p->ev_ch[0], p->ev_ch[1]}) (void)hipEventDestroy(e);
+    p->res_ready = false;
+  }
+}
+}  // namespace
+
+static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipStream_t s0);
 
 extern "C" {
 
@@ -493,6 +634,8 @@ int cap_mpchol_plan_create(cap_mpchol_plan** plan, int64_t n, int64_t nrhs_max) 
   p->n = n; p->nb = 1024; p->nrhs_cap = cap_round_up(nrhs_max, 128);
   p->strip = getenv("CAP_MP_STRIP") ? atoll(getenv("CAP_MP_STRIP")) : 2;
   p->split = getenv("CAP_MP_SPLIT") ? atoi(getenv("CAP_MP_SPLIT")) : 1;
+  p->solve3 = getenv("CAP_MP_SOLVE3") ? atoi(getenv("CAP_MP_SOLVE3")) : 1;
+  p->reserve = getenv("CAP_MP_RESERVE") ? atoi(getenv("CAP_MP_RESERVE")) : 0;
   // largest power of two <= min(n, 1024) (>= 128 because n % 128 == 0): the fused diagonal-block chain and the bf16 tile
   // kernel (k % 64, m % 128) need it; the last panel of a non-power-of-two n is a shorter multiple of 128
   while (p->nb > n) p->nb /= 2;
@@ -501,11 +644,15 @@ int cap_mpchol_plan_create(cap_mpchol_plan** plan, int64_t n, int64_t nrhs_max) 
   const int64_t nb = p->nb, w = p->nrhs_cap, nblk = cap_ceil_div(n, p->tb);
   hipError_t e = hipMalloc((void**)&p->R32, sizeof(float) * n * n);
   if (e == hipSuccess) e = hipMalloc((void**)&p->R64, sizeof(double) * n * n);
+  if (e == hipSuccess) e = hipMemset(p->R64, 0, sizeof(double) * n * n);      // nothing ever writes below its diagonal
   for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void**)&p->P16[i], sizeof(__bf16) * 2 * nb * n);     // strip buffers, ld = 2 nb
   if (e == hipSuccess) e = hipMalloc((void**)&p->D64, sizeof(double) * (2 * nb * nb + 2 * nb * n + p->wcap));
   if (e == hipSuccess) e = hipMalloc((void**)&p->Inv, sizeof(double) * (nblk * p->tb * p->tb + p->tb * w));
   if (e == hipSuccess) e = hipMalloc((void**)&p->Xw, sizeof(double) * (3 * n * w + 8));
   if (e == hipSuccess) e = hipMalloc((void**)&p->info_dev, sizeof(int));
+  for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void**)&p->A3[i], sizeof(__bf16) * 3 * nb * nb);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->B3far, sizeof(__bf16) * 3 * nb * n);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->B3near, sizeof(__bf16) * 3 * nb * nb);
   if (e != hipSuccess) { cap_mpchol_plan_destroy(p); return CAP_ERR_ALLOC; }
   p->Dinv = p->D64 + nb * nb; p->T64 = p->Dinv + nb * nb; p->S64 = p->T64 + nb * n; p->W = p->S64 + nb * n;
   p->Xt = p->Inv + nblk * p->tb * p->tb; p->Wt = nullptr;
@@ -517,18 +664,10 @@ int cap_mpchol_plan_create(cap_mpchol_plan** plan, int64_t n, int64_t nrhs_max) 
 int cap_mpchol_plan_destroy(cap_mpchol_plan* p) {
   if (!p) return CAP_OK;
   if (p->prof_ev) { for (hipEvent_t e : *p->prof_ev) (void)hipEventDestroy(e); delete p->prof_ev; delete p->prof_flops; delete p->prof_bytes; }
-  for (void* q : {(void*)p->R32, (void*)p->R64, (void*)p->P16[0], (void*)p->P16[1], (void*)p->D64, (void*)p->Inv, (void*)p->Xw, (void*)p->info_dev})
+  for (void* q : {(void*)p->R32, (void*)p->R64, (void*)p->P16[0], (void*)p->P16[1], (void*)p->D64, (void*)p->Inv, (void*)p->Xw, (void*)p->info_dev,
+                  (void*)p->A3[0], (void*)p->A3[1], (void*)p->B3far, (void*)p->B3near})
     if (q) (void)hipFree(q);
-  if (p->split_ready) {
-    (void)hipStreamDestroy(p->s_far);
-    for (hipEvent_t e : {p->ev_c, p->ev_ns, p->ev_hf, p->ev_fs[0], p->ev_fs[1], p->ev_far[0], p->ev_far[1], p->ev_join2}) (void)hipEventDestroy(e);
-    if (p->Tn) (void)hipFree(p->Tn);
-  }
-  if (p->streams_ready) {
-    (void)hipStreamDestroy(p->s_panel);
-    for (int i = 0; i < 2; i++) { (void)hipEventDestroy(p->ev_rest[i]); (void)hipEventDestroy(p->ev_panel[i]); }
-    (void)hipEventDestroy(p->ev_fork); (void)hipEventDestroy(p->ev_join);
-  }
+  mp_release_streams(p);
   delete p;
   return CAP_OK;
 }
@@ -539,12 +678,24 @@ int cap_mpchol_plan_destroy(cap_mpchol_plan* p) {
 // and the fp64 row solve hide behind the bf16 MFMA update once that is the longer of the two.
 int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* stream) {
   if (!p || !A || lda < p->n) return CAP_ERR_ARG;
-  hipStream_t s0 = cap_stream(stream);
+  hipStream_t su = cap_stream(stream);
+  if (p->reserve <= 0) return mp_factor_impl(p, A, lda, su);
+  // reserve mode: the whole factorization runs on the plan's masked streams, forked off / joined into the caller's stream
+  CAP_TRY(mp_ensure_reserved(p));
+  CAP_HIP(hipEventRecord(p->ev_user, su));
+  CAP_HIP(hipStreamWaitEvent(p->s_bulk, p->ev_user, 0));
+  const int st = mp_factor_impl(p, A, lda, p->s_bulk);
+  CAP_HIP(hipEventRecord(p->ev_bulk_done, p->s_bulk));
+  CAP_HIP(hipStreamWaitEvent(su, p->ev_bulk_done, 0));
+  return st;
+}
+
+}  // extern "C"
+
+static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipStream_t s0) {
   const int64_t n = p->n, nb = p->nb;
   if (!p->streams_ready) {
-    int lo = 0, hi = 0;
-    CAP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    CAP_HIP(hipStreamCreateWithPriority(&p->s_panel, hipStreamNonBlocking, hi));
+    CAP_TRY(mp_make_stream(p, &p->s_panel));
     for (int i = 0; i < 2; i++) {
       CAP_HIP(hipEventCreateWithFlags(&p->ev_rest[i], hipEventDisableTiming));
       CAP_HIP(hipEventCreateWithFlags(&p->ev_panel[i], hipEventDisableTiming));
@@ -578,9 +729,7 @@ int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* st
   // does not depend on the option bit for bit.
   if (p->split && sp == 2) {
     if (!p->split_ready) {
-      int lo = 0, hi = 0;
-      CAP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      CAP_HIP(hipStreamCreateWithPriority(&p->s_far, hipStreamNonBlocking, hi));
+      CAP_TRY(mp_make_stream(p, &p->s_far));
       for (hipEvent_t* e : {&p->ev_c, &p->ev_ns, &p->ev_hf, &p->ev_fs[0], &p->ev_fs[1], &p->ev_far[0], &p->ev_far[1], &p->ev_join2})
         CAP_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
       CAP_HIP(hipMalloc((void**)&p->Tn, sizeof(double) * 2 * nb * nb));
@@ -595,6 +744,16 @@ int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* st
       const int64_t j0 = k * nb, jb = std::min(nb, n - j0), w = c1 - c0;
       if (w <= 0) return CAP_OK;
       float* Row32 = p->R32 + j0 + c0 * n;
+      if (p->solve3 && jb == nb) {
+        // S = Dinv^T Row on the bf16 pipe with split operands (K = 3 jb): the row is split into B3 and cleared, the product is
+        // accumulated straight back into it (fp32 atomics of the update kernel), then rounded into the strip buffer
+        __bf16* B3 = (T == Tn) ? p->B3near : p->B3far;             // the near / far solves of a panel run side by side
+        hipLaunchKernelGGL(split3_row_kernel, grid2(jb, w), dim3(256), 0, s, Row32, n, B3, jb, w, 1);
+        CAP_TRY(launch_bf16_update(jb, w, 3 * jb, 1.0f, p->A3[k & 1], 3 * jb, B3, 3 * jb, Row32, n, 0, s));
+        hipLaunchKernelGGL(f32_to_bf16_kernel, grid2(jb, w), dim3(256), 0, s, Row32, n, SP + roff + c0 * ldp, ldp, jb, w);
+        CAP_HIP(hipGetLastError());
+        return CAP_OK;
+      }
       hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, w), dim3(256), 0, s, Row32, n, T, jb, jb, w, 0);
       CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, w, jb, 1.0, p->Inv + k * nb * nb, nb, T, jb, 0.0, S, jb, 0, s, 2 | 16));
       hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(jb, w), dim3(256), 0, s, S, jb, Row32, n, SP + roff + c0 * ldp, ldp, jb, w, 0);
@@ -607,8 +766,16 @@ int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* st
       double* Dinv = p->Inv + k * nb * nb;
       hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, jb), dim3(256), 0, s1, D32, n, p->D64, jb, jb, jb, 1);
       CAP_HIP(hipMemsetAsync(Dinv, 0, sizeof(double) * nb * nb, s1));
+      if (p->res_ready) {           // the latency-bound launches on the reserved CUs
+        CAP_HIP(hipEventRecord(p->ev_ch[0], s1));
+        CAP_HIP(hipStreamWaitEvent(p->s_chain, p->ev_ch[0], 0));
+        CAP_TRY(cap_rec_cholinv_full(p->D64, jb, Dinv, nb, jb, p->W, p->wcap, p->info_dev, p->s_chain, j0));
+        CAP_HIP(hipEventRecord(p->ev_ch[1], p->s_chain));
+        CAP_HIP(hipStreamWaitEvent(s1, p->ev_ch[1], 0));
+      } else
       CAP_TRY(cap_rec_cholinv_full(p->D64, jb, Dinv, nb, jb, p->W, p->wcap, p->info_dev, s1, j0));
       hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(jb, jb), dim3(256), 0, s1, p->D64, jb, D32, n, (__bf16*)nullptr, (int64_t)0, jb, jb, 1);
+      if (p->solve3 && jb == nb) hipLaunchKernelGGL(split3_tri_kernel, grid2(jb, jb), dim3(256), 0, s1, Dinv, nb, p->A3[k & 1], jb);
       CAP_HIP(hipGetLastError());
       return CAP_OK;
     };
@@ -626,6 +793,16 @@ int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* st
         CAP_HIP(hipEventRecord(p->ev_ns, s1));
         CAP_TRY(solve_cols(k, j1n, n, p->T64, p->S64, SP, roff, s2));
         CAP_HIP(hipEventRecord(p->ev_fs[k & 1], s2));
+        {
+          // fp64 promotion of the finished block row for the refinement sweeps, off the critical path (far stream) - it used to be one
+          // 15 ms pass over the whole factor behind the last panel
+          const int64_t j0 = k * nb, jb = std::min(nb, n - j0);
+          if (n > j1n) hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, n - j1n), dim3(256), 0, s2, p->R32 + j0 + j1n * n, n, p->R64 + j0 + j1n * n, n, jb, n - j1n, 0);
+          CAP_HIP(hipStreamWaitEvent(s2, p->ev_ns, 0));
+          hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, jb), dim3(256), 0, s2, p->R32 + j0 + j0 * n, n, p->R64 + j0 + j0 * n, n, jb, jb, 1);
+          if (j1n > j1) hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, j1n - j1), dim3(256), 0, s2, p->R32 + j0 + j1 * n, n, p->R64 + j0 + j1 * n, n, jb, j1n - j1, 0);
+          CAP_HIP(hipGetLastError());
+        }
         if (k < kb) {
           // head of panel a inside the strip: rows of panel b.  near = its diagonal block, far = the rectangle to the right
           const int64_t rb = j1n - j1;
@@ -680,9 +857,7 @@ int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* st
     CAP_HIP(hipStreamWaitEvent(s0, p->ev_join2, 0));
     CAP_HIP(hipEventRecord(p->ev_join, s1));
     CAP_HIP(hipStreamWaitEvent(s0, p->ev_join, 0));
-    hipLaunchKernelGGL(f32_to_f64_kernel, grid2(n, n), dim3(256), 0, s0, p->R32, n, p->R64, n, n, n, 1);
-    CAP_HIP(hipGetLastError());
-    p->have_r64 = true;
+    p->have_r64 = true;                        // promoted block row by block row above
     return CAP_OK;
   }
 
@@ -696,7 +871,16 @@ int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* st
     CAP_TRY(cap_rec_cholinv_full(p->D64, jb, Dinv, nb, jb, p->W, p->wcap, p->info_dev, s, j0));
     hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(jb, jb), dim3(256), 0, s, p->D64, jb, D32, n, (__bf16*)nullptr, (int64_t)0, jb, jb, 1);
     CAP_HIP(hipGetLastError());
-    if (m > 0) {
+    if (m > 0 && p->solve3 && jb == nb) {
+      // the block-row solve on the bf16 pipe with split operands - the same three kernels, per element the same sums, as the
+      // column-split schedule's solve_cols (the two schedules stay bit-identical)
+      float* Row32 = p->R32 + j0 + j1 * n;
+      hipLaunchKernelGGL(split3_tri_kernel, grid2(jb, jb), dim3(256), 0, s, Dinv, nb, p->A3[k & 1], jb);
+      hipLaunchKernelGGL(split3_row_kernel, grid2(jb, m), dim3(256), 0, s, Row32, n, p->B3far, jb, m, 1);
+      CAP_TRY(launch_bf16_update(jb, m, 3 * jb, 1.0f, p->A3[k & 1], 3 * jb, p->B3far, 3 * jb, Row32, n, 0, s));
+      hipLaunchKernelGGL(f32_to_bf16_kernel, grid2(jb, m), dim3(256), 0, s, Row32, n, SP + roff + j1 * ldp, ldp, jb, m);
+      CAP_HIP(hipGetLastError());
+    } else if (m > 0) {
       float* Row32 = p->R32 + j0 + j1 * n;
       hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, m), dim3(256), 0, s, Row32, n, p->T64, jb, jb, m, 0);
       CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, m, jb, 1.0, Dinv, nb, p->T64, jb, 0.0, p->S64, jb, 0, s, 2 | 16));
@@ -768,6 +952,8 @@ int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* st
   return CAP_OK;
 }
 
+extern "C" {
+
 // "profile" = 1: bracket every bf16 trailing update on the caller's stream with HIP events (read back by cap_mpchol_profile)
 int cap_mpchol_set_option(cap_mpchol_plan* p, const char* key, int64_t value) {
   if (!p || !key) return CAP_ERR_ARG;
@@ -779,6 +965,12 @@ int cap_mpchol_set_option(cap_mpchol_plan* p, const char* key, int64_t value) {
     return CAP_OK;
   }
   if (!strcmp(key, "split")) { p->split = value != 0; return CAP_OK; }     // column-split schedule (near / far columns), see cap_mpchol_factor
+  if (!strcmp(key, "reserve")) {     // CUs kept for the diagonal-block chains (0 = off; a multiple of 8 keeps the XCDs balanced)
+    if (value < 0 || value > 64) return CAP_ERR_ARG;
+    if (value != p->reserve) { mp_release_streams(p); p->reserve = (int)value; }
+    return CAP_OK;
+  }
+  if (!strcmp(key, "solve3")) { p->solve3 = value != 0; return CAP_OK; }   // block-row solves on the bf16 pipe with split operands (split schedule)
   // process-wide A/B switches of the bf16 update (see launch_bf16_update): which kernel, chunk length, smallest launch for the new one
   if (!strcmp(key, "update_kernel")) { if (value < 0 || value > 1) return CAP_ERR_ARG; g_bf16_variant = (int)value; return CAP_OK; }
   if (!strcmp(key, "update_tpw")) { if (value < 1 || value > 64) return CAP_ERR_ARG; g_bf16_tpw = (int)value; return CAP_OK; }

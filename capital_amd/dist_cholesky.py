@@ -248,6 +248,13 @@ class Context2D:
         torch.cuda.synchronize()
         return out[: self.local_cols, : self.local_rows].cpu().numpy().T.copy()
 
+    def local_Rinv(self):
+        """numpy (local_rows x local_cols): my piece of R^-1 (options complete_inv = 0 / 1), zero below the global diagonal."""
+        out = torch.zeros(max(self.local_cols, 1), self.lda, dtype=torch.float64, device=self.device)
+        _lib.check(_lib.lib().cap_dist2d_get_Rinv(self.plan, out.data_ptr(), self.lda, cur_stream()), "cap_dist2d_get_Rinv")
+        torch.cuda.synchronize()
+        return out[: self.local_cols, : self.local_rows].cpu().numpy().T.copy()
+
     def launch_counts(self):
         L = _lib.lib()
         return {"mfma_kernels": int(L.cap_dist2d_get(self.plan, 8)), "chains": int(L.cap_dist2d_get(self.plan, 9)),

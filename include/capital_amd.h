@@ -369,10 +369,11 @@ int64_t cap_bc_num_local_cols(int64_t n, int64_t nb, int P, int p);
 
 /* The same factorization on a 2D Pr x Pc BLOCK-CYCLIC process grid (csrc/dist2d.hip): block (I, J) of nb x nb elements on
  * process (I % Pr, J % Pc) as local block (I / Pr, J / Pc), rank = pr * Pc + pc, local arrays column-major; Pr must divide
- * Pc (1 x P, 2 x 2, 2 x 4, 4 x 4).  Per block row: diagonal block on its owner, Dinv broadcast along the owner's process row,
- * block-row solve there, the solved row broadcast down the process columns (B operand) and re-broadcast along the process
- * rows by the Pc / Pr columns that hold the blocks I = pr mod Pr (A operand), staircase MFMA update of the local blocks
- * k < I <= J.  Replaces topo::square's row / column communicators + summa::distribute (topology.h:67-143, summa.hpp:163-221).
+ * Pc (1 x P, 2 x 2, 2 x 4, 4 x 4).  Strips of two block rows like cap_dist_*: per block row the diagonal block on its owner,
+ * [R(a,b) | Dinv] along the owner's process row, block-row solve there, the solved row down the process columns into a
+ * K-contiguous strip buffer (B operand); per strip the pieces I = pr mod Pr re-broadcast along the process rows by the Pc / Pr
+ * columns that hold them (A operand) and ONE K = 2 nb staircase MFMA update of the local blocks b < I <= J, look-ahead depth 2.
+ * Replaces topo::square's row / column communicators + summa::distribute (topology.h:67-143, summa.hpp:163-221).
  * row / col: communicators of my process row (ordered by pc) / column (ordered by pr), or NULL to split them off `world`
  * (ncclCommSplit).  Alocal / get_R: the valid local piece (cap_bc2d_local_extent rows x columns, column-major).
  * cap_dist2d_get: 0 valid local rows, 1 valid local columns, 2 Pr, 3 Pc, 4 pr, 5 pc, 6 nb, 7 padded n, 8..11 = MFMA kernels,
@@ -385,7 +386,14 @@ int cap_dist2d_factor(cap_dist2d_plan* plan, const double* Alocal, int64_t lda, 
 double* cap_dist2d_R_ptr(cap_dist2d_plan* plan, int64_t* ld);
 int cap_dist2d_get_R(cap_dist2d_plan* plan, double* out, int64_t ld, void* stream);
 int cap_dist2d_info(cap_dist2d_plan* plan, void* stream, int64_t* info);
-int cap_dist2d_set_option(cap_dist2d_plan* plan, const char* key, int64_t value);     /* "occ1_m" */
+/* options: "strip" (block rows per K = strip nb update, 1 | 2; default 2 from 8 block rows on), "depth2" (bulk update split so that
+ * the rows of strip t + 2 release the panel stream early; on), "occ1_m", "safe" (one communicator family, one communication stream),
+ * "complete_inv" = 0 / 1 + "split": the factor call also leaves my piece of R^-1 (cap_dist2d_get_Rinv), streamed with the sweep as in
+ * cap_dist_*: per block row Dinv(k) down the owner's process column, the finished block column of R^-1 along the process rows, one
+ * local MFMA GEMM with my piece of the solved row - no replicated R.                                                        */
+int cap_dist2d_set_option(cap_dist2d_plan* plan, const char* key, int64_t value);
+int cap_dist2d_get_Rinv(cap_dist2d_plan* plan, double* out, int64_t ld, void* stream);
+double* cap_dist2d_Rinv_ptr(cap_dist2d_plan* plan, int64_t* ld);
 int64_t cap_bc2d_local_extent(int64_t n, int64_t nb, int Pr, int Pc, int pr, int pc, int which);   /* which: 0 rows, 1 columns */
 /* pure index helper of the update kernel's staircase enumeration: local row tiles (128 rows) of process row pr of Pr, from
  * local row block rlb0 on, whose global tile index relative to block J0 is <= X (nbT = nb / 128)                        */

@@ -83,23 +83,40 @@ def main():
         torch.cuda.synchronize()
         if rows.size and cols.size:
             assert np.array_equal(ctx.A[: ctx.local_cols, : ctx.local_rows].cpu().numpy().T, a[np.ix_(rows, cols)]), "2D block-cyclic generator mismatch"
+        if args.strip:
+            ctx.set_option("strip", args.strip)
+        if args.depth2 >= 0:
+            ctx.set_option("depth2", args.depth2)
+        if args.safe:
+            ctx.set_option("safe", 1)
+        if args.ci >= 0:
+            ctx.set_option("complete_inv", args.ci); ctx.set_option("split", args.split)
         for rep in range(2):                       # plan reuse
             ctx.factor()
         info = ctx.last_info()
         rl = ctx.local_R()
+        ril = ctx.local_Rinv() if args.ci >= 0 else None
 
         def allred(t):
             h = t.cpu(); dist.all_reduce(h); return h.to(t.device)
         probe = ctx.probe(allred)
         counts = ctx.launch_counts()
         pieces = [None] * size
-        dist.all_gather_object(pieces, (ctx.pr, ctx.pc, rows, cols, rl))
+        dist.all_gather_object(pieces, (ctx.pr, ctx.pc, rows, cols, rl, ril))
         if rank == 0:
-            R = np.zeros((n, n))
+            R = np.zeros((n, n)); Ri = np.zeros((n, n))
             seen = np.zeros((n, n), dtype=np.int32)
-            for (qr, qc, rr, cc, piece) in pieces:
+            for (qr, qc, rr, cc, piece, ipiece) in pieces:
                 if rr.size and cc.size:
                     R[np.ix_(rr, cc)] = piece; seen[np.ix_(rr, cc)] += 1
+                    if ipiece is not None:
+                        Ri[np.ix_(rr, cc)] = ipiece
+            if args.ci >= 0:
+                # R^-1 on the 2D grid against the oracle's recursion (same empty root block for complete_inv = 0)
+                r_ref, ri_ref = orc.cholinv(a, args.ci, args.split, -2, 1, 1)
+                assert np.linalg.norm(Ri - ri_ref) / np.linalg.norm(ri_ref) < 1e-12
+                assert np.array_equal(Ri != 0, ri_ref != 0), "R^-1 pattern (triangle + empty root block, cholinv.hpp:147)"
+                print("DIST2DINV-OK ci=%d split=%d" % (args.ci, args.split), flush=True)
             assert np.array_equal(seen, np.ones_like(seen)), "every element has exactly one owner"
             assert np.array_equal(np.tril(R, -1), np.zeros_like(R)), "construct_R must zero the part below the global diagonal"
             ref = np.linalg.cholesky(a).T

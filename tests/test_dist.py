@@ -177,6 +177,29 @@ def test_2d_block_cyclic_schedule_on_one_gpu(nproc, pr, n, nb):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc,pr,n,nb,extra", [
+    (4, 2, 4096, 128, ("--strip", 1, "--depth2", 0)),          # the round-3 schedule: one block row per update, look-ahead 1
+    (4, 2, 4096, 128, ("--strip", 2, "--depth2", 0)),
+    (8, 2, 4096, 128, ("--strip", 2, "--depth2", 1)),          # 2 x 4, strips of two block rows that live on different process rows
+    (8, 2, 2049, 256, ("--strip", 2, "--depth2", 1)),          # ragged n, odd number of block rows (the last strip is one row)
+    (16, 4, 4096, 128, ("--strip", 2,)),                       # 4 x 4
+    (4, 1, 2048, 128, ("--strip", 2,)), (1, 1, 2048, 128, ("--strip", 2,)),
+    (8, 2, 4096, 128, ("--safe", 1)),                          # one communicator family, collectives in program order
+    (4, 2, 2048, 128, ("--ci", 1)), (8, 2, 2048, 128, ("--ci", 0)), (8, 2, 1000, 128, ("--ci", 0)),     # R^-1 streamed on the 2D grid
+    (4, 2, 1024, 128, ("--ci", 0, "--split", 2)), (8, 2, 4096, 256, ("--ci", 1, "--safe", 1)), (1, 1, 1024, 128, ("--ci", 1)),
+    (16, 4, 2048, 128, ("--ci", 1)),
+])
+def test_2d_block_cyclic_schedule_options(nproc, pr, n, nb, extra):
+    """The Pr x Pc plan at parity with the 1 x P plan: strips of two block rows (K = 2 nb updates), look-ahead depth 2, safe mode,
+    R^-1 (complete_inv = 0 / 1) streamed with the sweep - against the oracle."""
+    r = _launch(nproc, "gpu2d", n, nb, 29901 + nproc + pr, ("--pr", pr) + tuple(extra))
+    assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    assert "DIST2D-OK" in r.stdout, r.stdout[-2000:]
+    if "--ci" in extra:
+        assert "DIST2DINV-OK" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nproc,n,nb", [(2, 1024, 128), (4, 2048, 256), (3, 1536, 128), (1, 1024, 256), (8, 8192, 512), (4, 1280, 256), (2, 1152, 256)])
 @pytest.mark.parametrize("hard", [0, 1])
 def test_distributed_mixed_precision_solve(nproc, n, nb, hard):

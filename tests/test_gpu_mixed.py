@@ -180,7 +180,7 @@ def test_bf16_update_dispatcher_and_refusals():
         p.factor(A)
         assert p.last_info() == 0
         fs.append(p.R32().cpu().numpy().astype(np.float64))
-        p.set_option("update_kernel", 1); p.set_option("update_min_tiles", 1024)
+        p.set_option("update_kernel", 0); p.set_option("update_min_tiles", 1024)
         p.close()
     ref = np.linalg.cholesky(a).T
     assert relerr(fs[0], ref) < 2e-2 and relerr(fs[1], ref) < 2e-2

@@ -16,7 +16,10 @@ for m in sizes:
     a16 = torch.randn(m, K, device="cuda").to(torch.bfloat16)
     c = torch.zeros(m, m, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
-    variants = [(0, 0, "v1 128x128"), (1, 4, "v2 tpw=4"), (1, 8, "v2 tpw=8"), (1, 16, "v2 tpw=16"), (1, 64, "v2 tpw=64")]
+    variants = [(0, 0, "v1 128x128"), (1, 8, "v2 tpw=8"), (116, 8, "v2 pfC/2"), (117, 8, "v2 pfC/4"), (118, 8, "v2 pfC/8"), (104, 8, "v2 -mfma"),
+                (120, 8, "v2 pfC/4 -mfma"), (101, 8, "v2 -atomics")]
+    if os.environ.get("BF16_PLAIN"):
+        variants = [v for v in variants if v[0] < 100]
     times = {v[2]: [] for v in variants}
     for r in range(rounds + 1):
         for (var, tpw, name) in variants:
@@ -24,11 +27,14 @@ for m in sizes:
             e0.record()
             st = L.cap_bf16_update(var, m, m, K, -1.0, a16.data_ptr(), K, a16.data_ptr(), K, c.data_ptr(), m, 1, tpw, s)
             e1.record(); torch.cuda.synchronize()
-            assert st == 0, (name, st)
+            if st != 0:
+                continue
             if r:
                 times[name].append(e0.elapsed_time(e1))
     fl = 2.0 * K * (m * (m + 1) / 2)
     for name, ts in times.items():
+        if not ts:
+            continue
         ts.sort()
         print("m=%d K=%d %-12s median %.3f ms = %.0f TF (%.3f of 2.5 PF)  min %.3f ms = %.0f TF" % (
             m, K, name, ts[len(ts) // 2], fl / ts[len(ts) // 2] / 1e9, fl / ts[len(ts) // 2] / 1e9 / 2500, ts[0], fl / ts[0] / 1e9), flush=True)

@@ -37,9 +37,18 @@ for n in sizes:
         fl = n ** 3 / 3.0 + (n ** 3 / 3.0 if ci == 1 else n ** 3 / 12.0)
         print("dist plan P=1 N=%d complete_inv=%d (factor + distributed-style inverse): %.1f ms  %.2f TF on N^3/3, %.2f TF true" % (n, ci, t * 1e3, n ** 3 / 3 / t / 1e12, fl / t / 1e12), flush=True)
         ctx.close(); torch.cuda.empty_cache()
-    # the Pr x Pc plan on a 1 x 1 grid (strip = 1 block row, look-ahead depth 1)
-    c2 = dc.Context2D(n, 512, comm, 1); c2.fill_symmetric(True)
-    t = timeit(c2.factor)
-    print("2D plan 1x1 N=%d: %.1f ms  %.2f TF  info=%d launches=%s" % (n, t * 1e3, n ** 3 / 3 / t / 1e12, c2.last_info(), c2.launch_counts()), flush=True)
-    c2.close(); torch.cuda.empty_cache()
+    # the Pr x Pc plan on a 1 x 1 grid: the round-3 schedule (strip = 1 block row, look-ahead depth 1) and the round-4 one
+    for (strip, d2) in ((1, 0), (2, 0), (2, 1)):
+        c2 = dc.Context2D(n, 512, comm, 1); c2.fill_symmetric(True)
+        c2.set_option("strip", strip); c2.set_option("depth2", d2)
+        t = timeit(c2.factor)
+        print("2D plan 1x1 N=%d strip=%d depth2=%d: %.1f ms  %.2f TF  info=%d launches=%s" % (n, strip, d2, t * 1e3, n ** 3 / 3 / t / 1e12, c2.last_info(), c2.launch_counts()), flush=True)
+        c2.close(); torch.cuda.empty_cache()
+    for ci in (1, 0):
+        c2 = dc.Context2D(n, 512, comm, 1); c2.fill_symmetric(True)
+        c2.set_option("complete_inv", ci)
+        t = timeit(c2.factor)
+        fl = n ** 3 / 3.0 + (n ** 3 / 3.0 if ci == 1 else n ** 3 / 12.0)
+        print("2D plan 1x1 N=%d complete_inv=%d: %.1f ms  %.2f TF on N^3/3, %.2f TF true" % (n, ci, t * 1e3, n ** 3 / 3 / t / 1e12, fl / t / 1e12), flush=True)
+        c2.close(); torch.cuda.empty_cache()
     comm.close()
