@@ -162,51 +162,65 @@ struct Bucket {
 };
 
 // map the peers' G buffers (collective over d->comm; synchronises).  On any failure the plan stays on the RCCL exchange.
+// Every LOCAL failure (allocation, handle export, copies, mapping) only clears `ok`: a rank never leaves before the two collectives
+// below, so a failing rank cannot strand its peers inside them; RCCL errors themselves are fatal for the communicator anyway.
 int ensure_ipc(cap_dist_plan* d, hipStream_t s) {
   if (d->ipc_ready || d->ipc_failed || d->P == 1) return CAP_OK;
   const int P = (int)d->P, p = (int)d->p;
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
-  double* hx = nullptr;                                   // [P][2][8 doubles] handles + [16] mine
-  CAP_HIP(hipMalloc((void**)&hx, sizeof(double) * (16 * (P + 1))));
-  hipIpcMemHandle_t mine[2];
+  auto soft = [](hipError_t e) { if (e != hipSuccess) { (void)hipGetLastError(); return false; } return true; };
   bool ok = true;
-  for (int b = 0; b < 2; b++) ok = ok && hipIpcGetMemHandle(&mine[b], d->G[b]) == hipSuccess;
-  if (!ok) { (void)hipGetLastError(); memset(mine, 0, sizeof(mine)); }
-  CAP_HIP(hipMemcpyAsync(hx + 16 * P, mine, 128, hipMemcpyHostToDevice, s));
+  // device scratch: [P][2] handles (8 doubles each) + my two + the agreement flag; part of the plan so that no path leaks it
+  if (!d->token) {
+    ok = soft(hipMalloc((void**)&d->token, sizeof(double) * (2 + 16 * (P + 1))));
+    if (ok) ok = soft(hipMemset(d->token, 0, sizeof(double) * (2 + 16 * (P + 1))));
+    if (!ok) { d->token = nullptr; d->ipc_failed = true; return CAP_ERR_ALLOC; }     // nothing collective has happened yet - but every rank
+  }                                                                                    // allocates the same few KB: treated as fatal
+  double* hx = d->token + 2;
+  hipIpcMemHandle_t mine[2];
+  for (int b = 0; b < 2; b++) ok = ok && soft(hipIpcGetMemHandle(&mine[b], d->G[b]));
+  if (!ok) memset(mine, 0, sizeof(mine));
+  if (!soft(hipMemcpyAsync(hx + 16 * P, mine, 128, hipMemcpyHostToDevice, s))) ok = false;
   CAP_TRY(cap_comm_allgather(d->comm, hx + 16 * P, hx, 16, (void*)s));
   std::vector<hipIpcMemHandle_t> all((size_t)2 * P);
-  CAP_HIP(hipMemcpyAsync(all.data(), hx, (size_t)128 * P, hipMemcpyDeviceToHost, s));
-  CAP_HIP(hipStreamSynchronize(s));
-  (void)hipFree(hx);
+  memset(all.data(), 0, all.size() * sizeof(hipIpcMemHandle_t));
+  if (!soft(hipMemcpyAsync(all.data(), hx, (size_t)128 * P, hipMemcpyDeviceToHost, s))) ok = false;
+  if (!soft(hipStreamSynchronize(s))) ok = false;
   hipIpcMemHandle_t zero; memset(&zero, 0, sizeof(zero));
   for (int r = 0; r < P && ok; r++) {
     if (r == p) continue;
     for (int b = 0; b < 2 && ok; b++) {
       if (!memcmp(&all[(size_t)2 * r + b], &zero, sizeof(zero))) { ok = false; break; }
       void* q = nullptr;
-      if (hipIpcOpenMemHandle(&q, all[(size_t)2 * r + b], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+      if (!soft(hipIpcOpenMemHandle(&q, all[(size_t)2 * r + b], hipIpcMemLazyEnablePeerAccess))) { ok = false; break; }
       d->peerG[r][b] = (double*)q;
     }
   }
+  if (ok) {
+    for (int r = 0; r < P && ok; r++) {
+      if (r == p) continue;
+      ok = soft(hipStreamCreateWithFlags(&d->s_peer[r], hipStreamNonBlocking)) && soft(hipEventCreateWithFlags(&d->ev_xr[r], hipEventDisableTiming));
+    }
+    if (ok) ok = soft(hipEventCreateWithFlags(&d->ev_x0, hipEventDisableTiming));
+  }
   // agree: one failing rank sends everybody back to RCCL (the exchange is collective)
-  if (!d->token) { CAP_HIP(hipMalloc((void**)&d->token, 2 * sizeof(double))); CAP_HIP(hipMemset(d->token, 0, 2 * sizeof(double))); }
   double flag = ok ? 0.0 : 1.0, tot = 0.0;
-  CAP_HIP(hipMemcpyAsync(d->token + 1, &flag, sizeof(double), hipMemcpyHostToDevice, s));
+  const bool up = soft(hipMemcpyAsync(d->token + 1, &flag, sizeof(double), hipMemcpyHostToDevice, s));
+  if (!up) (void)hipMemsetAsync(d->token + 1, 0x7f, sizeof(double), s);        // any non-zero pattern: "failed" (a huge positive double)
   CAP_TRY(cap_comm_allreduce_sum(d->comm, d->token + 1, 1, (void*)s));
-  CAP_HIP(hipMemcpyAsync(&tot, d->token + 1, sizeof(double), hipMemcpyDeviceToHost, s));
-  CAP_HIP(hipStreamSynchronize(s));
-  if (tot != 0.0) {
-    for (int r = 0; r < P; r++) for (int b = 0; b < 2; b++) if (d->peerG[r][b]) { (void)hipIpcCloseMemHandle(d->peerG[r][b]); d->peerG[r][b] = nullptr; }
+  if (!soft(hipMemcpyAsync(&tot, d->token + 1, sizeof(double), hipMemcpyDeviceToHost, s)) || !soft(hipStreamSynchronize(s))) tot = 1.0;
+  (void)hipMemsetAsync(d->token + 1, 0, sizeof(double), s);                    // the strip exchange uses token[0] only; keep [1] clean
+  if (tot != 0.0 || !ok) {
+    for (int r = 0; r < P; r++) {
+      for (int b = 0; b < 2; b++) if (d->peerG[r][b]) { (void)hipIpcCloseMemHandle(d->peerG[r][b]); d->peerG[r][b] = nullptr; }
+      if (d->s_peer[r]) { (void)hipStreamDestroy(d->s_peer[r]); d->s_peer[r] = nullptr; }
+      if (d->ev_xr[r]) { (void)hipEventDestroy(d->ev_xr[r]); d->ev_xr[r] = nullptr; }
+    }
+    if (d->ev_x0) { (void)hipEventDestroy(d->ev_x0); d->ev_x0 = nullptr; }
     d->ipc_failed = true;
     fprintf(stderr, "capital_amd: IPC mapping of the peers' strip buffers failed on %s rank; using the RCCL all-gather\n", ok ? "another" : "this");
     return CAP_OK;
   }
-  for (int r = 0; r < P; r++) {
-    if (r == p) continue;
-    CAP_HIP(hipStreamCreateWithFlags(&d->s_peer[r], hipStreamNonBlocking));
-    CAP_HIP(hipEventCreateWithFlags(&d->ev_xr[r], hipEventDisableTiming));
-  }
-  CAP_HIP(hipEventCreateWithFlags(&d->ev_x0, hipEventDisableTiming));
   d->ipc_ready = true;
   return CAP_OK;
 }

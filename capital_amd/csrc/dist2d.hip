@@ -49,7 +49,8 @@ struct cap_dist2d_plan {
   int64_t lr_valid, lc_valid;    // local rows / columns that exist in the n x n matrix
   double* R; int64_t ld;         // (nlr nb) x (nlc nb)
   double* Bt[2];                 // solved block row k, my columns J > k, contiguous (ld = nb): payload of the column broadcast; ring over block rows
-  double* S[2];                  // strip buffer: the strip's solved rows at my columns J > a, K-contiguous (ld = q nb); ring over strips
+  double* S[3];                  // strip buffer: the strip's solved rows at my columns J > a, K-contiguous (ld = q nb); ring of THREE over
+                                 // strips: it is the B operand of the bulk update of its strip, which runs two strips behind the panel
   double* A[2];                  // A operand: Pc / Pr pieces of (q nb) x maxcols; ring over strips
   double* msg[4];                // [ R(a, b) | Dinv(k) ], ring over block rows
   double* W; int64_t wcap;
@@ -268,7 +269,8 @@ int cap_dist2d_plan_create(cap_dist2d_plan** plan, int64_t n, int64_t nb, cap_co
   d->Pr = Pr; d->Pc = Pc; d->P = P; d->rank = rank; d->pr = rank / Pc; d->pc = rank % Pc;
   d->world = world; d->row = row; d->col = col; d->owns_row = d->owns_col = false; d->row2 = d->row3 = d->col3 = nullptr;
   d->R = nullptr; d->W = nullptr; d->info_dev = nullptr; d->info_red = nullptr;
-  for (int i = 0; i < 2; i++) d->Bt[i] = d->S[i] = d->A[i] = d->Dc[i] = d->Xc[i] = nullptr;
+  for (int i = 0; i < 2; i++) d->Bt[i] = d->A[i] = d->Dc[i] = d->Xc[i] = nullptr;
+  for (int i = 0; i < 3; i++) d->S[i] = nullptr;
   for (int i = 0; i < 4; i++) d->msg[i] = nullptr;
   d->Ri = d->Dall = nullptr;
   d->s_panel = d->s_comm = d->s_msg = d->s_inv = nullptr;
@@ -304,9 +306,11 @@ int cap_dist2d_plan_create(cap_dist2d_plan** plan, int64_t n, int64_t nb, cap_co
   hipError_t e = hipMalloc((void**)&d->R, sizeof(double) * std::max<int64_t>(d->ld * d->nlc * nb, 2));
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
     e = hipMalloc((void**)&d->Bt[i], sizeof(double) * nb * (d->maxcols + nb));
-    if (e == hipSuccess) e = hipMalloc((void**)&d->S[i], sizeof(double) * 2 * nb * (d->maxcols + nb));
-    if (e == hipSuccess) e = hipMemset(d->S[i], 0, sizeof(double) * 2 * nb * (d->maxcols + nb));
     if (e == hipSuccess) e = hipMalloc((void**)&d->A[i], sizeof(double) * d->apiece * (Pc / Pr));
+  }
+  for (int i = 0; i < 3 && e == hipSuccess; i++) {
+    e = hipMalloc((void**)&d->S[i], sizeof(double) * 2 * nb * (d->maxcols + nb));
+    if (e == hipSuccess) e = hipMemset(d->S[i], 0, sizeof(double) * 2 * nb * (d->maxcols + nb));
   }
   for (int i = 0; i < 4 && e == hipSuccess; i++) {
     e = hipMalloc((void**)&d->msg[i], sizeof(double) * 2 * nb * nb);
@@ -322,7 +326,7 @@ int cap_dist2d_plan_create(cap_dist2d_plan** plan, int64_t n, int64_t nb, cap_co
 
 int cap_dist2d_plan_destroy(cap_dist2d_plan* d) {
   if (!d) return CAP_OK;
-  for (double* q : {d->R, d->Bt[0], d->Bt[1], d->S[0], d->S[1], d->A[0], d->A[1], d->msg[0], d->msg[1], d->msg[2], d->msg[3], d->W, d->info_red, d->Ri,
+  for (double* q : {d->R, d->Bt[0], d->Bt[1], d->S[0], d->S[1], d->S[2], d->A[0], d->A[1], d->msg[0], d->msg[1], d->msg[2], d->msg[3], d->W, d->info_red, d->Ri,
                     d->Dall, d->Dc[0], d->Dc[1], d->Xc[0], d->Xc[1]})
     if (q) (void)hipFree(q);
   if (d->info_dev) (void)hipFree(d->info_dev);
@@ -399,12 +403,12 @@ int cap_dist2d_factor(cap_dist2d_plan* d, const double* Aloc, int64_t lda, void*
     const int64_t a = sb[t], q = sq[t], b = a + q - 1, e = b + 1;
     const int64_t ldS = q * nb;
     const int64_t lbS = lbfirst2(pc, a, Pc);                      // my first local column block with J > a: column origin of S[par]
-    double* S = d->S[par]; double* Ak = d->A[par];
-    // S[par] / A[par] were read by the HEAD (panel stream), the bulk update (caller's stream) and the inverse of strip t - 2
-    if (t >= 2) {
-      CAP_HIP(hipStreamWaitEvent(sc, d->ev_head[t - 2], 0));
-      CAP_HIP(hipStreamWaitEvent(sc, d->ev_rest[t - 2], 0));
-      if (inv_overlap) CAP_HIP(hipStreamWaitEvent(sc, d->ev_inv[sb[t - 2] + sq[t - 2] - 1], 0));
+    double* S = d->S[t % 3]; double* Ak = d->A[par];
+    // S[t % 3] was read by the HEAD (panel stream), the bulk update (caller's stream) and the inverse of strip t - 3
+    if (t >= 3) {
+      CAP_HIP(hipStreamWaitEvent(sc, d->ev_head[t - 3], 0));
+      CAP_HIP(hipStreamWaitEvent(sc, d->ev_rest[t - 3], 0));
+      if (inv_overlap) CAP_HIP(hipStreamWaitEvent(sc, d->ev_inv[sb[t - 3] + sq[t - 3] - 1], 0));
     }
     for (int64_t r = 0; r < q; r++) {
       const int64_t k = a + r;
@@ -476,6 +480,10 @@ int cap_dist2d_factor(cap_dist2d_plan* d, const double* Aloc, int64_t lda, void*
     int gstart[8];
     for (int m = 0; m < 8; m++) gstart[m] = 0;
     const double* G = Ak; int64_t gpiece = d->apiece;
+    if (t >= 2) {                                                // A[par] was read by the HEAD and the bulk update of strip t - 2
+      CAP_HIP(hipStreamWaitEvent(sc, d->ev_head[t - 2], 0));
+      CAP_HIP(hipStreamWaitEvent(sc, d->ev_rest[t - 2], 0));
+    }
     if (Pc == 1) {                                               // one process: the strip buffer IS the A operand
       gstart[0] = (int)lbe; G = S + (lbe - lbS) * nb * ldS; gpiece = 0;
     } else {
