@@ -74,6 +74,7 @@ SIGNATURES = {
     "cap_redist_plan_create": (cint, [C.POINTER(ptr), i64, i64, ptr, cint, cint]),
     "cap_redist_plan_destroy": (cint, [ptr]),
     "cap_redist_get": (i64, [ptr, cint]),
+    "cap_redist_message_elems": (i64, [i64, i64, cint, cint, cint, cint, cint, cint]),
     "cap_redistribute_cyclic_to_bc": (cint, [ptr, ptr, i64, ptr, i64, ptr]),
     "cap_redistribute_bc_to_cyclic": (cint, [ptr, ptr, i64, ptr, i64, ptr]),
     "cap_cholinv_plan_create": (cint, [C.POINTER(ptr), i64, cint, i64, i64, C.c_char, ptr]),

@@ -409,6 +409,10 @@ int cap_dist2d_factor(cap_dist2d_plan* d, const double* Aloc, int64_t lda, void*
       CAP_HIP(hipStreamWaitEvent(sc, d->ev_head[t - 3], 0));
       CAP_HIP(hipStreamWaitEvent(sc, d->ev_rest[t - 3], 0));
       if (inv_overlap) CAP_HIP(hipStreamWaitEvent(sc, d->ev_inv[sb[t - 3] + sq[t - 3] - 1], 0));
+      if (Pr == 1) {                                             // one process row: the panel stream writes the strip buffer itself
+        CAP_HIP(hipStreamWaitEvent(s1, d->ev_rest[t - 3], 0));
+        if (inv_overlap) CAP_HIP(hipStreamWaitEvent(s1, d->ev_inv[sb[t - 3] + sq[t - 3] - 1], 0));
+      }
     }
     for (int64_t r = 0; r < q; r++) {
       const int64_t k = a + r;
@@ -424,7 +428,7 @@ int cap_dist2d_factor(cap_dist2d_plan* d, const double* Aloc, int64_t lda, void*
         double* D = d->R + rlk * nb + (k / Pc) * nb * ld;
         if (r == 1) {
           // in-strip: D(b) -= S_a(:, b)^T S_a(:, b); S_a's column block b came down my process column
-          CAP_HIP(hipStreamWaitEvent(s1, d->ev_colb[a], 0));
+          if (Pr > 1) CAP_HIP(hipStreamWaitEvent(s1, d->ev_colb[a], 0));
           const double* Sab = S + (k / Pc - lbS) * nb * ldS;
           CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, nb, nb, -1.0, Sab, ldS, Sab, ldS, 1.0, D, ld, 1, s1, 2)); d->cnt_gemm++;
         }
@@ -450,20 +454,28 @@ int cap_dist2d_factor(cap_dist2d_plan* d, const double* Aloc, int64_t lda, void*
           CapRange range("CI::trsm");
           double* Rrow = d->R + rlk * nb + lbk * nb * ld;
           if (r == 1) {   // in-strip update: R[b, mine] -= R(a, b)^T S_a(:, mine)
-            CAP_HIP(hipStreamWaitEvent(s1, d->ev_colb[a], 0));
+            if (Pr > 1) CAP_HIP(hipStreamWaitEvent(s1, d->ev_colb[a], 0));
             CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, ncols, nb, -1.0, mb, nb, S + (lbk - lbS) * nb * ldS, ldS, 1.0, Rrow, ld, 0, s1, 2));
             d->cnt_gemm++;
           }
-          CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, ncols, nb, 1.0, Dinv, nb, Rrow, ld, 0.0, Bt, nb, 0, s1, 2 | 16));
-          CAP_TRY(cap_copy_rect(Bt, nb, Rrow, ld, nb, ncols, s1));
+          // one process row: nobody else needs the row - solve straight into the strip buffer (no payload copy, no hop to the
+          // communication stream on the strip's critical path), like the 1 x P plan
+          double* Sk = S + r * nb + (lbk - lbS) * nb * ldS;
+          if (Pr == 1) {
+            CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, ncols, nb, 1.0, Dinv, nb, Rrow, ld, 0.0, Sk, ldS, 0, s1, 2 | 16));
+            CAP_TRY(cap_copy_rect(Sk, ldS, Rrow, ld, nb, ncols, s1));
+          } else {
+            CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, ncols, nb, 1.0, Dinv, nb, Rrow, ld, 0.0, Bt, nb, 0, s1, 2 | 16));
+            CAP_TRY(cap_copy_rect(Bt, nb, Rrow, ld, nb, ncols, s1));
+          }
           d->cnt_gemm++; d->cnt_copy++;
         }
       }
       CAP_HIP(hipEventRecord(d->ev_rowdone[k], s1));
       // ---- 4. S_k's piece down my process column (root: process row prk), then into the strip buffer (rows r nb .., ld = q nb)
       CAP_HIP(hipStreamWaitEvent(sc, d->ev_rowdone[k], 0));
-      if (ncols > 0) {
-        if (Pr > 1) { CAP_TRY(cap_comm_bcast(d->col, Bt, nb * ncols, prk, (void*)sc)); d->cnt_coll++; }
+      if (ncols > 0 && Pr > 1) {
+        CAP_TRY(cap_comm_bcast(d->col, Bt, nb * ncols, prk, (void*)sc)); d->cnt_coll++;
         CAP_TRY(cap_copy_rect(Bt, nb, S + r * nb + (lbk - lbS) * nb * ldS, ldS, nb, ncols, sc)); d->cnt_copy++;
       }
       CAP_HIP(hipEventRecord(d->ev_colb[k], sc));

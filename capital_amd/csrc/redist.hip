@@ -148,6 +148,22 @@ int cap_redist_plan_create(cap_redist_plan** plan, int64_t n, int64_t nb, cap_co
   return CAP_OK;
 }
 
+// pure index helper (no GPU, no communicator): doubles rank `from` sends to rank `to` in direction dir (0: cyclic -> block-cyclic, the
+// sender is the cyclic rank; 1: block-cyclic -> cyclic, the sender is the block-cyclic rank) - the same counts the plan derives; -1 on
+// a size that is no d x d x c grid / Pr does not divide it
+int64_t cap_redist_message_elems(int64_t n, int64_t nb, int P, int c, int Pr, int from, int to, int dir) {
+  if (n <= 0 || nb <= 0 || P < 1 || c < 1 || Pr < 1 || P % Pr || from < 0 || to < 0 || from >= P || to >= P || dir < 0 || dir > 1) return -1;
+  int d = 0, x = 0, y = 0, z = 0;
+  const int cyc = dir == 0 ? from : to, bc = dir == 0 ? to : from;
+  if (cap_topo_coords(0, cyc, P, c, &d, &x, &y, &z) != CAP_OK) return -1;
+  const int Pc = P / Pr, bpr = bc / Pc, bpc = bc % Pc;
+  if (dir == 0 && z != bc % c) return 0;                      // only the layer bc mod c supplies bc
+  int64_t rows = 0, cols = 0;
+  for (int64_t g = y; g < n; g += d) rows += (int)((g / nb) % Pr) == bpr;
+  for (int64_t g = x; g < n; g += d) cols += (int)((g / nb) % Pc) == bpc;
+  return rows * cols;
+}
+
 int cap_redist_plan_destroy(cap_redist_plan* r) {
   if (!r) return CAP_OK;
   if (r->idx) (void)hipFree(r->idx);

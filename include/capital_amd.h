@@ -248,6 +248,8 @@ typedef struct cap_redist_plan cap_redist_plan;
 int cap_redist_plan_create(cap_redist_plan** plan, int64_t n, int64_t nb, cap_comm* world, int c, int Pr);
 int cap_redist_plan_destroy(cap_redist_plan* plan);
 int64_t cap_redist_get(const cap_redist_plan* plan, int which);
+/* pure index helper (no GPU): doubles rank `from` sends to rank `to`; dir 0 = cyclic -> block-cyclic, 1 = the way back */
+int64_t cap_redist_message_elems(int64_t n, int64_t nb, int P, int c, int Pr, int from, int to, int dir);
 int cap_redistribute_cyclic_to_bc(cap_redist_plan* plan, const double* piece, int64_t ldp, double* bc_local, int64_t ldb, void* stream);
 int cap_redistribute_bc_to_cyclic(cap_redist_plan* plan, const double* bc_local, int64_t ldb, double* piece, int64_t ldp, void* stream);
 

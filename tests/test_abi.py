@@ -174,3 +174,29 @@ def test_2d_block_cyclic_index_maps(built):
                         got = L.cap_bc2d_rows_le(X, nbT, J0, Pr, pr, rlb0)
                         if X < (pr + Pr * (rlb0 + nloc - 1) - J0 + 1) * nbT:     # beyond the local extent the kernel clamps to its tile count
                             assert got == want, (X, nbT, J0, Pr, pr, rlb0, got, want)
+
+
+def test_redistribution_message_counts_property(built):
+    """cap_redist_message_elems (pure, no GPU): the all-to-all of the element-cyclic <-> block-cyclic redistribution moves every element of the
+    matrix exactly once per direction-0 pass (the replicas share the supply: destination t takes from layer t mod c only) and once PER LAYER on
+    the way back, and what a rank sends to a peer is what a brute-force walk over the two index maps finds (matrix.hpp:8-11)."""
+    import numpy as np
+    from capital_amd import _lib
+    L = _lib.lib()
+    for (n, nb, P, c, Pr) in [(64, 16, 8, 2, 1), (64, 16, 8, 2, 2), (50, 8, 4, 1, 2), (37, 5, 9, 1, 3), (96, 32, 8, 2, 1), (20, 128, 4, 1, 1), (33, 4, 1, 1, 1)]:
+        d = int(round((P / c) ** 0.5)); Pc = P // Pr
+        tot0 = tot1 = 0
+        for s in range(P):
+            z, x, y = s % c, (s % (d * c)) // c, s // (d * c)
+            for t in range(P):
+                pr, pc = t // Pc, t % Pc
+                rows = [g for g in range(y, n, d) if (g // nb) % Pr == pr]
+                cols = [g for g in range(x, n, d) if (g // nb) % Pc == pc]
+                want = len(rows) * len(cols)
+                got0 = L.cap_redist_message_elems(n, nb, P, c, Pr, s, t, 0)
+                got1 = L.cap_redist_message_elems(n, nb, P, c, Pr, t, s, 1)
+                assert got0 == (want if z == t % c else 0), (n, nb, P, c, Pr, s, t)
+                assert got1 == want
+                tot0 += got0; tot1 += got1
+        assert tot0 == n * n and tot1 == c * n * n
+    assert L.cap_redist_message_elems(64, 16, 6, 1, 1, 0, 0, 0) == -1          # 6 ranks are no d x d x c grid
