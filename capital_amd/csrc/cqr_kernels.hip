@@ -447,8 +447,11 @@ int cap_qrapply256_launch(const double* Qin, int64_t ldin, const double* Ri, dou
     else if (diag == 3) hipLaunchKernelGGL((qrapply256_kernel<3, 0>), gr, bl, lds, s, g);
     if (diag >= 1 && diag <= 3) { CAP_HIP(hipGetLastError()); return CAP_OK; }
   }
-  // paired K tiles (qrapply256p_kernel): uniform steps, half the barriers; CAP_CQR_PAIR=0 selects the one-K-tile-per-step kernel
-  static const int pair = getenv("CAP_CQR_PAIR") ? atoi(getenv("CAP_CQR_PAIR")) : 1;
+  // paired K tiles (qrapply256p_kernel, CAP_CQR_PAIR=1): uniform steps and half the barriers - measured 4 % SLOWER on the whole
+  // CholeskyQR2 call (10.69-10.77 ms against 10.31-10.32, profiles/r04_experiments.log section 5): its hand-over sits at the top of a step
+  // (vmcnt(0) + barrier + refill + first fragment reads with no MFMA queued behind them), where the kernel above hides it between the
+  // two k-halves of a tile.  Kept as a tested alternative (tests run both), off by default.
+  static const int pair = getenv("CAP_CQR_PAIR") ? atoi(getenv("CAP_CQR_PAIR")) : 0;
   if (pair) {
     const size_t ldsp = 2 * (2 * TA + 40 * 128) * sizeof(double);
     static bool attr_set = false;

@@ -71,6 +71,13 @@ struct cap_dist2d_plan {
   double* Xc[2];                 // the finished block column k of R^-1 at my rows ((nlr nb) x nb), ring
   cap_comm *row3, *col3;         // the inverse's broadcasts (owned duplicates)
   hipStream_t s_inv;
+  // option "ipc": both operand moves as IPC peer copies (SDMA engines, one xGMI link per peer) instead of RCCL broadcasts - the column
+  // move pushes the solved row into the payload buffers of my process column, the row move pushes my strip piece into slot m of the A
+  // buffers of my process row; two 8-byte all-reduces per move carry the synchronisation (buffers free / pushes landed), like dist.hip
+  int ipc; bool ipc_ready, ipc_failed;
+  double* peerBt[4][2]; double* peerA[8][2];
+  hipStream_t s_pcol[4], s_prow[8]; hipEvent_t ev_px, ev_pcol[4], ev_prow[8];
+  double* tok;                   // [0] barrier token, [1] agreement flag, then handle scratch
 };
 
 namespace {
@@ -215,6 +222,85 @@ int inverse_step2d(cap_dist2d_plan* d, int64_t k, const double* Srow, int64_t ld
   return CAP_OK;
 }
 
+// map the column peers' payload buffers and the row peers' A buffers (collective over the row and column communicators).  Local
+// failures only clear `ok`; every rank runs every collective; one failing rank sends everybody back to the RCCL broadcasts.
+int ensure_ipc2d(cap_dist2d_plan* d, hipStream_t s) {
+  if (d->ipc_ready || d->ipc_failed || d->P == 1) return CAP_OK;
+  auto soft = [](hipError_t e) { if (e != hipSuccess) { (void)hipGetLastError(); return false; } return true; };
+  const int Pr = d->Pr, Pc = d->Pc;
+  const int64_t scratch = 2 + 16 * (Pr + Pc + 2);
+  if (!d->tok) {
+    if (!soft(hipMalloc((void**)&d->tok, sizeof(double) * scratch)) || !soft(hipMemset(d->tok, 0, sizeof(double) * scratch))) { d->tok = nullptr; return CAP_ERR_ALLOC; }
+  }
+  bool ok = true;
+  auto gather_handles = [&](cap_comm* comm, int np, int me, double* const bufs[2], double* scratch_dev, std::vector<hipIpcMemHandle_t>& all) -> int {
+    hipIpcMemHandle_t mine[2];
+    for (int b = 0; b < 2; b++) ok = ok && soft(hipIpcGetMemHandle(&mine[b], bufs[b]));
+    if (!ok) memset(mine, 0, sizeof(mine));
+    if (!soft(hipMemcpyAsync(scratch_dev + 16 * np, mine, 128, hipMemcpyHostToDevice, s))) ok = false;
+    CAP_TRY(cap_comm_allgather(comm, scratch_dev + 16 * np, scratch_dev, 16, (void*)s));
+    all.assign((size_t)2 * np, hipIpcMemHandle_t());
+    memset(all.data(), 0, all.size() * sizeof(hipIpcMemHandle_t));
+    if (!soft(hipMemcpyAsync(all.data(), scratch_dev, (size_t)128 * np, hipMemcpyDeviceToHost, s)) || !soft(hipStreamSynchronize(s))) ok = false;
+    (void)me;
+    return CAP_OK;
+  };
+  std::vector<hipIpcMemHandle_t> hc, hr;
+  double* const bt[2] = {d->Bt[0], d->Bt[1]}; double* const aa[2] = {d->A[0], d->A[1]};
+  if (Pr > 1) CAP_TRY(gather_handles(d->col, Pr, d->pr, bt, d->tok + 2, hc));
+  if (Pc > 1) CAP_TRY(gather_handles(d->row, Pc, d->pc, aa, d->tok + 2 + 16 * (Pr + 1), hr));
+  hipIpcMemHandle_t zero; memset(&zero, 0, sizeof(zero));
+  auto open_all = [&](const std::vector<hipIpcMemHandle_t>& all, int np, int me, double* (*peer)[2], hipStream_t* streams, hipEvent_t* events) {
+    for (int r = 0; r < np && ok; r++) {
+      if (r == me) continue;
+      for (int b = 0; b < 2 && ok; b++) {
+        if (!memcmp(&all[(size_t)2 * r + b], &zero, sizeof(zero))) { ok = false; break; }
+        void* q = nullptr;
+        if (!soft(hipIpcOpenMemHandle(&q, all[(size_t)2 * r + b], hipIpcMemLazyEnablePeerAccess))) { ok = false; break; }
+        peer[r][b] = (double*)q;
+      }
+      if (ok) ok = soft(hipStreamCreateWithFlags(&streams[r], hipStreamNonBlocking)) && soft(hipEventCreateWithFlags(&events[r], hipEventDisableTiming));
+    }
+  };
+  if (Pr > 1 && ok) open_all(hc, Pr, d->pr, d->peerBt, d->s_pcol, d->ev_pcol);
+  if (Pc > 1 && ok) open_all(hr, Pc, d->pc, d->peerA, d->s_prow, d->ev_prow);
+  if (ok) ok = soft(hipEventCreateWithFlags(&d->ev_px, hipEventDisableTiming));
+  double flag = ok ? 0.0 : 1.0, tot = 0.0;
+  if (!soft(hipMemcpyAsync(d->tok + 1, &flag, sizeof(double), hipMemcpyHostToDevice, s))) (void)hipMemsetAsync(d->tok + 1, 0x7f, sizeof(double), s);
+  CAP_TRY(cap_comm_allreduce_sum(d->world, d->tok + 1, 1, (void*)s));
+  if (!soft(hipMemcpyAsync(&tot, d->tok + 1, sizeof(double), hipMemcpyDeviceToHost, s)) || !soft(hipStreamSynchronize(s))) tot = 1.0;
+  (void)hipMemsetAsync(d->tok + 1, 0, sizeof(double), s);
+  if (tot != 0.0 || !ok) {
+    for (int r = 0; r < 4; r++) for (int b = 0; b < 2; b++) if (d->peerBt[r][b]) { (void)hipIpcCloseMemHandle(d->peerBt[r][b]); d->peerBt[r][b] = nullptr; }
+    for (int r = 0; r < 8; r++) for (int b = 0; b < 2; b++) if (d->peerA[r][b]) { (void)hipIpcCloseMemHandle(d->peerA[r][b]); d->peerA[r][b] = nullptr; }
+    d->ipc_failed = true;
+    fprintf(stderr, "capital_amd: IPC mapping of the 2D plan's peer buffers failed on %s rank; using the RCCL broadcasts\n", ok ? "another" : "this");
+    return CAP_OK;
+  }
+  d->ipc_ready = true;
+  return CAP_OK;
+}
+
+// one operand move as peer copies: `count` doubles from `src` to offset `off` of buffer `b` of every peer of the communicator (np ranks,
+// I am `me`); roots push, everybody runs the two barriers.  sc: the communication stream.
+int push_move(cap_dist2d_plan* d, cap_comm* comm, int np, int me, bool i_push, const double* src, double* (*peer)[2], int b, int64_t off, int64_t count,
+              hipStream_t* streams, hipEvent_t* events, hipStream_t sc) {
+  CAP_TRY(cap_comm_allreduce_sum(comm, d->tok, 1, (void*)sc)); d->cnt_coll++;            // every target buffer is free
+  if (i_push && count > 0) {
+    CAP_HIP(hipEventRecord(d->ev_px, sc));
+    for (int r = 0; r < np; r++) {
+      if (r == me) continue;
+      CAP_HIP(hipStreamWaitEvent(streams[r], d->ev_px, 0));
+      CAP_HIP(hipMemcpyAsync(peer[r][b] + off, src, sizeof(double) * count, hipMemcpyDeviceToDevice, streams[r]));
+      CAP_HIP(hipEventRecord(events[r], streams[r]));
+      d->cnt_copy++;
+    }
+    for (int r = 0; r < np; r++) if (r != me) CAP_HIP(hipStreamWaitEvent(sc, events[r], 0));
+  }
+  CAP_TRY(cap_comm_allreduce_sum(comm, d->tok, 1, (void*)sc)); d->cnt_coll++;            // every push has landed
+  return CAP_OK;
+}
+
 int ensure_inverse2d(cap_dist2d_plan* d) {
   if (d->Ri) return CAP_OK;
   hipError_t e = hipMalloc((void**)&d->Ri, sizeof(double) * std::max<int64_t>(d->ld * d->nlc * d->nb, 2));
@@ -276,6 +362,9 @@ int cap_dist2d_plan_create(cap_dist2d_plan** plan, int64_t n, int64_t nb, cap_co
   d->s_panel = d->s_comm = d->s_msg = d->s_inv = nullptr;
   d->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
   d->strip = d->nblk >= 8 ? 2 : 1; d->depth2 = 1; d->safe = 0; d->complete_inv = -1; d->split = 1;
+  d->ipc = 0; d->ipc_ready = d->ipc_failed = false; d->tok = nullptr; d->ev_px = nullptr;
+  for (int r = 0; r < 4; r++) { d->peerBt[r][0] = d->peerBt[r][1] = nullptr; d->s_pcol[r] = nullptr; d->ev_pcol[r] = nullptr; }
+  for (int r = 0; r < 8; r++) { d->peerA[r][0] = d->peerA[r][1] = nullptr; d->s_prow[r] = nullptr; d->ev_prow[r] = nullptr; }
   d->cnt_gemm = d->cnt_chain = d->cnt_copy = d->cnt_coll = 0;
   if (!d->row && P > 1) {
     int st = cap_comm_split(world, d->pr, d->pc, &d->row);
@@ -336,6 +425,18 @@ int cap_dist2d_plan_destroy(cap_dist2d_plan* d) {
     for (hipEvent_t e : {d->ev_init, d->ev_join_p, d->ev_join_c, d->ev_join_m, d->ev_join_i}) (void)hipEventDestroy(e);
     for (hipStream_t st : {d->s_panel, d->s_comm, d->s_msg, d->s_inv}) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   }
+  for (int r = 0; r < 4; r++) {
+    for (int b = 0; b < 2; b++) if (d->peerBt[r][b]) (void)hipIpcCloseMemHandle(d->peerBt[r][b]);
+    if (d->s_pcol[r]) { (void)hipStreamSynchronize(d->s_pcol[r]); (void)hipStreamDestroy(d->s_pcol[r]); }
+    if (d->ev_pcol[r]) (void)hipEventDestroy(d->ev_pcol[r]);
+  }
+  for (int r = 0; r < 8; r++) {
+    for (int b = 0; b < 2; b++) if (d->peerA[r][b]) (void)hipIpcCloseMemHandle(d->peerA[r][b]);
+    if (d->s_prow[r]) { (void)hipStreamSynchronize(d->s_prow[r]); (void)hipStreamDestroy(d->s_prow[r]); }
+    if (d->ev_prow[r]) (void)hipEventDestroy(d->ev_prow[r]);
+  }
+  if (d->ev_px) (void)hipEventDestroy(d->ev_px);
+  if (d->tok) (void)hipFree(d->tok);
   for (cap_comm* c : {d->row2, d->row3, d->col3}) if (c) cap_comm_destroy(c);
   if (d->owns_row && d->row) cap_comm_destroy(d->row);
   if (d->owns_col && d->col) cap_comm_destroy(d->col);
@@ -351,6 +452,7 @@ int64_t cap_dist2d_get(const cap_dist2d_plan* d, int which) {
     case 0: return d->lr_valid; case 1: return d->lc_valid; case 2: return d->Pr; case 3: return d->Pc; case 4: return d->pr; case 5: return d->pc;
     case 6: return d->nb; case 7: return d->npad; case 8: return d->cnt_gemm; case 9: return d->cnt_chain; case 10: return d->cnt_copy;
     case 11: return d->cnt_coll;
+    case 12: return (d->ipc && d->ipc_ready) ? 1 : 0;        // the operand moves really run as IPC peer copies
   }
   return -1;
 }
@@ -365,6 +467,8 @@ int cap_dist2d_factor(cap_dist2d_plan* d, const double* Aloc, int64_t lda, void*
   CAP_TRY(ensure_events2(d));
   const bool inv = d->complete_inv >= 0;
   if (inv) CAP_TRY(ensure_inverse2d(d));
+  if (d->ipc) CAP_TRY(ensure_ipc2d(d, cap_stream(stream)));
+  const bool ipc = d->ipc && d->ipc_ready;
   CapRange frange("CI::factor");
   hipStream_t s0 = cap_stream(stream), s1 = d->s_panel, sc = d->s_comm, sm = d->safe ? d->s_comm : d->s_msg;
   cap_comm* rmsg = (d->safe || !d->row2) ? d->row : d->row2;
@@ -475,7 +579,8 @@ int cap_dist2d_factor(cap_dist2d_plan* d, const double* Aloc, int64_t lda, void*
       // ---- 4. S_k's piece down my process column (root: process row prk), then into the strip buffer (rows r nb .., ld = q nb)
       CAP_HIP(hipStreamWaitEvent(sc, d->ev_rowdone[k], 0));
       if (ncols > 0 && Pr > 1) {
-        CAP_TRY(cap_comm_bcast(d->col, Bt, nb * ncols, prk, (void*)sc)); d->cnt_coll++;
+        if (ipc) CAP_TRY(push_move(d, d->col, Pr, pr, pr == prk, Bt, d->peerBt, (int)(k & 1), 0, nb * ncols, d->s_pcol, d->ev_pcol, sc));
+        else { CAP_TRY(cap_comm_bcast(d->col, Bt, nb * ncols, prk, (void*)sc)); d->cnt_coll++; }
         CAP_TRY(cap_copy_rect(Bt, nb, S + r * nb + (lbk - lbS) * nb * ldS, ldS, nb, ncols, sc)); d->cnt_copy++;
       }
       CAP_HIP(hipEventRecord(d->ev_colb[k], sc));
@@ -506,7 +611,8 @@ int cap_dist2d_factor(cap_dist2d_plan* d, const double* Aloc, int64_t lda, void*
         if (cs <= 0) continue;
         double* slot = Ak + (int64_t)m * d->apiece;
         if (pcs == pc) { CAP_TRY(cap_copy_rect(S + (lbe - lbS) * nb * ldS, ldS, slot, ldS, ldS, cs, sc)); d->cnt_copy++; }
-        CAP_TRY(cap_comm_bcast(d->row, slot, ldS * cs, pcs, (void*)sc)); d->cnt_coll++;
+        if (ipc) CAP_TRY(push_move(d, d->row, Pc, pc, pcs == pc, slot, d->peerA, par, (int64_t)m * d->apiece, ldS * cs, d->s_prow, d->ev_prow, sc));
+        else { CAP_TRY(cap_comm_bcast(d->row, slot, ldS * cs, pcs, (void*)sc)); d->cnt_coll++; }
       }
     }
     CAP_HIP(hipEventRecord(d->ev_gather[t], sc));
@@ -624,6 +730,7 @@ int cap_dist2d_set_option(cap_dist2d_plan* d, const char* key, int64_t value) {
   if (!strcmp(key, "strip")) { if (value < 1 || value > 2) return CAP_ERR_ARG; d->strip = (int)value; return CAP_OK; }
   if (!strcmp(key, "depth2")) { d->depth2 = value != 0; return CAP_OK; }
   if (!strcmp(key, "safe")) { d->safe = value != 0; return CAP_OK; }
+  if (!strcmp(key, "ipc")) { d->ipc = value != 0; return CAP_OK; }
   if (!strcmp(key, "complete_inv")) {
     if (value < -1 || value > 1) return CAP_ERR_ARG;
     if (value >= 0) CAP_TRY(ensure_inverse2d(d));

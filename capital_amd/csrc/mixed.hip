@@ -643,6 +643,7 @@ int cap_mpchol_plan_create(cap_mpchol_plan** plan, int64_t n, int64_t nrhs_max) 
   p->tb = p->nb;                      // the TRSM blocks ARE the panels: their inverses fall out of the factorization
   const int64_t nb = p->nb, w = p->nrhs_cap, nblk = cap_ceil_div(n, p->tb);
   hipError_t e = hipMalloc((void**)&p->R32, sizeof(float) * n * n);
+  if (e == hipSuccess) e = hipMemset(p->R32, 0, sizeof(float) * n * n);        // the strictly-lower part stays zero for the plan's life
   if (e == hipSuccess) e = hipMalloc((void**)&p->R64, sizeof(double) * n * n);
   if (e == hipSuccess) e = hipMemset(p->R64, 0, sizeof(double) * n * n);      // nothing ever writes below its diagonal
   for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void**)&p->P16[i], sizeof(__bf16) * 2 * nb * n);     // strip buffers, ld = 2 nb

@@ -6,11 +6,13 @@
 #include "common.h"
 
 namespace {
+// fp32 import of A's upper triangle.  Only rows <= col are touched: the strictly-lower part of the factor is zeroed once per plan and
+// never written afterwards (every update and solve is masked to the upper triangle), so the import moves half the matrix
 static __global__ void f64_to_f32_upper_kernel(const double* A, int64_t lda, float* R, int64_t ldr, int64_t n) {
   const int64_t col = blockIdx.y + (int64_t)blockIdx.z * 65535;
   if (col >= n) return;
-  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x)
-    R[row + col * ldr] = row <= col ? (float)A[row + col * lda] : 0.0f;
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row <= col; row += (int64_t)gridDim.x * blockDim.x)
+    R[row + col * ldr] = (float)A[row + col * lda];
 }
 static __global__ void f32_to_f64_kernel(const float* S, int64_t lds_, double* D, int64_t ldd, int64_t rows, int64_t cols, int upper_only) {
   const int64_t col = blockIdx.y + (int64_t)blockIdx.z * 65535;

@@ -379,7 +379,7 @@ int64_t cap_bc_num_local_cols(int64_t n, int64_t nb, int P, int p);
  * row / col: communicators of my process row (ordered by pc) / column (ordered by pr), or NULL to split them off `world`
  * (ncclCommSplit).  Alocal / get_R: the valid local piece (cap_bc2d_local_extent rows x columns, column-major).
  * cap_dist2d_get: 0 valid local rows, 1 valid local columns, 2 Pr, 3 Pc, 4 pr, 5 pc, 6 nb, 7 padded n, 8..11 = MFMA kernels,
- * diagonal-block chains, copy kernels, collectives issued by the last factor call on this rank.                        */
+ * diagonal-block chains, copy kernels, collectives issued by the last factor call on this rank; 12 = IPC moves active.    */
 typedef struct cap_dist2d_plan cap_dist2d_plan;
 int cap_dist2d_plan_create(cap_dist2d_plan** plan, int64_t n, int64_t nb, cap_comm* world, int Pr, cap_comm* row, cap_comm* col);
 int cap_dist2d_plan_destroy(cap_dist2d_plan* plan);
@@ -392,7 +392,9 @@ int cap_dist2d_info(cap_dist2d_plan* plan, void* stream, int64_t* info);
  * the rows of strip t + 2 release the panel stream early; on), "occ1_m", "safe" (one communicator family, one communication stream),
  * "complete_inv" = 0 / 1 + "split": the factor call also leaves my piece of R^-1 (cap_dist2d_get_Rinv), streamed with the sweep as in
  * cap_dist_*: per block row Dinv(k) down the owner's process column, the finished block column of R^-1 along the process rows, one
- * local MFMA GEMM with my piece of the solved row - no replicated R.                                                        */
+ * local MFMA GEMM with my piece of the solved row - no replicated R.  "ipc" = 1: both operand moves (the solved row down the process
+ * columns, the strip pieces along the process rows) as IPC peer copies on SDMA engines with two 8-byte all-reduces each as barriers,
+ * like the 1 x P plan's strip exchange (cap_dist2d_get(plan, 12) tells whether the peers could be mapped).                  */
 int cap_dist2d_set_option(cap_dist2d_plan* plan, const char* key, int64_t value);
 int cap_dist2d_get_Rinv(cap_dist2d_plan* plan, double* out, int64_t ld, void* stream);
 double* cap_dist2d_Rinv_ptr(cap_dist2d_plan* plan, int64_t* ld);

@@ -89,11 +89,16 @@ def main():
             ctx.set_option("depth2", args.depth2)
         if args.safe:
             ctx.set_option("safe", 1)
+        if args.ipc:
+            ctx.set_option("ipc", 1)
         if args.ci >= 0:
             ctx.set_option("complete_inv", args.ci); ctx.set_option("split", args.split)
         for rep in range(2):                       # plan reuse
             ctx.factor()
         info = ctx.last_info()
+        if args.ipc and size > 1:
+            from capital_amd import _lib
+            assert _lib.lib().cap_dist2d_get(ctx.plan, 12) == 1, "the peers' buffers were not mapped: the run fell back to the broadcasts"
         rl = ctx.local_R()
         ril = ctx.local_Rinv() if args.ci >= 0 else None
 

@@ -188,6 +188,9 @@ def test_2d_block_cyclic_schedule_on_one_gpu(nproc, pr, n, nb):
     (4, 2, 2048, 128, ("--ci", 1)), (8, 2, 2048, 128, ("--ci", 0)), (8, 2, 1000, 128, ("--ci", 0)),     # R^-1 streamed on the 2D grid
     (4, 2, 1024, 128, ("--ci", 0, "--split", 2)), (8, 2, 4096, 256, ("--ci", 1, "--safe", 1)), (1, 1, 1024, 128, ("--ci", 1)),
     (16, 4, 2048, 128, ("--ci", 1)),
+    # both operand moves (solved row down the process columns, strip pieces along the process rows) as IPC peer copies
+    (4, 2, 2048, 128, ("--ipc", 1)), (8, 2, 4096, 128, ("--ipc", 1)), (8, 2, 2049, 256, ("--ipc", 1, "--ci", 1)), (16, 4, 2048, 128, ("--ipc", 1)),
+    (4, 1, 2048, 128, ("--ipc", 1)),
 ])
 def test_2d_block_cyclic_schedule_options(nproc, pr, n, nb, extra):
     """The Pr x Pc plan at parity with the 1 x P plan: strips of two block rows (K = 2 nb updates), look-ahead depth 2, safe mode,
