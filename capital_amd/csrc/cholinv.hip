@@ -83,6 +83,31 @@ int rec_cholinv(const RecCtx& c, int64_t off, int64_t n, bool is_root, int64_t i
   return CAP_OK;
 }
 
+// ---- one-launch diagonal-block chain: process-wide switch + the barrier counters of its launches -----------------------------------
+// g_coop_wgs resident workgroups (0 / 1: one launch per step, the round-3 form); g_coop_cap > 0 bounds it while a caller launches
+// on a CU-masked stream (every workgroup of the launch must find a slot or the others spin for ever).
+int g_coop_wgs = getenv("CAP_CHAIN_COOP") ? atoi(getenv("CAP_CHAIN_COOP")) : 0;
+int g_coop_cap = 0;
+// a ring of counter pairs per device: a launch takes the next pair and leaves it zeroed, so only launches that are in flight at the
+// same time on different streams must not share one (64 of them would have to)
+constexpr int COOP_SLOTS = 64;
+std::mutex g_coop_mu;
+int* g_coop_ctr[16] = {};
+unsigned g_coop_next[16] = {};
+int coop_counter(int** out) {
+  int dev = 0;
+  CAP_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return CAP_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lk(g_coop_mu);
+  if (!g_coop_ctr[dev]) {
+    CAP_HIP(hipMalloc((void**)&g_coop_ctr[dev], COOP_SLOTS * 2 * sizeof(int)));
+    CAP_HIP(hipMemset(g_coop_ctr[dev], 0, COOP_SLOTS * 2 * sizeof(int)));
+    CAP_HIP(hipDeviceSynchronize());
+  }
+  *out = g_coop_ctr[dev] + 2 * (g_coop_next[dev]++ % COOP_SLOTS);
+  return CAP_OK;
+}
+
 int64_t rec_work_size(int64_t n) { return cap_round_up(std::max<int64_t>((n / 2 + 1) * (n / 2 + 1), 128 * n), 2); }
 
 // Diagonal-block fast path (n = 64 * nblk <= 1024): 64-blocked right-looking potrf with ONE fused launch per step
@@ -95,7 +120,15 @@ int blocked_cholinv(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, 
   const int nblk = (int)(n / 64);
   if (128 * n > wcap) return CAP_ERR_ALLOC;
   static const bool fold = getenv("CAP_FOLD_LEAF") ? atoi(getenv("CAP_FOLD_LEAF")) != 0 : true;
-  if (fold) {
+  int coop = g_coop_wgs;
+  if (g_coop_cap > 0) coop = std::min(coop, g_coop_cap);
+  if (coop >= 2 && nblk >= 4) {
+    // the whole factor phase in one launch of `coop` resident workgroups (chain64_coop_kernel, leaf.hip)
+    int* ctr = nullptr;
+    CAP_TRY(coop_counter(&ctr));
+    static const int fence = getenv("CAP_CHAIN_FENCE") ? atoi(getenv("CAP_CHAIN_FENCE")) : 0;
+    CAP_TRY(cap_chain64_coop(R, ldr, Ri, ldi, nblk, W, 64 * n, info, (int)info_base, ctr, coop, fence, s));
+  } else if (fold) {
     // one launch per step: the fused solve + update of step i also runs the leaf of step i + 1 (leaf.hip).  The solved block
     // row of step i sits in half (i & 1) of W until the launch of step i + 1 moves it into R (the other workgroups of step i
     // still read the unsolved blocks), the last step - a single workgroup - writes its piece in place.
@@ -401,7 +434,10 @@ int panel_chain(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t j0, int64_t
       CAP_HIP(hipEventRecord(p->ev_chain[0], s));
       CAP_HIP(hipStreamWaitEvent(sc, p->ev_chain[0], 0));
     }
-    CAP_TRY(blocked_cholinv(R + j0 + j0 * ldr, ldr, Dinv, p->ldi, jb, Wrec, rec_work_size(p->nb), p->info_dev, j0, sc));
+    if (sc != s) cap_chain_coop_cap((int)std::max<int64_t>(p->reserve, 1));   // masked stream: no more resident workgroups than its CUs
+    const int st_chain = blocked_cholinv(R + j0 + j0 * ldr, ldr, Dinv, p->ldi, jb, Wrec, rec_work_size(p->nb), p->info_dev, j0, sc);
+    if (sc != s) cap_chain_coop_cap(0);
+    CAP_TRY(st_chain);
     if (sc != s) {
       CAP_HIP(hipEventRecord(p->ev_chain[1], sc));
       CAP_HIP(hipStreamWaitEvent(s, p->ev_chain[1], 0));
@@ -1061,6 +1097,8 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
     p->reserve = value; return CAP_OK;
   }
   if (k == "reserve_m") { if (value < 0) return CAP_ERR_ARG; p->reserve_m = value; return CAP_OK; }
+  // process-wide: resident workgroups of the one-launch diagonal-block chain (leaf.hip chain64_coop_kernel), 0 = one launch per step
+  if (k == "chain_coop") { if (value < 0 || value > 256) return CAP_ERR_ARG; cap_chain_coop_set((int)value); return CAP_OK; }
   if (k == "fuse_copy") { p->fuse_copy = value != 0; return CAP_OK; }
   if (k == "profile") {
     p->profile = value != 0;
@@ -1097,6 +1135,7 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
   if (k == "fastdiag") return p->fastdiag;
   if (k == "reserve") return p->reserve;
   if (k == "reserve_m") return p->reserve_m;
+  if (k == "chain_coop") return cap_chain_coop_get();
   if (k == "fuse_copy") return p->fuse_copy;
   if (k == "inner_la") return p->inner_la;
   if (k == "occ1_m") return p->occ1_m;
@@ -1379,6 +1418,10 @@ int cap_trsm_apply(int side, int trans, int64_t m, int64_t n, const double* T, i
   }
   return CAP_OK;
 }
+
+void cap_chain_coop_set(int wgs) { g_coop_wgs = wgs < 0 ? 0 : wgs; }
+int cap_chain_coop_get() { return g_coop_wgs; }
+void cap_chain_coop_cap(int cap) { g_coop_cap = cap < 0 ? 0 : cap; }
 
 // used by cacqr.hip: full cholinv (R in place, Ri = R^-1) of an n x n block on one stream
 int cap_rec_cholinv_full(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, double* W, int64_t wcap, int* info,

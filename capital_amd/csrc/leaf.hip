@@ -464,7 +464,279 @@ __global__ void __launch_bounds__(LTHREADS) trinv_merge_kernel(const double* R, 
     for (int r = 0; r < 4; r++) Out[16 * (wid + 4 * q) + kg + 4 * r + (int64_t)lr * ldi] = -acc[q][r];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Whole factor phase of one diagonal block in ONE launch (round 4): the 64-blocked right-looking sweep above costs one launch per
+// step, and next to a bulk update every launch of the chain waits ~ 70 us for workgroup slots before it does 30 us of work
+// (profiles/r04_experiments.log: 960 fused steps x 102 us per mixed-precision factorization of N = 65536).  Here G workgroups stay
+// resident for all nblk steps and meet at a counter in global memory once per step:
+//   workgroup 0        block (i+1, i+1) of step i, then - still in LDS - the leaf of step i + 1 (factor + invert), exactly the fold of
+//                      panel64_solve_update_kernel
+//   workgroups 1..G-1  the other trailing blocks (a, b) of step i, round-robin; each recomputes X_a, X_b like the fused step
+// Nothing but G <= free workgroup slots is assumed about placement: a workgroup that arrives late only delays the others at the
+// counter (the kernels it waits behind are finite), there is no cooperative-launch API involved.
+// Coherence across the 8 XCDs (one L2 each): everything the workgroups exchange travels with agent-scope accesses (sc1: written
+// through to / read from the memory side), so the barrier is just s_waitcnt vmcnt(0) + one counter - no L2 write-back or
+// invalidate, which would also hit the operand lines of the bulk update that shares the L2s.  `fence` != 0 adds the release /
+// acquire fences around the counter (A/B switch, CAP_CHAIN_FENCE).
+struct Chain64 {
+  double* R; int64_t ldr; double* Ri; int64_t ldi; int nblk; double* Xs; int64_t xs_half; int* info; int info_base; int* ctr; int fence;
+};
+
+__device__ __forceinline__ double gld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gst(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Returns false when a workgroup never showed up (tens of seconds of polling: the launch was given more workgroups than the stream
+// it runs on can hold at once) - the caller stops meeting at the counter and reports through `info`.
+__device__ __forceinline__ bool chain_barrier(int* ctr, int target, int fence, int* lds_flag) {
+  __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): this lane's write-through stores have reached the memory side
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int polls = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && polls < (1 << 24)) { __builtin_amdgcn_s_sleep(2); polls++; }
+    if (fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *lds_flag = polls < (1 << 24);
+  }
+  __syncthreads();
+  return *lds_flag != 0;
+}
+
+__global__ void __launch_bounds__(LTHREADS) chain64_coop_kernel(const Chain64 g) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* B0 = lds;
+  double* B1 = lds + LMAX * LLD;
+  double* Dp = lds + 2 * LMAX * LLD;      // Dinv_i, packed upper; scratch of the folded leaf
+  __builtin_amdgcn_s_setprio(3);
+  const int G = (int)gridDim.x, w = (int)blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int lr = lane & 15, kg = lane >> 4;
+  const int nblk = g.nblk;
+  double* const R = g.R; const int64_t ldr = g.ldr;
+  int& bad = *reinterpret_cast<int*>(Dp);
+  double* dinv = Dp + 2; double* rowbuf = dinv + LMAX;
+  int epoch = 0;
+  int& barrier_ok = *reinterpret_cast<int*>(Dp + LMAX * (LMAX + 1) / 2);      // (all LDS stays in the dynamic region)
+
+  // leaf on S = B1 (upper part of the block, rest zero), T = B0: R_bb in place, Dinv_b = R_bb^-1 with a zero-filled lower part
+  auto leaf = [&](int bk) {
+    double* S = B1; double* T = B0;
+    double* C = R + (int64_t)bk * 64 * (ldr + 1);
+    double* Dn = g.Ri + (int64_t)bk * 64 * (g.ldi + 1);
+    potrf_lds(S, dinv, rowbuf, 64, &bad);
+    for (int e = t; e < 64 * 64; e += LTHREADS) {
+      const int ii = e & 63, jj = e >> 6;
+      if (ii <= jj) gst(C + ii + (int64_t)jj * ldr, SM(S, ii, jj));
+    }
+    trtri_lds(S, T, dinv, 64);
+    __syncthreads();
+    for (int e = t; e < 64 * 64; e += LTHREADS) {
+      const int ii = e & 63, jj = e >> 6;
+      gst(Dn + ii + (int64_t)jj * g.ldi, (ii <= jj) ? SM(T, ii, jj) : 0.0);
+    }
+    if (t == 0 && bad != 0 && g.info) atomicCAS(g.info, 0, g.info_base + bk * 64 + bad);
+  };
+
+  // step -1 = the leaf of block 0 alone
+  for (int i = -1; i + 1 < nblk; i++) {
+    const int r = nblk - 1 - i, npairs = (i < 0) ? 0 : r * (r + 1) / 2;
+    // the block row solved by step i - 1 moves from its scratch half into R (nobody reads row i - 1 any more)
+    if (i > 0 && r >= 1) {
+      const double* src = g.Xs + (int64_t)((i - 1) & 1) * g.xs_half;
+      for (int blk = w; blk < nblk - i; blk += G) {
+        const double* sb = src + (int64_t)blk * 64 * 64;
+        double* db = R + (int64_t)(i - 1) * 64 + (int64_t)(i + blk) * 64 * ldr;
+        for (int e0 = 0; e0 < 64 * 64; e0 += 4 * LTHREADS) {
+          double v[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) v[u] = gld(sb + e0 + u * LTHREADS + t);
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const int e = e0 + u * LTHREADS + t; gst(db + (e & 63) + (int64_t)(e >> 6) * ldr, v[u]); }
+        }
+      }
+    }
+    const double* Dinv = g.Ri + (int64_t)i * 64 * (g.ldi + 1);
+    const int first = (w == 0) ? (G == 1 ? 1 : npairs) : w;          // workgroup 0 takes pair 0 (below) unless it is alone
+    const int stride = (G == 1) ? 1 : G - 1;
+    const bool mine = i >= 0 && ((w == 0) || first < npairs);
+    if (mine) {
+      __syncthreads();                                                // the previous step's readers of Dp (leaf scratch) are done
+      for (int e0 = 0; e0 < 64 * 64; e0 += 4 * LTHREADS) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
+          v[u] = (ii <= jj) ? gld(Dinv + ii + (int64_t)jj * g.ldi) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
+          if (ii <= jj) Dp[jj * (jj + 1) / 2 + ii] = v[u];
+        }
+      }
+    }
+    // one trailing block (a, b) = pair q of step i; fold: go on to the leaf of step i + 1 (pair 0 only)
+    auto pair = [&](int q, bool fold) {
+      int bjt = 0;
+      while (q >= bjt + 1) { q -= bjt + 1; bjt++; }
+      const int a = i + 1 + q, b = i + 1 + bjt;
+      const bool diag = (a == b);
+      const double* Aia = R + (int64_t)i * 64 + (int64_t)a * 64 * ldr;
+      const double* Aib = R + (int64_t)i * 64 + (int64_t)b * 64 * ldr;
+      __syncthreads();                                                // B0 / B1 of the previous pair are free, Dp is complete
+      for (int e0 = 0; e0 < 64 * 64; e0 += 4 * LTHREADS) {
+        double v1[4], v2[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
+          v1[u] = gld(Aia + ii + (int64_t)jj * ldr);
+          v2[u] = diag ? 0.0 : gld(Aib + ii + (int64_t)jj * ldr);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
+          SM(B0, ii, jj) = v1[u];
+          if (!diag) SM(B1, ii, jj) = v2[u];
+        }
+      }
+      __syncthreads();
+      auto solve = [&](const double* B, d4 (&acc)[4]) {
+#pragma unroll
+        for (int sblk = 0; sblk < 4; sblk++) {
+          const int id = wid + 4 * sblk, bi = id & 3, bj = id >> 2;
+          d4 c = {0.0, 0.0, 0.0, 0.0};
+          const int p = bi * 16 + lr;
+          for (int k0 = 0; k0 < 16 * (bi + 1); k0 += 4) {
+            const int k = k0 + kg;
+            const double av = (k <= p) ? Dp[p * (p + 1) / 2 + k] : 0.0;
+            const double bv = SM(B, k, bj * 16 + lr);
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
+          }
+          acc[sblk] = c;
+        }
+      };
+      auto put = [&](double* B, const d4 (&acc)[4]) {
+#pragma unroll
+        for (int sblk = 0; sblk < 4; sblk++) {
+          const int id = wid + 4 * sblk, bi = id & 3, bj = id >> 2;
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) SM(B, bi * 16 + kg + 4 * rr, bj * 16 + lr) = acc[sblk][rr];
+        }
+      };
+      d4 xa[4], xb[4];
+      solve(B0, xa);
+      if (!diag) solve(B1, xb);
+      __syncthreads();
+      put(B0, xa);
+      if (!diag) put(B1, xb);
+      __syncthreads();
+      if (diag) {                      // the solved block R_ia: scratch (other workgroups still read the unsolved A_ia), or in place
+        if (r == 1) {
+          double* dst = R + (int64_t)i * 64 + (int64_t)a * 64 * ldr;
+          for (int e = t; e < 64 * 64; e += LTHREADS) gst(dst + (e & 63) + (int64_t)(e >> 6) * ldr, SM(B0, e & 63, e >> 6));
+        } else {
+          double* dst = g.Xs + (int64_t)(i & 1) * g.xs_half + (int64_t)(a - i - 1) * 64 * 64;
+          for (int e = t; e < 64 * 64; e += LTHREADS) gst(dst + e, SM(B0, e & 63, e >> 6));
+        }
+      }
+      const double* XB = diag ? B0 : B1;
+      double* C = R + (int64_t)a * 64 + (int64_t)b * 64 * ldr;
+      if (fold) {
+        for (int e = t; e < 64 * LLD; e += LTHREADS) B1[e] = 0.0;
+        __syncthreads();
+      }
+      double cin[4][4];
+#pragma unroll
+      for (int sblk = 0; sblk < 4; sblk++) {
+        const int id = wid + 4 * sblk, bi = id & 3, bj = id >> 2;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int row = bi * 16 + lr, col = bj * 16 + kg + 4 * rr;
+          cin[sblk][rr] = (!diag || row <= col) ? gld(C + row + (int64_t)col * ldr) : 0.0;
+        }
+      }
+#pragma unroll
+      for (int sblk = 0; sblk < 4; sblk++) {
+        const int id = wid + 4 * sblk, bi = id & 3, bj = id >> 2;
+        if (diag && bi > bj) continue;
+        d4 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int k0 = 0; k0 < 64; k0 += 4) {
+          const double colv = SM(XB, k0 + kg, bj * 16 + lr);
+          const double rowv = SM(B0, k0 + kg, bi * 16 + lr);
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(colv, rowv, c, 0, 0, 0);   // result: (col = kg + 4r, row = lr)
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int row = bi * 16 + lr, col = bj * 16 + kg + 4 * rr;
+          if (!diag || row <= col) {
+            if (fold) SM(B1, row, col) = cin[sblk][rr] - c[rr];
+            else gst(C + row + (int64_t)col * ldr, cin[sblk][rr] - c[rr]);
+          }
+        }
+      }
+    };
+    // this workgroup's pairs of the step; workgroup 0 ends with pair 0 and keeps the updated block (i+1, i+1) in B1
+    const int cnt = (i >= 0 && (w > 0 || G == 1) && first < npairs) ? (npairs - first + stride - 1) / stride : 0;
+    const int total = cnt + ((w == 0 && i >= 0) ? 1 : 0);
+    for (int it = 0; it < total; it++) pair(it < cnt ? first + it * stride : 0, it >= cnt);
+    if (w == 0) {
+      __syncthreads();                                               // every read of B0 (X_a) is done, S = B1 is complete
+      if (i < 0) {
+        for (int e = t; e < 64 * LLD; e += LTHREADS) B1[e] = 0.0;
+        __syncthreads();
+        for (int e0 = 0; e0 < 64 * 64; e0 += 4 * LTHREADS) {
+          double v[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
+            v[u] = (ii <= jj) ? gld(R + ii + (int64_t)jj * ldr) : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int e = e0 + u * LTHREADS + t;
+            SM(B1, e & 63, e >> 6) = v[u];
+          }
+        }
+      }
+      for (int e = t; e < 64 * LLD; e += LTHREADS) B0[e] = 0.0;
+      if (t == 0) bad = 0;
+      __syncthreads();
+      leaf(i + 1);
+    }
+    epoch += G;
+    if (!chain_barrier(g.ctr, epoch, g.fence, &barrier_ok)) {
+      if (t == 0 && g.info) atomicExch(g.info, -64);                 // "a workgroup of the chain never became resident"
+      break;
+    }
+  }
+  // the last workgroup through resets the counters for the next launch that is handed this slot
+  if (t == 0) {
+    const int done = __hip_atomic_fetch_add(g.ctr + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == G - 1) {
+      __hip_atomic_store(g.ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(g.ctr + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 }  // namespace
+
+// Factor phase of blocked_cholinv (cholinv.hip) in one launch of `wgs` resident workgroups (chain64_coop_kernel): R (n = 64 nblk)
+// factored in place, the 64 x 64 diagonal blocks of Ri = their inverses.  Xs: 2 x xs_half doubles of scratch (xs_half >= 64 n).
+// ctr: two ints, zero before the first use (the kernel leaves them zero).
+int cap_chain64_coop(double* R, int64_t ldr, double* Ri, int64_t ldi, int nblk, double* Xs, int64_t xs_half, int* info, int info_base,
+                     int* ctr, int wgs, int fence, hipStream_t stream) {
+  if (nblk <= 0) return CAP_OK;
+  if (wgs < 1 || xs_half < (int64_t)64 * 64 * nblk) return CAP_ERR_ARG;
+  const int useful = std::max(1, (nblk - 1) * nblk / 2);           // one workgroup per trailing block of the first step
+  wgs = std::min(wgs, useful);
+  const size_t lds_bytes = (2 * LMAX * LLD + LMAX * (LMAX + 1) / 2 + 2) * sizeof(double);
+  const Chain64 g{R, ldr, Ri, ldi, nblk, Xs, xs_half, info, info_base, ctr, fence};
+  hipLaunchKernelGGL(chain64_coop_kernel, dim3((unsigned)wgs), dim3(LTHREADS), lds_bytes, stream, g);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
 
 // Ri12 = -Ri11 (R12 Ri22) for npairs aligned pairs of h x h diagonal blocks (h = 64, 128 or 256), one launch
 int cap_trinv_merge(const double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t h, int npairs, hipStream_t stream) {

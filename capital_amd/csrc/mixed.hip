@@ -770,7 +770,10 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
       if (p->res_ready) {           // the latency-bound launches on the reserved CUs
         CAP_HIP(hipEventRecord(p->ev_ch[0], s1));
         CAP_HIP(hipStreamWaitEvent(p->s_chain, p->ev_ch[0], 0));
-        CAP_TRY(cap_rec_cholinv_full(p->D64, jb, Dinv, nb, jb, p->W, p->wcap, p->info_dev, p->s_chain, j0));
+        cap_chain_coop_cap(p->reserve);          // no more resident workgroups than the masked stream has CUs
+        const int st_chain = cap_rec_cholinv_full(p->D64, jb, Dinv, nb, jb, p->W, p->wcap, p->info_dev, p->s_chain, j0);
+        cap_chain_coop_cap(0);
+        CAP_TRY(st_chain);
         CAP_HIP(hipEventRecord(p->ev_ch[1], p->s_chain));
         CAP_HIP(hipStreamWaitEvent(s1, p->ev_ch[1], 0));
       } else
@@ -971,6 +974,7 @@ int cap_mpchol_set_option(cap_mpchol_plan* p, const char* key, int64_t value) {
     if (value != p->reserve) { mp_release_streams(p); p->reserve = (int)value; }
     return CAP_OK;
   }
+  if (!strcmp(key, "chain_coop")) { if (value < 0 || value > 256) return CAP_ERR_ARG; cap_chain_coop_set((int)value); return CAP_OK; }   // process-wide, see cap_cholinv_set_option
   if (!strcmp(key, "solve3")) { p->solve3 = value != 0; return CAP_OK; }   // block-row solves on the bf16 pipe with split operands (split schedule)
   // process-wide A/B switches of the bf16 update (see launch_bf16_update): which kernel, chunk length, smallest launch for the new one
   if (!strcmp(key, "update_kernel")) { if (value < 0 || value > 1) return CAP_ERR_ARG; g_bf16_variant = (int)value; return CAP_OK; }

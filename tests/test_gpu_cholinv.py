@@ -206,6 +206,72 @@ def test_fused_first_step_copy_is_bitwise_identical():
         assert np.array_equal(outs[-1], outs[-2])
 
 
+def _with_chain(G, fn):
+    """run fn() with the process-wide "chain_coop" switch at G, then put the default back"""
+    from capital_amd import cholinv
+    probe = cholinv.info(-1, 1, -2, 'U'); probe._ensure(128)
+    old = probe.get_option("chain_coop")
+    probe.set_option("chain_coop", G)
+    try:
+        return fn()
+    finally:
+        probe.set_option("chain_coop", old)
+
+
+@pytest.mark.parametrize("n,nb,ci", [(256, 256, 1), (512, 512, 1), (1024, 1024, 1), (3072, 512, -1), (2048, 1024, 0), (4096, 256, 1)])
+def test_one_launch_diagonal_block_chain_is_bitwise_identical(n, nb, ci):
+    """"chain_coop" = G > 1: the factor phase of every diagonal block runs as ONE launch of G resident workgroups that meet at a
+    counter in global memory after every 64-column step (leaf.hip chain64_coop_kernel) instead of one launch per step.  Same blocks,
+    same association order -> R and R^-1 must not differ by one bit, for every G (more workgroups than trailing blocks, fewer,
+    one worker); the counters are left zero, so plans can follow each other on the same slots."""
+    from capital_amd import cholinv
+    def run(G):
+        def go():
+            _, pack = _factor(n, ci, 1, -2, opts={"nb": nb})
+            out = [cholinv.construct_R(pack).to_numpy()]
+            if ci >= 0:
+                out.append(cholinv.construct_Rinv(pack).to_numpy())
+            assert pack.last_info() == 0
+            return out
+        return _with_chain(G, go)
+    ref = run(0)
+    assert orc.cholesky_residual(orc.symmetric_global(n, True), ref[0]) < RES_TOL
+    for G in (2, 3, 7, 32, 200):
+        got = run(G)
+        for x, y in zip(ref, got):
+            assert np.array_equal(x, y), (G, float(np.abs(x - y).max()))
+
+
+def test_one_launch_chain_reports_pivots_and_survives_a_busy_gpu():
+    """not-SPD input: the failing pivot's index comes out of the one-launch chain like out of the stepwise one (any block, any
+    workgroup count); then 40 factorizations back to back next to a stream that keeps every CU busy with large products - the resident
+    workgroups only ever wait for finite kernels, results stay bit-identical."""
+    from capital_amd import cholinv
+    n = 1024
+    for row in (0, 63, 64, 200, 1023):
+        a = orc.symmetric_global(n, True); a[row, row] = -5.0
+        def go():
+            _, pack = _factor(n, 1, 1, -2, a=a, opts={"nb": 1024})
+            return pack.last_info()
+        assert _with_chain(0, go) == row + 1
+        assert _with_chain(32, go) == row + 1
+    def stress():
+        side = torch.cuda.Stream()
+        x = torch.randn(8192, 8192, device="cuda", dtype=torch.float32)
+        A, pack = _factor(2048, 1, 1, -2, opts={"nb": 1024})
+        r0 = cholinv.construct_R(pack).to_numpy(); i0 = cholinv.construct_Rinv(pack).to_numpy()
+        with torch.cuda.stream(side):
+            for _ in range(60):
+                y = x @ x
+        for _ in range(40):
+            cholinv.factor(A, pack, None)
+        torch.cuda.synchronize()
+        assert np.array_equal(cholinv.construct_R(pack).to_numpy(), r0)
+        assert np.array_equal(cholinv.construct_Rinv(pack).to_numpy(), i0)
+        del y
+    _with_chain(32, stress)
+
+
 def test_harder_spd_input():
     """A = B^T B + eps I (kappa ~ 1e6): residual stays at fp64 level relative to ||A||."""
     from capital_amd import cholinv
