@@ -86,7 +86,7 @@ int rec_cholinv(const RecCtx& c, int64_t off, int64_t n, bool is_root, int64_t i
 // ---- one-launch diagonal-block chain: process-wide switch + the barrier counters of its launches -----------------------------------
 // g_coop_wgs resident workgroups (0 / 1: one launch per step, the round-3 form); g_coop_cap > 0 bounds it while a caller launches
 // on a CU-masked stream (every workgroup of the launch must find a slot or the others spin for ever).
-int g_coop_wgs = getenv("CAP_CHAIN_COOP") ? atoi(getenv("CAP_CHAIN_COOP")) : 0;
+int g_coop_wgs = getenv("CAP_CHAIN_COOP") ? atoi(getenv("CAP_CHAIN_COOP")) : 32;
 int g_coop_cap = 0;
 // a ring of counter pairs per device: a launch takes the next pair and leaves it zeroed, so only launches that are in flight at the
 // same time on different streams must not share one (64 of them would have to)
@@ -94,6 +94,8 @@ constexpr int COOP_SLOTS = 64;
 std::mutex g_coop_mu;
 int* g_coop_ctr[16] = {};
 unsigned g_coop_next[16] = {};
+long long* g_coop_trace = nullptr;
+int64_t g_coop_trace_at = -1;
 int coop_counter(int** out) {
   int dev = 0;
   CAP_HIP(hipGetDevice(&dev));
@@ -122,12 +124,17 @@ int blocked_cholinv(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, 
   static const bool fold = getenv("CAP_FOLD_LEAF") ? atoi(getenv("CAP_FOLD_LEAF")) != 0 : true;
   int coop = g_coop_wgs;
   if (g_coop_cap > 0) coop = std::min(coop, g_coop_cap);
+  int64_t merged = 0;             // the launch above has already assembled the inverse up to pairs of this size
   if (coop >= 2 && nblk >= 4) {
     // the whole factor phase in one launch of `coop` resident workgroups (chain64_coop_kernel, leaf.hip)
     int* ctr = nullptr;
     CAP_TRY(coop_counter(&ctr));
     static const int fence = getenv("CAP_CHAIN_FENCE") ? atoi(getenv("CAP_CHAIN_FENCE")) : 0;
-    CAP_TRY(cap_chain64_coop(R, ldr, Ri, ldi, nblk, W, 64 * n, info, (int)info_base, ctr, coop, fence, s));
+    long long* trace = nullptr;
+    if (g_coop_trace && g_coop_trace_at-- == 0) trace = g_coop_trace;       // instrumentation of ONE launch (cap_chain_trace_arm)
+    static const int merge_env = getenv("CAP_CHAIN_MERGE") ? atoi(getenv("CAP_CHAIN_MERGE")) : 256;   // inverse levels done in the same launch
+    merged = std::min<int64_t>(merge_env, n / 2);
+    CAP_TRY(cap_chain64_coop(R, ldr, Ri, ldi, nblk, W, 64 * n, info, (int)info_base, ctr, coop, fence, (int)merged, s, trace));
   } else if (fold) {
     // one launch per step: the fused solve + update of step i also runs the leaf of step i + 1 (leaf.hip).  The solved block
     // row of step i sits in half (i & 1) of W until the launch of step i + 1 moves it into R (the other workgroups of step i
@@ -155,6 +162,7 @@ int blocked_cholinv(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, 
   }
   for (int64_t h = 64; h < n; h *= 2) {
     const int npairs = (int)(n / (2 * h));
+    if (h <= merged) continue;
     if (h * h * npairs > wcap) return CAP_ERR_ALLOC;
     static const bool merge1 = getenv("CAP_TRINV_MERGE") ? atoi(getenv("CAP_TRINV_MERGE")) != 0 : true;
     if (merge1 && h <= 256) {
@@ -1422,6 +1430,22 @@ int cap_trsm_apply(int side, int trans, int64_t m, int64_t n, const double* T, i
 void cap_chain_coop_set(int wgs) { g_coop_wgs = wgs < 0 ? 0 : wgs; }
 int cap_chain_coop_get() { return g_coop_wgs; }
 void cap_chain_coop_cap(int cap) { g_coop_cap = cap < 0 ? 0 : cap; }
+
+// Instrumentation (tools/chain_trace.py): the `which`-th one-launch chain from now on records, per workgroup (first 64) and step,
+// four 100 MHz time stamps (step start / own blocks done / arrival at the counter / release); cap_chain_trace_read copies them out.
+extern "C" int cap_chain_trace_arm(int64_t which) {
+  if (!g_coop_trace) CAP_HIP(hipMalloc((void**)&g_coop_trace, 64 * 32 * 8 * sizeof(long long)));
+  CAP_HIP(hipMemset(g_coop_trace, 0, 64 * 32 * 8 * sizeof(long long)));
+  CAP_HIP(hipDeviceSynchronize());
+  g_coop_trace_at = which;
+  return CAP_OK;
+}
+extern "C" int cap_chain_trace_read(int64_t* out) {
+  if (!g_coop_trace || !out) return CAP_ERR_ARG;
+  CAP_HIP(hipDeviceSynchronize());
+  CAP_HIP(hipMemcpy(out, g_coop_trace, 64 * 32 * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+  return CAP_OK;
+}
 
 // used by cacqr.hip: full cholinv (R in place, Ri = R^-1) of an n x n block on one stream
 int cap_rec_cholinv_full(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, double* W, int64_t wcap, int* info,

@@ -29,15 +29,26 @@ constexpr int LTHREADS = 256;
 // op(A)[i][k] = TA ? A[k][i] : A[i][k];  m, n multiples of 16, k multiple of 4.
 // UPPER: only blocks with bi <= bj are computed (C is the window's diagonal-aligned square).
 template <bool TA, bool ACC, bool UPPER>
-__device__ __forceinline__ void lds_mm(double* C, const double* A, const double* B, int m, int n, int k, double alpha) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+__device__ __forceinline__ void lds_mm(double* C, const double* A, const double* B, int m, int n, int k, double alpha, int tid = threadIdx.x) {
+  const int lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 15, kg = lane >> 4;
   const int mb = m >> 4, nb = n >> 4;
   for (int blk = wid; blk < mb * nb; blk += LTHREADS / 64) {
     const int bi = blk % mb, bj = blk / mb;
     if (UPPER && bi > bj) continue;
     d4 acc = {0.0, 0.0, 0.0, 0.0};
-    for (int kk = 0; kk < k; kk += 4) {
+    int kk = 0;
+    for (; kk + 16 <= k; kk += 16) {     // four k steps per trip: eight LDS reads in flight, then the MFMAs (same summation order)
+      double a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        a[u] = TA ? SM(A, kk + 4 * u + kg, bi * 16 + lr) : SM(A, bi * 16 + lr, kk + 4 * u + kg);
+        b[u] = SM(B, kk + 4 * u + kg, bj * 16 + lr);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+    for (; kk < k; kk += 4) {
       // MFMA A operand: lane -> op(A)[bi*16 + lr][kk + kg];  B operand: B[kk + kg][bj*16 + lr]
       double a = TA ? SM(A, kk + kg, bi * 16 + lr) : SM(A, bi * 16 + lr, kk + kg);
       double b = SM(B, kk + kg, bj * 16 + lr);
@@ -64,11 +75,16 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
   return y;
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 // 16 x 16 Cholesky of S[off.., off..] by ONE wave, block held in registers: lane (j = lane & 15, q = lane >> 4)
 // owns rows 4q..4q+3 of column j.  Per pivot only the pivot row travels through LDS (rowbuf, double
 // buffered); no workgroup barrier inside.  Also leaves 1/R[k][k] in dinv.
-__device__ __forceinline__ void potrf16_wave(double* S, double* dinv, double* rowbuf, int off, int* bad) {
-  const int lane = threadIdx.x & 63;
+__device__ __forceinline__ void potrf16_wave(double* S, double* dinv, double* rowbuf, int off, int* bad, int tid = threadIdx.x) {
+  const int lane = tid & 63;
   const int j = lane & 15, q = lane >> 4;
   double a[4];
 #pragma unroll
@@ -77,10 +93,13 @@ __device__ __forceinline__ void potrf16_wave(double* S, double* dinv, double* ro
   for (int k = 0; k < 16; k++) {
     const int kq = k >> 2, ke = k & 3;
     double* rb = rowbuf + (k & 1) * 16;
+    // the pivot comes straight out of its owner's register (lane k + 16 kq): its reciprocal square root (~ 150 dependent cycles)
+    // is under way while the pivot row travels through LDS
+    const double d = readlane_f64(a[ke], k + 16 * kq);
     if (q == kq) rb[j] = a[ke];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const double d = rb[k], rj = rb[j];
+    const double rj = rb[j];
     const d2 r01 = *reinterpret_cast<const d2*>(rb + 4 * q), r23 = *reinterpret_cast<const d2*>(rb + 4 * q + 2);
     const double ri[4] = {r01.x, r01.y, r23.x, r23.y};
     if (!(d > 0.0) && lane == 0 && *bad == 0) *bad = off + k + 1;
@@ -101,11 +120,13 @@ __device__ __forceinline__ void potrf16_wave(double* S, double* dinv, double* ro
 // Right-looking blocked Cholesky of the np x np (np = 16, 32 or 64) block in S, 16-wide panels:
 //   potrf16 (wave 0, registers) | row panel by forward substitution (one lane per column, R11 broadcast from LDS)
 //   | rank-16 update of the trailing blocks on MFMA.
-__device__ __forceinline__ void potrf_lds(double* S, double* dinv, double* rowbuf, int np, int* bad) {
-  const int t = threadIdx.x;
+__device__ __forceinline__ void potrf_lds(double* S, double* dinv, double* rowbuf, int np, int* bad, int tid = threadIdx.x,
+                                          long long* stamps = nullptr) {
+  const int t = tid;
   for (int off = 0; off < np; off += 16) {
-    if (t < 64) potrf16_wave(S, dinv, rowbuf, off, bad);
+    if (t < 64) potrf16_wave(S, dinv, rowbuf, off, bad, tid);
     __syncthreads();
+    if (stamps) stamps[(off >> 4) * 3 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
     const int rest = np - off - 16;
     if (rest > 0) {
       if (t < rest) {   // X = R11^-T * A12, column t of the panel
@@ -122,8 +143,10 @@ __device__ __forceinline__ void potrf_lds(double* S, double* dinv, double* rowbu
         for (int i = 0; i < 16; i++) SM(S, off + i, c) = x[i];
       }
       __syncthreads();
-      lds_mm<true, true, true>(&SM(S, off + 16, off + 16), &SM(S, off, off + 16), &SM(S, off, off + 16), rest, rest, 16, -1.0);
+      if (stamps) stamps[(off >> 4) * 3 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+      lds_mm<true, true, true>(&SM(S, off + 16, off + 16), &SM(S, off, off + 16), &SM(S, off, off + 16), rest, rest, 16, -1.0, tid);
       __syncthreads();
+      if (stamps) stamps[(off >> 4) * 3 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
     }
   }
 }
@@ -131,8 +154,8 @@ __device__ __forceinline__ void potrf_lds(double* S, double* dinv, double* rowbu
 // T = R^-1 for the np x np upper-triangular block in S (T zero on entry): the 16 x 16 diagonal blocks by back
 // substitution (all blocks in parallel, reciprocals from dinv), then Ri12 = -Ri11 R12 Ri22 level by level on MFMA;
 // S's strictly-lower blocks serve as scratch.
-__device__ __forceinline__ void trtri_lds(double* S, double* T, const double* dinv, int np) {
-  const int t = threadIdx.x;
+__device__ __forceinline__ void trtri_lds(double* S, double* T, const double* dinv, int np, int tid = threadIdx.x) {
+  const int t = tid;
   const int nblk = np / 16;
   if (t < 16 * nblk) {
     const int off = (t >> 4) * 16, c = t & 15;
@@ -153,10 +176,10 @@ __device__ __forceinline__ void trtri_lds(double* S, double* T, const double* di
   __syncthreads();
   for (int h = 16; h < np; h *= 2) {
     for (int off = 0; off < np; off += 2 * h)
-      lds_mm<false, false, false>(&SM(S, off + h, off), &SM(S, off, off + h), &SM(T, off + h, off + h), h, h, h, 1.0);
+      lds_mm<false, false, false>(&SM(S, off + h, off), &SM(S, off, off + h), &SM(T, off + h, off + h), h, h, h, 1.0, tid);
     __syncthreads();
     for (int off = 0; off < np; off += 2 * h)
-      lds_mm<false, false, false>(&SM(T, off, off + h), &SM(T, off, off), &SM(S, off + h, off), h, h, h, -1.0);
+      lds_mm<false, false, false>(&SM(T, off, off + h), &SM(T, off, off), &SM(S, off + h, off), h, h, h, -1.0, tid);
     __syncthreads();
   }
 }
@@ -468,10 +491,11 @@ __global__ void __launch_bounds__(LTHREADS) trinv_merge_kernel(const double* R, 
 // Whole factor phase of one diagonal block in ONE launch (round 4): the 64-blocked right-looking sweep above costs one launch per
 // step, and next to a bulk update every launch of the chain waits ~ 70 us for workgroup slots before it does 30 us of work
 // (profiles/r04_experiments.log: 960 fused steps x 102 us per mixed-precision factorization of N = 65536).  Here G workgroups stay
-// resident for all nblk steps and meet at a counter in global memory once per step:
-//   workgroup 0        block (i+1, i+1) of step i, then - still in LDS - the leaf of step i + 1 (factor + invert), exactly the fold of
-//                      panel64_solve_update_kernel
-//   workgroups 1..G-1  the other trailing blocks (a, b) of step i, round-robin; each recomputes X_a, X_b like the fused step
+// resident for all nblk steps and meet at a counter in global memory twice per step:
+//   phase S   the block row of step i is solved in place, one workgroup per 64 x 64 block (no redundant solves as in the fused step:
+//             a second meeting per step costs ~ 1 us, a solve ~ 8 us)
+//   phase U   the trailing blocks (a, b) are updated round-robin; workgroup 0 owns block (i+1, i+1) and goes on - still in LDS -
+//             to the leaf of step i + 1 (factor + invert) while the workers finish their share
 // Nothing but G <= free workgroup slots is assumed about placement: a workgroup that arrives late only delays the others at the
 // counter (the kernels it waits behind are finite), there is no cooperative-launch API involved.
 // Coherence across the 8 XCDs (one L2 each): everything the workgroups exchange travels with agent-scope accesses (sc1: written
@@ -480,19 +504,26 @@ __global__ void __launch_bounds__(LTHREADS) trinv_merge_kernel(const double* R, 
 // acquire fences around the counter (A/B switch, CAP_CHAIN_FENCE).
 struct Chain64 {
   double* R; int64_t ldr; double* Ri; int64_t ldi; int nblk; double* Xs; int64_t xs_half; int* info; int info_base; int* ctr; int fence;
+  int hmax;             // the inverse is assembled in the same launch up to pairs of hmax x hmax blocks (0: not at all; <= 256)
+  long long* trace;     // nullptr, or [64 workgroups][32 steps][8]: 100 MHz stamps (step start, S done, released, U done, leaf done, released)
 };
 
 __device__ __forceinline__ double gld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void gst(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Returns false when a workgroup never showed up (tens of seconds of polling: the launch was given more workgroups than the stream
-// it runs on can hold at once) - the caller stops meeting at the counter and reports through `info`.
-__device__ __forceinline__ bool chain_barrier(int* ctr, int target, int fence, int* lds_flag) {
+// The meeting point: every workgroup adds one to the counter per meeting (chain_arrive) and, if it needs what the others wrote, polls
+// until all have (chain_wait).  Returns false when a workgroup never showed up (tens of seconds of polling: the launch was given more
+// workgroups than the stream it runs on can hold at once) - the caller stops meeting and reports through `info`.
+__device__ __forceinline__ void chain_arrive(int* ctr, int fence) {
   __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): this lane's write-through stores have reached the memory side
   __syncthreads();
   if (threadIdx.x == 0) {
     if (fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ bool chain_wait(int* ctr, int target, int fence, int* lds_flag) {
+  if (threadIdx.x == 0) {
     int polls = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && polls < (1 << 24)) { __builtin_amdgcn_s_sleep(2); polls++; }
     if (fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -501,186 +532,258 @@ __device__ __forceinline__ bool chain_barrier(int* ctr, int target, int fence, i
   __syncthreads();
   return *lds_flag != 0;
 }
+__device__ __forceinline__ bool chain_barrier(int* ctr, int target, int fence, int* lds_flag) {
+  chain_arrive(ctr, fence);
+  return chain_wait(ctr, target, fence, lds_flag);
+}
 
-__global__ void __launch_bounds__(LTHREADS) chain64_coop_kernel(const Chain64 g) {
+// One task of the triangular-inverse assembly inside the resident chain: strip `sidx` (16 columns) of Ri12 = -Ri11 (R12 Ri22) for one
+// pair of h x h diagonal blocks (h = 64 RBW) - the arithmetic of trinv_merge_kernel in the same order, operands through agent-scope
+// loads (they were written by other workgroups of this launch), 4 KU k values per trip so that 4 KU (RBW + 1) loads are in flight.
+template <int RBW, int KU>
+__device__ __forceinline__ void chain_merge_task(const double* R12, int64_t ldr, const double* Ri11, const double* Ri22, double* Out,
+                                                 int64_t ldi, int sidx, double* Wl, int t) {
+  constexpr int H = 64 * RBW, LDW = H + 1;
+  const int lane = t & 63, wid = t >> 6, lr = lane & 15, kg = lane >> 4;
+  d4 acc[RBW];
+#pragma unroll
+  for (int q = 0; q < RBW; q++) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int kmax = 16 * (sidx + 1);
+  for (int kb = 0; kb < kmax; kb += 4 * KU) {
+    double b[KU], a[KU][RBW];
+#pragma unroll
+    for (int u = 0; u < KU; u++) {
+      if (kb + 4 * u < kmax) {
+        b[u] = gld(Ri22 + (kb + 4 * u + kg) + (int64_t)lr * ldi);
+#pragma unroll
+        for (int q = 0; q < RBW; q++) a[u][q] = gld(R12 + (16 * (wid + 4 * q) + lr) + (int64_t)(kb + 4 * u + kg) * ldr);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < KU; u++)
+      if (kb + 4 * u < kmax) {
+#pragma unroll
+        for (int q = 0; q < RBW; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][q], b[u], acc[q], 0, 0, 0);   // rows kg + 4r, column lr
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < RBW; q++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) Wl[16 * (wid + 4 * q) + kg + 4 * r + lr * LDW] = acc[q][r];
+    acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
+  }
+  __syncthreads();
+  for (int kb = 16 * wid; kb < H; kb += 4 * KU) {
+    double b[KU], a[KU][RBW];
+#pragma unroll
+    for (int u = 0; u < KU; u++) {
+      if (kb + 4 * u < H) {
+        b[u] = Wl[kb + 4 * u + kg + lr * LDW];
+#pragma unroll
+        for (int q = 0; q < RBW; q++) a[u][q] = gld(Ri11 + (16 * (wid + 4 * q) + lr) + (int64_t)(kb + 4 * u + kg) * ldi);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < KU; u++)
+      if (kb + 4 * u < H) {
+#pragma unroll
+        for (int q = 0; q < RBW; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][q], b[u], acc[q], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < RBW; q++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) gst(Out + 16 * (wid + 4 * q) + kg + 4 * r + (int64_t)lr * ldi, -acc[q][r]);
+}
+
+// <= 256 registers per lane (189 used): the workgroup must fit next to the waves of a running bulk update (2 x 120 registers per SIMD
+// for the bf16 update, 240 for the fp64 one, of 512) - the first version took 458 and every launch waited for a CU to drain
+// completely (2.7 ms per launch, profiles/r04_experiments.log).
+__global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) chain64_coop_kernel(const Chain64 g) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* B0 = lds;
-  double* B1 = lds + LMAX * LLD;
-  double* Dp = lds + 2 * LMAX * LLD;      // Dinv_i, packed upper; scratch of the folded leaf
+  double* B0 = lds;                       // X_a; T of the leaf
+  double* B1 = lds + LMAX * LLD;          // X_b; S of the leaf
+  double* Dp = lds + 2 * LMAX * LLD;      // Dinv_i, packed upper: (k, p), k <= p, at p(p+1)/2 + k; scratch of the leaf
   __builtin_amdgcn_s_setprio(3);
   const int G = (int)gridDim.x, w = (int)blockIdx.x;
-  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  const int lr = lane & 15, kg = lane >> 4;
   const int nblk = g.nblk;
   double* const R = g.R; const int64_t ldr = g.ldr;
   int& bad = *reinterpret_cast<int*>(Dp);
   double* dinv = Dp + 2; double* rowbuf = dinv + LMAX;
-  int epoch = 0;
   int& barrier_ok = *reinterpret_cast<int*>(Dp + LMAX * (LMAX + 1) / 2);      // (all LDS stays in the dynamic region)
-
-  // leaf on S = B1 (upper part of the block, rest zero), T = B0: R_bb in place, Dinv_b = R_bb^-1 with a zero-filled lower part
-  auto leaf = [&](int bk) {
-    double* S = B1; double* T = B0;
-    double* C = R + (int64_t)bk * 64 * (ldr + 1);
-    double* Dn = g.Ri + (int64_t)bk * 64 * (g.ldi + 1);
-    potrf_lds(S, dinv, rowbuf, 64, &bad);
-    for (int e = t; e < 64 * 64; e += LTHREADS) {
-      const int ii = e & 63, jj = e >> 6;
-      if (ii <= jj) gst(C + ii + (int64_t)jj * ldr, SM(S, ii, jj));
-    }
-    trtri_lds(S, T, dinv, 64);
-    __syncthreads();
-    for (int e = t; e < 64 * 64; e += LTHREADS) {
-      const int ii = e & 63, jj = e >> 6;
-      gst(Dn + ii + (int64_t)jj * g.ldi, (ii <= jj) ? SM(T, ii, jj) : 0.0);
-    }
-    if (t == 0 && bad != 0 && g.info) atomicCAS(g.info, 0, g.info_base + bk * 64 + bad);
-  };
+  int epoch = 0;
+  bool alive = true;
+  long long* tr = (g.trace && w < 64 && threadIdx.x == 0) ? g.trace + (int64_t)w * 32 * 8 : nullptr;
+#define CHAIN_STAMP(step, j) do { if (tr) tr[(step) * 8 + (j)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+  // (the leaf's inner stamps of workgroup 0 go to the row of workgroup 63, which a launch of <= 63 workgroups leaves free)
+#define LEAF_STAMP(step, j) do { if (tr && G < 64) (tr + 63 * 32 * 8)[(step) * 8 + (j)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 
   // step -1 = the leaf of block 0 alone
   for (int i = -1; i + 1 < nblk; i++) {
-    const int r = nblk - 1 - i, npairs = (i < 0) ? 0 : r * (r + 1) / 2;
-    // the block row solved by step i - 1 moves from its scratch half into R (nobody reads row i - 1 any more)
-    if (i > 0 && r >= 1) {
-      const double* src = g.Xs + (int64_t)((i - 1) & 1) * g.xs_half;
-      for (int blk = w; blk < nblk - i; blk += G) {
-        const double* sb = src + (int64_t)blk * 64 * 64;
-        double* db = R + (int64_t)(i - 1) * 64 + (int64_t)(i + blk) * 64 * ldr;
+    const int r = nblk - 1 - i;
+    // the lane's indices are recomputed from an opaque copy of threadIdx.x every step: hoisted out of this (long) loop they cost the
+    // kernel ~ 100 registers of loop-invariant offsets and masks, i.e. scratch spills under the 168-register cap
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int lane = t & 63, wid = t >> 6, lr = lane & 15, kg = lane >> 4;
+    CHAIN_STAMP(i + 1, 0);
+    if (i >= 0) {
+      // ---- phase S: the block row of step i, X_a = Dinv_i^T A_ia, in place (A_ia has no other reader).  Workgroup 0 owns a = i + 1
+      // (Dinv_i is still in its LDS from the leaf), the workers share the rest.
+      const int nmine = (w == 0) ? 1 : (r - 1 > w - 1 ? (r - 1 - (w - 1) + (G - 2)) / (G - 1) : 0);
+      if (w > 0 && nmine > 0) {
+        const double* Dinv = g.Ri + (int64_t)i * 64 * (g.ldi + 1);
+        __syncthreads();
         for (int e0 = 0; e0 < 64 * 64; e0 += 4 * LTHREADS) {
           double v[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) v[u] = gld(sb + e0 + u * LTHREADS + t);
-#pragma unroll
-          for (int u = 0; u < 4; u++) { const int e = e0 + u * LTHREADS + t; gst(db + (e & 63) + (int64_t)(e >> 6) * ldr, v[u]); }
-        }
-      }
-    }
-    const double* Dinv = g.Ri + (int64_t)i * 64 * (g.ldi + 1);
-    const int first = (w == 0) ? (G == 1 ? 1 : npairs) : w;          // workgroup 0 takes pair 0 (below) unless it is alone
-    const int stride = (G == 1) ? 1 : G - 1;
-    const bool mine = i >= 0 && ((w == 0) || first < npairs);
-    if (mine) {
-      __syncthreads();                                                // the previous step's readers of Dp (leaf scratch) are done
-      for (int e0 = 0; e0 < 64 * 64; e0 += 4 * LTHREADS) {
-        double v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
-          v[u] = (ii <= jj) ? gld(Dinv + ii + (int64_t)jj * g.ldi) : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
-          if (ii <= jj) Dp[jj * (jj + 1) / 2 + ii] = v[u];
-        }
-      }
-    }
-    // one trailing block (a, b) = pair q of step i; fold: go on to the leaf of step i + 1 (pair 0 only)
-    auto pair = [&](int q, bool fold) {
-      int bjt = 0;
-      while (q >= bjt + 1) { q -= bjt + 1; bjt++; }
-      const int a = i + 1 + q, b = i + 1 + bjt;
-      const bool diag = (a == b);
-      const double* Aia = R + (int64_t)i * 64 + (int64_t)a * 64 * ldr;
-      const double* Aib = R + (int64_t)i * 64 + (int64_t)b * 64 * ldr;
-      __syncthreads();                                                // B0 / B1 of the previous pair are free, Dp is complete
-      for (int e0 = 0; e0 < 64 * 64; e0 += 4 * LTHREADS) {
-        double v1[4], v2[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
-          v1[u] = gld(Aia + ii + (int64_t)jj * ldr);
-          v2[u] = diag ? 0.0 : gld(Aib + ii + (int64_t)jj * ldr);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
-          SM(B0, ii, jj) = v1[u];
-          if (!diag) SM(B1, ii, jj) = v2[u];
-        }
-      }
-      __syncthreads();
-      auto solve = [&](const double* B, d4 (&acc)[4]) {
-#pragma unroll
-        for (int sblk = 0; sblk < 4; sblk++) {
-          const int id = wid + 4 * sblk, bi = id & 3, bj = id >> 2;
-          d4 c = {0.0, 0.0, 0.0, 0.0};
-          const int p = bi * 16 + lr;
-          for (int k0 = 0; k0 < 16 * (bi + 1); k0 += 4) {
-            const int k = k0 + kg;
-            const double av = (k <= p) ? Dp[p * (p + 1) / 2 + k] : 0.0;
-            const double bv = SM(B, k, bj * 16 + lr);
-            c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
+          for (int u = 0; u < 4; u++) {
+            const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
+            v[u] = (ii <= jj) ? gld(Dinv + ii + (int64_t)jj * g.ldi) : 0.0;
           }
-          acc[sblk] = c;
-        }
-      };
-      auto put = [&](double* B, const d4 (&acc)[4]) {
 #pragma unroll
-        for (int sblk = 0; sblk < 4; sblk++) {
-          const int id = wid + 4 * sblk, bi = id & 3, bj = id >> 2;
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++) SM(B, bi * 16 + kg + 4 * rr, bj * 16 + lr) = acc[sblk][rr];
-        }
-      };
-      d4 xa[4], xb[4];
-      solve(B0, xa);
-      if (!diag) solve(B1, xb);
-      __syncthreads();
-      put(B0, xa);
-      if (!diag) put(B1, xb);
-      __syncthreads();
-      if (diag) {                      // the solved block R_ia: scratch (other workgroups still read the unsolved A_ia), or in place
-        if (r == 1) {
-          double* dst = R + (int64_t)i * 64 + (int64_t)a * 64 * ldr;
-          for (int e = t; e < 64 * 64; e += LTHREADS) gst(dst + (e & 63) + (int64_t)(e >> 6) * ldr, SM(B0, e & 63, e >> 6));
-        } else {
-          double* dst = g.Xs + (int64_t)(i & 1) * g.xs_half + (int64_t)(a - i - 1) * 64 * 64;
-          for (int e = t; e < 64 * 64; e += LTHREADS) gst(dst + e, SM(B0, e & 63, e >> 6));
+          for (int u = 0; u < 4; u++) {
+            const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
+            if (ii <= jj) Dp[jj * (jj + 1) / 2 + ii] = v[u];
+          }
         }
       }
-      const double* XB = diag ? B0 : B1;
-      double* C = R + (int64_t)a * 64 + (int64_t)b * 64 * ldr;
-      if (fold) {
-        for (int e = t; e < 64 * LLD; e += LTHREADS) B1[e] = 0.0;
-        __syncthreads();
-      }
+      // workgroup 0 has its trailing block (i+1, i+1) on the way while it solves
       double cin[4][4];
+      if (w == 0) {
+        const double* C = R + (int64_t)(i + 1) * 64 * (ldr + 1);
 #pragma unroll
-      for (int sblk = 0; sblk < 4; sblk++) {
-        const int id = wid + 4 * sblk, bi = id & 3, bj = id >> 2;
+        for (int sb = 0; sb < 4; sb++) {
+          const int id = wid + 4 * sb, bi = id & 3, bj = id >> 2;
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-          const int row = bi * 16 + lr, col = bj * 16 + kg + 4 * rr;
-          cin[sblk][rr] = (!diag || row <= col) ? gld(C + row + (int64_t)col * ldr) : 0.0;
-        }
-      }
-#pragma unroll
-      for (int sblk = 0; sblk < 4; sblk++) {
-        const int id = wid + 4 * sblk, bi = id & 3, bj = id >> 2;
-        if (diag && bi > bj) continue;
-        d4 c = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-        for (int k0 = 0; k0 < 64; k0 += 4) {
-          const double colv = SM(XB, k0 + kg, bj * 16 + lr);
-          const double rowv = SM(B0, k0 + kg, bi * 16 + lr);
-          c = __builtin_amdgcn_mfma_f64_16x16x4f64(colv, rowv, c, 0, 0, 0);   // result: (col = kg + 4r, row = lr)
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-          const int row = bi * 16 + lr, col = bj * 16 + kg + 4 * rr;
-          if (!diag || row <= col) {
-            if (fold) SM(B1, row, col) = cin[sblk][rr] - c[rr];
-            else gst(C + row + (int64_t)col * ldr, cin[sblk][rr] - c[rr]);
+          for (int rr = 0; rr < 4; rr++) {
+            const int row = bi * 16 + lr, col = bj * 16 + kg + 4 * rr;
+            cin[sb][rr] = (row <= col) ? gld(C + row + (int64_t)col * ldr) : 0.0;
           }
         }
       }
-    };
-    // this workgroup's pairs of the step; workgroup 0 ends with pair 0 and keeps the updated block (i+1, i+1) in B1
-    const int cnt = (i >= 0 && (w > 0 || G == 1) && first < npairs) ? (npairs - first + stride - 1) / stride : 0;
-    const int total = cnt + ((w == 0 && i >= 0) ? 1 : 0);
-    for (int it = 0; it < total; it++) pair(it < cnt ? first + it * stride : 0, it >= cnt);
+      for (int m = 0; m < nmine; m++) {
+        const int a = (w == 0) ? i + 1 : i + 2 + (w - 1) + m * (G - 1);
+        double* Aia = R + (int64_t)i * 64 + (int64_t)a * 64 * ldr;
+        __syncthreads();
+        for (int e0 = 0; e0 < 64 * 64; e0 += 4 * LTHREADS) {
+          double v[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const int e = e0 + u * LTHREADS + t; v[u] = gld(Aia + (e & 63) + (int64_t)(e >> 6) * ldr); }
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const int e = e0 + u * LTHREADS + t; SM(B0, e & 63, e >> 6) = v[u]; }
+        }
+        __syncthreads();
+        // wave `wid` owns the 16 x 16 blocks (bi, bj) = ((wid + s) & 3, s): every wave meets each K range 16 (bi + 1) once
+        d4 acc[4];
+#pragma unroll
+        for (int sb = 0; sb < 4; sb++) {
+          const int bi = (wid + sb) & 3, bj = sb;
+          d4 c = {0.0, 0.0, 0.0, 0.0};
+          const int pcol = bi * 16 + lr;
+          const double* dcol = Dp + pcol * (pcol + 1) / 2;
+          for (int k0 = 0; k0 < 16 * (bi + 1); k0 += 16) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int k = k0 + 4 * u + kg;
+              av[u] = (k <= pcol) ? dcol[k] : 0.0;                       // Dinv[k][pcol]
+              bv[u] = SM(B0, k, bj * 16 + lr);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], c, 0, 0, 0);    // rows kg + 4r, cols lr
+          }
+          acc[sb] = c;
+        }
+        __syncthreads();                 // every read of the unsolved block is done
+#pragma unroll
+        for (int sb = 0; sb < 4; sb++) {
+          const int bi = (wid + sb) & 3, bj = sb;
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) SM(B0, bi * 16 + kg + 4 * rr, bj * 16 + lr) = acc[sb][rr];
+        }
+        __syncthreads();
+        for (int e = t; e < 64 * 64; e += LTHREADS) gst(Aia + (e & 63) + (int64_t)(e >> 6) * ldr, SM(B0, e & 63, e >> 6));
+      }
+      CHAIN_STAMP(i + 1, 1);
+      epoch += G;
+      chain_arrive(g.ctr, g.fence);
+      // (workgroup 0 only needs its own X_{i+1} for what follows: it says that it is there and goes on)
+      if (w > 0 && !chain_wait(g.ctr, epoch, g.fence, &barrier_ok)) { if (t == 0 && g.info) atomicExch(g.info, -64); alive = false; break; }
+      CHAIN_STAMP(i + 1, 2);
+      // ---- phase U: C_ab -= X_a^T X_b on the trailing blocks (upper part on the diagonal ones).  Workgroup 0: block (i+1, i+1), kept
+      // in LDS for the leaf; workers: pairs w, w + G - 1, ... of the triangular enumeration.
+      const int npairs = r * (r + 1) / 2;
+      const int cnt = (w == 0) ? 1 : (npairs > w ? (npairs - w + (G - 2)) / (G - 1) : 0);
+      for (int m = 0; m < cnt; m++) {
+        int q = (w == 0) ? 0 : w + m * (G - 1), bjt = 0;
+        while (q >= bjt + 1) { q -= bjt + 1; bjt++; }
+        const int a = i + 1 + q, b = i + 1 + bjt;
+        const bool diag = (a == b);
+        const double* Xa = R + (int64_t)i * 64 + (int64_t)a * 64 * ldr;
+        const double* Xb = R + (int64_t)i * 64 + (int64_t)b * 64 * ldr;
+        double* C = R + (int64_t)a * 64 + (int64_t)b * 64 * ldr;
+        if (w > 0) {
+#pragma unroll
+          for (int sb = 0; sb < 4; sb++) {
+            const int id = wid + 4 * sb, bi = id & 3, bj = id >> 2;
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+              const int row = bi * 16 + lr, col = bj * 16 + kg + 4 * rr;
+              cin[sb][rr] = (!diag || row <= col) ? gld(C + row + (int64_t)col * ldr) : 0.0;
+            }
+          }
+        }
+        if (w > 0) {                                                  // (workgroup 0 still holds X_{i+1} in B0)
+          __syncthreads();
+          for (int e0 = 0; e0 < 64 * 64; e0 += 4 * LTHREADS) {
+            double v1[4], v2[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
+              v1[u] = gld(Xa + ii + (int64_t)jj * ldr);
+              v2[u] = diag ? 0.0 : gld(Xb + ii + (int64_t)jj * ldr);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
+              SM(B0, ii, jj) = v1[u];
+              if (!diag) SM(B1, ii, jj) = v2[u];
+            }
+          }
+        } else {
+          for (int e = t; e < 64 * LLD; e += LTHREADS) B1[e] = 0.0;    // becomes S of the leaf
+        }
+        __syncthreads();
+        const double* XB = diag ? B0 : B1;
+#pragma unroll
+        for (int sb = 0; sb < 4; sb++) {
+          const int id = wid + 4 * sb, bi = id & 3, bj = id >> 2;     // bi: row block of C (from X_a), bj: column block (from X_b)
+          if (diag && bi > bj) continue;
+          d4 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+          for (int k0 = 0; k0 < 64; k0 += 4) {
+            const double colv = SM(XB, k0 + kg, bj * 16 + lr);
+            const double rowv = SM(B0, k0 + kg, bi * 16 + lr);
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(colv, rowv, c, 0, 0, 0);   // result: (col = kg + 4r, row = lr)
+          }
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const int row = bi * 16 + lr, col = bj * 16 + kg + 4 * rr;
+            if (!diag || row <= col) {
+              if (w == 0) SM(B1, row, col) = cin[sb][rr] - c[rr];
+              else gst(C + row + (int64_t)col * ldr, cin[sb][rr] - c[rr]);
+            }
+          }
+        }
+      }
+      CHAIN_STAMP(i + 1, 3);
+    }
     if (w == 0) {
+      // ---- leaf of block i + 1: S = B1 (upper part, rest zero), T = B0 -> R_bb in place, Dinv_b with a zero-filled lower part
+      const int bk = i + 1;
+      double* C = R + (int64_t)bk * 64 * (ldr + 1);
+      double* Dn = g.Ri + (int64_t)bk * 64 * (g.ldi + 1);
       __syncthreads();                                               // every read of B0 (X_a) is done, S = B1 is complete
       if (i < 0) {
         for (int e = t; e < 64 * LLD; e += LTHREADS) B1[e] = 0.0;
@@ -690,28 +793,68 @@ __global__ void __launch_bounds__(LTHREADS) chain64_coop_kernel(const Chain64 g)
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const int e = e0 + u * LTHREADS + t, ii = e & 63, jj = e >> 6;
-            v[u] = (ii <= jj) ? gld(R + ii + (int64_t)jj * ldr) : 0.0;
+            v[u] = (ii <= jj) ? gld(C + ii + (int64_t)jj * ldr) : 0.0;
           }
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int e = e0 + u * LTHREADS + t;
-            SM(B1, e & 63, e >> 6) = v[u];
-          }
+          for (int u = 0; u < 4; u++) { const int e = e0 + u * LTHREADS + t; SM(B1, e & 63, e >> 6) = v[u]; }
         }
       }
       for (int e = t; e < 64 * LLD; e += LTHREADS) B0[e] = 0.0;
       if (t == 0) bad = 0;
       __syncthreads();
-      leaf(i + 1);
+      LEAF_STAMP(i + 1, 0);
+      potrf_lds(B1, dinv, rowbuf, 64, &bad, t, (tr && G < 62) ? tr + 62 * 32 * 8 + ((i + 1) & 15) * 16 : nullptr);
+      LEAF_STAMP(i + 1, 1);
+      for (int e = t; e < 64 * 64; e += LTHREADS) {
+        const int ii = e & 63, jj = e >> 6;
+        if (ii <= jj) gst(C + ii + (int64_t)jj * ldr, SM(B1, ii, jj));
+      }
+      LEAF_STAMP(i + 1, 2);
+      trtri_lds(B1, B0, dinv, 64, t);
+      __syncthreads();
+      LEAF_STAMP(i + 1, 3);
+      if (t == 0 && bad != 0 && g.info) atomicCAS(g.info, 0, g.info_base + bk * 64 + bad);
+      __syncthreads();                                               // (`bad` lives in the region Dp is about to reuse)
+      for (int e = t; e < 64 * 64; e += LTHREADS) {
+        const int ii = e & 63, jj = e >> 6;
+        const double v = (ii <= jj) ? SM(B0, ii, jj) : 0.0;
+        gst(Dn + ii + (int64_t)jj * g.ldi, v);
+        if (ii <= jj) Dp[jj * (jj + 1) / 2 + ii] = v;                // Dinv_{i+1} stays here for workgroup 0's solve of the next step
+      }
     }
+    CHAIN_STAMP(i + 1, 4);
     epoch += G;
-    if (!chain_barrier(g.ctr, epoch, g.fence, &barrier_ok)) {
-      if (t == 0 && g.info) atomicExch(g.info, -64);                 // "a workgroup of the chain never became resident"
-      break;
+    if (!chain_barrier(g.ctr, epoch, g.fence, &barrier_ok)) { if (t == 0 && g.info) atomicExch(g.info, -64); alive = false; break; }
+    CHAIN_STAMP(i + 1, 5);
+  }
+  // ---- the inverse, level by level: pairs of h x h diagonal blocks, one task per 16-column strip (cf. trinv_merge_kernel)
+  CHAIN_STAMP(nblk, 0);
+  for (int h = 64, lvl = 1; alive && h <= g.hmax && 2 * h <= 64 * nblk; h *= 2, lvl++) {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int strips = h / 16, ntask = (64 * nblk / (2 * h)) * strips;
+    for (int task = w; task < ntask; task += G) {
+      const int z = task / strips, sidx = task - z * strips;
+      const int64_t o = (int64_t)z * 2 * h;
+      const double* R12 = R + o + (o + h) * ldr;
+      const double* Ri22 = g.Ri + (o + h) + (o + h + 16 * sidx) * g.ldi;
+      const double* Ri11 = g.Ri + o + o * g.ldi;
+      double* Out = g.Ri + o + (o + h + 16 * sidx) * g.ldi;
+      __syncthreads();                                               // the strip buffer of the previous task is free
+      if (h == 64) chain_merge_task<1, 8>(R12, ldr, Ri11, Ri22, Out, g.ldi, sidx, B0, t);
+      else if (h == 128) chain_merge_task<2, 8>(R12, ldr, Ri11, Ri22, Out, g.ldi, sidx, B0, t);
+      else chain_merge_task<4, 8>(R12, ldr, Ri11, Ri22, Out, g.ldi, sidx, B0, t);
+    }
+    CHAIN_STAMP(nblk, lvl);
+    epoch += G;
+    if (2 * h <= g.hmax && 4 * h <= 64 * nblk) {                     // (nothing follows the last level)
+      if (!chain_barrier(g.ctr, epoch, g.fence, &barrier_ok)) { if (threadIdx.x == 0 && g.info) atomicExch(g.info, -64); alive = false; }
     }
   }
+#undef CHAIN_STAMP
+#undef LEAF_STAMP
   // the last workgroup through resets the counters for the next launch that is handed this slot
-  if (t == 0) {
+  if (threadIdx.x == 0) {
     const int done = __hip_atomic_fetch_add(g.ctr + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (done == G - 1) {
       __hip_atomic_store(g.ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -723,16 +866,17 @@ __global__ void __launch_bounds__(LTHREADS) chain64_coop_kernel(const Chain64 g)
 }  // namespace
 
 // Factor phase of blocked_cholinv (cholinv.hip) in one launch of `wgs` resident workgroups (chain64_coop_kernel): R (n = 64 nblk)
-// factored in place, the 64 x 64 diagonal blocks of Ri = their inverses.  Xs: 2 x xs_half doubles of scratch (xs_half >= 64 n).
+// factored in place, the 64 x 64 diagonal blocks of Ri = their inverses (Xs / xs_half: unused since the block row is solved in place).
 // ctr: two ints, zero before the first use (the kernel leaves them zero).
 int cap_chain64_coop(double* R, int64_t ldr, double* Ri, int64_t ldi, int nblk, double* Xs, int64_t xs_half, int* info, int info_base,
-                     int* ctr, int wgs, int fence, hipStream_t stream) {
+                     int* ctr, int wgs, int fence, int hmax, hipStream_t stream, long long* trace) {
   if (nblk <= 0) return CAP_OK;
-  if (wgs < 1 || xs_half < (int64_t)64 * 64 * nblk) return CAP_ERR_ARG;
+  if (nblk > 31) trace = nullptr;
+  if (wgs < 2 || hmax < 0 || hmax > 256 || (hmax & (hmax - 1))) return CAP_ERR_ARG;
   const int useful = std::max(1, (nblk - 1) * nblk / 2);           // one workgroup per trailing block of the first step
   wgs = std::min(wgs, useful);
   const size_t lds_bytes = (2 * LMAX * LLD + LMAX * (LMAX + 1) / 2 + 2) * sizeof(double);
-  const Chain64 g{R, ldr, Ri, ldi, nblk, Xs, xs_half, info, info_base, ctr, fence};
+  const Chain64 g{R, ldr, Ri, ldi, nblk, Xs, xs_half, info, info_base, ctr, fence, hmax, trace};
   hipLaunchKernelGGL(chain64_coop_kernel, dim3((unsigned)wgs), dim3(LTHREADS), lds_bytes, stream, g);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
