@@ -80,67 +80,104 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// 16 x 16 Cholesky of S[off.., off..] by ONE wave, block held in registers: lane (j = lane & 15, q = lane >> 4)
-// owns rows 4q..4q+3 of column j.  Per pivot only the pivot row travels through LDS (rowbuf, double
-// buffered); no workgroup barrier inside.  Also leaves 1/R[k][k] in dinv.
-__device__ __forceinline__ void potrf16_wave(double* S, double* dinv, double* rowbuf, int off, int* bad, int tid = threadIdx.x) {
+// An opaque zero: added to an LDS pointer it keeps the compiler from turning every uniform LDS address of an unrolled loop into
+// its own constant (hoisted into SGPRs, spilled to VGPR lanes and fetched back with v_readlane + v_mov in front of every ds_read -
+// what the row solve below looked like in round 3); with it the accesses are "one VGPR + immediate offset".
+__device__ __forceinline__ int opaque_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
+
+// 16 x 16 Cholesky of S[off.., off..] by ONE wave, block held in registers: lane j (< 16; the other lanes mirror it and store
+// nothing) owns column j.  Per pivot k the chain that the next pivot waits for is short: the pivot itself and R[k][k+1] come out of
+// their owners' registers (v_readlane, uniform lane numbers after unrolling) and only row k + 1 is updated at once; the finished row
+// k goes to LDS (rt, row-major: also what the row-panel solve reads) and the remaining rows take their update from there one pivot
+// later (same products in the same order as the plain right-looking loop).  ~ 180 cycles per pivot instead of 360 with an LDS row
+// exchange in every pivot's chain.  Leaves 1/R[k][k] in dinv.
+__device__ __forceinline__ void potrf16_wave(double* S, double* dinv, double* rt, int off, int* bad, int tid = threadIdx.x) {
   const int lane = tid & 63;
-  const int j = lane & 15, q = lane >> 4;
-  double a[4];
+  const int j = lane & 15;
+  const int z = opaque_zero();
+  double* Sj = S + z + (off + j) * LLD + off;              // column j of the block
+  double* rtz = rt + z;
+  double a[16];
 #pragma unroll
-  for (int e = 0; e < 4; e++) a[e] = SM(S, off + 4 * q + e, off + j);
+  for (int i = 0; i < 16; i++) a[i] = Sj[i];
+  double prev = 0.0;                                       // R[k-1][j]
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    const int kq = k >> 2, ke = k & 3;
-    double* rb = rowbuf + (k & 1) * 16;
-    // the pivot comes straight out of its owner's register (lane k + 16 kq): its reciprocal square root (~ 150 dependent cycles)
-    // is under way while the pivot row travels through LDS
-    const double d = readlane_f64(a[ke], k + 16 * kq);
-    if (q == kq) rb[j] = a[ke];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const double rj = rb[j];
-    const d2 r01 = *reinterpret_cast<const d2*>(rb + 4 * q), r23 = *reinterpret_cast<const d2*>(rb + 4 * q + 2);
-    const double ri[4] = {r01.x, r01.y, r23.x, r23.y};
+    // (row k - 1 is fetched first: its LDS latency hides behind the reciprocal square root; the scheduling fences keep the compiler
+    // from sinking the reads to their uses, where every multiply-add would wait for its own read)
+    double rv[16];
+    if (k >= 1) {
+#pragma unroll
+      for (int i = k + 1; i < 16; i++) rv[i] = rtz[(k - 1) * 16 + i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const double d = readlane_f64(a[k], k);
     if (!(d > 0.0) && lane == 0 && *bad == 0) *bad = off + k + 1;
     const double rinv = fast_rsqrt(d);
-    const double rjs = rj * rinv;
+    const double rjs = a[k] * rinv;
+    const double fin = (j == k) ? d * rinv : (j > k ? rjs : a[k]);
+    if (lane < 16) rtz[k * 16 + j] = fin;
+    if (k >= 1) {                                          // rows k + 1 .. 15 take the update of pivot k - 1 (in the shadow of the chain above)
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int i = 4 * q + e;
-      if (i > k && j >= i) a[e] -= (ri[e] * rinv) * rjs;
+      for (int i = k + 1; i < 16; i++)
+        if (j >= i) a[i] -= rv[i] * prev;
     }
-    if (q == kq) a[ke] = (j == k) ? d * rinv : (j > k ? rjs : a[ke]);
+    if (k < 15) {                                          // row k + 1 takes the update of pivot k now
+      const double r1 = readlane_f64(rjs, k + 1);
+      if (j >= k + 1) a[k + 1] -= r1 * rjs;
+    }
+    a[k] = fin; prev = rjs;
     if (lane == 0) dinv[off + k] = rinv;
   }
+  if (lane < 16) {
 #pragma unroll
-  for (int e = 0; e < 4; e++) SM(S, off + 4 * q + e, off + j) = a[e];
+    for (int i = 0; i < 16; i++) Sj[i] = a[i];
+  }
 }
 
 // Right-looking blocked Cholesky of the np x np (np = 16, 32 or 64) block in S, 16-wide panels:
 //   potrf16 (wave 0, registers) | row panel by forward substitution (one lane per column, R11 broadcast from LDS)
 //   | rank-16 update of the trailing blocks on MFMA.
-__device__ __forceinline__ void potrf_lds(double* S, double* dinv, double* rowbuf, int np, int* bad, int tid = threadIdx.x,
+__device__ __forceinline__ void potrf_lds(double* S, double* dinv, double* rt, int np, int* bad, int tid = threadIdx.x,
                                           long long* stamps = nullptr) {
   const int t = tid;
   for (int off = 0; off < np; off += 16) {
-    if (t < 64) potrf16_wave(S, dinv, rowbuf, off, bad, tid);
+    if (t < 64) potrf16_wave(S, dinv, rt, off, bad, tid);
     __syncthreads();
     if (stamps) stamps[(off >> 4) * 3 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
     const int rest = np - off - 16;
     if (rest > 0) {
-      if (t < rest) {   // X = R11^-T * A12, column t of the panel
+      if (t < rest) {   // X = R11^-T * A12, column t of the panel: right-looking, so that the 16-long dependent chain is one multiply and
+        // one multiply-add per step; R11's rows come contiguous out of rt (same products in the same order as the dot-product form)
         const int c = off + 16 + t;
+        const int z = opaque_zero();
+        double* Sc = S + z + c * LLD + off;                 // column c, rows off ..
+        const double* rtz = rt + z;
+        const double* dv = dinv + z + off;
         double x[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-          double sacc = SM(S, off + i, c);
+        for (int i = 0; i < 16; i++) x[i] = Sc[i];
+        double dl[16], cur[16], nxt[16];                    // reciprocals; row l of R11 (columns > l); row l + 1 on its way
 #pragma unroll
-          for (int l = 0; l < i; l++) sacc -= SM(S, off + l, off + i) * x[l];
-          x[i] = sacc * dinv[off + i];
+        for (int i = 0; i < 16; i++) dl[i] = dv[i];
+#pragma unroll
+        for (int i = 1; i < 16; i++) cur[i] = rtz[i];
+#pragma unroll
+        for (int l = 0; l < 16; l++) {
+          if (l + 1 < 16) {
+#pragma unroll
+            for (int i = l + 2; i < 16; i++) nxt[i] = rtz[(l + 1) * 16 + i];
+          }
+          __builtin_amdgcn_sched_barrier(0);                 // (the reads stay up here: a row of multiply-adds hides their latency)
+          x[l] = x[l] * dl[l];
+#pragma unroll
+          for (int i = l + 1; i < 16; i++) x[i] -= cur[i] * x[l];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = l + 2; i < 16; i++) cur[i] = nxt[i];
         }
 #pragma unroll
-        for (int i = 0; i < 16; i++) SM(S, off + i, c) = x[i];
+        for (int i = 0; i < 16; i++) Sc[i] = x[i];
       }
       __syncthreads();
       if (stamps) stamps[(off >> 4) * 3 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -159,16 +196,33 @@ __device__ __forceinline__ void trtri_lds(double* S, double* T, const double* di
   const int nblk = np / 16;
   if (t < 16 * nblk) {
     const int off = (t >> 4) * 16, c = t & 15;
+    // column c of the block's inverse by back substitution, right-looking: once x[l] is known every remaining row takes its term
+    // (independent multiply-adds, R's column l contiguous in LDS) - the dependent chain is one multiply + one multiply-add per row
+    const int z = opaque_zero();
+    const double* Sb = S + z + off * LLD + off;             // the diagonal block: element (ii, l) at Sb[l * LLD + ii]
+    const double* dv = dinv + z + off;
     double x[16];
 #pragma unroll
-    for (int q = 0; q < 16; q++) x[q] = 0.0;
+    for (int q = 0; q < 16; q++) x[q] = (q == c) ? 1.0 : 0.0;
+    double dl[16], cur[16], nxt[16];                        // reciprocals; column l of R11 (rows < l); column l - 1 on its way
 #pragma unroll
-    for (int ii = 15; ii >= 0; ii--) {
-      double sacc = (ii == c) ? 1.0 : 0.0;
+    for (int q = 0; q < 16; q++) dl[q] = dv[q];
 #pragma unroll
-      for (int l = ii + 1; l < 16; l++) sacc -= SM(S, off + ii, off + l) * x[l];
-      double v = sacc * dinv[off + ii];
-      x[ii] = (ii <= c) ? v : 0.0;
+    for (int ii = 0; ii < 15; ii++) cur[ii] = Sb[15 * LLD + ii];
+#pragma unroll
+    for (int l = 15; l >= 0; l--) {
+      if (l >= 1) {
+#pragma unroll
+        for (int ii = 0; ii < l - 1; ii++) nxt[ii] = Sb[(l - 1) * LLD + ii];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const double v = x[l] * dl[l];
+      x[l] = (l <= c) ? v : 0.0;
+#pragma unroll
+      for (int ii = 0; ii < l; ii++) x[ii] -= cur[ii] * x[l];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ii = 0; ii < l - 1; ii++) cur[ii] = nxt[ii];
     }
 #pragma unroll
     for (int q = 0; q < 16; q++) SM(T, off + q, off + c) = x[q];
@@ -200,7 +254,7 @@ __global__ void __launch_bounds__(LTHREADS) leaf_cholinv_kernel(double* A, int64
   double* T = lds + LMAX * LLD;
   int& bad = *reinterpret_cast<int*>(lds + 2 * LMAX * LLD);   // keep ALL LDS in the dynamic region (16-B aligned base)
   double* dinv = lds + 2 * LMAX * LLD + 2;                    // 1/R[k][k], 64 doubles
-  double* rowbuf = dinv + LMAX;                               // pivot-row exchange, 2 x 16 doubles
+  double* rowbuf = dinv + LMAX;                               // the finished 16 x 16 diagonal block, row-major (256 doubles)
   const int t = threadIdx.x;
   const int np = n <= 16 ? 16 : (n <= 32 ? 32 : 64);
   __builtin_amdgcn_s_setprio(3);      // latency-critical single workgroup: win issue arbitration against co-resident bulk waves
@@ -901,7 +955,7 @@ int cap_panel64_solve_update(double* R, int64_t ldr, const double* Dinv, int64_t
   const int r = nblk - 1 - i;
   if (r <= 0) return CAP_OK;
   const size_t lds_bytes = (2 * LMAX * LLD + LMAX * (LMAX + 1) / 2) * sizeof(double);
-  static_assert(LMAX * (LMAX + 1) / 2 >= 2 + LMAX + 32, "the folded leaf keeps bad / dinv / rowbuf in the packed-Dinv region");
+  static_assert(LMAX * (LMAX + 1) / 2 >= 2 + LMAX + 256, "the folded leaf keeps bad / dinv / rowbuf in the packed-Dinv region");
   const Panel64Fold f{Dnext, ldn, info, info_base, cj_src, cj_dst, cj_ld, cj_cols, direct};
   hipLaunchKernelGGL(panel64_solve_update_kernel, dim3(r * (r + 1) / 2), dim3(LTHREADS), lds_bytes, stream, R, ldr, Dinv, ldi, i, nblk,
                      Xs, f);
@@ -909,7 +963,7 @@ int cap_panel64_solve_update(double* R, int64_t ldr, const double* Dinv, int64_t
   return CAP_OK;
 }
 
-constexpr size_t LEAF_LDS_BYTES = (2 * LMAX * LLD + 2 + LMAX + 32) * sizeof(double);
+constexpr size_t LEAF_LDS_BYTES = (2 * LMAX * LLD + 2 + LMAX + 256) * sizeof(double);
 
 int cap_leaf_cholinv(double* A, int64_t lda, double* Rinv, int64_t ldr, int n, int zero_lower, int* info,
                      int info_base, hipStream_t stream, const double* cjob_src, double* cjob_dst, int64_t cjob_ld,

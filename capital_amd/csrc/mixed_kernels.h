@@ -6,17 +6,48 @@
 #include "common.h"
 
 namespace {
+// The element-wise kernels below move four consecutive rows per lane (16-byte accesses) when sizes, leading dimensions and base
+// addresses allow it - one element per lane and 256 elements per workgroup left them at 1 - 2.5 TB/s (round 4: the import of
+// N = 65536 took 10.2 ms of the 170 ms factorization) - and fall back to the scalar loop otherwise.  grid2 sizes the launch for the
+// vector form (1024 rows per workgroup pass); the scalar loop just takes more passes.
+static __device__ __forceinline__ bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+static __device__ __forceinline__ bool al8(const void* p) { return ((uintptr_t)p & 7) == 0; }
+struct __attribute__((aligned(8))) bf16x4 { __bf16 v[4]; };
+
 // fp32 import of A's upper triangle.  Only rows <= col are touched: the strictly-lower part of the factor is zeroed once per plan and
 // never written afterwards (every update and solve is masked to the upper triangle), so the import moves half the matrix
 static __global__ void f64_to_f32_upper_kernel(const double* A, int64_t lda, float* R, int64_t ldr, int64_t n) {
   const int64_t col = blockIdx.y + (int64_t)blockIdx.z * 65535;
   if (col >= n) return;
+  if ((lda % 2 == 0) && (ldr % 4 == 0) && al16(A) && al16(R)) {
+    const double* a = A + col * lda; float* r = R + col * ldr;
+    for (int64_t r4 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; r4 <= col; r4 += (int64_t)gridDim.x * blockDim.x * 4) {
+      if (r4 + 3 <= col) {
+        const double2 lo = *reinterpret_cast<const double2*>(a + r4), hi = *reinterpret_cast<const double2*>(a + r4 + 2);
+        *reinterpret_cast<float4*>(r + r4) = make_float4((float)lo.x, (float)lo.y, (float)hi.x, (float)hi.y);
+      } else {
+        for (int64_t row = r4; row <= col; row++) r[row] = (float)a[row];
+      }
+    }
+    return;
+  }
   for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row <= col; row += (int64_t)gridDim.x * blockDim.x)
     R[row + col * ldr] = (float)A[row + col * lda];
 }
 static __global__ void f32_to_f64_kernel(const float* S, int64_t lds_, double* D, int64_t ldd, int64_t rows, int64_t cols, int upper_only) {
   const int64_t col = blockIdx.y + (int64_t)blockIdx.z * 65535;
   if (col >= cols) return;
+  if ((rows % 4 == 0) && (lds_ % 4 == 0) && (ldd % 2 == 0) && al16(S) && al16(D)) {
+    const float* sc = S + col * lds_; double* dc = D + col * ldd;
+    for (int64_t r4 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; r4 < rows; r4 += (int64_t)gridDim.x * blockDim.x * 4) {
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (!upper_only || r4 <= col) v = *reinterpret_cast<const float4*>(sc + r4);
+      if (upper_only) { if (r4 > col) v.x = 0.0f; if (r4 + 1 > col) v.y = 0.0f; if (r4 + 2 > col) v.z = 0.0f; if (r4 + 3 > col) v.w = 0.0f; }
+      *reinterpret_cast<double2*>(dc + r4) = make_double2((double)v.x, (double)v.y);
+      *reinterpret_cast<double2*>(dc + r4 + 2) = make_double2((double)v.z, (double)v.w);
+    }
+    return;
+  }
   for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < rows; row += (int64_t)gridDim.x * blockDim.x)
     D[row + col * ldd] = (!upper_only || row <= col) ? (double)S[row + col * lds_] : 0.0;
 }
@@ -44,6 +75,17 @@ static __global__ void split3_row_kernel(float* S, int64_t lds_, __bf16* B3, int
   const int64_t col = blockIdx.y + (int64_t)blockIdx.z * 65535;
   if (col >= cols) return;
   __bf16* out = B3 + col * 3 * rows;
+  if ((rows % 4 == 0) && (lds_ % 4 == 0) && al16(S) && al8(B3)) {
+    float* sc = S + col * lds_;
+    for (int64_t r4 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; r4 < rows; r4 += (int64_t)gridDim.x * blockDim.x * 4) {
+      const float4 v = *reinterpret_cast<const float4*>(sc + r4);
+      bf16x4 hi, lo;
+      bf16_split(v.x, hi.v[0], lo.v[0]); bf16_split(v.y, hi.v[1], lo.v[1]); bf16_split(v.z, hi.v[2], lo.v[2]); bf16_split(v.w, hi.v[3], lo.v[3]);
+      *reinterpret_cast<bf16x4*>(out + r4) = hi; *reinterpret_cast<bf16x4*>(out + rows + r4) = lo; *reinterpret_cast<bf16x4*>(out + 2 * rows + r4) = hi;
+      if (zero_src) *reinterpret_cast<float4*>(sc + r4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    return;
+  }
   for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < rows; row += (int64_t)gridDim.x * blockDim.x) {
     __bf16 hi, lo;
     bf16_split(S[row + col * lds_], hi, lo);
@@ -65,6 +107,15 @@ static __global__ void split3_tri_kernel(const double* D, int64_t ldd, __bf16* A
 static __global__ void f32_to_bf16_kernel(const float* S, int64_t lds_, __bf16* P, int64_t ldp, int64_t rows, int64_t cols) {
   const int64_t col = blockIdx.y + (int64_t)blockIdx.z * 65535;
   if (col >= cols) return;
+  if ((rows % 4 == 0) && (lds_ % 4 == 0) && (ldp % 4 == 0) && al16(S) && al8(P)) {
+    const float* sc = S + col * lds_; __bf16* pc = P + col * ldp;
+    for (int64_t r4 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; r4 < rows; r4 += (int64_t)gridDim.x * blockDim.x * 4) {
+      const float4 v = *reinterpret_cast<const float4*>(sc + r4);
+      bf16x4 o; o.v[0] = (__bf16)v.x; o.v[1] = (__bf16)v.y; o.v[2] = (__bf16)v.z; o.v[3] = (__bf16)v.w;
+      *reinterpret_cast<bf16x4*>(pc + r4) = o;
+    }
+    return;
+  }
   for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < rows; row += (int64_t)gridDim.x * blockDim.x)
     P[row + col * ldp] = (__bf16)S[row + col * lds_];
 }
@@ -75,6 +126,6 @@ static __global__ void axpy_cols_kernel(double* X, int64_t ldx, const double* D,
 }
 
 static inline dim3 grid2(int64_t rows, int64_t cols) {
-  return dim3((unsigned)std::min<int64_t>(cap_ceil_div(rows, 256), 4096), (unsigned)std::min<int64_t>(cols, 65535), (unsigned)cap_ceil_div(cols, 65535));
+  return dim3((unsigned)std::min<int64_t>(cap_ceil_div(rows, 1024), 4096), (unsigned)std::min<int64_t>(cols, 65535), (unsigned)cap_ceil_div(cols, 65535));
 }
 }  // namespace
