@@ -88,7 +88,7 @@ int rec_cholinv(const RecCtx& c, int64_t off, int64_t n, bool is_root, int64_t i
 // on a CU-masked stream (every workgroup of the launch must find a slot or the others spin for ever).
 int g_coop_wgs = getenv("CAP_CHAIN_COOP") ? atoi(getenv("CAP_CHAIN_COOP")) : 32;
 int g_coop_cap = 0;
-// a ring of counter pairs per device: a launch takes the next pair and leaves it zeroed, so only launches that are in flight at the
+// a ring of counter slots (four words) per device: a launch takes the next pair and leaves it zeroed, so only launches that are in flight at the
 // same time on different streams must not share one (64 of them would have to)
 constexpr int COOP_SLOTS = 64;
 std::mutex g_coop_mu;
@@ -102,11 +102,11 @@ int coop_counter(int** out) {
   if (dev < 0 || dev >= 16) return CAP_ERR_UNSUPPORTED;
   std::lock_guard<std::mutex> lk(g_coop_mu);
   if (!g_coop_ctr[dev]) {
-    CAP_HIP(hipMalloc((void**)&g_coop_ctr[dev], COOP_SLOTS * 2 * sizeof(int)));
-    CAP_HIP(hipMemset(g_coop_ctr[dev], 0, COOP_SLOTS * 2 * sizeof(int)));
+    CAP_HIP(hipMalloc((void**)&g_coop_ctr[dev], COOP_SLOTS * 4 * sizeof(int)));
+    CAP_HIP(hipMemset(g_coop_ctr[dev], 0, COOP_SLOTS * 4 * sizeof(int)));
     CAP_HIP(hipDeviceSynchronize());
   }
-  *out = g_coop_ctr[dev] + 2 * (g_coop_next[dev]++ % COOP_SLOTS);
+  *out = g_coop_ctr[dev] + 4 * (g_coop_next[dev]++ % COOP_SLOTS);
   return CAP_OK;
 }
 

@@ -665,7 +665,7 @@ __global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2
   int& bad = *reinterpret_cast<int*>(Dp);
   double* dinv = Dp + 2; double* rowbuf = dinv + LMAX;
   int& barrier_ok = *reinterpret_cast<int*>(Dp + LMAX * (LMAX + 1) / 2);      // (all LDS stays in the dynamic region)
-  int epoch = 0;
+  int epoch = 0, epoch1 = 0;             // arrivals expected at the end-of-step meetings (ctr[0]) / the mid-step ones (ctr[2])
   bool alive = true;
   long long* tr = (g.trace && w < 64 && threadIdx.x == 0) ? g.trace + (int64_t)w * 32 * 8 : nullptr;
 #define CHAIN_STAMP(step, j) do { if (tr) tr[(step) * 8 + (j)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
@@ -760,10 +760,12 @@ __global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2
         for (int e = t; e < 64 * 64; e += LTHREADS) gst(Aia + (e & 63) + (int64_t)(e >> 6) * ldr, SM(B0, e & 63, e >> 6));
       }
       CHAIN_STAMP(i + 1, 1);
-      epoch += G;
-      chain_arrive(g.ctr, g.fence);
-      // (workgroup 0 only needs its own X_{i+1} for what follows: it says that it is there and goes on)
-      if (w > 0 && !chain_wait(g.ctr, epoch, g.fence, &barrier_ok)) { if (t == 0 && g.info) atomicExch(g.info, -64); alive = false; break; }
+      epoch1 += G;
+      chain_arrive(g.ctr + 2, g.fence);
+      // (workgroup 0 only needs its own X_{i+1} for what follows: it says that it is there and goes on.  This meeting counts on its
+      // OWN word: on a shared counter workgroup 0's early arrival at the end-of-step meeting would stand in for a worker that has
+      // not stored its solved block yet - seen as wrong factors when eight processes time-slice one GPU)
+      if (w > 0 && !chain_wait(g.ctr + 2, epoch1, g.fence, &barrier_ok)) { if (t == 0 && g.info) atomicExch(g.info, -64); alive = false; break; }
       CHAIN_STAMP(i + 1, 2);
       // ---- phase U: C_ab -= X_a^T X_b on the trailing blocks (upper part on the diagonal ones).  Workgroup 0: block (i+1, i+1), kept
       // in LDS for the leaf; workers: pairs w, w + G - 1, ... of the triangular enumeration.
@@ -912,6 +914,7 @@ __global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2
     const int done = __hip_atomic_fetch_add(g.ctr + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (done == G - 1) {
       __hip_atomic_store(g.ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(g.ctr + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(g.ctr + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -921,7 +924,7 @@ __global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2
 
 // Factor phase of blocked_cholinv (cholinv.hip) in one launch of `wgs` resident workgroups (chain64_coop_kernel): R (n = 64 nblk)
 // factored in place, the 64 x 64 diagonal blocks of Ri = their inverses (Xs / xs_half: unused since the block row is solved in place).
-// ctr: two ints, zero before the first use (the kernel leaves them zero).
+// ctr: four ints (end-of-step meetings, exit count, mid-step meetings, spare), zero before the first use (the kernel leaves them zero).
 int cap_chain64_coop(double* R, int64_t ldr, double* Ri, int64_t ldi, int nblk, double* Xs, int64_t xs_half, int* info, int info_base,
                      int* ctr, int wgs, int fence, int hmax, hipStream_t stream, long long* trace) {
   if (nblk <= 0) return CAP_OK;
