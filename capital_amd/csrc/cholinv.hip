@@ -134,7 +134,7 @@ int blocked_cholinv(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, 
     if (g_coop_trace && g_coop_trace_at-- == 0) trace = g_coop_trace;       // instrumentation of ONE launch (cap_chain_trace_arm)
     static const int merge_env = getenv("CAP_CHAIN_MERGE") ? atoi(getenv("CAP_CHAIN_MERGE")) : 256;   // inverse levels done in the same launch
     merged = std::min<int64_t>(merge_env, n / 2);
-    CAP_TRY(cap_chain64_coop(R, ldr, Ri, ldi, nblk, W, 64 * n, info, (int)info_base, ctr, coop, fence, (int)merged, s, trace));
+    CAP_TRY(cap_chain64_coop(R, ldr, Ri, ldi, nblk, info, (int)info_base, ctr, coop, fence, (int)merged, s, trace));
   } else if (fold) {
     // one launch per step: the fused solve + update of step i also runs the leaf of step i + 1 (leaf.hip).  The solved block
     // row of step i sits in half (i & 1) of W until the launch of step i + 1 moves it into R (the other workgroups of step i

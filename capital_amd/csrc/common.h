@@ -88,8 +88,8 @@ int cap_panel64_solve_update(double* R, int64_t ldr, const double* Dinv, int64_t
                              int direct = 0);
 // leaf.hip: one level of the triangular-inverse assembly, Ri12 = -Ri11 (R12 Ri22) for npairs aligned pairs (h = 64 / 128 / 256)
 int cap_trinv_merge(const double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t h, int npairs, hipStream_t stream);
-int cap_chain64_coop(double* R, int64_t ldr, double* Ri, int64_t ldi, int nblk, double* Xs, int64_t xs_half, int* info, int info_base,
-                     int* ctr, int wgs, int fence, int hmax, hipStream_t stream, long long* trace = nullptr);
+int cap_chain64_coop(double* R, int64_t ldr, double* Ri, int64_t ldi, int nblk, int* info, int info_base, int* ctr, int wgs, int fence,
+                     int hmax, hipStream_t stream, long long* trace = nullptr);
 // resident workgroups of the one-launch diagonal-block chain (0: one launch per step); cap > 0 bounds it (CU-masked streams)
 void cap_chain_coop_set(int wgs);
 int cap_chain_coop_get();

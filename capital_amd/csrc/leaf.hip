@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(LTHREADS) trinv_merge_kernel(const double* R, 
 // invalidate, which would also hit the operand lines of the bulk update that shares the L2s.  `fence` != 0 adds the release /
 // acquire fences around the counter (A/B switch, CAP_CHAIN_FENCE).
 struct Chain64 {
-  double* R; int64_t ldr; double* Ri; int64_t ldi; int nblk; double* Xs; int64_t xs_half; int* info; int info_base; int* ctr; int fence;
+  double* R; int64_t ldr; double* Ri; int64_t ldi; int nblk; int* info; int info_base; int* ctr; int fence;
   int hmax;             // the inverse is assembled in the same launch up to pairs of hmax x hmax blocks (0: not at all; <= 256)
   long long* trace;     // nullptr, or [64 workgroups][32 steps][8]: 100 MHz stamps (step start, S done, released, U done, leaf done, released)
 };
@@ -650,7 +650,7 @@ __device__ __forceinline__ void chain_merge_task(const double* R12, int64_t ldr,
     for (int r = 0; r < 4; r++) gst(Out + 16 * (wid + 4 * q) + kg + 4 * r + (int64_t)lr * ldi, -acc[q][r]);
 }
 
-// <= 256 registers per lane (189 used): the workgroup must fit next to the waves of a running bulk update (2 x 120 registers per SIMD
+// <= 256 registers per lane (212 used): the workgroup must fit next to the waves of a running bulk update (2 x 120 registers per SIMD
 // for the bf16 update, 240 for the fp64 one, of 512) - the first version took 458 and every launch waited for a CU to drain
 // completely (2.7 ms per launch, profiles/r04_experiments.log).
 __global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) chain64_coop_kernel(const Chain64 g) {
@@ -923,17 +923,17 @@ __global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2
 }  // namespace
 
 // Factor phase of blocked_cholinv (cholinv.hip) in one launch of `wgs` resident workgroups (chain64_coop_kernel): R (n = 64 nblk)
-// factored in place, the 64 x 64 diagonal blocks of Ri = their inverses (Xs / xs_half: unused since the block row is solved in place).
+// factored in place, the 64 x 64 diagonal blocks of Ri = their inverses, the off-diagonal blocks up to pairs of hmax x hmax.
 // ctr: four ints (end-of-step meetings, exit count, mid-step meetings, spare), zero before the first use (the kernel leaves them zero).
-int cap_chain64_coop(double* R, int64_t ldr, double* Ri, int64_t ldi, int nblk, double* Xs, int64_t xs_half, int* info, int info_base,
-                     int* ctr, int wgs, int fence, int hmax, hipStream_t stream, long long* trace) {
+int cap_chain64_coop(double* R, int64_t ldr, double* Ri, int64_t ldi, int nblk, int* info, int info_base, int* ctr, int wgs, int fence,
+                     int hmax, hipStream_t stream, long long* trace) {
   if (nblk <= 0) return CAP_OK;
   if (nblk > 31) trace = nullptr;
   if (wgs < 2 || hmax < 0 || hmax > 256 || (hmax & (hmax - 1))) return CAP_ERR_ARG;
   const int useful = std::max(1, (nblk - 1) * nblk / 2);           // one workgroup per trailing block of the first step
   wgs = std::min(wgs, useful);
   const size_t lds_bytes = (2 * LMAX * LLD + LMAX * (LMAX + 1) / 2 + 2) * sizeof(double);
-  const Chain64 g{R, ldr, Ri, ldi, nblk, Xs, xs_half, info, info_base, ctr, fence, hmax, trace};
+  const Chain64 g{R, ldr, Ri, ldi, nblk, info, info_base, ctr, fence, hmax, trace};
   hipLaunchKernelGGL(chain64_coop_kernel, dim3((unsigned)wgs), dim3(LTHREADS), lds_bytes, stream, g);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
