@@ -290,7 +290,8 @@ int cap_cholinv_get_Rinv(cap_cholinv_plan* plan, double* out, int64_t ld, void* 
 /* device pointers to the resident factors (leading dimension returned through *ld).        */
 double* cap_cholinv_R_ptr(cap_cholinv_plan* plan, int64_t* ld);
 double* cap_cholinv_Rinv_ptr(cap_cholinv_plan* plan, int64_t* ld);
-/* host-readable status of the last factor: 0, or 1-based index of the failing pivot.
+/* host-readable status of the last factor: 0, or 1-based index of the failing pivot; -64: a launch of the one-launch
+ * diagonal-block chain (option "chain_coop") never had all its workgroups resident (stream restricted to fewer CUs).
  * Synchronises the stream.                                                                 */
 int cap_cholinv_info(cap_cholinv_plan* plan, void* stream, int64_t* info);
 /* tuning knobs of the GPU schedule: "nb" (panel width), "leaf", "lookahead", "outer" (strip height = K of
@@ -303,7 +304,10 @@ int cap_cholinv_info(cap_cholinv_plan* plan, void* stream, int64_t* info);
  * "inv_overlap" (tree nodes are enqueued as their inputs become final; on), "inv_start_m" (columns left below which the
  * tree starts), "fuse_copy" (only the first strip's rows of A are copied into R, the updates of step 0 read their C input
  * from A; on, bit-identical), "reserve_m" (with "reserve": the CU masks only apply once at most reserve_m columns are left;
- * measured slower, off).  Multi-GPU plans forward to cap_dist_set_option.                                                */
+ * measured slower, off), "chain_coop" (PROCESS-WIDE: resident workgroups of the one-launch diagonal-block chain - the
+ * whole 64-blocked factor phase of a diagonal block + the inverse levels up to 256 as one launch whose workgroups meet at a
+ * counter in device memory, csrc/leaf.hip; 32; 0 = one launch per 64-column step, bit-identical).
+ * Multi-GPU plans forward to cap_dist_set_option.                                                                         */
 int cap_cholinv_set_option(cap_cholinv_plan* plan, const char* key, int64_t value);
 int64_t cap_cholinv_get_option(cap_cholinv_plan* plan, const char* key);
 /* Live measurement of the dominant kernel (trailing-update DSYRK) of the LAST factor call, enabled
