@@ -96,16 +96,23 @@ int* g_coop_ctr[16] = {};
 unsigned g_coop_next[16] = {};
 long long* g_coop_trace = nullptr;
 int64_t g_coop_trace_at = -1;
-int coop_counter(int** out) {
+hipEvent_t g_coop_ready[16] = {};
+// (no host synchronisation in here: the first chain of a rank is enqueued in the middle of a multi-stream, multi-rank schedule, and a
+// host that waits for its device there waits for collectives whose partners may not have been enqueued yet)
+int coop_counter(int** out, hipStream_t s) {
   int dev = 0;
   CAP_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16) return CAP_ERR_UNSUPPORTED;
   std::lock_guard<std::mutex> lk(g_coop_mu);
   if (!g_coop_ctr[dev]) {
-    CAP_HIP(hipMalloc((void**)&g_coop_ctr[dev], COOP_SLOTS * 4 * sizeof(int)));
-    CAP_HIP(hipMemset(g_coop_ctr[dev], 0, COOP_SLOTS * 4 * sizeof(int)));
-    CAP_HIP(hipDeviceSynchronize());
+    int* c = nullptr;
+    CAP_HIP(hipMalloc((void**)&c, COOP_SLOTS * 4 * sizeof(int)));
+    CAP_HIP(hipEventCreateWithFlags(&g_coop_ready[dev], hipEventDisableTiming));
+    CAP_HIP(hipMemsetAsync(c, 0, COOP_SLOTS * 4 * sizeof(int), s));
+    CAP_HIP(hipEventRecord(g_coop_ready[dev], s));
+    g_coop_ctr[dev] = c;
   }
+  CAP_HIP(hipStreamWaitEvent(s, g_coop_ready[dev], 0));        // (a launch on another stream than the one that zeroed the words)
   *out = g_coop_ctr[dev] + 4 * (g_coop_next[dev]++ % COOP_SLOTS);
   return CAP_OK;
 }
@@ -128,7 +135,7 @@ int blocked_cholinv(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, 
   if (coop >= 2 && nblk >= 4) {
     // the whole factor phase in one launch of `coop` resident workgroups (chain64_coop_kernel, leaf.hip)
     int* ctr = nullptr;
-    CAP_TRY(coop_counter(&ctr));
+    CAP_TRY(coop_counter(&ctr, s));
     static const int fence = getenv("CAP_CHAIN_FENCE") ? atoi(getenv("CAP_CHAIN_FENCE")) : 0;
     long long* trace = nullptr;
     if (g_coop_trace && g_coop_trace_at-- == 0) trace = g_coop_trace;       // instrumentation of ONE launch (cap_chain_trace_arm)
