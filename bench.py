@@ -2,8 +2,9 @@
 """bench.py - fp64 Cholesky TFLOP/s on MI355X (BASELINE.json metric), one process per GPU.
 
     python bench.py --gpus 1 --steps 3 --warmup 1            # N = 65536 on one GPU
+    python bench.py --gpus 8 --steps 3 --warmup 1            # starts its own 8 ranks (one per GPU, RCCL) and relays rank 0's line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-           --master-port 29501 bench.py --gpus 8 --steps 3 --warmup 1
+           --master-port 29501 bench.py --gpus 8 --steps 3 --warmup 1      # the same under an external launcher
     python bench.py --workload cacqr                          # CholeskyQR2 2^21 x 256 per GPU (BASELINE config 4 shape)
     python bench.py --workload mixed                          # bf16 MFMA factor + fp64 refinement, 1 GPU (BASELINE config 5's method)
 
@@ -76,6 +77,7 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs runs")
     ap.add_argument("--no-check", action="store_true", help="skip the residual checks (profiling runs)")
     ap.add_argument("--cpu-n", type=int, default=16384, help="bounded CPU-baseline sample size")
+    ap.add_argument("--cpu-budget-s", type=float, default=100.0, help="seconds of host time the CPU baseline may take")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the residual is always computed)")
     args = ap.parse_args()
     if args.steps <= 0:
@@ -93,13 +95,14 @@ def _largest_cube(limit):
 def cpu_baseline(cpu_n, budget_s=100.0):
     """Reference CPU/MPI path on the host cores (protocol bench/cholesky/cholinv.cpp:44-60), bounded to about `budget_s` seconds.
 
-    The REAL reference (oracle/_ref), MKL 1 thread per rank.  What the budget is spent on (round-3 measurements on the GPU box's
+    The REAL reference (oracle/_ref); MKL with 1 thread per rank and, hybrid, 8 / 16 threads per rank.  What the budget is spent on (round-3 measurements on the GPU box's
     256-core EPYC: upstream's own 2 x 2 x 2 grid wins; 64 ranks and one rank x 128 MKL threads are 2-4x SLOWER):
       c1     BASELINE configs[0], the plumbing case: 1 rank, N = 2048, bcMult = 0, the bench's default policy; its residual is
              the number SURVEY App. A pins (1.70e-16);
-      8 ranks, bcMult = -3 (the winner of every sweep so far) at N = cpu_n / 2, then at N = cpu_n (about 7 s per factor at 16384;
-             a run = generation + warm-up + timed factor + the validator's own SUMMA product, i.e. several factor times),
-             then bcMult = -2 at N = cpu_n / 2 for the record; the first MPI start of a fresh box (15 - 25 s of paging) is
+      8 ranks, bcMult = -3 (the winner of every sweep so far) at N = cpu_n / 2 with 1, 8 and 16 MKL threads per rank (8 / 64 / 128
+             host cores), the best of the three at N = cpu_n (8 x 1: about 7 s per factor at 16384; a run = generation + warm-up +
+             timed factor + the validator's own SUMMA product, i.e. several factor times), the one-thread grid at N = cpu_n as well
+             when time is left, then bcMult = -2 at N = cpu_n / 2 for the record; the first MPI start of a fresh box (15 - 25 s of paging) is
              absorbed by c1;
       one documented run each of the 64-rank (4 x 4 x 4) grid and of 1 rank x all cores inside MKL (GNU threading layer), at
              N = cpu_n / 4 so that they stay cheap - scaling evidence, never the reported value unless they win.
@@ -150,19 +153,31 @@ def cpu_baseline(cpu_n, budget_s=100.0):
                      "what": "BASELINE configs[0]: N=2048 fp64 cholinv, 1 MPI rank, reference CPU BLAS path (MKL, 1 thread)"} if r else None)
         c1 = c1_of(c1r)
         if ncores >= 8:
-            # order of importance: the winning configuration (bcMult = -3 in every sweep so far) at N / 2, then at N, then the
-            # second candidate at N / 2 for the record
+            # order of importance: upstream's own 8-rank grid (2 x 2 x 2, the only valid multi-rank grid among 2 / 4 / 8) with bcMult = -3
+            # (the winner of every sweep so far) at N / 2 - one MKL thread per rank, then HYBRID: 8 ranks x {8, 16} MKL threads (GNU
+            # threading layer; bench/set_critter_env.sh:3-18 is the upstream script that sets the per-rank thread count) - then the best
+            # of those at N, then the one-thread grid at N for continuity with earlier rounds, then the second bcMult for the record
             first = run_ref(8, half_n, -3, 1, min(left(), 0.3 * budget_s)) if left() > 10 else None
             if first is None and left() > 10:
                 first = run_ref(8, half_n, -2, 1, min(left(), 0.25 * budget_s))
-            if first is not None and left() > 20:
-                run_ref(8, cpu_n, first["bcMult"], 1, left() - 4)          # about 7 s per factor at N = 16384, several per run
-            if first is not None and first["bcMult"] == -3 and left() > 10:
-                run_ref(8, half_n, -2, 1, min(left() - 2, 0.25 * budget_s))
+            cands = [first] if first else []
+            if first is not None:
+                for th in (8, 16):
+                    if ncores >= 8 * th and left() > 25:
+                        r = run_ref(8, half_n, first["bcMult"], th, min(left() - 20, 0.2 * budget_s))
+                        if r:
+                            cands.append(r)
+            if cands and left() > 20:
+                b0 = max(cands, key=lambda r: r["tflops"])
+                big = run_ref(8, cpu_n, b0["bcMult"], b0["threads_per_rank"], left() - 4)   # 8 x 1: about 7 s per factor at N = 16384, several per run
+                if big is not None and b0["threads_per_rank"] > 1 and left() > 45:
+                    run_ref(8, cpu_n, first["bcMult"], 1, left() - 4)
+            if first is not None and first["bcMult"] == -3 and left() > 15:
+                run_ref(8, half_n, -2, 1, min(left() - 2, 0.2 * budget_s))
         quarter_n = max(1024, cpu_n // 4)
-        if ncores >= 64 and left() > 8:
+        if ncores >= 64 and left() > 12:
             run_ref(64, quarter_n, -2, 1, min(left() - 2, 20.0))
-        if ncores >= 16 and left() > 6:
+        if ncores >= 16 and left() > 8:
             run_ref(1, quarter_n, -2, min(ncores, 128), min(left() - 1, 20.0))
         if not runs and left() > 5:      # fewer than 8 cores: whatever the host has
             run_ref(1, min(cpu_n, 4096), -2, 1, left())
@@ -237,14 +252,58 @@ def traffic_from_profile(n, args):
     return None
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args, argv=None):
+    """Re-run this file as N ranks: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port <free> bench.py <the same arguments>` - one process per GPU (RCCL), or per rank on cuda:0 under
+    CAPITAL_BENCH_EMULATE=1.  stdout / stderr are inherited, so rank 0's one JSON line is this process's JSON line; the exit
+    code is the launcher's.  Never returns without a JSON line: a box with fewer GPUs than ranks gets one with value null."""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    fixed = []
+    for a in argv:                         # torch.distributed.run's own parser trips over "--n": hand the size over as --size
+        if a == "--n":
+            a = "--size"
+        elif a.startswith("--n="):
+            a = "--size=" + a[4:]
+        fixed.append(a)
+    emulate = os.environ.get("CAPITAL_BENCH_EMULATE") == "1"
+    if not emulate:
+        try:
+            import torch
+            have = torch.cuda.device_count()
+        except Exception:
+            have = 0
+        if have < args.gpus:
+            print(json.dumps({"metric": args.workload, "value": None, "unit": "TFLOP/s", "n_gpus": args.gpus, "steps": args.steps,
+                              "warmup": args.warmup, "higher_is_better": True,
+                              "error": "--gpus %d but this box shows %d GPU(s)" % (args.gpus, have)}), flush=True)
+            return 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + fixed
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL and the IPC strip exchange need it on this driver
+    print("[bench] starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (the reference's protocol is one binary under
+        # `mpirun -n P`, bench/cholesky/cholinv.cpp:44-60) and relay rank 0's JSON line and the exit code
+        sys.exit(self_launch(args))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch as many ranks as GPUs" % (args.gpus, world))
     # CAPITAL_BENCH_EMULATE=1 (tests only): all ranks share cuda:0 and talk through gloo + the host-staged communicator,
     # which exercises this file's N > 1 path on a 1-GPU box; the product path is RCCL, one GPU per rank.
     emulate = os.environ.get("CAPITAL_BENCH_EMULATE") == "1"
@@ -418,7 +477,7 @@ def bench_cholesky(args, torch, L, C, rank, world, dist, emulate, timed, allredu
                                "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF,
                                "launches": nl.value, "avg_launch_ms": ms.value / nl.value,
                                "algorithmic_flops_per_launch_avg": fl.value / nl.value, "traffic": traffic_from_profile(n, args)}
-    if world > 1 and sec is not None and not emulate:
+    if world > 1 and sec is not None:
         r = ctx.roofline(L, C)
         if rank == 0 and r:
             out["roofline"] = r
@@ -480,7 +539,7 @@ def bench_cholesky(args, torch, L, C, rank, world, dist, emulate, timed, allredu
             torch.cuda.empty_cache()
         out["extra_configs"] = extra
     if rank == 0 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_n)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_budget_s)
     if not ok:
         out["value"] = None
         out["error"] = "factorization failed its parity gate (info != 0 or residual above %g)" % RES_TOL if sec is not None else \
@@ -754,6 +813,8 @@ def bench_mixed(args, torch, L, C, rank, world, timed):
     if not ok:
         out["error"] = "mixed-precision solve failed its parity gate"
     p.close()
+    if not getattr(args, "no_cpu_baseline", False):
+        out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_budget_s)     # the reference has no solve path: its fp64 factor is the comparator
     return out, ok
 
 
@@ -814,6 +875,8 @@ def bench_mixed_dist(args, torch, L, C, rank, world, timed):
     if not ok:
         out["error"] = "distributed mixed-precision solve failed its parity gate"
     p.close()
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_budget_s)     # the reference has no solve path: its fp64 factor is the comparator
     return out, ok
 
 

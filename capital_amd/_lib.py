@@ -135,6 +135,8 @@ SIGNATURES = {
     "cap_mpchol_R32_ptr": (ptr, [ptr, C.POINTER(i64)]),
     "cap_mpchol_set_option": (cint, [ptr, C.c_char_p, i64]),
     "cap_mpchol_profile": (cint, [ptr, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]),
+    "cap_chain_fallbacks": (i64, []),
+    "cap_chain_inject_timeouts": (cint, [cint]),
     "cap_bf16_update": (cint, [cint, i64, i64, i64, C.c_float, ptr, i64, ptr, i64, ptr, i64, cint, cint, ptr]),
     "cap_dmp_plan_create": (cint, [C.POINTER(ptr), i64, i64, i64, ptr]),
     "cap_dmp_plan_destroy": (cint, [ptr]),

@@ -83,37 +83,48 @@ int rec_cholinv(const RecCtx& c, int64_t off, int64_t n, bool is_root, int64_t i
   return CAP_OK;
 }
 
-// ---- one-launch diagonal-block chain: process-wide switch + the barrier counters of its launches -----------------------------------
-// g_coop_wgs resident workgroups (0 / 1: one launch per step, the round-3 form); g_coop_cap > 0 bounds it while a caller launches
-// on a CU-masked stream (every workgroup of the launch must find a slot or the others spin for ever).
-int g_coop_wgs = getenv("CAP_CHAIN_COOP") ? atoi(getenv("CAP_CHAIN_COOP")) : 32;
-int g_coop_cap = 0;
-// a ring of counter slots (four words) per device: a launch takes the next pair and leaves it zeroed, so only launches that are in flight at the
-// same time on different streams must not share one (64 of them would have to)
-constexpr int COOP_SLOTS = 64;
+// ---- one-launch diagonal-block chain: workgroup count (process default, per-thread override) + the per-stream state of its launches ---
+// Resident workgroups of a launch (0 / 1: one launch per step, the round-3 form): the process default comes from CAP_CHAIN_COOP; a plan
+// that was given its own value (option "chain_coop") installs it for the duration of ITS factor call on the calling host thread
+// (CapChainScope), and a caller that launches on a CU-masked stream bounds the count the same way (cap_chain_coop_cap) - both are
+// thread_local: two host threads / two plans never see each other's settings (they were process globals in round 4).
+const int g_coop_default = getenv("CAP_CHAIN_COOP") ? atoi(getenv("CAP_CHAIN_COOP")) : 32;
+thread_local int tl_coop_wgs = -1;        // -1: the process default
+thread_local int tl_coop_cap = 0;
+// Per (device, stream): four counter words (end-of-step meetings, exit count, mid-step meetings, state: 0 / 1 = a workgroup gave up
+// waiting / 2 = recovery under way) and a backup of the diagonal block's upper 64 x 64 blocks (n <= 1024: 136 blocks = 4.25 MiB).
+// Launches on one stream are ordered, so they can share the words (the kernel leaves them zero) and the backup; launches on
+// different streams never share (round 4's ring of 64 slots could hand one slot to two streams' launches that were enqueued far
+// apart but ran together).
+constexpr int COOP_MAX_NBLK = 16;
+constexpr size_t COOP_BACKUP_DOUBLES = (size_t)COOP_MAX_NBLK * (COOP_MAX_NBLK + 1) / 2 * 64 * 64;
+struct CoopSlot { int dev; hipStream_t s; int* ctr; double* backup; hipEvent_t ready; };
 std::mutex g_coop_mu;
-int* g_coop_ctr[16] = {};
-unsigned g_coop_next[16] = {};
+std::vector<CoopSlot>* g_coop_slots = nullptr;
+int* g_coop_fallbacks[16] = {};           // per device: how many chains were re-run after a workgroup gave up waiting (device word)
 long long* g_coop_trace = nullptr;
 int64_t g_coop_trace_at = -1;
-hipEvent_t g_coop_ready[16] = {};
 // (no host synchronisation in here: the first chain of a rank is enqueued in the middle of a multi-stream, multi-rank schedule, and a
 // host that waits for its device there waits for collectives whose partners may not have been enqueued yet)
-int coop_counter(int** out, hipStream_t s) {
+int coop_slot(int** ctr, double** backup, int** fallbacks, hipStream_t s) {
   int dev = 0;
   CAP_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16) return CAP_ERR_UNSUPPORTED;
   std::lock_guard<std::mutex> lk(g_coop_mu);
-  if (!g_coop_ctr[dev]) {
-    int* c = nullptr;
-    CAP_HIP(hipMalloc((void**)&c, COOP_SLOTS * 4 * sizeof(int)));
-    CAP_HIP(hipEventCreateWithFlags(&g_coop_ready[dev], hipEventDisableTiming));
-    CAP_HIP(hipMemsetAsync(c, 0, COOP_SLOTS * 4 * sizeof(int), s));
-    CAP_HIP(hipEventRecord(g_coop_ready[dev], s));
-    g_coop_ctr[dev] = c;
+  if (!g_coop_slots) g_coop_slots = new std::vector<CoopSlot>();
+  if (!g_coop_fallbacks[dev]) {
+    CAP_HIP(hipMalloc((void**)&g_coop_fallbacks[dev], 4 * sizeof(int)));
+    CAP_HIP(hipMemsetAsync(g_coop_fallbacks[dev], 0, 4 * sizeof(int), s));    // (first use below is stream-ordered behind the slot's event)
   }
-  CAP_HIP(hipStreamWaitEvent(s, g_coop_ready[dev], 0));        // (a launch on another stream than the one that zeroed the words)
-  *out = g_coop_ctr[dev] + 4 * (g_coop_next[dev]++ % COOP_SLOTS);
+  *fallbacks = g_coop_fallbacks[dev];
+  for (const CoopSlot& c : *g_coop_slots)
+    if (c.dev == dev && c.s == s) { *ctr = c.ctr; *backup = c.backup; return CAP_OK; }
+  CoopSlot c{dev, s, nullptr, nullptr, nullptr};
+  CAP_HIP(hipMalloc((void**)&c.ctr, 4 * sizeof(int)));
+  if (hipMalloc((void**)&c.backup, COOP_BACKUP_DOUBLES * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); c.backup = nullptr; }   // no backup: no recovery
+  CAP_HIP(hipMemsetAsync(c.ctr, 0, 4 * sizeof(int), s));
+  g_coop_slots->push_back(c);
+  *ctr = c.ctr; *backup = c.backup;
   return CAP_OK;
 }
 
@@ -129,19 +140,23 @@ int blocked_cholinv(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, 
   const int nblk = (int)(n / 64);
   if (128 * n > wcap) return CAP_ERR_ALLOC;
   static const bool fold = getenv("CAP_FOLD_LEAF") ? atoi(getenv("CAP_FOLD_LEAF")) != 0 : true;
-  int coop = g_coop_wgs;
-  if (g_coop_cap > 0) coop = std::min(coop, g_coop_cap);
+  int coop = cap_chain_coop_get();
+  if (tl_coop_cap > 0) coop = std::min(coop, tl_coop_cap);
+  coop = std::min(coop, cap_chain64_coop_max_resident());      // never more workgroups than the device can hold at once
   int64_t merged = 0;             // the launch above has already assembled the inverse up to pairs of this size
   if (coop >= 2 && nblk >= 4) {
     // the whole factor phase in one launch of `coop` resident workgroups (chain64_coop_kernel, leaf.hip)
-    int* ctr = nullptr;
-    CAP_TRY(coop_counter(&ctr, s));
-    static const int fence = getenv("CAP_CHAIN_FENCE") ? atoi(getenv("CAP_CHAIN_FENCE")) : 0;
+    int* ctr = nullptr; double* backup = nullptr; int* fallbacks = nullptr;
+    CAP_TRY(coop_slot(&ctr, &backup, &fallbacks, s));
+    if (nblk > COOP_MAX_NBLK) backup = nullptr;
+    // release / acquire fences around the meeting counter: on by default since round 5 (the relaxed protocol relies on behaviour the
+    // AMDGPU memory model does not promise; measured cost in profiles/r05_experiments.log), CAP_CHAIN_FENCE=0 for the A/B run
+    static const int fence = getenv("CAP_CHAIN_FENCE") ? atoi(getenv("CAP_CHAIN_FENCE")) : 1;
     long long* trace = nullptr;
     if (g_coop_trace && g_coop_trace_at-- == 0) trace = g_coop_trace;       // instrumentation of ONE launch (cap_chain_trace_arm)
     static const int merge_env = getenv("CAP_CHAIN_MERGE") ? atoi(getenv("CAP_CHAIN_MERGE")) : 256;   // inverse levels done in the same launch
     merged = std::min<int64_t>(merge_env, n / 2);
-    CAP_TRY(cap_chain64_coop(R, ldr, Ri, ldi, nblk, info, (int)info_base, ctr, coop, fence, (int)merged, s, trace));
+    CAP_TRY(cap_chain64_coop(R, ldr, Ri, ldi, nblk, info, (int)info_base, ctr, coop, fence, (int)merged, s, trace, backup, fallbacks));
   } else if (fold) {
     // one launch per step: the fused solve + update of step i also runs the leaf of step i + 1 (leaf.hip).  The solved block
     // row of step i sits in half (i & 1) of W until the launch of step i + 1 moves it into R (the other workgroups of step i
@@ -277,6 +292,7 @@ struct cap_cholinv_plan {
   int fastdiag;     // diagonal blocks by the 64-blocked fused path (default) instead of the recursion
   int ctag;         // CAP_TAG_NO_ATOMIC when the factor lives in caller memory that is not a plain device allocation (cap_dpotrf)
   int depth2;       // split each bulk update into head (next-next strip's rows) + rest: look-ahead depth 2
+  int chain_coop;   // resident workgroups of the one-launch diagonal-block chain for THIS plan (-1: the process default)
   // device state
   double* R; int64_t ldr;
   double* Rinv; int64_t ldi;      // n x n (complete_inv >= 0) or nb x nb diagonal-block inverse
@@ -1005,6 +1021,7 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   // below ~16K remaining columns a step's chain (2 x 512 diagonal blocks, ~4 ms next to the bulk update) outlasts its bulk
   // update (m^2 x 1024 flops): from there on the bulk runs one workgroup per CU (N = 32768: 59.3 -> 61.2 TF, 16384: 34.4 -> 37.1)
   p->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
+  p->chain_coop = -1;
   p->depth2 = n >= 24576;     // look-ahead depth 2 pays once a bulk update is long enough to split (+2 % at N = 32768)
   // reference semantics (R and R^-1): blocked factorization + inverse tree; the tree starts once the sweep is chain-bound
   p->use_sb = getenv("CAP_USE_SB") ? atoi(getenv("CAP_USE_SB")) : 1;
@@ -1048,6 +1065,9 @@ int cap_cholinv_plan_destroy(cap_cholinv_plan* p) {
 int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) {
   if (!p || !key) return CAP_ERR_ARG;
   std::string k(key);
+  // resident workgroups of the one-launch diagonal-block chain (leaf.hip chain64_coop_kernel) for THIS plan's factor calls (also a
+  // multi-rank plan's: the schedule behind it runs on the calling thread), 0 = one launch per step; -1 = back to the process default
+  if (k == "chain_coop") { if (value < -1 || value > 256) return CAP_ERR_ARG; p->chain_coop = (int)value; return CAP_OK; }
   if (p->dist) {
     if (k == "nb") {        // block width of the distribution: rebuild the inner plan
       if (value < 128 || value % 128) return CAP_ERR_ARG;
@@ -1112,8 +1132,6 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
     p->reserve = value; return CAP_OK;
   }
   if (k == "reserve_m") { if (value < 0) return CAP_ERR_ARG; p->reserve_m = value; return CAP_OK; }
-  // process-wide: resident workgroups of the one-launch diagonal-block chain (leaf.hip chain64_coop_kernel), 0 = one launch per step
-  if (k == "chain_coop") { if (value < 0 || value > 256) return CAP_ERR_ARG; cap_chain_coop_set((int)value); return CAP_OK; }
   if (k == "fuse_copy") { p->fuse_copy = value != 0; return CAP_OK; }
   if (k == "profile") {
     p->profile = value != 0;
@@ -1126,6 +1144,8 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
 int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
   if (!p || !key) return -1;
   std::string k(key);
+  if (k == "chain_coop") { if (p->chain_coop >= 0) return p->chain_coop; return cap_chain_coop_get(); }
+  if (k == "chain_fallbacks") return cap_chain_fallbacks();
   if (p->dist) {
     if (k == "complete_inv") return p->complete_inv;
     if (k == "split") return p->split;
@@ -1150,7 +1170,6 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
   if (k == "fastdiag") return p->fastdiag;
   if (k == "reserve") return p->reserve;
   if (k == "reserve_m") return p->reserve_m;
-  if (k == "chain_coop") return cap_chain_coop_get();
   if (k == "fuse_copy") return p->fuse_copy;
   if (k == "inner_la") return p->inner_la;
   if (k == "occ1_m") return p->occ1_m;
@@ -1163,6 +1182,7 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
 
 int cap_cholinv_factor(cap_cholinv_plan* p, const double* A, int64_t lda, void* stream) {
   if (!p) return CAP_ERR_ARG;
+  CapChainScope chain_scope(p->chain_coop);     // this plan's own "chain_coop", visible to every launch made from this call
   if (p->dist && p->redist) {       // A = my element-cyclic piece (ceil(n/d) x ceil(n/d), lda)
     CAP_TRY(cap_redistribute_cyclic_to_bc(p->redist, A, lda, p->bcA, p->n, stream));
     return cap_dist_factor(p->dist, p->bcA, p->n, stream);
@@ -1434,9 +1454,38 @@ int cap_trsm_apply(int side, int trans, int64_t m, int64_t n, const double* T, i
   return CAP_OK;
 }
 
-void cap_chain_coop_set(int wgs) { g_coop_wgs = wgs < 0 ? 0 : wgs; }
-int cap_chain_coop_get() { return g_coop_wgs; }
-void cap_chain_coop_cap(int cap) { g_coop_cap = cap < 0 ? 0 : cap; }
+int cap_chain_coop_swap(int wgs) { const int old = tl_coop_wgs; tl_coop_wgs = wgs < 0 ? -1 : wgs; return old; }
+int cap_chain_coop_get() { return tl_coop_wgs >= 0 ? tl_coop_wgs : g_coop_default; }
+void cap_chain_coop_cap(int cap) { tl_coop_cap = cap < 0 ? 0 : cap; }
+// chains that were re-run by the recovery launch on the current device (a workgroup gave up waiting for its peers); synchronises
+extern "C" int64_t cap_chain_fallbacks() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -1;
+  int* w = nullptr;
+  { std::lock_guard<std::mutex> lk(g_coop_mu); w = g_coop_fallbacks[dev]; }
+  if (!w) return 0;
+  int h[4] = {0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, w, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return h[0];
+}
+// test hook: the next `count` chain launches on this device behave as if a workgroup had given up at their first meeting
+extern "C" int cap_chain_inject_timeouts(int count) {
+  int dev = 0;
+  CAP_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return CAP_ERR_UNSUPPORTED;
+  CAP_HIP(hipDeviceSynchronize());
+  int* w = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    if (!g_coop_fallbacks[dev]) {
+      CAP_HIP(hipMalloc((void**)&g_coop_fallbacks[dev], 4 * sizeof(int)));
+      CAP_HIP(hipMemset(g_coop_fallbacks[dev], 0, 4 * sizeof(int)));
+    }
+    w = g_coop_fallbacks[dev];
+  }
+  CAP_HIP(hipMemcpy(w + 1, &count, sizeof(int), hipMemcpyHostToDevice));
+  return CAP_OK;
+}
 
 // Instrumentation (tools/chain_trace.py): the `which`-th one-launch chain from now on records, per workgroup (first 64) and step,
 // four 100 MHz time stamps (step start / own blocks done / arrival at the counter / release); cap_chain_trace_read copies them out.

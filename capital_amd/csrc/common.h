@@ -88,12 +88,22 @@ int cap_panel64_solve_update(double* R, int64_t ldr, const double* Dinv, int64_t
                              int direct = 0);
 // leaf.hip: one level of the triangular-inverse assembly, Ri12 = -Ri11 (R12 Ri22) for npairs aligned pairs (h = 64 / 128 / 256)
 int cap_trinv_merge(const double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t h, int npairs, hipStream_t stream);
+// backup != nullptr (room for the upper 64 x 64 blocks of the diagonal block): the launch saves the block before it touches it and a
+// second, normally empty launch re-runs the chain on two workgroups if a workgroup of the first gave up waiting (fallbacks[0]++)
 int cap_chain64_coop(double* R, int64_t ldr, double* Ri, int64_t ldi, int nblk, int* info, int info_base, int* ctr, int wgs, int fence,
-                     int hmax, hipStream_t stream, long long* trace = nullptr);
-// resident workgroups of the one-launch diagonal-block chain (0: one launch per step); cap > 0 bounds it (CU-masked streams)
-void cap_chain_coop_set(int wgs);
+                     int hmax, hipStream_t stream, long long* trace = nullptr, double* backup = nullptr, int* fallbacks = nullptr);
+int cap_chain64_coop_max_resident();      // workgroups of that kernel the current device holds at once (occupancy x CUs)
+// resident workgroups of the one-launch diagonal-block chain (0: one launch per step) as the CALLING THREAD sees it: the process
+// default unless a CapChainScope is active; cap > 0 bounds it (CU-masked streams), also per thread
+int cap_chain_coop_swap(int wgs);         // installs wgs (-1: process default) for this thread, returns the previous value
 int cap_chain_coop_get();
 void cap_chain_coop_cap(int cap);
+struct CapChainScope {
+  int prev; bool on;
+  explicit CapChainScope(int wgs) : prev(-1), on(wgs >= 0) { if (on) prev = cap_chain_coop_swap(wgs); }
+  ~CapChainScope() { if (on) cap_chain_coop_swap(prev); }
+  CapChainScope(const CapChainScope&) = delete; CapChainScope& operator=(const CapChainScope&) = delete;
+};
 // gemm.hip: batched 64x64-tile products (batch = blockIdx.z, affine strides)
 int cap_gemm_small_batched(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
                            int64_t sa, const double* B, int64_t ldb, int64_t sb, double beta, double* C, int64_t ldc, int64_t sc,

@@ -560,6 +560,12 @@ struct Chain64 {
   double* R; int64_t ldr; double* Ri; int64_t ldi; int nblk; int* info; int info_base; int* ctr; int fence;
   int hmax;             // the inverse is assembled in the same launch up to pairs of hmax x hmax blocks (0: not at all; <= 256)
   long long* trace;     // nullptr, or [64 workgroups][32 steps][8]: 100 MHz stamps (step start, S done, released, U done, leaf done, released)
+  // recovery (round 5).  ctr[3] is the state word of the slot: 0 normal; 1 = a workgroup of the primary launch gave up waiting for its
+  // peers (every workgroup that sees it stops meeting and leaves); 2 = the recovery launch has taken over; 3 = it gave up too.  The
+  // recovery launch (recover = 1, two workgroups, enqueued behind every primary launch) returns at once if it finds 0; else it restores the block from `backup` (upper 64 x 64 blocks, packed
+  // column by column of blocks, written by the primary launch before it touched the block), clears info's -64, counts the event in
+  // fallbacks[0] and runs the same sweep.  fallbacks[1] > 0: test hook, the primary launch gives up at its first meeting.
+  double* backup; int* fallbacks; int recover;
 };
 
 __device__ __forceinline__ double gld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -576,19 +582,32 @@ __device__ __forceinline__ void chain_arrive(int* ctr, int fence) {
     __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-__device__ __forceinline__ bool chain_wait(int* ctr, int target, int fence, int* lds_flag) {
+constexpr int CHAIN_POLLS = 1 << 21;         // ~ 1.5 us per poll: a workgroup gives up after ~ 3 s (the kernels it can wait behind take ms)
+__device__ __forceinline__ bool chain_wait(int* ctr, int target, int fence, int* lds_flag, int* state, int gave_up) {
   if (threadIdx.x == 0) {
     int polls = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && polls < (1 << 24)) { __builtin_amdgcn_s_sleep(2); polls++; }
+    bool ok = true;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++polls >= CHAIN_POLLS || ((polls & 63) == 0 && __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gave_up)) { ok = false; break; }
+    }
     if (fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    *lds_flag = polls < (1 << 24);
+    *lds_flag = ok;
   }
   __syncthreads();
   return *lds_flag != 0;
 }
-__device__ __forceinline__ bool chain_barrier(int* ctr, int target, int fence, int* lds_flag) {
+__device__ __forceinline__ bool chain_barrier(int* ctr, int target, int fence, int* lds_flag, int* state, int gave_up) {
   chain_arrive(ctr, fence);
-  return chain_wait(ctr, target, fence, lds_flag);
+  return chain_wait(ctr, target, fence, lds_flag, state, gave_up);
+}
+// a workgroup that gave up: mark the slot (its peers leave at their next poll) and report through info - unless a failing pivot is
+// already recorded there - until the recovery launch clears it
+__device__ __forceinline__ void chain_give_up(int* state, int* info, int gave_up) {
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(state, gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (info) atomicCAS(info, 0, -64);
+  }
 }
 
 // One task of the triangular-inverse assembly inside the resident chain: strip `sidx` (16 columns) of Ri12 = -Ri11 (R12 Ri22) for one
@@ -672,8 +691,51 @@ __global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2
   // (the leaf's inner stamps of workgroup 0 go to the row of workgroup 63, which a launch of <= 63 workgroups leaves free)
 #define LEAF_STAMP(step, j) do { if (tr && G < 64) (tr + 63 * 32 * 8)[(step) * 8 + (j)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 
+  // ---- prologue: the state word of the slot, then save (primary launch) or restore (recovery launch) the block
+  const int GU = g.recover ? 3 : 1;        // what a workgroup of this launch writes into the state word when it gives up
+  bool inject = false;
+  {
+    int* sflag = reinterpret_cast<int*>(Dp) + 1;
+    if (threadIdx.x == 0) {
+      const int st = __hip_atomic_load(g.ctr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int inj = 0;
+      if (!g.recover && g.fallbacks) inj = __hip_atomic_load(g.fallbacks + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0;
+      *sflag = st | (inj << 8);
+    }
+    __syncthreads();
+    const int sv = *sflag;
+    __syncthreads();
+    inject = (sv >> 8) != 0;
+    const int st = sv & 255;
+    // primary launch that finds 1: a peer has already given up (I was dispatched late) - nothing to do but be counted out.
+    // recovery launch: 0 = the primary launch went through - return (the slot's words are untouched); 1 / 2 = it gave up - take
+    // over (2: my peer has already started); 3 = my peer has given up in the recovery itself - be counted out.
+    if (g.recover && st == 0) return;
+    if (g.recover && st == 1 && threadIdx.x == 0) atomicCAS(g.ctr + 3, 1, 2);
+    if ((!g.recover && st == 1) || (g.recover && st == 3)) alive = false;
+    if (alive && g.backup) {
+      // block q of the packed upper enumeration (column by column of blocks): workgroup 0 takes block (0, 0) - the only one that is
+      // modified before the first meeting (by its own leaf) - the workers share the rest; the meeting orders save / restore before use
+      const int nq = nblk * (nblk + 1) / 2;
+      for (int q = (w == 0) ? 0 : w; q < nq; q += (w == 0) ? nq : (G - 1)) {
+        int a = q, b = 0;
+        while (a >= b + 1) { a -= b + 1; b++; }
+        double* blk = R + (int64_t)a * 64 + (int64_t)b * 64 * ldr;
+        double* sav = g.backup + (int64_t)q * 64 * 64;
+        for (int e = threadIdx.x; e < 64 * 64; e += LTHREADS) {
+          if (g.recover) gst(blk + (e & 63) + (int64_t)(e >> 6) * ldr, sav[e]);
+          else sav[e] = gld(blk + (e & 63) + (int64_t)(e >> 6) * ldr);
+        }
+      }
+      if (g.recover && w == 0 && threadIdx.x == 0) {
+        if (g.info) atomicCAS(g.info, -64, 0);
+        if (g.fallbacks) atomicAdd(g.fallbacks, 1);
+      }
+    }
+    if (inject && w == 0 && threadIdx.x == 0) atomicSub(g.fallbacks + 1, 1);
+  }
   // step -1 = the leaf of block 0 alone
-  for (int i = -1; i + 1 < nblk; i++) {
+  for (int i = -1; alive && i + 1 < nblk; i++) {
     const int r = nblk - 1 - i;
     // the lane's indices are recomputed from an opaque copy of threadIdx.x every step: hoisted out of this (long) loop they cost the
     // kernel ~ 100 registers of loop-invariant offsets and masks, i.e. scratch spills under the 168-register cap
@@ -765,7 +827,7 @@ __global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2
       // (workgroup 0 only needs its own X_{i+1} for what follows: it says that it is there and goes on.  This meeting counts on its
       // OWN word: on a shared counter workgroup 0's early arrival at the end-of-step meeting would stand in for a worker that has
       // not stored its solved block yet - seen as wrong factors when eight processes time-slice one GPU)
-      if (w > 0 && !chain_wait(g.ctr + 2, epoch1, g.fence, &barrier_ok)) { if (t == 0 && g.info) atomicExch(g.info, -64); alive = false; break; }
+      if (w > 0 && !chain_wait(g.ctr + 2, epoch1, g.fence, &barrier_ok, g.ctr + 3, GU)) { chain_give_up(g.ctr + 3, g.info, GU); alive = false; break; }
       CHAIN_STAMP(i + 1, 2);
       // ---- phase U: C_ab -= X_a^T X_b on the trailing blocks (upper part on the diagonal ones).  Workgroup 0: block (i+1, i+1), kept
       // in LDS for the leaf; workers: pairs w, w + G - 1, ... of the triangular enumeration.
@@ -880,7 +942,8 @@ __global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2
     }
     CHAIN_STAMP(i + 1, 4);
     epoch += G;
-    if (!chain_barrier(g.ctr, epoch, g.fence, &barrier_ok)) { if (t == 0 && g.info) atomicExch(g.info, -64); alive = false; break; }
+    if (inject && i < 0) { chain_give_up(g.ctr + 3, g.info, GU); alive = false; break; }     // (test hook: as if a peer never arrived)
+    if (!chain_barrier(g.ctr, epoch, g.fence, &barrier_ok, g.ctr + 3, GU)) { chain_give_up(g.ctr + 3, g.info, GU); alive = false; break; }
     CHAIN_STAMP(i + 1, 5);
   }
   // ---- the inverse, level by level: pairs of h x h diagonal blocks, one task per 16-column strip (cf. trinv_merge_kernel)
@@ -904,7 +967,7 @@ __global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2
     CHAIN_STAMP(nblk, lvl);
     epoch += G;
     if (2 * h <= g.hmax && 4 * h <= 64 * nblk) {                     // (nothing follows the last level)
-      if (!chain_barrier(g.ctr, epoch, g.fence, &barrier_ok)) { if (threadIdx.x == 0 && g.info) atomicExch(g.info, -64); alive = false; }
+      if (!chain_barrier(g.ctr, epoch, g.fence, &barrier_ok, g.ctr + 3, GU)) { chain_give_up(g.ctr + 3, g.info, GU); alive = false; }
     }
   }
 #undef CHAIN_STAMP
@@ -916,6 +979,9 @@ __global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2
       __hip_atomic_store(g.ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(g.ctr + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(g.ctr + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (a recovery launch ends the episode whatever happened in it - a second give-up leaves info = -64 for the caller;
+      //  a primary launch without a backup has no recovery launch behind it and clears its own mark)
+      if (g.recover || !g.backup) __hip_atomic_store(g.ctr + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -925,17 +991,41 @@ __global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2
 // Factor phase of blocked_cholinv (cholinv.hip) in one launch of `wgs` resident workgroups (chain64_coop_kernel): R (n = 64 nblk)
 // factored in place, the 64 x 64 diagonal blocks of Ri = their inverses, the off-diagonal blocks up to pairs of hmax x hmax.
 // ctr: four ints (end-of-step meetings, exit count, mid-step meetings, spare), zero before the first use (the kernel leaves them zero).
+constexpr size_t CHAIN_LDS_BYTES = (2 * LMAX * LLD + LMAX * (LMAX + 1) / 2 + 2) * sizeof(double);
+
+// Workgroups of chain64_coop_kernel the current device can hold at once (occupancy of the kernel x compute units), cached per device.
+// A launch with more workgroups than that could never have them all resident: its meetings would only end by the give-up path.
+int cap_chain64_coop_max_resident() {
+  static int cached[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 32;
+  if (cached[dev] > 0) return cached[dev];
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(chain64_coop_kernel), LTHREADS, CHAIN_LDS_BYTES) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu <= 0 || cus <= 0) {
+    (void)hipGetLastError();
+    return 32;
+  }
+  cached[dev] = per_cu * cus;
+  return cached[dev];
+}
+
 int cap_chain64_coop(double* R, int64_t ldr, double* Ri, int64_t ldi, int nblk, int* info, int info_base, int* ctr, int wgs, int fence,
-                     int hmax, hipStream_t stream, long long* trace) {
+                     int hmax, hipStream_t stream, long long* trace, double* backup, int* fallbacks) {
   if (nblk <= 0) return CAP_OK;
   if (nblk > 31) trace = nullptr;
   if (wgs < 2 || hmax < 0 || hmax > 256 || (hmax & (hmax - 1))) return CAP_ERR_ARG;
   const int useful = std::max(1, (nblk - 1) * nblk / 2);           // one workgroup per trailing block of the first step
-  wgs = std::min(wgs, useful);
-  const size_t lds_bytes = (2 * LMAX * LLD + LMAX * (LMAX + 1) / 2 + 2) * sizeof(double);
-  const Chain64 g{R, ldr, Ri, ldi, nblk, info, info_base, ctr, fence, hmax, trace};
-  hipLaunchKernelGGL(chain64_coop_kernel, dim3((unsigned)wgs), dim3(LTHREADS), lds_bytes, stream, g);
+  wgs = std::max(2, std::min(wgs, useful));
+  Chain64 g{R, ldr, Ri, ldi, nblk, info, info_base, ctr, fence, hmax, trace, backup, fallbacks, 0};
+  hipLaunchKernelGGL(chain64_coop_kernel, dim3((unsigned)wgs), dim3(LTHREADS), CHAIN_LDS_BYTES, stream, g);
   CAP_HIP(hipGetLastError());
+  if (backup) {
+    // the recovery launch: two workgroups that return at once unless a workgroup of the launch above gave up (ctr[3] == 1)
+    g.recover = 1; g.trace = nullptr;
+    hipLaunchKernelGGL(chain64_coop_kernel, dim3(2), dim3(LTHREADS), CHAIN_LDS_BYTES, stream, g);
+    CAP_HIP(hipGetLastError());
+  }
   return CAP_OK;
 }
 

@@ -460,11 +460,13 @@ static int g_bf16_dbg = 0;              // timing surgery (CAP_EXPERIMENTS build
 
 template <int SCHED, int DBG, int PFI = 0>
 int launch_bf16_v2_t(const Bf2Args& g, unsigned grid, hipStream_t s) {
-  static bool attr_set = false;
+  static bool attr_set[16] = {};                            // per device: the attribute belongs to the device's copy of the function
   constexpr int LDS_BYTES = 3 * V2_STAGE + 1024;            // ring + the dummy slot of the C prefetch
-  if (!attr_set) {
+  int dev = 0;
+  CAP_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16 || !attr_set[dev]) {
     CAP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_tn_v2_kernel<SCHED, DBG, PFI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_set = true;
+    if (dev >= 0 && dev < 16) attr_set[dev] = true;
   }
   hipLaunchKernelGGL((bf16_tn_v2_kernel<SCHED, DBG, PFI>), dim3(grid), dim3(512), LDS_BYTES, s, g);
   CAP_HIP(hipGetLastError());
@@ -562,6 +564,7 @@ struct cap_mpchol_plan {
   // 64-steps, inverse merges: <= 15 workgroups of 84 KiB LDS each) on a stream masked to exactly those CUs - they start at once and
   // never share a SIMD with bf16-MFMA waves (measured under contention: 91 us per fused step against 30 us alone, 88 of a 198 ms factor)
   int reserve; hipStream_t s_bulk, s_chain; hipEvent_t ev_user, ev_bulk_done, ev_ch[2]; bool res_ready;
+  int chain_coop;                   // resident workgroups of the one-launch diagonal-block chain for THIS plan (-1: process default)
   // block-row solve on the bf16 pipe (option "solve3", default on): split operands, see mixed_kernels.h
   int solve3; __bf16* A3[2]; __bf16* B3far; __bf16* B3near;
   hipStream_t s_panel; hipEvent_t ev_rest[2], ev_panel[2], ev_fork, ev_join; bool streams_ready;
@@ -636,6 +639,7 @@ int cap_mpchol_plan_create(cap_mpchol_plan** plan, int64_t n, int64_t nrhs_max) 
   p->split = getenv("CAP_MP_SPLIT") ? atoi(getenv("CAP_MP_SPLIT")) : 1;
   p->solve3 = getenv("CAP_MP_SOLVE3") ? atoi(getenv("CAP_MP_SOLVE3")) : 1;
   p->reserve = getenv("CAP_MP_RESERVE") ? atoi(getenv("CAP_MP_RESERVE")) : 0;
+  p->chain_coop = -1;
   // largest power of two <= min(n, 1024) (>= 128 because n % 128 == 0): the fused diagonal-block chain and the bf16 tile
   // kernel (k % 64, m % 128) need it; the last panel of a non-power-of-two n is a shorter multiple of 128
   while (p->nb > n) p->nb /= 2;
@@ -679,6 +683,7 @@ int cap_mpchol_plan_destroy(cap_mpchol_plan* p) {
 // and the fp64 row solve hide behind the bf16 MFMA update once that is the longer of the two.
 int cap_mpchol_factor(cap_mpchol_plan* p, const double* A, int64_t lda, void* stream) {
   if (!p || !A || lda < p->n) return CAP_ERR_ARG;
+  CapChainScope chain_scope(p->chain_coop);     // this plan's own "chain_coop" for every launch made from this call
   hipStream_t su = cap_stream(stream);
   if (p->reserve <= 0) return mp_factor_impl(p, A, lda, su);
   // reserve mode: the whole factorization runs on the plan's masked streams, forked off / joined into the caller's stream
@@ -974,7 +979,7 @@ int cap_mpchol_set_option(cap_mpchol_plan* p, const char* key, int64_t value) {
     if (value != p->reserve) { mp_release_streams(p); p->reserve = (int)value; }
     return CAP_OK;
   }
-  if (!strcmp(key, "chain_coop")) { if (value < 0 || value > 256) return CAP_ERR_ARG; cap_chain_coop_set((int)value); return CAP_OK; }   // process-wide, see cap_cholinv_set_option
+  if (!strcmp(key, "chain_coop")) { if (value < -1 || value > 256) return CAP_ERR_ARG; p->chain_coop = (int)value; return CAP_OK; }   // per plan, see cap_cholinv_set_option
   if (!strcmp(key, "solve3")) { p->solve3 = value != 0; return CAP_OK; }   // block-row solves on the bf16 pipe with split operands (split schedule)
   // process-wide A/B switches of the bf16 update (see launch_bf16_update): which kernel, chunk length, smallest launch for the new one
   if (!strcmp(key, "update_kernel")) { if (value < 0 || value > 1) return CAP_ERR_ARG; g_bf16_variant = (int)value; return CAP_OK; }

@@ -290,8 +290,10 @@ int cap_cholinv_get_Rinv(cap_cholinv_plan* plan, double* out, int64_t ld, void* 
 /* device pointers to the resident factors (leading dimension returned through *ld).        */
 double* cap_cholinv_R_ptr(cap_cholinv_plan* plan, int64_t* ld);
 double* cap_cholinv_Rinv_ptr(cap_cholinv_plan* plan, int64_t* ld);
-/* host-readable status of the last factor: 0, or 1-based index of the failing pivot; -64: a launch of the one-launch
- * diagonal-block chain (option "chain_coop") never had all its workgroups resident (stream restricted to fewer CUs).
+/* host-readable status of the last factor: 0, or 1-based index of the failing pivot.  A launch of the one-launch
+ * diagonal-block chain (option "chain_coop") whose workgroups were never all resident gives up after ~3 s of polling, and the
+ * recovery launch behind it restores that diagonal block and re-runs it on two workgroups (counted in option
+ * "chain_fallbacks"); -64 is only left if that re-run could not complete either (a stream restricted to fewer than two CUs).
  * Synchronises the stream.                                                                 */
 int cap_cholinv_info(cap_cholinv_plan* plan, void* stream, int64_t* info);
 /* tuning knobs of the GPU schedule: "nb" (panel width), "leaf", "lookahead", "outer" (strip height = K of
@@ -304,12 +306,20 @@ int cap_cholinv_info(cap_cholinv_plan* plan, void* stream, int64_t* info);
  * "inv_overlap" (tree nodes are enqueued as their inputs become final; on), "inv_start_m" (columns left below which the
  * tree starts), "fuse_copy" (only the first strip's rows of A are copied into R, the updates of step 0 read their C input
  * from A; on, bit-identical), "reserve_m" (with "reserve": the CU masks only apply once at most reserve_m columns are left;
- * measured slower, off), "chain_coop" (PROCESS-WIDE: resident workgroups of the one-launch diagonal-block chain - the
+ * measured slower, off), "chain_coop" (PER PLAN since round 5: resident workgroups of the one-launch diagonal-block chain - the
  * whole 64-blocked factor phase of a diagonal block + the inverse levels up to 256 as one launch whose workgroups meet at a
- * counter in device memory, csrc/leaf.hip; 32; 0 = one launch per 64-column step, bit-identical).
+ * counter in device memory, csrc/leaf.hip; process default 32 (CAP_CHAIN_COOP), clamped to what the device holds at once; 0 = one
+ * launch per 64-column step, bit-identical; -1 = back to the process default), get only: "chain_fallbacks" (diagonal blocks of
+ * this process that the recovery launch had to re-run on this device; synchronises).
  * Multi-GPU plans forward to cap_dist_set_option.                                                                         */
 int cap_cholinv_set_option(cap_cholinv_plan* plan, const char* key, int64_t value);
 int64_t cap_cholinv_get_option(cap_cholinv_plan* plan, const char* key);
+/* Diagnostics of the one-launch diagonal-block chain (no counterpart upstream: its base case is one LAPACKE_dpotrf + dtrtri on the
+ * host, policy.h:307-414).  cap_chain_fallbacks: diagonal blocks of this process that the recovery launch restored and re-ran on the
+ * current device because a workgroup gave up waiting for its peers (synchronises the device).  cap_chain_inject_timeouts(count):
+ * TEST HOOK - the next `count` chain launches on the current device give up at their first meeting, so the recovery path runs.   */
+int64_t cap_chain_fallbacks(void);
+int cap_chain_inject_timeouts(int count);
 /* Live measurement of the dominant kernel (trailing-update DSYRK) of the LAST factor call, enabled
  * with cap_cholinv_set_option(plan, "profile", 1): number of launches, their summed duration in ms
  * (HIP events recorded on the stream each launch went to) and summed algorithmic flops

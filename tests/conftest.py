@@ -17,3 +17,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_collection_finish(session):
+    """Register the multi-rank GPU cases of the SELECTED tests so that tests/test_dist.py can run all cases of one rank count
+    inside one torch.distributed.run launch (see the comment there)."""
+    for item in session.items:
+        spec = getattr(getattr(item, "function", None), "_dist_case", None)
+        if spec is None or not hasattr(item, "callspec"):
+            continue
+        mod = sys.modules.get(item.function.__module__)
+        case = spec(**item.callspec.params)
+        if case is not None and mod is not None:
+            mod.register_case(*case)

@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 
 
-def main():
+def parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="index")
     ap.add_argument("--size", dest="n", type=int, default=1024)
@@ -34,9 +34,55 @@ def main():
     ap.add_argument("--hard", type=int, default=0, help="mixed: 1 = an SPD input that is not diagonally dominant")
     ap.add_argument("--k", type=int, default=0, help="summa: inner dimension")
     ap.add_argument("--chunks", type=int, default=0, help="summa: num_chunks")
-    args = ap.parse_args()
+    ap.add_argument("--expect-fail", default="", help="the case must raise an error whose text contains this (refused configurations)")
+    ap.add_argument("--cases", default="", help="JSON file [{\"id\": ..., \"argv\": [...]}, ...]: run them all inside THIS launch (one rendezvous, "
+                                                "one torch import per rank for a whole list of cases); per case CASE-BEGIN / CASE-END lines")
+    return ap
+
+
+def main():
+    args = parser().parse_args()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    if not args.cases:
+        run(args)
+    else:
+        import json
+        import traceback
+        for case in json.load(open(args.cases)):
+            a = parser().parse_args([str(x) for x in case["argv"]])
+            if rank == 0:
+                print("CASE-BEGIN %s" % case["id"], flush=True)
+            try:
+                if a.expect_fail:
+                    try:
+                        run(a)
+                    except BaseException as e:      # (SystemExit from a refused plan included)
+                        if a.expect_fail not in (repr(e) + str(e)):
+                            raise
+                        if rank == 0:
+                            print("REFUSED-OK %s" % a.expect_fail, flush=True)
+                    else:
+                        raise AssertionError("case was expected to be refused (%s) but ran" % a.expect_fail)
+                else:
+                    run(a)
+            except BaseException:
+                # a rank that fails leaves its peers inside a collective: end the whole launch here; the cases that did not run
+                # are re-run one by one by the test module, so every failure is still reported per case
+                sys.stdout.flush()
+                print("CASE-FAIL %s rank %d\n%s" % (case["id"], rank, traceback.format_exc()), flush=True)
+                os._exit(1)
+            if torch.cuda.is_available():
+                torch.cuda.synchronize(); torch.cuda.empty_cache()
+            dist.barrier()
+            if rank == 0:
+                print("CASE-END %s" % case["id"], flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run(args):
     rank, size = dist.get_rank(), dist.get_world_size()
     from oracle import capital_oracle as orc   # checker
     n, nb = args.n, args.nb
@@ -663,8 +709,6 @@ def main():
             assert res < 1e-14, res
             print("DIST-OK world=%d n=%d nb=%d err=%.2e residual=%.2e collectives=%s launches(rank0)=%s" % (size, n, nb, err, res, comm.calls, counts), flush=True)
         close(); comm.close()
-    dist.barrier()
-    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

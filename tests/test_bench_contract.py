@@ -36,3 +36,39 @@ def test_cpu_baseline_leg_returns_a_reported_comparator():
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "cholinv_ref")) and os.path.exists("/opt/conda/bin/mpiexec"):
         assert r["kind"] == "reference" and 1 <= r["cores"] <= (os.cpu_count() or 1)    # largest cube of ranks the host holds / all-cores MKL
         assert all(x["residual"] < 1e-14 for x in r["runs"]) and len(r["runs"]) >= 1
+
+
+def test_gpus_n_without_a_launcher_never_leaves_without_a_json_line():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts its own ranks (bench.self_launch); on a box with fewer GPUs than
+    ranks it must still print ONE JSON line (value null + the reason) and exit non-zero - never a bare usage message."""
+    import json
+    import subprocess
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        return                                           # (a multi-GPU box would really run it: covered by the -m gpu tests)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CAPITAL_BENCH_EMULATE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode != 0 and len(lines) == 1, r.stdout + r.stderr
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and "GPU" in d["error"]
+
+
+def test_self_launch_hands_the_arguments_on(monkeypatch):
+    """The relaunch is `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    <same arguments>` with --n rewritten to --size (torchrun's parser trips over --n)."""
+    b = _bench()
+    seen = {}
+    monkeypatch.setenv("CAPITAL_BENCH_EMULATE", "1")
+    monkeypatch.setattr(b.subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+
+    class A:
+        gpus, steps, warmup, workload = 4, 1, 1, "cholesky"
+    assert b.self_launch(A, ["--gpus", "4", "--n", "4096", "--workload", "cacqr", "--n=512"]) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "4", "--size", "4096", "--workload", "cacqr", "--size=512"]
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

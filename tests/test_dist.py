@@ -31,6 +31,86 @@ def _launch(nproc, mode, n, nb, port, extra=()):
     return r
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# One launch per rank count.  A torch.distributed.run start costs 5 - 10 s per rank set on the GPU box (python + torch import per
+# rank, rendezvous) - two thirds of the suite's wall time in round 4 - while a case itself runs for a second or two.  Every
+# multi-rank GPU case of this module is therefore registered at collection time (tests/conftest.py, only the SELECTED tests) and the
+# first test of a rank count runs ALL registered cases of that count inside one launch (tests/dist_worker.py --cases); the others
+# read their own segment of that output.  A case that fails ends its launch (a failed rank leaves its peers inside a collective);
+# the cases behind it are then run one launch each, so every test still reports its own result.  CAPITAL_TEST_NOBATCH=1 = one
+# launch per test as before.
+_REGISTERED = {}          # nproc -> {case id: argv}
+_RESULTS = {}             # case id -> result
+
+
+class _Result:
+    def __init__(self, returncode, stdout, stderr=""):
+        self.returncode, self.stdout, self.stderr = returncode, stdout, stderr
+
+
+def _argv(mode, n, nb, extra):
+    return ["--mode", mode, "--size", str(n), "--nb", str(nb)] + [str(x) for x in extra]
+
+
+def _case_id(nproc, mode, n, nb, extra):
+    return "p%d %s" % (nproc, " ".join(_argv(mode, n, nb, extra)))
+
+
+def register_case(nproc, mode, n, nb, extra=()):
+    _REGISTERED.setdefault(int(nproc), {})[_case_id(nproc, mode, n, nb, extra)] = _argv(mode, n, nb, extra)
+
+
+def _run_batch(nproc):
+    import json
+    import tempfile
+    todo = [(cid, argv) for cid, argv in _REGISTERED.get(nproc, {}).items() if cid not in _RESULTS]
+    if not todo:
+        return
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump([{"id": cid, "argv": argv} for cid, argv in todo], f)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + nproc), os.path.join(ROOT, "tests", "dist_worker.py"), "--cases", f.name]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=120 + 60 * len(todo), env=env)
+        out, err, rc = r.stdout, r.stderr, r.returncode
+    except subprocess.TimeoutExpired as e:
+        out = (e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or "")
+        err = "batch launch timed out"; rc = -9
+    finally:
+        os.unlink(f.name)
+    seg, cur = {}, None
+    for line in out.splitlines():
+        if line.startswith("CASE-BEGIN "):
+            cur = line[len("CASE-BEGIN "):]; seg[cur] = {"lines": [], "ended": False}
+        elif line.startswith("CASE-END ") and cur is not None:
+            seg[cur]["ended"] = True
+        elif cur is not None:
+            seg[cur]["lines"].append(line)
+    for cid, _ in todo:
+        if cid in seg and seg[cid]["ended"]:
+            _RESULTS[cid] = _Result(0, "\n".join(seg[cid]["lines"]))
+        elif cid in seg:                      # the case the launch died in
+            _RESULTS[cid] = _Result(rc or 1, "\n".join(seg[cid]["lines"]), err[-3000:])
+            try:
+                d = os.path.join(ROOT, "gpurun_out"); os.makedirs(d, exist_ok=True)
+                with open(os.path.join(d, "dist_fail_batch_p%d.log" % nproc), "w") as g:
+                    g.write(" ".join(cmd) + "\n---- stdout\n" + out + "\n---- stderr\n" + err)
+            except OSError:
+                pass
+        # (cases behind a failed one: no entry - run alone on demand)
+
+
+def _case(nproc, mode, n, nb, extra=(), port=29700):
+    cid = _case_id(nproc, mode, n, nb, extra)
+    if os.environ.get("CAPITAL_TEST_NOBATCH") != "1" and cid in _REGISTERED.get(int(nproc), {}):
+        if cid not in _RESULTS:
+            _run_batch(int(nproc))
+        if cid in _RESULTS:
+            return _RESULTS[cid]
+    return _launch(nproc, mode, n, nb, port + int(nproc), extra)
+
+
 @pytest.mark.parametrize("nproc,n,nb", [(2, 1024, 128), (3, 1000, 100), (2, 640, 256)])
 def test_block_cyclic_index_logic_gloo(nproc, n, nb):
     r = _launch(nproc, "index", n, nb, 29611 + nproc)
@@ -82,7 +162,7 @@ def test_index_helpers_match_library_when_built():
 @pytest.mark.parametrize("nproc,n,nb", [(1, 1024, 128), (2, 1024, 128), (4, 2048, 128), (3, 1536, 256), (2, 2048, 512),
                                         (8, 8192, 512)])   # the driver's 8-GPU shape: P = 8, nb = 512 (2 block columns per rank)
 def test_multirank_schedule_on_one_gpu(nproc, n, nb):
-    r = _launch(nproc, "gpu", n, nb, 29621 + nproc)
+    r = _case(nproc, "gpu", n, nb)
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "DIST-OK" in r.stdout, r.stdout[-2000:]
 
@@ -103,7 +183,7 @@ def test_multirank_schedule_on_one_gpu(nproc, n, nb):
     (4, 4096, 128, ("--ipc", 1, "--jitter", 200)),
 ])
 def test_multirank_schedule_variants(nproc, n, nb, extra):
-    r = _launch(nproc, "gpu", n, nb, 29671 + nproc, extra)
+    r = _case(nproc, "gpu", n, nb, extra)
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "DIST-OK" in r.stdout, r.stdout[-2000:]
 
@@ -114,7 +194,7 @@ def test_multirank_schedule_under_random_stream_delays(nproc, n, nb, jitter):
     """Event-edge stress: every launch group of the four streams is preceded by a spin kernel of random length (different
     per rank), and the host-staged collectives only wait for their own stream - a missing dependency between the panel /
     msg / comm / main streams changes R."""
-    r = _launch(nproc, "gpu", n, nb, 29681 + nproc, ("--jitter", jitter))
+    r = _case(nproc, "gpu", n, nb, ("--jitter", jitter))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "DIST-OK" in r.stdout, r.stdout[-2000:]
 
@@ -135,7 +215,7 @@ def test_multirank_schedule_under_random_stream_delays(nproc, n, nb, jitter):
     (2, 4096, 128, ("--ci", 1)), (8, 8192, 512, ("--ci", 0, "--safe", 1)),
 ])
 def test_distributed_inverse_matches_oracle(nproc, n, nb, extra):
-    r = _launch(nproc, "gpu", n, nb, 29761 + nproc, extra)
+    r = _case(nproc, "gpu", n, nb, extra)
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "DIST-OK" in r.stdout and "DISTINV-OK" in r.stdout, r.stdout[-2000:]
 
@@ -145,7 +225,7 @@ def test_distributed_inverse_matches_oracle(nproc, n, nb, extra):
 def test_distributed_factors_match_the_8rank_reference_dumps(name):
     """The REAL reference on 8 MPI ranks (2 x 2 x 2 grid, element-cyclic) and this library on 8 ranks (1 x 8 block columns):
     same input, same knobs -> the gathered R and R^-1 agree, including which part of R^-1 stays empty."""
-    r = _launch(8, "gpu", 128, 128, 29781, ("--golden", name))
+    r = _case(8, "gpu", 128, 128, ("--golden", name))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "DIST-OK" in r.stdout and "DISTINV-OK" in r.stdout and "golden=ok" in r.stdout, r.stdout[-2000:]
 
@@ -168,10 +248,10 @@ def test_2d_block_cyclic_schedule_on_one_gpu(nproc, pr, n, nb):
     distributed probe against the oracle; row / column communicators are host-staged gloo groups."""
     if nproc // pr % pr:
         # not a supported grid: the plan must refuse it (status, no hang)
-        r = _launch(nproc, "gpu2d", n, nb, 29741 + nproc + pr, ("--pr", pr))
-        assert r.returncode != 0 and "cap_dist2d_plan_create" in (r.stdout + r.stderr)
+        r = _case(nproc, "gpu2d", n, nb, ("--pr", pr, "--expect-fail", "cap_dist2d_plan_create"))
+        assert r.returncode == 0 and "REFUSED-OK" in r.stdout, (r.stdout[-3000:] + r.stderr[-3000:])
         return
-    r = _launch(nproc, "gpu2d", n, nb, 29741 + nproc + pr, ("--pr", pr))
+    r = _case(nproc, "gpu2d", n, nb, ("--pr", pr))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "DIST2D-OK" in r.stdout, r.stdout[-2000:]
 
@@ -195,7 +275,7 @@ def test_2d_block_cyclic_schedule_on_one_gpu(nproc, pr, n, nb):
 def test_2d_block_cyclic_schedule_options(nproc, pr, n, nb, extra):
     """The Pr x Pc plan at parity with the 1 x P plan: strips of two block rows (K = 2 nb updates), look-ahead depth 2, safe mode,
     R^-1 (complete_inv = 0 / 1) streamed with the sweep - against the oracle."""
-    r = _launch(nproc, "gpu2d", n, nb, 29901 + nproc + pr, ("--pr", pr) + tuple(extra))
+    r = _case(nproc, "gpu2d", n, nb, ("--pr", pr) + tuple(extra))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "DIST2D-OK" in r.stdout, r.stdout[-2000:]
     if "--ci" in extra:
@@ -211,7 +291,7 @@ def test_distributed_mixed_precision_solve(nproc, n, nb, hard):
     against the one-rank factor of the same arithmetic (fp32 rounding level); hard = an input that is not diagonally dominant."""
     if hard and nproc not in (2, 3, 4):
         pytest.skip("the non-dominant input is run on three grids")
-    r = _launch(nproc, "mixed", n, nb, 29801 + nproc + 20 * hard, ("--hard", hard))
+    r = _case(nproc, "mixed", n, nb, ("--hard", hard))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "DMP-OK" in r.stdout, r.stdout[-2000:]
 
@@ -302,48 +382,49 @@ def test_single_rank_dist_path_matches_single_gpu_plan():
 @pytest.mark.parametrize("nproc,m,n", [(2, 4096, 64), (4, 10000, 48), (3, 6000, 128)])
 def test_multirank_cacqr_on_one_gpu(nproc, m, n):
     """CholeskyQR2 1D: row-cyclic pieces on several ranks, Gram all-reduce through the (host-staged) communicator."""
-    r = _launch(nproc, "cacqr", m, n, 29641 + nproc)
+    r = _case(nproc, "cacqr", m, n)
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "CACQR-OK" in r.stdout, r.stdout[-2000:]
 
 
-@pytest.mark.gpu
-def test_bench_multi_gpu_code_path_emulated():
-    """bench.py --gpus 2 end to end (rank bootstrap, timing reduce, JSON) with both ranks on cuda:0 (gloo + host-staged
-    collectives instead of RCCL); the numbers are meaningless, the contract fields are checked."""
+def _bench_self_launched(nproc, extra, timeout=900):
+    """`python bench.py --gpus N ...` WITHOUT a launcher: bench.py starts its own N ranks (torch.distributed.run, free port) and relays
+    rank 0's JSON line - the form the driver uses.  CAPITAL_BENCH_EMULATE=1: all ranks on cuda:0, gloo + host-staged collectives."""
     import json
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29655", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--size", "4096",
-           "--no-cpu-baseline"]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CAPITAL_BENCH_EMULATE="1", OMP_NUM_THREADS="1")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "1", "--warmup", "1"] + list(extra)
+    env = dict(os.environ, CAPITAL_BENCH_EMULATE="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_self_launch_emulated():
+    """bench.py --gpus 2 end to end with no torchrun around it (rank bootstrap, timing reduce, JSON) - the numbers are meaningless
+    on a shared GPU, the contract fields are checked: both ranks seen by the communicator, the mode ladder, the roofline of rank 0's
+    share of the trailing update, the CPU comparator (the REAL reference, bounded)."""
+    d = _bench_self_launched(2, ("--size", "4096", "--cpu-n", "1024", "--cpu-budget-s", "40"))
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["unit"] == "TFLOP/s" and d["value"] > 0
     assert d["config"]["info"] == 0 and d["dtype"] == "f64" and d["higher_is_better"] is True
+    assert d["config"]["n_ranks_seen"] == 2 and set(d["config"]["modes"]) == {"safe", "overlap", "ipc"}
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["launches"] > 0 and 0 < d["roofline"]["frac"] < 1
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["cores"] >= 1
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nproc,extra,key", [
-    (4, ("--size", "4096", "--nb", "256", "--grid-rows", "2"), "2x2"),                       # the Pr x Pc plan through bench.py
-    (2, ("--size", "2048", "--nb", "256", "--workload", "mixed"), "mixed"),                   # config 5's method on P ranks
-    (2, ("--size", "4096", "--nb", "256", "--dist-mode", "auto", "--exchange", "rccl"), "auto"),   # safe, overlap and ipc modes in turn
-    (4, ("--size", "4096", "--nb", "256"), "layouts"),                                       # default --grid-rows auto: 1 x 4 modes, then 2 x 2
-    (2, ("--workload", "cacqr", "--qr-rows", "8192", "--qr-cols", "64"), "cacqr"),            # CholeskyQR2 under the polled watchdog
+    (4, ("--size", "4096", "--nb", "256", "--grid-rows", "2", "--no-cpu-baseline"), "2x2"),             # the Pr x Pc plan through bench.py
+    (2, ("--size", "2048", "--nb", "256", "--workload", "mixed", "--cpu-n", "1024", "--cpu-budget-s", "40"), "mixed"),   # config 5's method on P ranks
+    (2, ("--size", "4096", "--nb", "256", "--dist-mode", "auto", "--exchange", "rccl", "--no-cpu-baseline"), "auto"),   # safe, overlap and ipc modes in turn
+    (4, ("--size", "4096", "--nb", "256", "--no-cpu-baseline"), "layouts"),                             # default --grid-rows auto: 1 x 4 modes, then 2 x 2
+    (2, ("--workload", "cacqr", "--qr-rows", "8192", "--qr-cols", "64"), "cacqr"),                      # CholeskyQR2 under the polled watchdog
 ])
 def test_bench_multi_gpu_variants_emulated(nproc, extra, key):
-    import json
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-           "--master-port", str(29660 + nproc + len(key)), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "1", "--warmup", "1",
-           "--no-cpu-baseline"] + list(extra)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CAPITAL_BENCH_EMULATE="1", OMP_NUM_THREADS="1")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
+    d = _bench_self_launched(nproc, extra)
     assert d["n_gpus"] == nproc and d["value"] > 0 and d["config"]["info"] == 0
     if key == "layouts":
         assert set(d["config"]["modes"]) == {"safe", "overlap", "ipc", "2x2"}, d["config"]["modes"]
@@ -351,6 +432,7 @@ def test_bench_multi_gpu_variants_emulated(nproc, extra, key):
         assert d["config"]["mode"] in d["config"]["modes"] and d["config"]["fallback"] is False
     if key == "cacqr":
         assert d["scaling"] == "weak" and d["config"]["residual"] <= 1e-13
+        assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0
     if key == "2x2":
         assert d["config"]["grid"] == "2x2" and d["config"]["n_ranks_seen"] == 4 and d["config"]["launches_per_factor_rank0"]["collectives"] > 0
     if key == "auto":
@@ -358,6 +440,7 @@ def test_bench_multi_gpu_variants_emulated(nproc, extra, key):
         assert d["config"]["fallback"] is False and d["config"]["mode"] in ("safe", "overlap", "ipc")
     if key == "mixed":
         assert d["config"]["residual"] <= 1e-14 and d["config"]["independent_residual"] <= 1e-13
+        assert "roofline" in d and d["cpu_baseline"]["value"] > 0
 
 
 @pytest.mark.gpu
@@ -367,7 +450,7 @@ def test_summa_gemm_on_process_grids(nproc, c, M, N, K, chunks):
     """matmult::summa GEMM on d x d x c grids sharing one GPU (host-staged row / column / depth communicators): 2 x 2 x 1
     (2D SUMMA, 2 steps), 2 x 2 x 2 (the reference's own 3D cube, one step per layer + depth all-reduce), 3 x 3 x 1, ragged
     cyclic pieces, chunked B broadcasts overlapped with the local GEMMs."""
-    r = _launch(nproc, "summa", M, N, 29701 + nproc + c, ("--c", c, "--k", K, "--chunks", chunks))
+    r = _case(nproc, "summa", M, N, ("--c", c, "--k", K, "--chunks", chunks))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "SUMMA-OK" in r.stdout, r.stdout[-2000:]
 
@@ -378,7 +461,7 @@ def test_summa_gemm_on_process_grids(nproc, c, M, N, K, chunks):
 def test_cacqr_3d_and_tunable_grid(nproc, c, m, n):
     """CholeskyQR2 on c x d x c grids: 2 x 2 x 2 (sweep_3d), 1 x 4 x 1 (degenerates to 1D), 2 x 4 x 2 (sweep_tune), ragged rows;
     256 x 16 on 2 x 2 x 2 and 1 x 8 x 1 are also compared with the real reference's 8-rank dumps (tests/golden/cacqr2_p8_*)."""
-    r = _launch(nproc, "cacqr3d", m, n, 29721 + nproc + c + (m == 256), ("--c", c))
+    r = _case(nproc, "cacqr3d", m, n, ("--c", c))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "CACQR3D-OK" in r.stdout, r.stdout[-2000:]
     if m == 256:
@@ -398,7 +481,7 @@ def test_cacqr_3d_and_tunable_grid(nproc, c, m, n):
 def test_distributed_redistribution_cyclic_block_cyclic(nproc, c, pr, n, nb):
     """Element-cyclic d x d x c pieces <-> Pr x Pc block-cyclic pieces by ONE all-to-all (csrc/redist.hip): both directions
     bit-exact against NumPy index arithmetic; the replicas share the supply (destination t reads layer t mod c)."""
-    r = _launch(nproc, "redist", n, nb, 29821 + nproc + pr, ("--c", c, "--pr", pr))
+    r = _case(nproc, "redist", n, nb, ("--c", c, "--pr", pr))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "REDIST-OK" in r.stdout, r.stdout[-2000:]
 
@@ -410,7 +493,7 @@ def test_reference_layout_end_to_end_against_the_8rank_piece_dumps(mode, pr, nam
     """A caller holding the reference's element-cyclic pieces on 8 ranks (2 x 2 x 2): factor, construct_R, construct_Rinv speak
     that layout end to end (1 x 8 behind cholinv::factor; 2 x 4 through redistribute + cap_dist2d) - every rank's piece is
     compared with the piece the REAL reference left on the same rank."""
-    r = _launch(8, mode, 128, 128, 29841 + pr, ("--golden", name, "--pr", pr))
+    r = _case(8, mode, 128, 128, ("--golden", name, "--pr", pr))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "CYCLIC-OK" in r.stdout and "golden=ok" in r.stdout, r.stdout[-2000:]
 
@@ -421,7 +504,7 @@ def test_reference_layout_end_to_end_against_the_8rank_piece_dumps(mode, pr, nam
     (8, 2, "cyclic2d", 2, 2048, 128, -1), (4, 1, "cyclic2d", 2, 1000, 128, -1), (8, 2, "cyclic", 1, 4096, 512, -1),
 ])
 def test_reference_layout_end_to_end_against_the_oracle(nproc, c, mode, pr, n, nb, ci):
-    r = _launch(nproc, mode, n, nb, 29851 + nproc + pr, ("--c", c, "--pr", pr, "--ci", ci))
+    r = _case(nproc, mode, n, nb, ("--c", c, "--pr", pr, "--ci", ci))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "CYCLIC-OK" in r.stdout, r.stdout[-2000:]
 
@@ -432,7 +515,7 @@ def test_reference_layout_end_to_end_against_the_oracle(nproc, c, mode, pr, n, n
 def test_summa_trmm_and_syrk_overloads_on_process_grids(nproc, c, M, N, K, chunks):
     """matmult::summa's TRMM (Left / Right x NoTrans / Trans, rect and packed-upper T) and SYRK (Trans / NoTrans, beta, rect and
     packed C) overloads on d x d x c grids sharing one GPU, util::transpose partner exchange included - against the oracle."""
-    r = _launch(nproc, "summa_tri", M, N, 29871 + nproc + c, ("--c", c, "--k", K, "--chunks", chunks))
+    r = _case(nproc, "summa_tri", M, N, ("--c", c, "--k", K, "--chunks", chunks))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "SUMMATRI-OK" in r.stdout, r.stdout[-2000:]
 
@@ -443,6 +526,25 @@ def test_reference_recursion_composed_from_the_distributed_operators(name):
     """One level of cholinv's recursion (CI::trsm, CI::tmu, the inverse completion - cholinv.hpp:107-159) composed from
     util::transpose + the distributed TRMM / SYRK on the pieces the REAL reference left on its 8 ranks: R12, the Schur
     complement and Rinv12 come out as the reference's own pieces."""
-    r = _launch(8, "summa_tri", 128, 128, 29891, ("--golden", name))
+    r = _case(8, "summa_tri", 128, 128, ("--golden", name))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "SUMMATRI-OK" in r.stdout and "golden=ok" in r.stdout, r.stdout[-2000:]
+
+
+# case of every batched test, from its parameters (read by tests/conftest.py at collection time)
+test_multirank_schedule_on_one_gpu._dist_case = lambda nproc, n, nb: (nproc, "gpu", n, nb, ())
+test_multirank_schedule_variants._dist_case = lambda nproc, n, nb, extra: (nproc, "gpu", n, nb, tuple(extra))
+test_multirank_schedule_under_random_stream_delays._dist_case = lambda nproc, n, nb, jitter: (nproc, "gpu", n, nb, ("--jitter", jitter))
+test_distributed_inverse_matches_oracle._dist_case = lambda nproc, n, nb, extra: (nproc, "gpu", n, nb, tuple(extra))
+test_distributed_factors_match_the_8rank_reference_dumps._dist_case = lambda name: (8, "gpu", 128, 128, ("--golden", name))
+test_2d_block_cyclic_schedule_options._dist_case = lambda nproc, pr, n, nb, extra: (nproc, "gpu2d", n, nb, ("--pr", pr) + tuple(extra))
+test_distributed_mixed_precision_solve._dist_case = lambda nproc, n, nb, hard: (nproc, "mixed", n, nb, ("--hard", hard)) if (not hard or nproc in (2, 3, 4)) else None
+test_multirank_cacqr_on_one_gpu._dist_case = lambda nproc, m, n: (nproc, "cacqr", m, n, ())
+test_summa_gemm_on_process_grids._dist_case = lambda nproc, c, M, N, K, chunks: (nproc, "summa", M, N, ("--c", c, "--k", K, "--chunks", chunks))
+test_cacqr_3d_and_tunable_grid._dist_case = lambda nproc, c, m, n: (nproc, "cacqr3d", m, n, ("--c", c))
+test_distributed_redistribution_cyclic_block_cyclic._dist_case = lambda nproc, c, pr, n, nb: (nproc, "redist", n, nb, ("--c", c, "--pr", pr))
+test_reference_layout_end_to_end_against_the_8rank_piece_dumps._dist_case = lambda mode, pr, name: (8, mode, 128, 128, ("--golden", name, "--pr", pr))
+test_reference_layout_end_to_end_against_the_oracle._dist_case = lambda nproc, c, mode, pr, n, nb, ci: (nproc, mode, n, nb, ("--c", c, "--pr", pr, "--ci", ci))
+test_summa_trmm_and_syrk_overloads_on_process_grids._dist_case = lambda nproc, c, M, N, K, chunks: (nproc, "summa_tri", M, N, ("--c", c, "--k", K, "--chunks", chunks))
+test_reference_recursion_composed_from_the_distributed_operators._dist_case = lambda name: (8, "summa_tri", 128, 128, ("--golden", name))
+test_2d_block_cyclic_schedule_on_one_gpu._dist_case = lambda nproc, pr, n, nb: (nproc, "gpu2d", n, nb, ("--pr", pr) + (("--expect-fail", "cap_dist2d_plan_create") if nproc // pr % pr else ()))

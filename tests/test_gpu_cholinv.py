@@ -206,34 +206,21 @@ def test_fused_first_step_copy_is_bitwise_identical():
         assert np.array_equal(outs[-1], outs[-2])
 
 
-def _with_chain(G, fn):
-    """run fn() with the process-wide "chain_coop" switch at G, then put the default back"""
-    from capital_amd import cholinv
-    probe = cholinv.info(-1, 1, -2, 'U'); probe._ensure(128)
-    old = probe.get_option("chain_coop")
-    probe.set_option("chain_coop", G)
-    try:
-        return fn()
-    finally:
-        probe.set_option("chain_coop", old)
-
-
 @pytest.mark.parametrize("n,nb,ci", [(256, 256, 1), (512, 512, 1), (1024, 1024, 1), (3072, 512, -1), (2048, 1024, 0), (4096, 256, 1)])
 def test_one_launch_diagonal_block_chain_is_bitwise_identical(n, nb, ci):
-    """"chain_coop" = G > 1: the factor phase of every diagonal block runs as ONE launch of G resident workgroups that meet at a
-    counter in global memory after every 64-column step (leaf.hip chain64_coop_kernel) instead of one launch per step.  Same blocks,
-    same association order -> R and R^-1 must not differ by one bit, for every G (more workgroups than trailing blocks, fewer,
-    one worker); the counters are left zero, so plans can follow each other on the same slots."""
+    """"chain_coop" = G > 1 (a PER-PLAN option since round 5): the factor phase of every diagonal block runs as ONE launch of G
+    resident workgroups that meet at a counter in global memory after every 64-column step (leaf.hip chain64_coop_kernel) instead of
+    one launch per step.  Same blocks, same association order -> R and R^-1 must not differ by one bit, for every G (more workgroups
+    than trailing blocks, fewer, one worker); the counters are left zero, so plans can follow each other on the same stream's slot."""
     from capital_amd import cholinv
     def run(G):
-        def go():
-            _, pack = _factor(n, ci, 1, -2, opts={"nb": nb})
-            out = [cholinv.construct_R(pack).to_numpy()]
-            if ci >= 0:
-                out.append(cholinv.construct_Rinv(pack).to_numpy())
-            assert pack.last_info() == 0
-            return out
-        return _with_chain(G, go)
+        _, pack = _factor(n, ci, 1, -2, opts={"nb": nb, "chain_coop": G})
+        assert pack.get_option("chain_coop") == G
+        out = [cholinv.construct_R(pack).to_numpy()]
+        if ci >= 0:
+            out.append(cholinv.construct_Rinv(pack).to_numpy())
+        assert pack.last_info() == 0
+        return out
     ref = run(0)
     assert orc.cholesky_residual(orc.symmetric_global(n, True), ref[0]) < RES_TOL
     for G in (2, 3, 7, 32, 200):
@@ -242,34 +229,75 @@ def test_one_launch_diagonal_block_chain_is_bitwise_identical(n, nb, ci):
             assert np.array_equal(x, y), (G, float(np.abs(x - y).max()))
 
 
+def test_chain_workgroup_count_is_a_per_plan_option():
+    """Round 4 kept "chain_coop" in a process global set through a per-plan call: one plan's set_option changed every other plan's
+    schedule.  Now a plan only sees its own value (or the process default), whatever other plans were told."""
+    from capital_amd import cholinv
+    a = cholinv.info(-1, 1, -2, 'U'); a._ensure(256)
+    b = cholinv.info(-1, 1, -2, 'U'); b._ensure(256)
+    default = b.get_option("chain_coop")
+    assert default >= 0
+    a.set_option("chain_coop", 0 if default else 7)
+    assert b.get_option("chain_coop") == default and a.get_option("chain_coop") == (0 if default else 7)
+    a.set_option("chain_coop", -1)                     # back to the process default
+    assert a.get_option("chain_coop") == default
+
+
 def test_one_launch_chain_reports_pivots_and_survives_a_busy_gpu():
     """not-SPD input: the failing pivot's index comes out of the one-launch chain like out of the stepwise one (any block, any
     workgroup count); then 40 factorizations back to back next to a stream that keeps every CU busy with large products - the resident
-    workgroups only ever wait for finite kernels, results stay bit-identical."""
+    workgroups only ever wait for finite kernels, results stay bit-identical to the stepwise chain's."""
     from capital_amd import cholinv
     n = 1024
     for row in (0, 63, 64, 200, 1023):
         a = orc.symmetric_global(n, True); a[row, row] = -5.0
-        def go():
-            _, pack = _factor(n, 1, 1, -2, a=a, opts={"nb": 1024})
-            return pack.last_info()
-        assert _with_chain(0, go) == row + 1
-        assert _with_chain(32, go) == row + 1
-    def stress():
-        side = torch.cuda.Stream()
-        x = torch.randn(8192, 8192, device="cuda", dtype=torch.float32)
-        A, pack = _factor(2048, 1, 1, -2, opts={"nb": 1024})
-        r0 = cholinv.construct_R(pack).to_numpy(); i0 = cholinv.construct_Rinv(pack).to_numpy()
-        with torch.cuda.stream(side):
-            for _ in range(60):
-                y = x @ x
-        for _ in range(40):
-            cholinv.factor(A, pack, None)
-        torch.cuda.synchronize()
-        assert np.array_equal(cholinv.construct_R(pack).to_numpy(), r0)
-        assert np.array_equal(cholinv.construct_Rinv(pack).to_numpy(), i0)
-        del y
-    _with_chain(32, stress)
+        for G in (0, 32):
+            _, pack = _factor(n, 1, 1, -2, a=a, opts={"nb": 1024, "chain_coop": G})
+            assert pack.last_info() == row + 1
+    _, p0 = _factor(2048, 1, 1, -2, opts={"nb": 1024, "chain_coop": 0})          # the stepwise chain: the reference bits
+    r0 = cholinv.construct_R(p0).to_numpy(); i0 = cholinv.construct_Rinv(p0).to_numpy()
+    side = torch.cuda.Stream()
+    x = torch.randn(8192, 8192, device="cuda", dtype=torch.float32)
+    A, pack = _factor(2048, 1, 1, -2, opts={"nb": 1024, "chain_coop": 32})
+    with torch.cuda.stream(side):
+        for _ in range(60):
+            y = x @ x
+    for _ in range(40):
+        cholinv.factor(A, pack, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(cholinv.construct_R(pack).to_numpy(), r0)
+    assert np.array_equal(cholinv.construct_Rinv(pack).to_numpy(), i0)
+    assert pack.last_info() == 0
+    del y
+
+
+@pytest.mark.parametrize("n,nb,ci,count", [(2048, 1024, 1, 1), (2048, 512, -1, 3), (2048, 256, 1, 2), (4096, 512, 0, 8)])
+def test_chain_that_gives_up_is_restored_and_rerun(n, nb, ci, count):
+    """A launch of the one-launch chain whose workgroups are never all resident used to poll for 25 s and leave a half-computed
+    factor with info = -64.  Now every launch saves its diagonal block before it touches it, a workgroup gives up after ~ 3 s (its
+    peers follow at their next poll), and the recovery launch behind it restores the block and re-runs the chain on two workgroups.
+    The test hook makes the next `count` launches give up at their first meeting: same bits as an undisturbed run, info = 0, and
+    the event is counted."""
+    from capital_amd import _lib, cholinv
+    L = _lib.lib()
+    _, p0 = _factor(n, ci, 1, -2, opts={"nb": nb, "chain_coop": 32})
+    ref = [cholinv.construct_R(p0).to_numpy()] + ([cholinv.construct_Rinv(p0).to_numpy()] if ci >= 0 else [])
+    before = p0.get_option("chain_fallbacks")
+    assert before >= 0
+    _lib.check(L.cap_chain_inject_timeouts(count), "cap_chain_inject_timeouts")
+    try:
+        _, p1 = _factor(n, ci, 1, -2, opts={"nb": nb, "chain_coop": 32})
+        assert p1.last_info() == 0
+    finally:
+        _lib.check(L.cap_chain_inject_timeouts(0), "cap_chain_inject_timeouts")       # (never leave a pending injection behind)
+    got = [cholinv.construct_R(p1).to_numpy()] + ([cholinv.construct_Rinv(p1).to_numpy()] if ci >= 0 else [])
+    assert p1.get_option("chain_fallbacks") == before + count
+    for x, y in zip(ref, got):
+        assert np.array_equal(x, y), float(np.abs(x - y).max())
+    # and the slot is clean again: the next factorization runs undisturbed
+    _, p2 = _factor(n, ci, 1, -2, opts={"nb": nb, "chain_coop": 32})
+    assert p2.last_info() == 0 and p2.get_option("chain_fallbacks") == before + count
+    assert np.array_equal(cholinv.construct_R(p2).to_numpy(), ref[0])
 
 
 def test_harder_spd_input():
