@@ -33,6 +33,16 @@ SIGNATURES = {
     "cap_dtrtri_work_size": (i64, [i64]),
     "cap_desc_create": (cint, [C.POINTER(ptr), i64, i64, i64, i64]),
     "cap_desc_create_view": (cint, [C.POINTER(ptr), i64, i64, i64, i64, ptr, i64]),
+    "cap_desc_create_bc": (cint, [C.POINTER(ptr), i64, i64, i64, cint, cint, cint, cint, ptr, i64]),
+    "cap_desc_set_position": (cint, [ptr, i64, i64]),
+    "cap_desc_import_host_global": (cint, [ptr, ptr, i64, ptr]),
+    "cap_desc_export_host_global": (cint, [ptr, ptr, i64, ptr]),
+    "cap_cholinv_factor_desc": (cint, [ptr, ptr, ptr]),
+    "cap_cholinv_get_R_desc": (cint, [ptr, ptr, ptr]),
+    "cap_cholinv_get_Rinv_desc": (cint, [ptr, ptr, ptr]),
+    "cap_dist2d_factor_desc": (cint, [ptr, ptr, ptr]),
+    "cap_dist2d_get_R_desc": (cint, [ptr, ptr, ptr]),
+    "cap_dist2d_get_Rinv_desc": (cint, [ptr, ptr, ptr]),
     "cap_desc_destroy": (cint, [ptr]),
     "cap_desc_data": (ptr, [ptr]),
     "cap_desc_get": (i64, [ptr, cint]),

@@ -1244,6 +1244,34 @@ double* cap_cholinv_Rinv_ptr(cap_cholinv_plan* p, int64_t* ld) {
   return p->Rinv;
 }
 
+// ---- the same three calls on descriptors: cholinv::factor(const Matrix& A, ...), construct_R / construct_Rinv -> matrix (cholinv.h:46-53)
+// The descriptor must describe exactly the piece the plan works on; anything else is CAP_ERR_ARG (never a silent reinterpretation):
+//   single-GPU plan              any descriptor whose local piece is the whole n x n matrix (1 x 1 grid of either kind)
+//   multi-rank plan (1 x P)      block-cyclic kind, Pr = 1, Pc = P, pc = my rank, nb = the plan's block width
+//   multi-rank plan, "cyclic_c"  element-cyclic kind on the d x d grid (upstream's own layout)
+static int desc_matches_plan(cap_cholinv_plan* p, const cap_desc* d) {
+  if (!p || !d) return CAP_ERR_ARG;
+  if (cap_desc_get(d, 0) != p->n || cap_desc_get(d, 1) != p->n) return CAP_ERR_ARG;
+  const int64_t kind = cap_desc_get(d, 9), px = cap_desc_get(d, 6), py = cap_desc_get(d, 7);
+  if (!p->dist) return (px == 1 && py == 1) ? CAP_OK : CAP_ERR_ARG;
+  if (p->redist) return (kind == 0 && px == py && cap_desc_get(d, 3) == cap_redist_get(p->redist, 0)) ? CAP_OK : CAP_ERR_ARG;
+  if (kind != 1 || py != 1 || px != cap_comm_size(p->comm) || cap_desc_get(d, 11) != cap_comm_rank(p->comm)) return CAP_ERR_ARG;
+  if (cap_desc_get(d, 10) != cap_dist_get_option(p->dist, "nb") || cap_desc_get(d, 2) != cap_dist_local_cols(p->dist)) return CAP_ERR_ARG;
+  return CAP_OK;
+}
+int cap_cholinv_factor_desc(cap_cholinv_plan* p, const cap_desc* A, void* stream) {
+  CAP_TRY(desc_matches_plan(p, A));
+  return cap_cholinv_factor(p, cap_desc_data(const_cast<cap_desc*>(A)), cap_desc_get(A, 4), stream);
+}
+int cap_cholinv_get_R_desc(cap_cholinv_plan* p, cap_desc* R, void* stream) {
+  CAP_TRY(desc_matches_plan(p, R));
+  return cap_cholinv_get_R(p, cap_desc_data(R), cap_desc_get(R, 4), stream);
+}
+int cap_cholinv_get_Rinv_desc(cap_cholinv_plan* p, cap_desc* Rinv, void* stream) {
+  CAP_TRY(desc_matches_plan(p, Rinv));
+  return cap_cholinv_get_Rinv(p, cap_desc_data(Rinv), cap_desc_get(Rinv, 4), stream);
+}
+
 int cap_cholinv_info(cap_cholinv_plan* p, void* stream, int64_t* info) {
   if (!p || !info) return CAP_ERR_ARG;
   if (p->dist) return cap_dist_info(p->dist, stream, info);

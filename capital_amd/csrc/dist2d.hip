@@ -724,6 +724,27 @@ int cap_dist2d_get_Rinv(cap_dist2d_plan* d, double* out, int64_t ldo, void* stre
   return CAP_OK;
 }
 
+// ---- descriptor forms (block-cyclic kind of cap_desc: nb, Pr x Pc, my position) - the layout is checked, not assumed
+static int desc_matches_plan2d(const cap_dist2d_plan* d, const cap_desc* m) {
+  if (!d || !m) return CAP_ERR_ARG;
+  if (cap_desc_get(m, 9) != 1 || cap_desc_get(m, 0) != d->n || cap_desc_get(m, 1) != d->n || cap_desc_get(m, 10) != d->nb) return CAP_ERR_ARG;
+  if (cap_desc_get(m, 7) != d->Pr || cap_desc_get(m, 6) != d->Pc || cap_desc_get(m, 12) != d->pr || cap_desc_get(m, 11) != d->pc) return CAP_ERR_ARG;
+  if (cap_desc_get(m, 3) != d->lr_valid || cap_desc_get(m, 2) != d->lc_valid) return CAP_ERR_ARG;
+  return CAP_OK;
+}
+int cap_dist2d_factor_desc(cap_dist2d_plan* d, const cap_desc* A, void* stream) {
+  CAP_TRY(desc_matches_plan2d(d, A));
+  return cap_dist2d_factor(d, cap_desc_data(const_cast<cap_desc*>(A)), cap_desc_get(A, 4), stream);
+}
+int cap_dist2d_get_R_desc(cap_dist2d_plan* d, cap_desc* R, void* stream) {
+  CAP_TRY(desc_matches_plan2d(d, R));
+  return cap_dist2d_get_R(d, cap_desc_data(R), cap_desc_get(R, 4), stream);
+}
+int cap_dist2d_get_Rinv_desc(cap_dist2d_plan* d, cap_desc* Rinv, void* stream) {
+  CAP_TRY(desc_matches_plan2d(d, Rinv));
+  return cap_dist2d_get_Rinv(d, cap_desc_data(Rinv), cap_desc_get(Rinv, 4), stream);
+}
+
 int cap_dist2d_set_option(cap_dist2d_plan* d, const char* key, int64_t value) {
   if (!d || !key) return CAP_ERR_ARG;
   if (!strcmp(key, "occ1_m")) { if (value < 0) return CAP_ERR_ARG; d->occ1_m = value; return CAP_OK; }

@@ -112,11 +112,29 @@ typedef struct cap_desc cap_desc;
 int cap_desc_create(cap_desc** desc, int64_t global_cols, int64_t global_rows, int64_t grid_x, int64_t grid_y);
 int cap_desc_create_view(cap_desc** desc, int64_t global_cols, int64_t global_rows, int64_t grid_x, int64_t grid_y,
                          double* device_data, int64_t ld);
+/* BLOCK-CYCLIC kind (north_star's "2D block-cyclic matrix descriptor"; upstream has only the element-cyclic map, matrix.hpp:8-11): nb x nb
+ * blocks, block (I, J) on process (I mod Pr, J mod Pc) as local block (I div Pr, J div Pc).  The descriptor is the piece of process
+ * (pr, pc): the VALID local rows x columns, compact, column-major - what cap_dist2d_factor / cap_dist2d_get_R take, and with Pr = 1 the
+ * block columns of a multi-rank cap_cholinv_plan / cap_dist_plan.  device_data = NULL: allocated, zero-filled and owned; otherwise the
+ * injection constructor (matrix.hpp:52-74) with leading dimension ld.  An empty piece (more processes than blocks) is valid.       */
+int cap_desc_create_bc(cap_desc** desc, int64_t global_cols, int64_t global_rows, int64_t nb, int Pr, int Pc, int pr, int pc,
+                       double* device_data, int64_t ld);
+/* element-cyclic descriptors do not store their grid position (upstream passes (x, y) to the generators again, matrix.h:65-68);
+ * the GLOBAL import / export below need it.                                                                                      */
+int cap_desc_set_position(cap_desc* desc, int64_t x, int64_t y);
 int cap_desc_destroy(cap_desc* desc);
 double* cap_desc_data(cap_desc* desc);
 int64_t cap_desc_get(const cap_desc* desc, int field);
 int cap_desc_import_host(cap_desc* desc, const double* host, int64_t ld_host, void* stream);
 int cap_desc_export_host(cap_desc* desc, double* host, int64_t ld_host, void* stream);
+/* The caller holds the GLOBAL matrix in host memory (column-major, ld_host >= global rows: upstream's matrix<> on one rank, or what
+ * a host application hands to a distributed solver): import picks this process's blocks (block-cyclic kind) or elements
+ * (element-cyclic kind with cap_desc_set_position) out of it, export writes them back to their global places and touches nothing
+ * else - every rank exporting into its own zero-filled copy and summing the copies assembles the global result.  Through the same
+ * two pinned 64 MiB buffers: host threads pack / unpack one range of local columns while the previous one is on the PCIe link.
+ * cap_desc_get adds: 9 kind (0 element-cyclic, 1 block-cyclic), 10 nb, 11 my grid column (pc / x; -1 unknown), 12 my grid row.  */
+int cap_desc_import_host_global(cap_desc* desc, const double* host_global, int64_t ld_host, void* stream);
+int cap_desc_export_host_global(cap_desc* desc, double* host_global, int64_t ld_host, void* stream);
 
 /* rect::_distribute_symmetric - structure.hpp:68-103.  Fills the local element-cyclic piece
  * (grid position x,y of a d x d grid) of the N x N SPD test matrix directly on the GPU:
@@ -287,6 +305,13 @@ int cap_cholinv_factor(cap_cholinv_plan* plan, const double* A, int64_t lda, voi
  * caller rect buffer (strictly lower part zero-filled).                                    */
 int cap_cholinv_get_R(cap_cholinv_plan* plan, double* out, int64_t ld, void* stream);
 int cap_cholinv_get_Rinv(cap_cholinv_plan* plan, double* out, int64_t ld, void* stream);
+/* The same three calls on descriptors - cholinv::factor(const Matrix& A, info&, Topo&&) and construct_R / construct_Rinv returning a
+ * matrix (cholinv.h:46-53).  The descriptor must describe exactly the piece the plan works on, else CAP_ERR_ARG: a single-GPU plan
+ * takes a 1 x 1-grid descriptor of the whole matrix; a multi-rank plan takes the block-cyclic kind with Pr = 1, Pc = P, pc = my rank
+ * and the plan's nb (cap_desc_create_bc), or - option "cyclic_c" - upstream's element-cyclic kind on the d x d grid.               */
+int cap_cholinv_factor_desc(cap_cholinv_plan* plan, const cap_desc* A, void* stream);
+int cap_cholinv_get_R_desc(cap_cholinv_plan* plan, cap_desc* R, void* stream);
+int cap_cholinv_get_Rinv_desc(cap_cholinv_plan* plan, cap_desc* Rinv, void* stream);
 /* device pointers to the resident factors (leading dimension returned through *ld).        */
 double* cap_cholinv_R_ptr(cap_cholinv_plan* plan, int64_t* ld);
 double* cap_cholinv_Rinv_ptr(cap_cholinv_plan* plan, int64_t* ld);
@@ -410,6 +435,12 @@ int cap_dist2d_info(cap_dist2d_plan* plan, void* stream, int64_t* info);
  * columns, the strip pieces along the process rows) as IPC peer copies on SDMA engines with two 8-byte all-reduces each as barriers,
  * like the 1 x P plan's strip exchange (cap_dist2d_get(plan, 12) tells whether the peers could be mapped).                  */
 int cap_dist2d_set_option(cap_dist2d_plan* plan, const char* key, int64_t value);
+/* descriptor forms: A / R / Rinv are block-cyclic descriptors (cap_desc_create_bc) of THIS plan's n, nb, Pr x Pc and position -
+ * checked, CAP_ERR_ARG otherwise.  Host matrix -> pieces -> factor -> host R: cap_desc_import_host_global, cap_dist2d_factor_desc,
+ * cap_dist2d_get_R_desc, cap_desc_export_host_global.                                                                            */
+int cap_dist2d_factor_desc(cap_dist2d_plan* plan, const cap_desc* A, void* stream);
+int cap_dist2d_get_R_desc(cap_dist2d_plan* plan, cap_desc* R, void* stream);
+int cap_dist2d_get_Rinv_desc(cap_dist2d_plan* plan, cap_desc* Rinv, void* stream);
 int cap_dist2d_get_Rinv(cap_dist2d_plan* plan, double* out, int64_t ld, void* stream);
 double* cap_dist2d_Rinv_ptr(cap_dist2d_plan* plan, int64_t* ld);
 int64_t cap_bc2d_local_extent(int64_t n, int64_t nb, int Pr, int Pc, int pr, int pc, int which);   /* which: 0 rows, 1 columns */

@@ -45,6 +45,15 @@ def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
     rank = dist.get_rank()
+    # every rank computes on ONE host thread (8 - 16 ranks share the box) except rank 0, which runs the oracle checks of all
+    # cases: its BLAS pool keeps the size the launcher's OMP_NUM_THREADS gave it
+    torch.set_num_threads(1)
+    if rank != 0:
+        try:
+            from threadpoolctl import threadpool_limits
+            threadpool_limits(limits=1)
+        except Exception:
+            pass
     if not args.cases:
         run(args)
     else:
@@ -179,6 +188,100 @@ def run(args):
             assert probe < 1e-13, probe
             print("DIST2D-OK world=%d grid=%dx%d n=%d nb=%d err=%.2e residual=%.2e probe=%.2e launches(rank0)=%s" % (size, ctx.Pr, ctx.Pc, n, nb, err, res, probe, counts), flush=True)
         ctx.close(); row.close(); col.close(); comm.close()
+    elif args.mode == "desc":
+        # The drop-in boundary for a caller with a HOST matrix (north_star: "2D block-cyclic matrix descriptor ... with pinned host
+        # staging"; matrix.h:9-97, injection ctor matrix.hpp:52-74): every rank holds the global matrix in host memory, builds the
+        # block-cyclic descriptor of its own piece, imports it through the pinned double buffer, factors through the descriptor
+        # entry points (--pr 1: cap_cholinv_factor_desc on a multi-rank plan = 1 x P block columns; --pr > 1: cap_dist2d_factor_desc
+        # on the Pr x Pc grid), gets R (and R^-1) back as descriptors and exports them into a zero-filled global host matrix; the
+        # sum over the ranks is the global factor, compared with the oracle.
+        torch.cuda.set_device(0)
+        import ctypes as C
+        from capital_amd import _lib, dist_cholesky as dc
+        from tests.host_staged import HostStagedComm, grid_groups
+        L = _lib.lib()
+        comm = HostStagedComm()
+        Pr = args.pr; Pc = size // Pr
+        pr, pc = rank // Pc, rank % Pc
+        a = orc.symmetric_global(n, True)
+        host = np.asfortranarray(a)                                   # column-major global matrix, ld = n
+        s = torch.cuda.current_stream().cuda_stream
+
+        def bc_desc():
+            h = C.c_void_p()
+            _lib.check(L.cap_desc_create_bc(C.byref(h), n, n, nb, Pr, Pc, pr, pc, None, 0), "cap_desc_create_bc")
+            return h
+        dA, dR, dRi = bc_desc(), bc_desc(), bc_desc()
+        rows = dc.global_index_2d(n, nb, Pr, pr); cols = dc.global_index_2d(n, nb, Pc, pc)
+        assert (L.cap_desc_get(dA, 3), L.cap_desc_get(dA, 2)) == (rows.size, cols.size)
+        assert [L.cap_desc_get(dA, f) for f in (9, 10, 6, 7, 11, 12)] == [1, nb, Pc, Pr, pc, pr]
+        _lib.check(L.cap_desc_import_host_global(dA, host.ctypes.data, n, s), "cap_desc_import_host_global")
+        # the piece on the device is what the 2D generator makes on the device
+        if rows.size and cols.size:
+            ld = L.cap_desc_get(dA, 4)
+            got = torch.empty(cols.size, ld, dtype=torch.float64, device="cuda")
+            torch.cuda.current_stream().synchronize()
+            from tests.host_staged import _memcpy
+            _memcpy(got.data_ptr(), L.cap_desc_data(dA), cols.size * ld * 8, 3)          # device -> device
+            assert np.array_equal(got[:, : rows.size].cpu().numpy().T, a[np.ix_(rows, cols)]), "block-cyclic import of the global host matrix"
+        if Pr == 1:
+            plan = C.c_void_p()
+            _lib.check(L.cap_cholinv_plan_create(C.byref(plan), n, args.ci, args.split, -2, b"U", comm.handle), "cap_cholinv_plan_create")
+            _lib.check(L.cap_cholinv_set_option(plan, b"nb", nb), "nb")
+            # a descriptor of another layout is refused, never reinterpreted
+            wrong = C.c_void_p()
+            _lib.check(L.cap_desc_create_bc(C.byref(wrong), n, n, 2 * nb, 1, Pc, 0, pc, None, 0))
+            if size > 1:
+                assert L.cap_cholinv_factor_desc(plan, wrong, s) == 1, "a descriptor with another block width must be CAP_ERR_ARG"
+            L.cap_desc_destroy(wrong)
+            for rep in range(2):
+                _lib.check(L.cap_cholinv_factor_desc(plan, dA, s), "cap_cholinv_factor_desc")
+            v = C.c_int64(0); L.cap_cholinv_info(plan, s, C.byref(v)); info = v.value
+            _lib.check(L.cap_cholinv_get_R_desc(plan, dR, s), "cap_cholinv_get_R_desc")
+            if args.ci >= 0:
+                _lib.check(L.cap_cholinv_get_Rinv_desc(plan, dRi, s), "cap_cholinv_get_Rinv_desc")
+            close = lambda: L.cap_cholinv_plan_destroy(plan)
+        else:
+            row, col = grid_groups(Pr)
+            plan = C.c_void_p()
+            _lib.check(L.cap_dist2d_plan_create(C.byref(plan), n, nb, comm.handle, Pr, row.handle, col.handle), "cap_dist2d_plan_create")
+            if args.ci >= 0:
+                _lib.check(L.cap_dist2d_set_option(plan, b"complete_inv", args.ci)); _lib.check(L.cap_dist2d_set_option(plan, b"split", args.split))
+            wrong = C.c_void_p()
+            _lib.check(L.cap_desc_create_bc(C.byref(wrong), n, n, nb, Pr, Pc, (pr + 1) % Pr, pc, None, 0))
+            assert L.cap_dist2d_factor_desc(plan, wrong, s) == 1, "a descriptor of another grid position must be CAP_ERR_ARG"
+            L.cap_desc_destroy(wrong)
+            for rep in range(2):
+                _lib.check(L.cap_dist2d_factor_desc(plan, dA, s), "cap_dist2d_factor_desc")
+            v = C.c_int64(0); L.cap_dist2d_info(plan, s, C.byref(v)); info = v.value
+            _lib.check(L.cap_dist2d_get_R_desc(plan, dR, s), "cap_dist2d_get_R_desc")
+            if args.ci >= 0:
+                _lib.check(L.cap_dist2d_get_Rinv_desc(plan, dRi, s), "cap_dist2d_get_Rinv_desc")
+            close = lambda: (L.cap_dist2d_plan_destroy(plan), row.close(), col.close())
+        assert info == 0, info
+        Rh = np.zeros((n, n), order="F"); Rih = np.zeros((n, n), order="F")
+        _lib.check(L.cap_desc_export_host_global(dR, Rh.ctypes.data, n, s), "cap_desc_export_host_global")
+        if args.ci >= 0:
+            _lib.check(L.cap_desc_export_host_global(dRi, Rih.ctypes.data, n, s), "cap_desc_export_host_global")
+        # nothing but my own blocks was written
+        mine = np.zeros((n, n), dtype=bool); mine[np.ix_(rows, cols)] = True
+        assert not Rh[~mine].any()
+        tR = torch.from_numpy(np.ascontiguousarray(Rh)); dist.all_reduce(tR)
+        tRi = torch.from_numpy(np.ascontiguousarray(Rih)); dist.all_reduce(tRi)
+        if rank == 0:
+            R = tR.numpy(); Ri = tRi.numpy()
+            ref = np.linalg.cholesky(a).T
+            err = np.linalg.norm(R - ref) / np.linalg.norm(ref)
+            assert err < 1e-13 and orc.cholesky_residual(a, R) < 1e-14, err
+            assert np.array_equal(np.tril(R, -1), np.zeros_like(R))
+            if args.ci >= 0:
+                r_ref, ri_ref = orc.cholinv(a, args.ci, args.split, -2, 1, 1)
+                assert np.linalg.norm(Ri - ri_ref) / np.linalg.norm(ri_ref) < 1e-12
+                assert np.array_equal(Ri != 0, ri_ref != 0)
+            print("DESC-OK world=%d grid=%dx%d n=%d nb=%d ci=%d err=%.2e" % (size, Pr, Pc, n, nb, args.ci, err), flush=True)
+        for h in (dA, dR, dRi):
+            L.cap_desc_destroy(h)
+        close(); comm.close()
     elif args.mode == "redist":
         # distributed redistribution element-cyclic (d x d x c) <-> block-cyclic (Pr x Pc), csrc/redist.hip: every rank on cuda:0,
         # all-to-all through the host-staged communicator (gloo point-to-point)

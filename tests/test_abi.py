@@ -132,19 +132,71 @@ def test_reference_enum_values_and_topology_maps():
     assert (r["c"], r["d"], r["x"], r["y"], r["z"]) == (1, 8, 0, 5, 0)
 
 
-def test_plain_c_host_compiles_against_the_header(built, tmp_path):
-    """north_star: "host code stays C" - a C (not C++) translation unit includes the header and links the library."""
-    import shutil
+DRIVERS = ("cholinv_driver", "summa_driver", "cacqr_driver", "integration_snippets")
+
+
+def _compile_c(built, name, out):
+    """gcc -std=c99 (C, not C++) of examples/<name>.c against include/capital_amd.h, linked with the library"""
     import subprocess
+    cmd = ["gcc", "-std=c99", "-D_POSIX_C_SOURCE=199309L", "-Wall", "-Werror=implicit-function-declaration", "-Werror=incompatible-pointer-types",
+           "-Werror=int-conversion", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", name + ".c"), "-L" + os.path.dirname(built), "-lcapital_amd", "-L/opt/rocm/lib",
+           "-lamdhip64", "-lm", "-Wl,-rpath," + os.path.dirname(built), "-Wl,-rpath,/opt/rocm/lib", "-o", str(out)]
+    return subprocess.run(cmd, capture_output=True, text=True)
+
+
+@pytest.mark.parametrize("name", DRIVERS)
+def test_plain_c_host_compiles_against_the_header(built, tmp_path, name):
+    """north_star: "host code stays C" - C (not C++) translation units include the header and link the library: the three bench
+    drivers (the C forms of bench/cholesky/cholinv.cpp, bench/matmult/summa_gemm.cpp, bench/qr/cacqr.cpp) and
+    examples/integration_snippets.c, which holds every call INTEGRATION.md shows - wrong arity, a char where an enum is expected or a
+    wrong pointer type is a compile error here, so the document cannot drift from the header again."""
+    import shutil
     if not shutil.which("gcc") or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
         pytest.skip("gcc / ROCm headers not available")
-    exe = tmp_path / "cholinv_driver.bin"
-    cmd = ["gcc", "-std=c99", "-D_POSIX_C_SOURCE=199309L", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "examples", "cholinv_driver.c"), "-L" + os.path.dirname(built), "-lcapital_amd", "-L/opt/rocm/lib",
-           "-lamdhip64", "-lm", "-Wl,-rpath," + os.path.dirname(built), "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    exe = tmp_path / (name + ".bin")
+    r = _compile_c(built, name, exe)
     assert r.returncode == 0, r.stderr
     assert exe.exists()
+
+
+def test_integration_md_snippets_are_the_compiled_ones():
+    """Every cap_* call line inside INTEGRATION.md's C / C++ code blocks of section B appears verbatim (modulo whitespace) in
+    examples/integration_snippets.c - the file the test above compiles."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    src = re.sub(r"\s+", "", open(os.path.join(ROOT, "examples", "integration_snippets.c")).read())
+    sec = md[md.index("## B."):md.index("## C.")]
+    calls = []
+    for block in re.findall(r"```cpp\n(.*?)```", sec, flags=re.S):
+        for stmt in re.findall(r"\bcap_[a-z0-9_]+\s*\([^;]*?\)\s*;", block, flags=re.S):
+            calls.append(stmt)
+    assert len(calls) >= 40, len(calls)
+    missing = [c for c in calls if re.sub(r"\s+", "", c) not in src]
+    assert not missing, "INTEGRATION.md shows calls that are not in the compiled snippet file: %s" % missing
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,argv,expect", [
+    ("cholinv_driver", ("2048", "-1", "1", "-3", "1", "1"), "residual"),
+    ("cholinv_driver", ("1024", "1", "1", "-2", "1", "1"), "residual"),
+    ("summa_driver", ("768", "512", "640", "1", "0", "2", "2", "1"), "trmm"),
+    ("cacqr_driver", ("2", "16384", "128", "1", "1", "1", "1", "0", "0", "0", "0", "1", "1"), "orthogonality"),
+    ("cacqr_driver", ("1", "4096", "256", "1", "1", "1", "1", "0", "0", "0", "0", "1", "1"), "orthogonality"),
+])
+def test_plain_c_drivers_run_on_the_gpu(built, tmp_path, name, argv, expect):
+    """The C drivers (no torch, no Python in the process) run on the GPU and pass their own validation blocks: the residual of
+    test/cholesky/validate.hpp:33-46, the three summa::invoke overloads against the local operators, the CholeskyQR residual and
+    orthogonality of test/qr/validate.hpp:24-51."""
+    import subprocess
+    exe = tmp_path / (name + ".bin")
+    r = _compile_c(built, name, exe)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([str(exe)] + list(argv), capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    assert expect in run.stdout, run.stdout[-2000:]
+    if name == "cholinv_driver":
+        res = float(re.search(r"= ([0-9.eE+-]+)\s*$", run.stdout.strip().splitlines()[-1]).group(1))
+        assert res < 1e-14, run.stdout
 
 
 def test_2d_block_cyclic_index_maps(built):
@@ -200,3 +252,37 @@ def test_redistribution_message_counts_property(built):
                 tot0 += got0; tot1 += got1
         assert tot0 == n * n and tot1 == c * n * n
     assert L.cap_redist_message_elems(64, 16, 6, 1, 1, 0, 0, 0) == -1          # 6 ranks are no d x d x c grid
+
+
+def test_block_cyclic_descriptor_extents(built):
+    """The block-cyclic kind of cap_desc (cap_desc_create_bc; the injection constructor needs no GPU): valid local rows x columns
+    per grid position agree with cap_bc2d_local_extent (what cap_dist2d_* allocate), add up to the global dimensions over the
+    grid, the fields are readable, and a wrong position / leading dimension is refused."""
+    import ctypes as C
+    from capital_amd import _lib
+    L = _lib.lib()
+    fake = C.c_void_p(0x1000)                       # never dereferenced: descriptors of caller-owned buffers do no device work
+    for (gx, gy, nb, Pr, Pc) in [(2048, 2048, 128, 2, 4), (1000, 1000, 128, 2, 2), (2049, 777, 256, 1, 8), (250, 250, 128, 2, 4),
+                                 (65536, 65536, 512, 2, 4), (5, 9, 4, 3, 2)]:
+        tot_r = [0] * Pc; tot_c = [0] * Pr
+        for pr in range(Pr):
+            for pc in range(Pc):
+                d = C.c_void_p()
+                assert L.cap_desc_create_bc(C.byref(d), gx, gy, nb, Pr, Pc, pr, pc, fake, max(gy, 1)) == 0
+                lr, lc = L.cap_desc_get(d, 3), L.cap_desc_get(d, 2)
+                assert lr == L.cap_bc2d_local_extent(gy, nb, Pr, Pc, pr, pc, 0) and lc == L.cap_bc2d_local_extent(gx, nb, Pr, Pc, pr, pc, 1)
+                assert [L.cap_desc_get(d, f) for f in (0, 1, 5, 6, 7, 9, 10, 11, 12)] == [gx, gy, 0, Pc, Pr, 1, nb, pc, pr]
+                tot_r[pc] += lr; tot_c[pr] += lc
+                L.cap_desc_destroy(d)
+        assert all(t == gy for t in tot_r) and all(t == gx for t in tot_c)
+    d = C.c_void_p()
+    assert L.cap_desc_create_bc(C.byref(d), 100, 100, 16, 2, 2, 2, 0, fake, 100) == 1        # pr out of range
+    assert L.cap_desc_create_bc(C.byref(d), 100, 100, 16, 2, 2, 0, 0, fake, 10) == 1         # ld below the local rows
+    assert L.cap_desc_create_bc(C.byref(d), 100, 100, 0, 2, 2, 0, 0, fake, 100) == 1
+    # element-cyclic descriptors learn their position through cap_desc_set_position (needed by the global import / export)
+    assert L.cap_desc_create_view(C.byref(d), 100, 100, 2, 2, fake, 50) == 0
+    assert L.cap_desc_get(d, 9) == 0 and L.cap_desc_get(d, 11) == -1
+    assert L.cap_desc_import_host_global(d, fake, 100, None) == 1                             # position unknown: refused
+    assert L.cap_desc_set_position(d, 1, 0) == 0 and (L.cap_desc_get(d, 11), L.cap_desc_get(d, 12)) == (1, 0)
+    assert L.cap_desc_set_position(d, 2, 0) == 1
+    L.cap_desc_destroy(d)

@@ -13,11 +13,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# BLAS pool size of a worker process: the workers pin themselves to ONE thread (tests/dist_worker.py) except rank 0, whose oracle
+# checks (a NumPy Cholesky and an R^T R product per case - 40 s at n = 8192 on one thread) may use the pool
+_WORKER_THREADS = str(max(1, min(16, (os.cpu_count() or 1) // 2)))
+
+
 def _launch(nproc, mode, n, nb, port, extra=()):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "--mode", mode, "--size", str(n),
            "--nb", str(nb)] + [str(x) for x in extra]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=_WORKER_THREADS)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     if r.returncode != 0:
         # keep the complete output of a failing multi-rank run (the assertion message only shows its tail)
@@ -70,7 +75,7 @@ def _run_batch(nproc):
         json.dump([{"id": cid, "argv": argv} for cid, argv in todo], f)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(29500 + nproc), os.path.join(ROOT, "tests", "dist_worker.py"), "--cases", f.name]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=_WORKER_THREADS)
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=120 + 60 * len(todo), env=env)
         out, err, rc = r.stdout, r.stderr, r.returncode
@@ -531,6 +536,24 @@ def test_reference_recursion_composed_from_the_distributed_operators(name):
     assert "SUMMATRI-OK" in r.stdout and "golden=ok" in r.stdout, r.stdout[-2000:]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,pr,n,nb,ci", [
+    (4, 2, 2048, 128, -1),       # 2 x 2: the round-trip the drop-in boundary promises (host matrix -> pieces -> factor -> host R)
+    (4, 2, 1000, 128, 1),        # ragged n, R^-1 too
+    (8, 2, 2049, 256, 0),        # 2 x 4
+    (4, 1, 2048, 128, 1),        # 1 x 4 behind cap_cholinv_factor_desc (block columns)
+    (3, 1, 1000, 128, -1),
+    (1, 1, 1024, 128, 1),
+    (8, 2, 250, 128, -1),        # fewer blocks than processes: empty pieces
+])
+def test_block_cyclic_descriptor_host_round_trip(nproc, pr, n, nb, ci):
+    """cap_desc_create_bc + cap_desc_import_host_global / export_host_global + the *_desc entry points: a caller with a host matrix
+    reaches the layout the multi-GPU plans run on and gets R / R^-1 back, against the oracle."""
+    r = _case(nproc, "desc", n, nb, ("--pr", pr, "--ci", ci))
+    assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    assert "DESC-OK" in r.stdout, r.stdout[-2000:]
+
+
 # case of every batched test, from its parameters (read by tests/conftest.py at collection time)
 test_multirank_schedule_on_one_gpu._dist_case = lambda nproc, n, nb: (nproc, "gpu", n, nb, ())
 test_multirank_schedule_variants._dist_case = lambda nproc, n, nb, extra: (nproc, "gpu", n, nb, tuple(extra))
@@ -548,3 +571,4 @@ test_reference_layout_end_to_end_against_the_oracle._dist_case = lambda nproc, c
 test_summa_trmm_and_syrk_overloads_on_process_grids._dist_case = lambda nproc, c, M, N, K, chunks: (nproc, "summa_tri", M, N, ("--c", c, "--k", K, "--chunks", chunks))
 test_reference_recursion_composed_from_the_distributed_operators._dist_case = lambda name: (8, "summa_tri", 128, 128, ("--golden", name))
 test_2d_block_cyclic_schedule_on_one_gpu._dist_case = lambda nproc, pr, n, nb: (nproc, "gpu2d", n, nb, ("--pr", pr) + (("--expect-fail", "cap_dist2d_plan_create") if nproc // pr % pr else ()))
+test_block_cyclic_descriptor_host_round_trip._dist_case = lambda nproc, pr, n, nb, ci: (nproc, "desc", n, nb, ("--pr", pr, "--ci", ci))
