@@ -366,9 +366,23 @@ int setup_cyclic(cap_cholinv_plan* p, int c) {
   CAP_TRY(cap_redist_plan_create(&p->redist, p->n, cap_dist_get_option(p->dist, "nb"), p->comm, c, 1));
   p->bc_cols = cap_dist_local_cols(p->dist);
   const size_t bytes = sizeof(double) * (size_t)p->n * (size_t)std::max<int64_t>(p->bc_cols, 1);
-  if (hipMalloc((void**)&p->bcA, bytes) != hipSuccess || hipMalloc((void**)&p->bcOut, bytes) != hipSuccess) {
-    (void)hipGetLastError();
-    return CAP_ERR_ALLOC;       // (the caller's plan stays usable on the block-column layout; destroy frees what was allocated)
+  bool ok = hipMalloc((void**)&p->bcA, bytes) == hipSuccess && hipMalloc((void**)&p->bcOut, bytes) == hipSuccess;
+  if (!ok) (void)hipGetLastError();
+  // every rank must come out of this call with the SAME answer: a rank that alone reported CAP_ERR_ALLOC would stay out of the
+  // redistribution all-to-all of the next factor call while its peers wait in it.  One 8-byte sum over the plan's communicator.
+  double* flag = nullptr;
+  if (hipMalloc((void**)&flag, sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return CAP_ERR_ALLOC; }
+  double h = ok ? 0.0 : 1.0;
+  int st = hipMemcpy(flag, &h, sizeof(double), hipMemcpyHostToDevice) == hipSuccess ? CAP_OK : CAP_ERR_HIP;
+  if (st == CAP_OK) st = cap_comm_allreduce_sum(p->comm, flag, 1, nullptr);
+  if (st == CAP_OK && (hipStreamSynchronize(nullptr) != hipSuccess || hipMemcpy(&h, flag, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)) st = CAP_ERR_HIP;
+  (void)hipFree(flag);
+  if (st != CAP_OK || h != 0.0) {
+    // (the caller's plan stays usable on the block-column layout)
+    if (p->bcA) { (void)hipFree(p->bcA); p->bcA = nullptr; }
+    if (p->bcOut) { (void)hipFree(p->bcOut); p->bcOut = nullptr; }
+    (void)cap_redist_plan_destroy(p->redist); p->redist = nullptr;
+    return st != CAP_OK ? st : CAP_ERR_ALLOC;
   }
   p->cyc_c = c;
   return CAP_OK;

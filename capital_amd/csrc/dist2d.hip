@@ -228,11 +228,7 @@ int ensure_ipc2d(cap_dist2d_plan* d, hipStream_t s) {
   if (d->ipc_ready || d->ipc_failed || d->P == 1) return CAP_OK;
   auto soft = [](hipError_t e) { if (e != hipSuccess) { (void)hipGetLastError(); return false; } return true; };
   const int Pr = d->Pr, Pc = d->Pc;
-  const int64_t scratch = 2 + 16 * (Pr + Pc + 2);
-  if (!d->tok) {
-    if (!soft(hipMalloc((void**)&d->tok, sizeof(double) * scratch)) || !soft(hipMemset(d->tok, 0, sizeof(double) * scratch))) { d->tok = nullptr; return CAP_ERR_ALLOC; }
-  }
-  bool ok = true;
+  bool ok = true;                              // (d->tok: allocated with the plan)
   auto gather_handles = [&](cap_comm* comm, int np, int me, double* const bufs[2], double* scratch_dev, std::vector<hipIpcMemHandle_t>& all) -> int {
     hipIpcMemHandle_t mine[2];
     for (int b = 0; b < 2; b++) ok = ok && soft(hipIpcGetMemHandle(&mine[b], bufs[b]));
@@ -273,6 +269,16 @@ int ensure_ipc2d(cap_dist2d_plan* d, hipStream_t s) {
   if (tot != 0.0 || !ok) {
     for (int r = 0; r < 4; r++) for (int b = 0; b < 2; b++) if (d->peerBt[r][b]) { (void)hipIpcCloseMemHandle(d->peerBt[r][b]); d->peerBt[r][b] = nullptr; }
     for (int r = 0; r < 8; r++) for (int b = 0; b < 2; b++) if (d->peerA[r][b]) { (void)hipIpcCloseMemHandle(d->peerA[r][b]); d->peerA[r][b] = nullptr; }
+    // ... and the copy streams / events open_all created before the failure (dist.hip's ensure_ipc does the same)
+    for (int r = 0; r < 4; r++) {
+      if (d->s_pcol[r]) { (void)hipStreamDestroy(d->s_pcol[r]); d->s_pcol[r] = nullptr; }
+      if (d->ev_pcol[r]) { (void)hipEventDestroy(d->ev_pcol[r]); d->ev_pcol[r] = nullptr; }
+    }
+    for (int r = 0; r < 8; r++) {
+      if (d->s_prow[r]) { (void)hipStreamDestroy(d->s_prow[r]); d->s_prow[r] = nullptr; }
+      if (d->ev_prow[r]) { (void)hipEventDestroy(d->ev_prow[r]); d->ev_prow[r] = nullptr; }
+    }
+    if (d->ev_px) { (void)hipEventDestroy(d->ev_px); d->ev_px = nullptr; }
     d->ipc_failed = true;
     fprintf(stderr, "capital_amd: IPC mapping of the 2D plan's peer buffers failed on %s rank; using the RCCL broadcasts\n", ok ? "another" : "this");
     return CAP_OK;
@@ -408,6 +414,11 @@ int cap_dist2d_plan_create(cap_dist2d_plan** plan, int64_t n, int64_t nb, cap_co
   if (e == hipSuccess) e = hipMalloc((void**)&d->W, sizeof(double) * d->wcap);
   if (e == hipSuccess) e = hipMalloc((void**)&d->info_dev, sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&d->info_red, sizeof(double) * (P + 1));
+  // the token / handle scratch of the IPC operand moves lives with the plan: an allocation that fails is reported HERE, by every
+  // rank's own create call, and never in the middle of ensure_ipc2d's collectives (where the peers would wait for ever)
+  const int64_t tok_elems = 2 + 16 * (Pr + Pc + 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&d->tok, sizeof(double) * tok_elems);
+  if (e == hipSuccess) e = hipMemset(d->tok, 0, sizeof(double) * tok_elems);
   if (e != hipSuccess) { cap_dist2d_plan_destroy(d); return CAP_ERR_ALLOC; }
   *plan = d;
   return CAP_OK;

@@ -609,10 +609,13 @@ int launch_nn_dma(const GemmArgs& g, int grid, hipStream_t stream) {
 
 template <int TAG>
 int launch_tn_dma(GemmArgs g, int grid, hipStream_t stream, int persist_wgs = 0) {
-  // persist_wgs == -1 (the only value still honoured): ask for 96 KiB of LDS so that only ONE workgroup of this launch fits a
-  // CU.  Used for the bulk updates of the chain-bound tail (cholinv.hip, option occ1_m): the bulk update has slack there,
-  // and a CU that runs one bulk workgroup always has room (LDS, VGPRs) for a workgroup of the diagonal-block chain.
-  size_t lds = (persist_wgs == -1 ? 6 : 4) * DMA_TILE * sizeof(double);
+  // persist_wgs == -1 (the only value still honoured): ask for 96 KiB of LDS so that only ONE workgroup of this launch fits a CU AND a
+  // workgroup of the one-launch diagonal-block chain (68.5 KiB) does NOT fit next to it.  Used for the bulk updates of the chain-bound
+  // tail (cholinv.hip, option occ1_m).  Round 5 measured why this works (profiles/r05_chain_fp64_occ1_lds{96,88}.log): the chain only
+  // reaches its isolated speed (0.31 ms per 512-block) on CUs it has to itself - next to one bulk workgroup every fp64 VALU operation of
+  // its leaf waits for the fp64 matrix pipe (1.9 ms per block at 88 KiB, where the two co-reside; N = 32768: 61.7 TF against 63.4).
+  static const size_t occ1_lds = (size_t)(getenv("CAP_OCC1_LDS_KB") ? atoi(getenv("CAP_OCC1_LDS_KB")) : 96) * 1024;
+  size_t lds = persist_wgs == -1 ? std::max<size_t>(occ1_lds, 4 * DMA_TILE * sizeof(double)) : 4 * DMA_TILE * sizeof(double);
   if constexpr (CAP_EXPERIMENTS && TAG == 0) {                       // timing experiments only (results are wrong)
     static const int diag_env = getenv("CAP_DIAG") ? atoi(getenv("CAP_DIAG")) : 0;
     if (diag_env == 1) {

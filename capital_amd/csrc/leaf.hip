@@ -674,16 +674,24 @@ __device__ __forceinline__ void chain_merge_task(const double* R12, int64_t ldr,
 // completely (2.7 ms per launch, profiles/r04_experiments.log).
 __global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) chain64_coop_kernel(const Chain64 g) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  // LDS (68.5 KiB since round 5; 82.3 before): B0, B1 and a small scratch block.  The packed Dinv_i that phase S reads lives IN B1:
+  // B1 (X_b of the workers; S of workgroup 0's leaf) is only used in phase U and in the leaf, the packed inverse only in phase S, and
+  // a workgroup-wide barrier separates the two in both directions (chain_arrive between S and U; the end-of-step meeting, resp. the
+  // barrier behind trtri_lds in workgroup 0's leaf, before the next inverse is packed).  (Tried for co-residence with a one-per-CU
+  // bulk workgroup of 88 KiB: co-residence itself turned out to be the problem - see launch_tn_dma in gemm.hip - the smaller
+  // footprint stayed.)
   double* B0 = lds;                       // X_a; T of the leaf
   double* B1 = lds + LMAX * LLD;          // X_b; S of the leaf
-  double* Dp = lds + 2 * LMAX * LLD;      // Dinv_i, packed upper: (k, p), k <= p, at p(p+1)/2 + k; scratch of the leaf
+  double* Dp = B1;                        // Dinv_i, packed upper: (k, p), k <= p, at p(p+1)/2 + k  (aliases B1, see above)
+  double* Sc = lds + 2 * LMAX * LLD;      // scratch: flags, the leaf's dinv / rowbuf
+  static_assert(LMAX * (LMAX + 1) / 2 <= LMAX * LLD, "the packed inverse must fit into B1");
   __builtin_amdgcn_s_setprio(3);
   const int G = (int)gridDim.x, w = (int)blockIdx.x;
   const int nblk = g.nblk;
   double* const R = g.R; const int64_t ldr = g.ldr;
-  int& bad = *reinterpret_cast<int*>(Dp);
-  double* dinv = Dp + 2; double* rowbuf = dinv + LMAX;
-  int& barrier_ok = *reinterpret_cast<int*>(Dp + LMAX * (LMAX + 1) / 2);      // (all LDS stays in the dynamic region)
+  int& bad = *reinterpret_cast<int*>(Sc);
+  double* dinv = Sc + 2; double* rowbuf = dinv + LMAX;
+  int& barrier_ok = *reinterpret_cast<int*>(Sc + 2 + LMAX + 256);             // (all LDS stays in the dynamic region)
   int epoch = 0, epoch1 = 0;             // arrivals expected at the end-of-step meetings (ctr[0]) / the mid-step ones (ctr[2])
   bool alive = true;
   long long* tr = (g.trace && w < 64 && threadIdx.x == 0) ? g.trace + (int64_t)w * 32 * 8 : nullptr;
@@ -695,7 +703,7 @@ __global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2
   const int GU = g.recover ? 3 : 1;        // what a workgroup of this launch writes into the state word when it gives up
   bool inject = false;
   {
-    int* sflag = reinterpret_cast<int*>(Dp) + 1;
+    int* sflag = reinterpret_cast<int*>(Sc) + 1;
     if (threadIdx.x == 0) {
       const int st = __hip_atomic_load(g.ctr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int inj = 0;
@@ -991,7 +999,7 @@ __global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2
 // Factor phase of blocked_cholinv (cholinv.hip) in one launch of `wgs` resident workgroups (chain64_coop_kernel): R (n = 64 nblk)
 // factored in place, the 64 x 64 diagonal blocks of Ri = their inverses, the off-diagonal blocks up to pairs of hmax x hmax.
 // ctr: four ints (end-of-step meetings, exit count, mid-step meetings, spare), zero before the first use (the kernel leaves them zero).
-constexpr size_t CHAIN_LDS_BYTES = (2 * LMAX * LLD + LMAX * (LMAX + 1) / 2 + 2) * sizeof(double);
+constexpr size_t CHAIN_LDS_BYTES = (2 * LMAX * LLD + 2 + LMAX + 256 + 2) * sizeof(double);      // B0, B1 (+ the packed inverse inside it), scratch
 
 // Workgroups of chain64_coop_kernel the current device can hold at once (occupancy of the kernel x compute units), cached per device.
 // A launch with more workgroups than that could never have them all resident: its meetings would only end by the give-up path.

@@ -58,6 +58,10 @@ struct BfArgs {
 };
 
 // C[M x N] += alpha * A^T B,  A: K x M, B: K x N (both K-contiguous bf16), C fp32 column-major.  M, N % 128 == 0, K % 64 == 0.
+// Epilogue: fire-and-forget fp32 atomics.  Every C tile has ONE writer per launch, so a plain read - add - write works too; round 5
+// measured it (buffer-addressed loads behind the last MFMAs, then stores): 786 TF against 800 alone, 171.0 ms against 170.0 in the
+// N = 65536 factorization (profiles/r05_bf16_bench.log, r05_mixed_rmw.log) - this kernel is bound by its LDS traffic (16 KiB + 16 KiB
+// staged and 64 KiB of fragment reads per 64 MFMAs), not by how C is written - and removed it again.
 __global__ void __launch_bounds__(256, 2) bf16_tn_kernel(const BfArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // block -> tile: XCD b % 8 walks a contiguous range of the tile list (column-major; upper triangle for tri)
@@ -187,6 +191,10 @@ __global__ void __launch_bounds__(256, 2) bf16_tn_kernel(const BfArgs g) {
   }
 }
 
+inline void launch_bf16_tn_kernel(const BfArgs& g, unsigned grid, hipStream_t s) {
+  hipLaunchKernelGGL(bf16_tn_kernel, dim3(grid), dim3(256), 4 * TILE_D * sizeof(double), s, g);
+}
+
 int launch_bf16_tn(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A, int64_t lda, const __bf16* B, int64_t ldb, float* C,
                    int64_t ldc, int tri, hipStream_t s) {
   if (m <= 0 || n <= 0 || k <= 0) return CAP_OK;
@@ -206,7 +214,7 @@ int launch_bf16_tn(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A
     tiles = ((tri && m == n) ? nsn * (nsn + 1) / 2 : (int64_t)g.nsm * nsn) * g.st * g.st;
   }
   g.chunk = (int)cap_ceil_div(tiles, 8);
-  hipLaunchKernelGGL(bf16_tn_kernel, dim3((unsigned)(g.chunk * 8)), dim3(256), 4 * TILE_D * sizeof(double), s, g);
+  launch_bf16_tn_kernel(g, (unsigned)(g.chunk * 8), s);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
@@ -549,7 +557,7 @@ int cap_bf16_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const void* 
   g.stair = 1; g.sP = P; g.sp = p; g.snbT = nb / TB; g.sJ0 = J0; g.slb0 = lb0; g.gpiece = piece; g.st = 0; g.nsm = 1;
   for (int i = 0; i < 8; i++) g.gstart[i] = i < P ? gstart[i] : 0;
   g.chunk = (int)cap_ceil_div((int64_t)g.tm * g.tn, 8);       // full grid; workgroups below the staircase return at once
-  hipLaunchKernelGGL(bf16_tn_kernel, dim3((unsigned)(g.chunk * 8)), dim3(256), 4 * TILE_D * sizeof(double), s, g);
+  launch_bf16_tn_kernel(g, (unsigned)(g.chunk * 8), s);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }

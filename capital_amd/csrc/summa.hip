@@ -33,6 +33,7 @@ struct cap_summa_plan {
   double* xch[2];                       // the transpose-partner copy of the SYRK overload + its exchange scratch
   hipStream_t s_row, s_col;
   std::vector<hipEvent_t> ev_a, ev_b, ev_free;   // [buf], [buf * num_chunks + chunk], [buf]
+  std::vector<hipEvent_t> ev_d;                  // collect: [chunk] = "column chunk of acc is final", [num_chunks] = "all depth sums done"
   hipEvent_t ev_start, ev_join_r, ev_join_c;
 };
 
@@ -79,7 +80,7 @@ int cap_summa_plan_create(cap_summa_plan** plan, cap_topo* topo, int64_t m, int6
     v.resize(cnt);
     for (auto& ev : v) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   };
-  mk(p->ev_a, 2); mk(p->ev_b, 2 * (size_t)p->num_chunks); mk(p->ev_free, 2);
+  mk(p->ev_a, 2); mk(p->ev_b, 2 * (size_t)p->num_chunks); mk(p->ev_free, 2); mk(p->ev_d, (size_t)p->num_chunks + 1);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_start, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join_r, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join_c, hipEventDisableTiming);
@@ -93,7 +94,7 @@ int cap_summa_plan_destroy(cap_summa_plan* p) {
   for (int i = 0; i < 2; i++)
     for (double* q : {p->bufA[i], p->bufB[i], p->triA[i], p->triB[i], p->xch[i]}) if (q) (void)hipFree(q);
   if (p->acc) (void)hipFree(p->acc);
-  for (auto* v : {&p->ev_a, &p->ev_b, &p->ev_free}) for (auto ev : *v) if (ev) (void)hipEventDestroy(ev);
+  for (auto* v : {&p->ev_a, &p->ev_b, &p->ev_free, &p->ev_d}) for (auto ev : *v) if (ev) (void)hipEventDestroy(ev);
   if (p->ev_start) { (void)hipEventDestroy(p->ev_start); (void)hipEventDestroy(p->ev_join_r); (void)hipEventDestroy(p->ev_join_c); }
   if (p->s_row) (void)hipStreamDestroy(p->s_row);
   if (p->s_col) (void)hipStreamDestroy(p->s_col);
@@ -163,11 +164,36 @@ static int summa_core(cap_summa_plan* p, int opa, int opb, const Slot& A, const 
       const int64_t c0 = N * ch / nch, c1 = N * (ch + 1) / nch;          // chunked: opb == NoTrans, B slot K x N (ld = K)
       CAP_HIP(hipStreamWaitEvent(s0, p->ev_b[(size_t)buf * p->num_chunks + ch], 0));
       CAP_TRY(cap_gemm_launch(opa, opb, M, c1 - c0, K, alpha, Ab, A.rows, Bb + c0 * B.rows, B.rows, si == 0 ? 0.0 : 1.0, p->acc + c0 * M, M, 0, s0, tag));
+      if (p->c > 1 && nch > 1 && si + 1 == steps.size()) CAP_HIP(hipEventRecord(p->ev_d[ch], s0));   // this column chunk of acc is final
     }
     CAP_HIP(hipEventRecord(p->ev_free[buf], s0));
   }
-  // ---- depth: sum the layers' partial products (collect, summa.hpp:223-253)
-  if (p->c > 1) CAP_TRY(cap_comm_allreduce_sum(p->depth, p->acc, M * N, (void*)s0));
+  // ---- depth: sum the layers' partial products (collect, summa.hpp:223-253).  num_chunks <= 1: one all-reduce (upstream's
+  // num_chunks == 0 branch, :229-237).  Otherwise num_chunks all-reduces like upstream's MPI_Iallreduce sequence (:238-249) - and where
+  // the local products ran chunk by chunk, the sum of column chunk j starts on the row stream (idle by now, its own communicator)
+  // as soon as the LAST step's product of that chunk is done, i.e. it overlaps the products of the chunks behind it; the caller's
+  // stream only waits for the last sum.
+  if (p->c > 1) {
+    const int dch = p->num_chunks;
+    if (dch <= 1) {
+      CAP_TRY(cap_comm_allreduce_sum(p->depth, p->acc, M * N, (void*)s0));
+    } else if (nch == dch) {
+      for (int ch = 0; ch < dch; ch++) {
+        const int64_t c0 = N * ch / dch, c1 = N * (ch + 1) / dch;
+        CAP_HIP(hipStreamWaitEvent(sr, p->ev_d[ch], 0));
+        if (c1 > c0) CAP_TRY(cap_comm_allreduce_sum(p->depth, p->acc + c0 * M, M * (c1 - c0), (void*)sr));
+      }
+      CAP_HIP(hipEventRecord(p->ev_d[dch], sr));
+      CAP_HIP(hipStreamWaitEvent(s0, p->ev_d[dch], 0));
+    } else {
+      // products that ran as one launch (right-sided TRMM, NoTrans SYRK): upstream's equal pieces, the remainder with the last one
+      const int64_t tot = M * N, per = tot / dch;
+      for (int ch = 0; ch < dch; ch++) {
+        const int64_t cnt = ch == dch - 1 ? tot - per * (dch - 1) : per;
+        if (cnt > 0) CAP_TRY(cap_comm_allreduce_sum(p->depth, p->acc + per * ch, cnt, (void*)s0));
+      }
+    }
+  }
   return CAP_OK;
 }
 

@@ -104,7 +104,8 @@ int main(int argc, char** argv) {
         const double res = sqrt(h[0]) / sqrt(h[1]), orth = sqrt(h[2]) / sqrt((double)n);
         printf("residual %.3e orthogonality %.3e\n", res, orth);
         hipFree(D); hipFree(G); hipFree(out);
-        if (!(res < 1e-13) || !(orth < 1e-14) || info != 0) return 4;
+        /* one sweep (variant 1) leaves ||Q^T Q - I|| ~ eps kappa(A)^2; the second sweep of CholeskyQR2 brings it to eps */
+        if (!(res < 1e-13) || !(orth < (variant == 2 ? 1e-14 : 1e-11)) || info != 0) return 4;
       }
       CAPCHECK(cap_cacqr_plan_destroy(pack));
     }

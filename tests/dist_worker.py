@@ -476,9 +476,16 @@ def run(args):
         Cm.distribute_random(T.x, T.y, d, d, 200 + rank // T.c)
         a, b, c0 = A.to_numpy(), B.to_numpy(), Cm.to_numpy()
         alpha, beta = 1.5, -0.5
+        depth_obj = T._subs[2] if T.c > 1 else None          # (row, column, depth, ...: the host-staged depth communicator counts its calls)
+        before = depth_obj.calls["allreduce"] if depth_obj else 0
         for rep in range(2):                                 # plan reuse; the second call starts from the first result
             summa.invoke(A, B, Cm, T, blas.ArgPack_gemm(blas.Order.AblasColumnMajor, blas.Transpose.AblasNoTrans, blas.Transpose.AblasNoTrans, alpha, beta))
         c2 = Cm.to_numpy()
+        if depth_obj:
+            # collect (summa.hpp:223-253): one depth all-reduce per call, or num_chunks of them (upstream's MPI_Iallreduce sequence),
+            # here started per column chunk behind the last step's product of that chunk
+            per_call = (depth_obj.calls["allreduce"] - before) // 2
+            assert per_call == max(1, min(args.chunks, -(-N // d))), (per_call, args.chunks)
         pieces = [None] * size
         dist.all_gather_object(pieces, (T.x, T.y, T.z, a, b, c0, c2))
         if rank == 0:

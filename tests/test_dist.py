@@ -449,7 +449,7 @@ def test_bench_multi_gpu_variants_emulated(nproc, extra, key):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproc,c,M,N,K,chunks", [(4, 1, 512, 384, 640, 0), (4, 1, 300, 200, 250, 3), (8, 2, 512, 512, 512, 2),
+@pytest.mark.parametrize("nproc,c,M,N,K,chunks", [(4, 1, 512, 384, 640, 0), (4, 1, 300, 200, 250, 3), (8, 2, 512, 512, 512, 2), (8, 2, 300, 210, 250, 3),
                                                    (1, 1, 256, 256, 256, 2), (9, 1, 300, 300, 300, 2)])
 def test_summa_gemm_on_process_grids(nproc, c, M, N, K, chunks):
     """matmult::summa GEMM on d x d x c grids sharing one GPU (host-staged row / column / depth communicators): 2 x 2 x 1

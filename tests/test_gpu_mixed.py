@@ -149,13 +149,18 @@ def test_bf16_update_kernels_against_torch(m, n, k, tri, tpw):
         torch.cuda.synchronize()
         got = c[:, :m].t().double()
         err = float((got - ref)[mask].abs().max()) / scale
-        assert err < 2e-5, (variant, err)                   # fp32 accumulation of exact bf16 products
+        # fp32 accumulation of exact bf16 products: k / 16 chained MFMA accumulations of partial sums that grow like sqrt(k), against a
+        # scale that grows the same way -> the relative error grows like sqrt(k / 16) ulp.  Model: 6e-8 * sqrt(k / 16) / 2 = 6e-8 at
+        # k = 64, 3.4e-7 at k = 2048 for the typical element; the bound keeps that k-scaling with a factor ~ 60 for the maximum over
+        # up to 1.7e7 elements and the order of the final read-modify-write (round 4 had replaced it by a flat 2e-5: 10 x looser at small k)
+        tol = 4e-6 * (k / 64.0) ** 0.5
+        assert err < tol, (variant, err, tol)
         if tri:
             assert torch.equal(c[:, :m].t()[~mask], c0[:, :m].t()[~mask]), "entries below the diagonal must not be touched"
         assert torch.equal(c[:, m:], c0[:, m:]), "padding of the leading dimension must not be touched"
         outs.append(got)
     if len(outs) == 2:
-        assert float((outs[0] - outs[1])[mask].abs().max()) / scale < 4e-5
+        assert float((outs[0] - outs[1])[mask].abs().max()) / scale < 8e-6 * (k / 64.0) ** 0.5
 
 
 def test_bf16_update_dispatcher_and_refusals():
