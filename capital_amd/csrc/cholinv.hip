@@ -334,7 +334,9 @@ struct cap_cholinv_plan {
   // Strip buffers (use_sb): the solved block rows of a strip are written K-contiguously into one of three NB x n buffers
   // (ld = NB) and every update reads its operands from there; the copy into R - R is only the OUTPUT after that - runs on
   // its own stream off the panel stream's critical path (it was 64 x 134 MB of copies on it at N = 32768)
-  int use_sb; double* SB; int64_t sb_ld, sb_cols; hipStream_t s_copy; hipEvent_t ev_sbg, ev_copy[3], ev_join_cp; bool sb_ready;
+  int use_sb; double* SB; int64_t sb_ld, sb_cols; hipStream_t s_copy; hipEvent_t ev_sbg, ev_copy[4], ev_join_cp; bool sb_ready;
+  int pair_rest;    // the far part of the trailing update takes two strips at a time (one K = 2 NB product per pair of steps), see right_looking
+  int cnt_paired;   // K = 2 NB far updates of the last factor call (get_option "count_paired")
   // R^-1 on top of the blocked factorization (complete_inv >= 0, see InvTree): its own stream, one event per panel
   int inv_fast;         // 1: blocked factorization + inverse tree (default for n >= 2 nb), 0: the plain recursion of cholinv.hpp:85-165
   int inv_overlap;      // 1: tree nodes are enqueued as their inputs become final (overlapped with the sweep), 0: after it
@@ -589,18 +591,20 @@ int factor_strip(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, int64_t
   return CAP_OK;
 }
 
+// Strip buffers: FOUR strips in two pair buffers of 2 NB x n (ld = 2 NB): strip t lives in pair (t / 2) % 2 at row offset (t % 2) NB, so the
+// solved rows of strips 2 j and 2 j + 1 are K-contiguous - what the paired far update (K = 2 NB) reads as ONE operand.
 int ensure_sb(cap_cholinv_plan* p, int64_t NB, int64_t n) {
-  if (p->sb_ready && p->sb_ld == NB && p->sb_cols == n) return CAP_OK;
+  if (p->sb_ready && p->sb_ld == 2 * NB && p->sb_cols == n) return CAP_OK;
   if (p->sb_ready) { CAP_HIP(hipDeviceSynchronize()); (void)hipFree(p->SB); p->SB = nullptr; }
   else {
     CAP_HIP(hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking));
     CAP_HIP(hipEventCreateWithFlags(&p->ev_sbg, hipEventDisableTiming));
     CAP_HIP(hipEventCreateWithFlags(&p->ev_join_cp, hipEventDisableTiming));
-    for (int i = 0; i < 3; i++) CAP_HIP(hipEventCreateWithFlags(&p->ev_copy[i], hipEventDisableTiming));
+    for (int i = 0; i < 4; i++) CAP_HIP(hipEventCreateWithFlags(&p->ev_copy[i], hipEventDisableTiming));
   }
   p->sb_ready = true; p->sb_ld = 0;
-  CAP_HIP(hipMalloc((void**)&p->SB, sizeof(double) * 3 * NB * n));
-  p->sb_ld = NB; p->sb_cols = n;
+  CAP_HIP(hipMalloc((void**)&p->SB, sizeof(double) * 4 * NB * n));
+  p->sb_ld = 2 * NB; p->sb_cols = n;
   return CAP_OK;
 }
 
@@ -608,7 +612,7 @@ void release_sb(cap_cholinv_plan* p) {
   if (!p->sb_ready) return;
   (void)hipStreamSynchronize(p->s_copy); (void)hipStreamDestroy(p->s_copy);
   (void)hipEventDestroy(p->ev_sbg); (void)hipEventDestroy(p->ev_join_cp);
-  for (int i = 0; i < 3; i++) (void)hipEventDestroy(p->ev_copy[i]);
+  for (int i = 0; i < 4; i++) (void)hipEventDestroy(p->ev_copy[i]);
   if (p->SB) (void)hipFree(p->SB);
   p->SB = nullptr; p->sb_ready = false;
 }
@@ -842,15 +846,16 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
   // strip-buffer mode (plan-owned factor, overlapped schedule): see cap_cholinv_plan::use_sb
   const bool sbm = p->use_sb && p->serial_m == 0 && R == p->R;
   if (sbm) CAP_TRY(ensure_sb(p, NB, n));
-  auto sctx = [&](int64_t t) { return StripCtx{p->SB + (t % 3) * p->sb_ld * n, p->sb_ld, bnd[(size_t)t]}; };
-  // strip t is factored into buffer t % 3: its previous tenant (strip t - 3) has been read by the bulk update of step t - 3
-  // (finished before the head of step t - 2 that the panel stream has waited for) and by the copy stream (ev_copy)
+  auto sctx = [&](int64_t t) { return StripCtx{p->SB + ((t / 2) % 2) * p->sb_ld * n + (t % 2) * NB, p->sb_ld, bnd[(size_t)t]}; };
+  // strip t is factored into slot t % 4: its previous tenant (strip t - 4) has been read by the bulk updates of the steps t - 4 and
+  // (paired far update) t - 3, both enqueued on the bulk stream before the head of step t - 2 that the panel stream has waited for,
+  // and by the copy stream (ev_copy)
   auto strip = [&](int64_t t, hipStream_t s) -> int {
     if (!sbm) return factor_strip(p, R, ldr, n, bnd[(size_t)t], bnd[(size_t)t + 1] - bnd[(size_t)t], s);
-    if (t >= 3) CAP_HIP(hipStreamWaitEvent(s, p->ev_copy[t % 3], 0));
+    if (t >= 4) CAP_HIP(hipStreamWaitEvent(s, p->ev_copy[t % 4], 0));
     const StripCtx c = sctx(t);
     CAP_TRY(factor_strip(p, R, ldr, n, bnd[(size_t)t], bnd[(size_t)t + 1] - bnd[(size_t)t], s, &c));
-    CAP_HIP(hipEventRecord(p->ev_copy[t % 3], p->s_copy));
+    CAP_HIP(hipEventRecord(p->ev_copy[t % 4], p->s_copy));
     return CAP_OK;
   };
   // fork: the panel stream (and the CU-masked bulk stream) join the caller's stream
@@ -873,6 +878,8 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
   // serial_m = 16384, N = 16384: 49.2 vs 50.7 - the overlapped schedule already costs about the serial sum, no gain.
   int64_t ksw = nstrip;
   for (int64_t k = 1; k < nstrip; k++) if (n - bnd[k + 1] <= p->serial_m) { ksw = k; break; }
+  bool deferred = false, deferred_cin = false;     // paired far update: an even step left the region below strip k+3 to the next step
+  p->cnt_paired = 0;
   for (int64_t k = 0; k < nstrip; k++) {
     const int64_t J0 = bnd[k], rows = bnd[k + 1] - J0, m = n - bnd[k + 1];
     if (m <= 0) break;
@@ -921,9 +928,26 @@ int right_looking(cap_cholinv_plan* p, double* R, int64_t ldr, int64_t n, hipStr
         // head: strip k+2's rows first, then signal the panel stream; rest: everything below
         CAP_TRY(trailing_update(p, rows2, m2, rows, S2, S2, R + J2 + J2 * ldr, ldr, s0, lds_, cin(J2), src_lda));
         CAP_HIP(hipEventRecord(p->ev_update[k & 1], s0));
-        const int64_t m3 = m2 - rows2;
+        const int64_t m3 = m2 - rows2, J3 = J2 + rows2;
         const double* S3 = S2 + rows2 * lds_;
-        CAP_TRY(trailing_update(p, m3, m3, rows, S3, S3, R + (J2 + rows2) + (J2 + rows2) * ldr, ldr, s0, lds_, cin(J2 + rows2), src_lda));
+        // Paired far update (round 5, option "pair_rest").  The rows below strip k+3 are not read before step k+2, so an EVEN step k
+        // only brings strip k+3's rows up to date (one more head) and leaves the region below to the ODD step k+1, whose own rest is
+        // exactly that region: it then takes the rows of BOTH strips in ONE product with K = 2 NB (the two strips are K-contiguous:
+        // adjacent rows of R, or the two halves of a pair buffer).  Half the launches, half the C traffic and half the per-tile
+        // prologue / epilogue for the bulk of the flops: the update kernel runs at a + b K per tile with b at 99 % of peak.
+        if (deferred) {
+          const int64_t Jp = bnd[k - 1];                              // first row of the pair (strip k-1)
+          const double* P = sbm ? sctx(k - 1).SB + J3 * p->sb_ld : R + Jp + J3 * ldr;
+          CAP_TRY(trailing_update(p, m3, m3, (J0 - Jp) + rows, P, P, R + J3 + J3 * ldr, ldr, s0, sbm ? p->sb_ld : ldr,
+                                  deferred_cin ? srcA + J3 + J3 * src_lda : nullptr, src_lda));
+          deferred = false; p->cnt_paired++;
+        } else if (p->pair_rest && (k & 1) == 0 && k + 4 < nstrip && k + 1 < ksw && rows == NB && rows1 == NB && !tail_res) {
+          const int64_t rows3 = bnd[k + 4] - bnd[k + 3];
+          CAP_TRY(trailing_update(p, rows3, m3, rows, S3, S3, R + J3 + J3 * ldr, ldr, s0, lds_, cin(J3), src_lda));
+          deferred = true; deferred_cin = fz;
+        } else {
+          CAP_TRY(trailing_update(p, m3, m3, rows, S3, S3, R + J3 + J3 * ldr, ldr, s0, lds_, cin(J3), src_lda));
+        }
       } else {
         CAP_TRY(trailing_update(p, m2, m2, rows, S2, S2, R + J2 + J2 * ldr, ldr, s0, lds_, cin(J2), src_lda));
         CAP_HIP(hipEventRecord(p->ev_update[k & 1], s0));
@@ -1036,6 +1060,8 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   // update (m^2 x 1024 flops): from there on the bulk runs one workgroup per CU (N = 32768: 59.3 -> 61.2 TF, 16384: 34.4 -> 37.1)
   p->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
   p->chain_coop = -1;
+  p->pair_rest = getenv("CAP_PAIR_REST") ? atoi(getenv("CAP_PAIR_REST")) : 1;
+  p->cnt_paired = 0;
   p->depth2 = n >= 24576;     // look-ahead depth 2 pays once a bulk update is long enough to split (+2 % at N = 32768)
   // reference semantics (R and R^-1): blocked factorization + inverse tree; the tree starts once the sweep is chain-bound
   p->use_sb = getenv("CAP_USE_SB") ? atoi(getenv("CAP_USE_SB")) : 1;
@@ -1127,6 +1153,7 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
   if (k == "tail") { if (value < 0) return CAP_ERR_ARG; p->tail = value; return CAP_OK; }
   if (k == "serial_m") { if (value < 0) return CAP_ERR_ARG; p->serial_m = value; return CAP_OK; }
   if (k == "depth2") { p->depth2 = value != 0; return CAP_OK; }
+  if (k == "pair_rest") { p->pair_rest = value != 0; return CAP_OK; }
   if (k == "inner_la") { p->inner_la = value != 0; return CAP_OK; }
   if (k == "occ1_m") { if (value < 0) return CAP_ERR_ARG; p->occ1_m = value; return CAP_OK; }
   if (k == "fastdiag") { p->fastdiag = value != 0; return CAP_OK; }
@@ -1181,6 +1208,8 @@ int64_t cap_cholinv_get_option(cap_cholinv_plan* p, const char* key) {
   if (k == "inv_overlap") return p->inv_overlap;
   if (k == "inv_start_m") return p->inv_start_m;
   if (k == "depth2") return p->depth2;
+  if (k == "pair_rest") return p->pair_rest;
+  if (k == "count_paired") return p->cnt_paired;
   if (k == "fastdiag") return p->fastdiag;
   if (k == "reserve") return p->reserve;
   if (k == "reserve_m") return p->reserve_m;

@@ -191,6 +191,8 @@ __global__ void __launch_bounds__(256, 2) bf16_tn_kernel(const BfArgs g) {
   }
 }
 
+// (One workgroup per CU for the chain-bound strips - the fp64 plan's occ1 form, 96 KiB of LDS - was measured here too in round 5: the
+// factorization does not move, 164.1 against 164.2 ms at N = 65536, and loses from 24576 rows up: profiles/r05_mixed_occ1.log.)
 inline void launch_bf16_tn_kernel(const BfArgs& g, unsigned grid, hipStream_t s) {
   hipLaunchKernelGGL(bf16_tn_kernel, dim3(grid), dim3(256), 4 * TILE_D * sizeof(double), s, g);
 }
@@ -573,6 +575,8 @@ struct cap_mpchol_plan {
   // never share a SIMD with bf16-MFMA waves (measured under contention: 91 us per fused step against 30 us alone, 88 of a 198 ms factor)
   int reserve; hipStream_t s_bulk, s_chain; hipEvent_t ev_user, ev_bulk_done, ev_ch[2]; bool res_ready;
   int chain_coop;                   // resident workgroups of the one-launch diagonal-block chain for THIS plan (-1: process default)
+  int pair_rest;                    // split schedule: the far part of the bulk update takes two strips at a time (K = 4 nb), see mp_factor_impl
+  int cnt_paired;                   // ... how many such launches the last factor call made
   // block-row solve on the bf16 pipe (option "solve3", default on): split operands, see mixed_kernels.h
   int solve3; __bf16* A3[2]; __bf16* B3far; __bf16* B3near;
   hipStream_t s_panel; hipEvent_t ev_rest[2], ev_panel[2], ev_fork, ev_join; bool streams_ready;
@@ -648,6 +652,8 @@ int cap_mpchol_plan_create(cap_mpchol_plan** plan, int64_t n, int64_t nrhs_max) 
   p->solve3 = getenv("CAP_MP_SOLVE3") ? atoi(getenv("CAP_MP_SOLVE3")) : 1;
   p->reserve = getenv("CAP_MP_RESERVE") ? atoi(getenv("CAP_MP_RESERVE")) : 0;
   p->chain_coop = -1;
+  p->pair_rest = getenv("CAP_MP_PAIR_REST") ? atoi(getenv("CAP_MP_PAIR_REST")) : 1;
+  p->cnt_paired = 0;
   // largest power of two <= min(n, 1024) (>= 128 because n % 128 == 0): the fused diagonal-block chain and the bf16 tile
   // kernel (k % 64, m % 128) need it; the last panel of a non-power-of-two n is a shorter multiple of 128
   while (p->nb > n) p->nb /= 2;
@@ -658,7 +664,7 @@ int cap_mpchol_plan_create(cap_mpchol_plan** plan, int64_t n, int64_t nrhs_max) 
   if (e == hipSuccess) e = hipMemset(p->R32, 0, sizeof(float) * n * n);        // the strictly-lower part stays zero for the plan's life
   if (e == hipSuccess) e = hipMalloc((void**)&p->R64, sizeof(double) * n * n);
   if (e == hipSuccess) e = hipMemset(p->R64, 0, sizeof(double) * n * n);      // nothing ever writes below its diagonal
-  for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void**)&p->P16[i], sizeof(__bf16) * 2 * nb * n);     // strip buffers, ld = 2 nb
+  for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void**)&p->P16[i], sizeof(__bf16) * 4 * nb * n);     // pair buffers: two strips each, ld = 4 nb (2 nb in the single-stream schedule)
   if (e == hipSuccess) e = hipMalloc((void**)&p->D64, sizeof(double) * (2 * nb * nb + 2 * nb * n + p->wcap));
   if (e == hipSuccess) e = hipMalloc((void**)&p->Inv, sizeof(double) * (nblk * p->tb * p->tb + p->tb * w));
   if (e == hipSuccess) e = hipMalloc((void**)&p->Xw, sizeof(double) * (3 * n * w + 8));
@@ -751,6 +757,7 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
     }
     hipStream_t s2 = p->s_far;
     CAP_HIP(hipStreamWaitEvent(s2, p->ev_fork, 0));
+    const int64_t ldp = 4 * nb;     // pair buffers (this schedule only; the single-stream schedule below keeps ld = 2 nb)
     double* Tn = p->Tn; double* Sn = p->Tn + nb * nb;
     bool have_hf = false;
     // block-row solve of panel k on the columns [c0, c1): X = Dinv_k^T R32[rows k, c0:c1] in fp64 -> fp32 (factor) + bf16 (strip buffer)
@@ -796,8 +803,11 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
       CAP_HIP(hipGetLastError());
       return CAP_OK;
     };
+    bool deferred = false;          // paired far update: an even strip left the region below strip t + 2 to the next strip
+    p->cnt_paired = 0;
     for (int64_t t = 0; t < nstrip; t++) {
-      __bf16* SP = p->P16[t & 1];
+      // strip t lives in pair buffer (t / 2) % 2 at row offset (t % 2) 2 nb (ld = 4 nb): strips 2 j and 2 j + 1 are K-contiguous
+      __bf16* SP = p->P16[(t >> 1) & 1] + (t & 1) * 2 * nb;
       const int64_t ka = 2 * t, kb = std::min(npan, ka + 2) - 1;           // first / last panel of the strip (kb == ka: one panel)
       for (int64_t k = ka; k <= kb; k++) {
         const int64_t j1 = std::min(n, (k + 1) * nb), j1n = std::min(n, j1 + nb), roff = (k - ka) * nb;
@@ -851,6 +861,7 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
       // rest: rows below the next strip, caller's stream
       CAP_HIP(hipStreamWaitEvent(s0, p->ev_panel[t & 1], 0));
       CAP_HIP(hipStreamWaitEvent(s0, p->ev_far[t & 1], 0));
+      bool rest_recorded = false, head_only = false;
       if (m > hb) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (p->profile && p->prof_ev) {
@@ -859,16 +870,43 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
           e0 = (*p->prof_ev)[p->prof_used]; e1 = (*p->prof_ev)[p->prof_used + 1];
           CAP_HIP(hipEventRecord(e0, s0));
         }
-        CAP_TRY(launch_bf16_update(m - hb, m - hb, K, -1.0f, S + hb * ldp, ldp, S + hb * ldp, ldp, p->R32 + (Js + hb) * (n + 1), n, 1, s0));
+        // Paired far update (round 5, option "pair_rest"; the fp64 plan's right_looking does the same): the rows below strip t + 2 are
+        // not read before strip t + 2 is factored, so an EVEN strip t only brings strip t + 2's rows up to date (one more head, K = 2 nb)
+        // and leaves the region below to the ODD strip t + 1, whose own rest is exactly that region: ONE product with K = 4 nb over
+        // the two strips (the halves of a pair buffer are K-contiguous) - half the C traffic and half the tiles' prologue / epilogue
+        // for the bulk of the flops.
+        const int64_t m3 = m - hb, J3 = Js + hb;
+        int64_t Kr = K; const __bf16* Sr = S + hb * ldp;                     // operand of the rest launch
+        bool launch_rest = true;
+        if (deferred) {
+          // rows of strip t - 1 and strip t.  The rows of strip t + 2 come first and release the other streams: the head of strip t + 1
+          // only has to wait for THEM (it touches the same rows), not for the whole K = 4 nb launch - without this second level of
+          // look-ahead the paired launch (twice a plain rest) and the next strip's panel work took turns instead of overlapping and
+          // the factorization gained nothing from a bulk that ran 15 % faster (profiles/r05_mixed_pair_first.log)
+          Kr = K + 2 * nb; Sr = p->P16[(t >> 1) & 1] + J3 * ldp;
+          const int64_t hh = std::min<int64_t>(2 * nb, m3);
+          CAP_TRY(launch_bf16_tn(hh, m3, Kr, -1.0f, Sr, ldp, Sr, ldp, p->R32 + J3 * (n + 1), n, 1, s0));
+          CAP_HIP(hipEventRecord(p->ev_rest[t & 1], s0)); rest_recorded = true;
+          launch_rest = false;
+          if (m3 > hh) CAP_TRY(launch_bf16_update(m3 - hh, m3 - hh, Kr, -1.0f, Sr + hh * ldp, ldp, Sr + hh * ldp, ldp, p->R32 + (J3 + hh) * (n + 1), n, 1, s0));
+          deferred = false; p->cnt_paired++;
+        } else if (p->pair_rest && (t & 1) == 0 && K == 2 * nb && hb == 2 * nb && m3 > 2 * nb) {
+          // head of strip t on strip t + 2's rows; the region below waits for strip t + 1
+          CAP_TRY(launch_bf16_tn(2 * nb, m3, K, -1.0f, Sr, ldp, Sr, ldp, p->R32 + J3 * (n + 1), n, 1, s0));
+          deferred = true; launch_rest = false; head_only = true;
+        }
+        if (launch_rest) CAP_TRY(launch_bf16_update(m3, m3, Kr, -1.0f, Sr, ldp, Sr, ldp, p->R32 + J3 * (n + 1), n, 1, s0));
         if (e0) {
           CAP_HIP(hipEventRecord(e1, s0));
           p->prof_used += 2;
-          const double mm = (double)(m - hb), elems = 0.5 * mm * (mm + 1.0);
-          p->prof_flops->push_back(2.0 * (double)K * elems);
-          p->prof_bytes->push_back(8.0 * elems + 2.0 * (double)K * mm);
+          // (an even strip of a pair: its launch is the head on strip t + 2's rows, 2 nb x m3 of the upper staircase)
+          const double mm = (double)m3, hh = (double)(2 * nb);
+          const double elems = head_only ? hh * mm - 0.5 * hh * (hh - 1.0) : 0.5 * mm * (mm + 1.0);
+          p->prof_flops->push_back(2.0 * (double)Kr * elems);
+          p->prof_bytes->push_back(8.0 * elems + 2.0 * (double)Kr * mm);
         }
       }
-      CAP_HIP(hipEventRecord(p->ev_rest[t & 1], s0));
+      if (!rest_recorded) CAP_HIP(hipEventRecord(p->ev_rest[t & 1], s0));
     }
     CAP_HIP(hipEventRecord(p->ev_join2, s2));
     CAP_HIP(hipStreamWaitEvent(s0, p->ev_join2, 0));
@@ -994,6 +1032,7 @@ int cap_mpchol_set_option(cap_mpchol_plan* p, const char* key, int64_t value) {
   if (!strcmp(key, "update_tpw")) { if (value < 1 || value > 64) return CAP_ERR_ARG; g_bf16_tpw = (int)value; return CAP_OK; }
   if (!strcmp(key, "update_min_tiles")) { if (value < 0) return CAP_ERR_ARG; g_bf16_min_tiles = value; return CAP_OK; }
   if (!strcmp(key, "strip")) { if (value < 1 || value > 2) return CAP_ERR_ARG; p->strip = value; return CAP_OK; }   // panels per bf16 update
+  if (!strcmp(key, "pair_rest")) { p->pair_rest = value != 0; return CAP_OK; }     // K = 4 nb far updates (split schedule), see mp_factor_impl
   return CAP_ERR_ARG;
 }
 

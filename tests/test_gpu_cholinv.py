@@ -193,6 +193,44 @@ def test_schedule_knobs_do_not_change_the_answer(opts):
     assert relerr(R, _knob_oracle_R(n)) < 1e-13
 
 
+@pytest.mark.parametrize("n,ci,opts", [
+    (2048, -1, {"nb": 128, "outer": 256, "depth2": 1}),                       # 8 strips: pairs (0,1) (2,3); the last steps run unpaired
+    (2304, -1, {"nb": 128, "outer": 256, "depth2": 1}),                       # 9 strips
+    (1280, -1, {"nb": 128, "outer": 256, "depth2": 1}),                       # 5 strips: exactly one pair
+    (1024, -1, {"nb": 128, "outer": 256, "depth2": 1}),                       # 4 strips: no step may defer (no strip k + 4)
+    (3072, -1, {"nb": 128, "outer": 512, "tail": 1024, "depth2": 1}),         # nb-wide strips in the tail: pairing stops there
+    (2048, -1, {"nb": 128, "outer": 256, "depth2": 1, "use_sb": 0}),          # operands inside R: the pair is two adjacent row blocks
+    (2048, -1, {"nb": 128, "outer": 256, "depth2": 1, "fuse_copy": 0}),
+    (2560, 1, {"nb": 128, "outer": 256, "depth2": 1}),                        # reference semantics: the inverse tree rides on the same sweep
+    (2176, -1, {"nb": 128, "outer": 256, "depth2": 1}),                       # ragged last strip
+])
+def test_paired_far_update_against_the_unpaired_schedule(n, ci, opts):
+    """Option "pair_rest" (round 5): the region below strip k + 3 takes the updates of the strips k and k + 1 in ONE product with K = 2 NB
+    instead of two with K = NB.  Same products, another association order: R (and R^-1) agree with the unpaired schedule to rounding and
+    with the oracle; with strip buffers on / off the paired schedule itself must not change by one bit (same K order either way)."""
+    from capital_amd import cholinv
+    a = orc.symmetric_global(n, True)
+    out = {}
+    for pr in (0, 1):
+        _, pack = _factor(n, ci, 1, -2, opts=dict(opts, pair_rest=pr))
+        assert pack.last_info() == 0 and pack.get_option("pair_rest") == pr
+        # an even step k defers when the strips k .. k + 4 exist (k, k + 1 of full height): (nstrip - 3) // 2 paired launches per call
+        nstrip = -(-n // opts["outer"])
+        if pr == 0:
+            assert pack.get_option("count_paired") == 0
+        elif "tail" not in opts:
+            assert pack.get_option("count_paired") == max(0, (nstrip - 3) // 2), (nstrip, pack.get_option("count_paired"))
+        else:
+            assert pack.get_option("count_paired") >= 1
+        out[pr] = [cholinv.construct_R(pack).to_numpy()] + ([cholinv.construct_Rinv(pack).to_numpy()] if ci >= 0 else [])
+        assert orc.cholesky_residual(a, out[pr][0]) < RES_TOL
+    for x, y in zip(out[0], out[1]):
+        assert relerr(x, y) < 1e-14
+    if opts.get("use_sb", 1):
+        _, p2 = _factor(n, ci, 1, -2, opts=dict(opts, pair_rest=1, use_sb=0))
+        assert np.array_equal(cholinv.construct_R(p2).to_numpy(), out[1][0]), "strip buffers on / off: same K order, same bits"
+
+
 def test_fused_first_step_copy_is_bitwise_identical():
     """fuse_copy: the step-0 updates read their C input from A and write R (load / add / store) instead of updating a copy with
     fire-and-forget atomics - the same single rounding per element, so R must not change by one bit; A stays untouched."""
