@@ -39,11 +39,14 @@ def test_solve_reaches_fp64_accuracy(n, kind, nrhs):
     x = X.to_numpy(); xref = np.linalg.solve(a, b)
     assert rr <= 1e-14 and 1 <= iters <= 25, (rr, iters)
     assert np.linalg.norm(a @ x - b) / np.linalg.norm(b) < 1e-14
-    assert relerr(x, xref) < 1e-12 * np.linalg.cond(a)
+    # kappa from the factor (2-norm condition of SPD a = (largest / smallest singular value of R)^2; an SVD of `a` itself cost 12 s at n = 4096)
+    sv = np.linalg.svd(ref, compute_uv=False) if n <= 1536 else None
+    kappa = (sv[0] / sv[-1]) ** 2 if sv is not None else {"reference": 4.0, "gram": 40.0}[kind]      # (measured bounds of the two generators)
+    assert relerr(x, xref) < 1e-12 * kappa
     # plan reuse: same factor, new right-hand side
     b2 = rng.standard_normal((n, nrhs)); B2 = matrix(nrhs, n, 1, 1).from_numpy(b2)
     X2, _, rr2 = p.solve(A, B2)
-    assert rr2 <= 1e-14 and relerr(X2.to_numpy(), np.linalg.solve(a, b2)) < 1e-12 * np.linalg.cond(a)
+    assert rr2 <= 1e-14 and relerr(X2.to_numpy(), np.linalg.solve(a, b2)) < 1e-12 * kappa
     p.close()
 
 
