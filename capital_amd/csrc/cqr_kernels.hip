@@ -268,142 +268,9 @@ __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {
 #undef CQR_STORE_COL
 }
 
-// ================================================================================================ qrapply256, paired K tiles
-// The kernel above loses a third of the MFMA rate to per-step fixed cost: with an upper-triangular Rinv the work of K tile kt is
-// 16 - kt block columns, so half of the 16 steps of a row tile carry a barrier, a refill and the fragment reads for a quarter of a
-// full step's MFMAs.  Here a step handles the K tiles (s, 15 - s) TOGETHER: 17 block columns of work in every step, 8 steps and 8
-// barriers per row tile instead of 16.
-//   stage = A sub-tiles of both K tiles (2 x 16 KiB) + the LIVE part of Rinv for both (block columns >= s resp. >= 15 - s: 17 x 2 KiB,
-//           40 pieces with the padding that keeps every wave's vmcnt uniform) = 72 KiB; two stages, the next one is requested right
-//           behind the barrier that frees it - a whole step (~4 us of MFMA work) ahead
-//   stores  a block column is complete after K tile cb: columns 0..7 at step cb, columns 8..15 with step 7.  They are issued one step
-//           LATE (behind the next barrier), so the only memory wait of the loop - vmcnt(0) at the top of a step - finds loads and
-//           stores that are a full step old.
-struct PairCtx { int wid, wn, wi, lr, kg, sw; };
-
-__global__ void __launch_bounds__(512, 2) qrapply256p_kernel(const ApplyArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int STG = 2 * TA + 40 * 128;                       // doubles per stage: 2 A sub-tiles + 40 pieces of 1 KiB
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int G = (int)gridDim.x, b = (int)blockIdx.x;
-  const int per = (g.ntiles + G - 1) / G;
-  const int t0 = g.contig ? b * per : b, tstride = g.contig ? 1 : G;
-  const int nmine = g.contig ? max(0, min(per, g.ntiles - t0)) : (b < g.ntiles ? (g.ntiles - 1 - b) / G + 1 : 0);
-  const int U = nmine * 8;                                     // steps: (my row tile, K-tile pair)
-  if (U == 0) return;
-  const int wq = wid >> 1;
-  const int wn = wq == 2 ? 3 : (wq == 3 ? 2 : wq);              // column waves (0, 3) and (1, 2) share a SIMD (see above)
-  const int wi = (wid & 1) * 64;
-  const int lr = lane & 15, kg = lane >> 4, sw = lr >> 1;
-  const DmaBuf dB = dma_buf_make(g.Ri, GN);
-  auto issue = [&](int u) {
-    if (u >= U) return;
-    const int s = u & 7;
-    const int64_t i0 = (int64_t)(t0 + (u >> 3) * tstride) * 128;
-    double* st = smem + (u & 1) * STG;
-    // A: k rows of both K tiles; one wave-instruction per k row (128 consecutive doubles of Q), halves swapped when (k >> 1) is odd
-#pragma unroll
-    for (int im = 0; im < 2; im++) {
-      const int kt = im ? 15 - s : s;
-#pragma unroll
-      for (int q = 0; q < 2; q++) {
-        const int kr = wid * 2 + q;
-        const int c = lane ^ (((kr >> 1) & 1) << 3);
-        const double* src = g.Qin + (int64_t)(kt * BK + kr) * g.ldin + i0 + c * 2;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(st + im * TA + kr * 128), 16, 0, 0);
-      }
-    }
-    // B: slots 0 .. 31 - 2 s = column groups 2 s .. 31 of K tile s; the next 2 s + 2 slots = column groups 30 - 2 s .. 31 of K tile 15 - s;
-    // slots 34 .. 39 repeat slots 0 .. 5 (same bytes to the same place: padding, so that every wave issues five pieces)
-    const int nA = 32 - 2 * s;
-#pragma unroll
-    for (int q = 0; q < 5; q++) {
-      int slot = wid * 5 + q;
-      if (slot >= 34) slot -= 34;
-      const bool second = slot >= nA;
-      const int g8 = second ? 30 - 2 * s + (slot - nA) : 2 * s + slot;
-      const uint32_t kb = (uint32_t)(second ? 15 - s : s) * BK * 8;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(dB.rsrc, (__attribute__((address_space(3))) void*)(st + 2 * TA + slot * 128), 16,
-                                               (int)((g8 & 1) ? dB.voff_odd : dB.voff_even), (int)((uint32_t)g8 * dB.rowgrp + kb), 0, 0);
-    }
-  };
-  d4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (d4){0, 0, 0, 0};
-  const int amc_flip = (kg & 1) << 4;
-  // block column cb = wn + 4 j of row tile `tile`: store and clear
-#define CQRP_STORE(j, cb, tile)                                                                                                \
-  {                                                                                                                            \
-    const int64_t i0_ = (int64_t)(t0 + (tile) * tstride) * 128;                                                                \
-    _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                                            \
-      const int64_t row = i0_ + wi + 16 * i + lr;                                                                              \
-      _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                                          \
-        g.Qout[row + (int64_t)(16 * (cb) + kg + 4 * r) * g.ldout] = acc[i][j][r];                                              \
-        acc[i][j][r] = 0.0;                                                                                                    \
-      }                                                                                                                        \
-    }                                                                                                                          \
-  }
-  // the columns step `up` completed (up = the step before the barrier just passed): cb = s (s <= 7) if it is mine, and with s = 7 my two
-  // columns >= 8.  In place (Qout == Qin) is fine: those columns of that row tile were consumed as K tiles <= cb; everything still to
-  // be read of the tile lies to the right, and the tile's remaining K tiles were requested before this barrier
-#define CQRP_LATE_STORES(up)                                                                                                   \
-  {                                                                                                                            \
-    const int sp_ = (up) & 7, tp_ = (up) >> 3;                                                                                 \
-    if ((sp_ & 3) == wn) {                                                                                                     \
-      if (sp_ < 4) CQRP_STORE(0, wn, tp_) else CQRP_STORE(1, wn + 4, tp_)                                                      \
-    }                                                                                                                          \
-    if (sp_ == 7) { CQRP_STORE(2, wn + 8, tp_) CQRP_STORE(3, wn + 12, tp_) }                                                   \
-  }
-  issue(0);
-  for (int u = 0; u < U; u++) {
-    const int s = u & 7;
-    // stage u has landed, my stores of the step before last are done, and nobody still reads the other stage
-    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8));         // vmcnt(0) lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
-    issue(u + 1);
-    if (u > 0) CQRP_LATE_STORES(u - 1)
-    const double* st = smem + (u & 1) * STG;
-    const int nA = 32 - 2 * s;
-#pragma unroll
-    for (int im = 0; im < 2; im++) {
-      const int kt = im ? 15 - s : s;
-      const int jlo = kt > wn ? (kt - wn + 3) >> 2 : 0;          // block column wn + 4 j is live at K tile kt iff wn + 4 j >= kt
-      const double* tA = st + im * TA;
-      // live columns start at block column kt: slot area of this K tile begins at piece (im ? nA : 0), block column cb sits 2 (cb - kt) pieces in
-      const double* tB = st + 2 * TA + (im ? nA : 0) * 128 - kt * 16 * BK;
-      if (jlo < 4) {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          d2 fa[4], fb[4];
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const int mm = (wi + 16 * i + lr) ^ amc_flip;
-            fa[i] = (d2){tA[(8 * h + 2 * kg) * 128 + mm], tA[(8 * h + 2 * kg + 1) * 128 + mm]};
-          }
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (j >= jlo) fb[j] = *reinterpret_cast<const d2*>(tB + (16 * (wn + 4 * j) + lr) * BK + (((h * 4 + kg) ^ sw) << 1));
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (j >= jlo) {
-#pragma unroll
-              for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-              for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
-            }
-        }
-      }
-    }
-  }
-  CQRP_LATE_STORES(U - 1)
-  __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
-#undef CQRP_STORE
-#undef CQRP_LATE_STORES
-}
+// (A variant that handled the K tiles (s, 15 - s) of a row tile in one step - 17 block columns of work in every step, half the barriers -
+// was built and measured in round 4: 4 % SLOWER on the whole CholeskyQR2 call, its hand-over sits at the top of a step where this kernel
+// hides it between the two k-halves of a tile; profiles/r04_experiments.log section 5.  Removed in round 5.)
 
 }  // namespace
 
@@ -446,22 +313,6 @@ int cap_qrapply256_launch(const double* Qin, int64_t ldin, const double* Ri, dou
     else if (diag == 2) hipLaunchKernelGGL((qrapply256_kernel<2, 0>), gr, bl, lds, s, g);
     else if (diag == 3) hipLaunchKernelGGL((qrapply256_kernel<3, 0>), gr, bl, lds, s, g);
     if (diag >= 1 && diag <= 3) { CAP_HIP(hipGetLastError()); return CAP_OK; }
-  }
-  // paired K tiles (qrapply256p_kernel, CAP_CQR_PAIR=1): uniform steps and half the barriers - measured 4 % SLOWER on the whole
-  // CholeskyQR2 call (10.69-10.77 ms against 10.31-10.32, profiles/r04_experiments.log section 5): its hand-over sits at the top of a step
-  // (vmcnt(0) + barrier + refill + first fragment reads with no MFMA queued behind them), where the kernel above hides it between the
-  // two k-halves of a tile.  Kept as a tested alternative (tests run both), off by default.
-  static const int pair = getenv("CAP_CQR_PAIR") ? atoi(getenv("CAP_CQR_PAIR")) : 0;
-  if (pair) {
-    const size_t ldsp = 2 * (2 * TA + 40 * 128) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-      CAP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qrapply256p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(qrapply256p_kernel, gr, bl, ldsp, s, g);
-    CAP_HIP(hipGetLastError());
-    return CAP_OK;
   }
   if (pipe == 1) hipLaunchKernelGGL((qrapply256_kernel<0, 1>), gr, bl, lds, s, g);
   else hipLaunchKernelGGL((qrapply256_kernel<0, 0>), gr, bl, lds, s, g);

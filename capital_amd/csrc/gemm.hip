@@ -1051,7 +1051,7 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   }
 
   int st;
-  static const bool use_v1 = getenv("CAP_GEMM_V1") != nullptr;   // A/B switch for profiling
+  constexpr bool use_v1 = false;       // (round 1's register-staged kernels for the aligned TN / NN forms: CAP_GEMM_V1 is gone)
   // a separate C input is only implemented in the LDS-DMA kernels' load / add / store epilogue
   if (Cin && !(a_kc && b_kc && !edge && !use_v1 && g.ksplit == 1)) return CAP_ERR_UNSUPPORTED;     // (the NN form has a_kc == false)
   if (a_kc && b_kc && !edge && !use_v1) st = (tag == 1) ? launch_tn_dma<1>(g, (int)grid, stream, persist_wgs) : launch_tn_dma<0>(g, (int)grid, stream, 0);

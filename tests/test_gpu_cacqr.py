@@ -81,30 +81,3 @@ def test_tall_skinny_properties_at_scale():
     assert pack.last_info() == 0
     assert validate.qr.residual(A, pack) < 1e-13
     assert validate.qr.orthogonality(A, pack) < 1e-15
-
-
-def test_paired_k_tile_apply_kernel_in_a_subprocess():
-    """qrapply256p_kernel (K tiles (s, 15 - s) per step; CAP_CQR_PAIR=1 is read once per process): same Q and R as the default kernel on a
-    shape that walks several row tiles per workgroup, residual / orthogonality at fp64 level."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
-        "from capital_amd import cacqr, cholinv, validate\n"
-        "from capital_amd.matrix import matrix\n"
-        "m, n = 65536 + 128 * 37, 256\n"
-        "A = matrix(n, m, 1, 1); A.distribute_random(0, 0, 1, 1, 3)\n"
-        "p = cacqr.info(2, cholinv.info(1, 1, 0, 'U')); cacqr.factor(A, p, None)\n"
-        "assert p.last_info() == 0\n"
-        "res = validate.qr.residual(A, p, None); orth = validate.qr.orthogonality(A, p, None)\n"
-        "q = cacqr.construct_Q(p, None).view(); print('PAIR', res, orth, float(q.double().abs().sum()))\n" % root)
-    outs = []
-    for pair in ("0", "1"):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, CAP_CQR_PAIR=pair))
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        line = [l for l in r.stdout.splitlines() if l.startswith("PAIR")][0].split()
-        outs.append([float(v) for v in line[1:]])
-        assert outs[-1][0] < 1e-13 and outs[-1][1] < 1e-15, outs[-1]
-    assert abs(outs[0][2] - outs[1][2]) < 1e-9 * abs(outs[0][2])           # the same Q up to summation order
