@@ -188,6 +188,46 @@ def run(args):
             assert probe < 1e-13, probe
             print("DIST2D-OK world=%d grid=%dx%d n=%d nb=%d err=%.2e residual=%.2e probe=%.2e launches(rank0)=%s" % (size, ctx.Pr, ctx.Pc, n, nb, err, res, probe, counts), flush=True)
         ctx.close(); row.close(); col.close(); comm.close()
+    elif args.mode == "chainstress":
+        # the one-launch diagonal-block chain (workgroups meeting at a counter in device memory) under several PROCESSES
+        # time-slicing one GPU, each with a saturating side stream - where round 4's only protocol race showed up.  Every rank factors its
+        # own matrix `nb` (= repetitions here) times with the one-launch chain next to a looping big product and compares every result
+        # bit for bit with the launch-per-step chain's; no give-up may have been needed.
+        torch.cuda.set_device(0)
+        from capital_amd import cholinv
+        from capital_amd.matrix import matrix
+        reps = nb
+        a = orc.symmetric_global(n, True)
+        a[rank, rank] += 1.0 + rank                                  # a different matrix per rank
+        A = matrix(n, n, 1, 1).from_numpy(a)
+        def plan(G):
+            pk = cholinv.info(1, 1, -2, 'U'); pk.set_option("nb", 1024 if n >= 2048 else 512); pk.set_option("chain_coop", G)
+            return pk
+        p0 = plan(0); cholinv.factor(A, p0, None)
+        r0 = cholinv.construct_R(p0).to_numpy(); i0 = cholinv.construct_Rinv(p0).to_numpy()
+        assert p0.last_info() == 0
+        p1 = plan(32)
+        side = torch.cuda.Stream()
+        x = torch.randn(4096, 4096, device="cuda", dtype=torch.float64)
+        dist.barrier()                                               # all ranks start their loops together
+        with torch.cuda.stream(side):
+            for _ in range(12):
+                y = x @ x
+        bad = 0
+        for rep in range(reps):
+            cholinv.factor(A, p1, None)
+            if rep % 5 == 4 or rep == reps - 1:
+                if not (np.array_equal(cholinv.construct_R(p1).to_numpy(), r0) and np.array_equal(cholinv.construct_Rinv(p1).to_numpy(), i0)):
+                    bad += 1
+        torch.cuda.synchronize()
+        assert p1.last_info() == 0 and bad == 0, (rank, bad)
+        fb = p1.get_option("chain_fallbacks")
+        res = [None] * size
+        dist.all_gather_object(res, (bad, int(fb)))
+        if rank == 0:
+            assert all(b == 0 for b, _ in res), res
+            print("CHAINSTRESS-OK world=%d n=%d reps=%d fallbacks=%s" % (size, n, reps, [f for _, f in res]), flush=True)
+        del y
     elif args.mode == "desc":
         # The drop-in boundary for a caller with a HOST matrix (north_star: "2D block-cyclic matrix descriptor ... with pinned host
         # staging"; matrix.h:9-97, injection ctor matrix.hpp:52-74): every rank holds the global matrix in host memory, builds the

@@ -554,6 +554,17 @@ def test_block_cyclic_descriptor_host_round_trip(nproc, pr, n, nb, ci):
     assert "DESC-OK" in r.stdout, r.stdout[-2000:]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,n,reps", [(4, 2048, 20), (8, 1024, 10)])
+def test_one_launch_chain_under_process_time_slicing(nproc, n, reps):
+    """The one-launch diagonal-block chain with 4 / 8 processes sharing the GPU, each next to its own saturating stream: bit-identical to the
+    launch-per-step chain in every process, every repetition checked (the memory-ordering side of the meeting protocol has
+    no CPU model - this is its stress test; release / acquire fences are on by default since round 5)."""
+    r = _case(nproc, "chainstress", n, reps)
+    assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    assert "CHAINSTRESS-OK" in r.stdout, r.stdout[-2000:]
+
+
 # case of every batched test, from its parameters (read by tests/conftest.py at collection time)
 test_multirank_schedule_on_one_gpu._dist_case = lambda nproc, n, nb: (nproc, "gpu", n, nb, ())
 test_multirank_schedule_variants._dist_case = lambda nproc, n, nb, extra: (nproc, "gpu", n, nb, tuple(extra))
@@ -572,3 +583,4 @@ test_summa_trmm_and_syrk_overloads_on_process_grids._dist_case = lambda nproc, c
 test_reference_recursion_composed_from_the_distributed_operators._dist_case = lambda name: (8, "summa_tri", 128, 128, ("--golden", name))
 test_2d_block_cyclic_schedule_on_one_gpu._dist_case = lambda nproc, pr, n, nb: (nproc, "gpu2d", n, nb, ("--pr", pr) + (("--expect-fail", "cap_dist2d_plan_create") if nproc // pr % pr else ()))
 test_block_cyclic_descriptor_host_round_trip._dist_case = lambda nproc, pr, n, nb, ci: (nproc, "desc", n, nb, ("--pr", pr, "--ci", ci))
+test_one_launch_chain_under_process_time_slicing._dist_case = lambda nproc, n, reps: (nproc, "chainstress", n, reps, ())
