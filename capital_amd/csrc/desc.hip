@@ -83,24 +83,29 @@ inline int64_t to_global(int kind, int64_t nb, int64_t p, int64_t q, int64_t l) 
   return ((l / nb) * p + q) * nb + l % nb;
 }
 
-// host GLOBAL matrix <-> packed image of local columns [c0, c0 + nc) (ld = local rows): the row runs of every column
+// host GLOBAL matrix <-> packed image of local columns [c0, c0 + nc) (ld = local rows): the row runs of every column.  Element-cyclic
+// pieces are ceil-sized (matrix.hpp:8-11): local rows / columns beyond what this position owns are padding - zero-filled on the way in,
+// skipped on the way out, never looked up in the host matrix.
 void host_pack_cols(const cap_desc* d, const double* hostg, int64_t ldh, double* img, int64_t c0, int64_t nc, bool to_image) {
   const int64_t rows = d->ly, rl = run_len(d->kind, d->nb, d->py);
+  const int64_t vrows = owned(d->kind, d->gy, d->nb, d->py, d->qy), vcols = owned(d->kind, d->gx, d->nb, d->px, d->qx);
   const int64_t bytes = rows * nc * 8;
   int nt = (int)std::min<int64_t>(8, std::max<int64_t>(1, bytes / (4 << 20)));
   nt = std::min<int>(nt, std::max(1u, std::thread::hardware_concurrency()));
   auto work = [&](int t) {
     for (int64_t c = nc * t / nt; c < nc * (t + 1) / nt; c++) {
-      const int64_t gc = to_global(d->kind, d->nb, d->px, d->qx, c0 + c);
       double* icol = img + c * rows;
-      for (int64_t r = 0; r < rows;) {
+      if (c0 + c >= vcols) { if (to_image) memset(icol, 0, (size_t)rows * 8); continue; }
+      const int64_t gc = to_global(d->kind, d->nb, d->px, d->qx, c0 + c);
+      for (int64_t r = 0; r < vrows;) {
         const int64_t gr = to_global(d->kind, d->nb, d->py, d->qy, r);
-        const int64_t len = std::min(rows - r, rl - (d->kind == 1 ? r % d->nb : 0));
+        const int64_t len = std::min(vrows - r, rl - (d->kind == 1 ? r % d->nb : 0));
         double* hp = const_cast<double*>(hostg) + gr + gc * ldh;
         if (to_image) memcpy(icol + r, hp, (size_t)len * 8);
         else memcpy(hp, icol + r, (size_t)len * 8);
         r += len;
       }
+      if (to_image && vrows < rows) memset(icol + vrows, 0, (size_t)(rows - vrows) * 8);
     }
   };
   if (nt == 1) { work(0); return; }

@@ -159,6 +159,69 @@ def test_descriptor_ownership_and_pinned_staging_round_trip():
         L.cap_desc_destroy(d)
 
 
+def test_global_host_import_export_of_both_descriptor_kinds():
+    """cap_desc_import_host_global / export_host_global: every grid position of several grids picks exactly its own blocks (block-cyclic
+    kind, cap_desc_create_bc) or elements (element-cyclic kind + cap_desc_set_position) out of a GLOBAL column-major host matrix and puts
+    them back where they came from - bit-exact against NumPy index arithmetic, strided host images, ragged blocks, empty pieces, pieces
+    of several pinned chunks (the 2-D packing runs on host threads while the previous chunk is on the PCIe link)."""
+    import ctypes as C
+    from capital_amd import _lib, dist_cholesky as dc
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(4)
+
+    def device_piece(d):
+        lx, ly, ld = L.cap_desc_get(d, 2), L.cap_desc_get(d, 3), L.cap_desc_get(d, 4)
+        out = np.empty((lx, ly))
+        _lib.check(L.cap_desc_export_host(d, out.ctypes.data, ly, s))          # the LOCAL export: the piece as it sits in HBM
+        return out.T                                                           # [row, col]
+
+    for (gy, gx, nb, Pr, Pc) in [(1000, 1000, 128, 2, 2), (2049, 777, 256, 2, 4), (250, 250, 128, 2, 4), (5000, 4200, 512, 1, 3), (130, 9000, 64, 3, 1)]:
+        ldh = gy + 5
+        host = np.zeros((gx, ldh)); host[:, :gy] = rng.standard_normal((gx, gy))        # [col][row], ld = ldh
+        a = host[:, :gy].T                                                     # [row, col]
+        back = np.zeros_like(host)
+        for pr in range(Pr):
+            for pc in range(Pc):
+                d = C.c_void_p()
+                _lib.check(L.cap_desc_create_bc(C.byref(d), gx, gy, nb, Pr, Pc, pr, pc, None, 0))
+                rows = dc.global_index_2d(gy, nb, Pr, pr); cols = dc.global_index_2d(gx, nb, Pc, pc)
+                assert (L.cap_desc_get(d, 3), L.cap_desc_get(d, 2)) == (rows.size, cols.size)
+                _lib.check(L.cap_desc_import_host_global(d, host.ctypes.data, ldh, s))
+                if rows.size and cols.size:
+                    assert np.array_equal(device_piece(d), a[np.ix_(rows, cols)])
+                _lib.check(L.cap_desc_export_host_global(d, back.ctypes.data, ldh, s))
+                L.cap_desc_destroy(d)
+        assert np.array_equal(back, host)                                       # every element written exactly where it came from, padding untouched
+    # element-cyclic kind (upstream's layout, matrix.hpp:8-11)
+    for (gy, gx, px, py) in [(1001, 777, 2, 2), (4096, 300, 1, 4), (513, 2050, 3, 2)]:
+        host = rng.standard_normal((gx, gy)); a = host.T
+        back = np.zeros_like(host)
+        for x in range(px):
+            for y in range(py):
+                d = C.c_void_p()
+                _lib.check(L.cap_desc_create(C.byref(d), gx, gy, px, py))
+                assert L.cap_desc_import_host_global(d, host.ctypes.data, gy, s) == 1     # position unknown: refused
+                _lib.check(L.cap_desc_set_position(d, x, y))
+                _lib.check(L.cap_desc_import_host_global(d, host.ctypes.data, gy, s))
+                want = orc.cyclic_local(a, x, y, px, py)
+                nr, nc = len(range(y, gy, py)), len(range(x, gx, px))
+                assert np.array_equal(device_piece(d)[:nr, :nc], want[:nr, :nc])
+                _lib.check(L.cap_desc_export_host_global(d, back.ctypes.data, gy, s))
+                L.cap_desc_destroy(d)
+        assert np.array_equal(back, host)
+    # a piece of several 64 MiB chunks: 9000 x 20000 on a 1 x 2 grid = 687 MiB per process
+    gy, gx, nb = 9000, 20000, 512
+    host = rng.standard_normal((gx, gy)); back = np.zeros_like(host)
+    for pc in range(2):
+        d = C.c_void_p()
+        _lib.check(L.cap_desc_create_bc(C.byref(d), gx, gy, nb, 1, 2, 0, pc, None, 0))
+        _lib.check(L.cap_desc_import_host_global(d, host.ctypes.data, gy, s))
+        _lib.check(L.cap_desc_export_host_global(d, back.ctypes.data, gy, s))
+        L.cap_desc_destroy(d)
+    assert np.array_equal(back, host)
+
+
 def test_matrix_numpy_round_trip_uses_the_descriptor():
     from capital_amd.matrix import matrix
     a = np.random.default_rng(1).standard_normal((777, 333))
