@@ -201,3 +201,10 @@ def check(status, what=""):
         msg = lib().cap_status_string(status)
         raise CapitalError("%s failed: status %d (%s)" % (what or "capital_amd call", status,
                                                           msg.decode() if msg else "?"))
+
+
+def check_info(status, what=""):
+    """Status of a *_info query: CAP_OK, or CAP_ERR_NOT_SPD when the info word it returns is non-zero (the caller reads the word);
+    anything else means the query itself failed and the info word was NOT written - never to be read as "info = 0"."""
+    if status not in (0, 3):
+        check(status, what)

@@ -49,7 +49,7 @@ class info:
 
     def last_info(self):
         v = C.c_int64(0)
-        _lib.lib().cap_cacqr_info(self._plan, cur_stream(), C.byref(v))
+        _lib.check_info(_lib.lib().cap_cacqr_info(self._plan, cur_stream(), C.byref(v)), "cap_cacqr_info")
         return v.value
 
     def __del__(self):

@@ -57,7 +57,7 @@ class info:
     def last_info(self):
         """0, or the 1-based index of the first non-positive pivot (upstream drops this, lapack/interface.hpp:39)."""
         v = C.c_int64(0)
-        _lib.lib().cap_cholinv_info(self._plan, cur_stream(), C.byref(v))
+        _lib.check_info(_lib.lib().cap_cholinv_info(self._plan, cur_stream(), C.byref(v)), "cap_cholinv_info")
         return v.value
 
     def __del__(self):

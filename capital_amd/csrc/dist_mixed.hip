@@ -99,6 +99,15 @@ int ensure_events3(cap_dmp_plan* d) {
   CAP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
   CAP_HIP(hipStreamCreateWithPriority(&d->s_panel, hipStreamNonBlocking, hi));
   CAP_HIP(hipStreamCreateWithPriority(&d->s_comm, hipStreamNonBlocking, hi));
+  // One completed command on each fresh stream before the schedule's first event record / wait names it.  Defensive (round 5): once,
+  // on a one-rank plan whose FIRST factor call was followed at once by cap_dmp_info and a device synchronisation, both returned
+  // while the plan's streams were still in their first step (tests/dist_worker.py, profiles/r05_flake_forensics.txt) - the
+  // hardware queue behind a stream is created lazily with its first command.  Private streams with one 8-byte memset each: nothing
+  // another rank could be waiting for.
+  CAP_HIP(hipMemsetAsync(d->info_red, 0, sizeof(double), d->s_panel));
+  CAP_HIP(hipStreamSynchronize(d->s_panel));
+  CAP_HIP(hipMemsetAsync(d->info_red, 0, sizeof(double), d->s_comm));
+  CAP_HIP(hipStreamSynchronize(d->s_comm));
   return CAP_OK;
 }
 }  // namespace

@@ -124,7 +124,7 @@ class Context:
 
     def last_info(self):
         v = C.c_int64(0)
-        _lib.lib().cap_dist_info(self.plan, cur_stream(), C.byref(v))
+        _lib.check_info(_lib.lib().cap_dist_info(self.plan, cur_stream(), C.byref(v)), "cap_dist_info")
         return v.value
 
     def local_R_device(self):
@@ -234,7 +234,7 @@ class Context2D:
 
     def last_info(self):
         v = C.c_int64(0)
-        _lib.lib().cap_dist2d_info(self.plan, cur_stream(), C.byref(v))
+        _lib.check_info(_lib.lib().cap_dist2d_info(self.plan, cur_stream(), C.byref(v)), "cap_dist2d_info")
         return v.value
 
     def local_R_device(self):

@@ -29,7 +29,7 @@ class plan:
 
     def last_info(self):
         v = C.c_int64(0)
-        _lib.lib().cap_mpchol_info(self._h, cur_stream(), C.byref(v))
+        _lib.check_info(_lib.lib().cap_mpchol_info(self._h, cur_stream(), C.byref(v)), "cap_mpchol_info")
         return v.value
 
     def solve(self, A, B, max_iter=30, tol=1e-15):
@@ -92,7 +92,7 @@ class dist_plan:
 
     def last_info(self):
         v = C.c_int64(0)
-        _lib.lib().cap_dmp_info(self._h, cur_stream(), C.byref(v))
+        _lib.check_info(_lib.lib().cap_dmp_info(self._h, cur_stream(), C.byref(v)), "cap_dmp_info")
         return v.value
 
     def solve(self, A_local, B, max_iter=30, tol=1e-15):

@@ -299,6 +299,12 @@ def test_distributed_mixed_precision_solve(nproc, n, nb, hard):
     r = _case(nproc, "mixed", n, nb, ("--hard", hard))
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
     assert "DMP-OK" in r.stdout, r.stdout[-2000:]
+    if "DMP-FLAKE" in r.stdout:
+        # the worker's one-rank cross-check read a factor that was still being computed (seen once in round 5, see the comment in
+        # tests/dist_worker.py and DESIGN.md section 9); the repeated read / factor agreed, so the case counts - but not silently
+        import warnings
+        warnings.warn("one-rank cross-check of the distributed mixed-precision factor had to be repeated:\n" +
+                      "\n".join(l for l in r.stdout.splitlines() if "DMP-FLAKE" in l)[:2000])
 
 
 @pytest.mark.gpu
