@@ -104,10 +104,13 @@ int ensure_events3(cap_dmp_plan* d) {
   // while the plan's streams were still in their first step (tests/dist_worker.py, profiles/r05_flake_forensics.txt) - the
   // hardware queue behind a stream is created lazily with its first command.  Private streams with one 8-byte memset each: nothing
   // another rank could be waiting for.
-  CAP_HIP(hipMemsetAsync(d->info_red, 0, sizeof(double), d->s_panel));
-  CAP_HIP(hipStreamSynchronize(d->s_panel));
-  CAP_HIP(hipMemsetAsync(d->info_red, 0, sizeof(double), d->s_comm));
-  CAP_HIP(hipStreamSynchronize(d->s_comm));
+  static const bool prime = getenv("CAP_DMP_PRIME") ? atoi(getenv("CAP_DMP_PRIME")) != 0 : true;     // (0: the A/B runs of tools/r05_late_read.py)
+  if (prime) {
+    CAP_HIP(hipMemsetAsync(d->info_red, 0, sizeof(double), d->s_panel));
+    CAP_HIP(hipStreamSynchronize(d->s_panel));
+    CAP_HIP(hipMemsetAsync(d->info_red, 0, sizeof(double), d->s_comm));
+    CAP_HIP(hipStreamSynchronize(d->s_comm));
+  }
   return CAP_OK;
 }
 }  // namespace

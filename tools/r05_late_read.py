@@ -1,10 +1,10 @@
 """Tries to reproduce the late read of DESIGN.md section 7 in ONE process: many one-rank cap_dmp plans, each created, factored ONCE and
 read at once (cap_dmp_info + device synchronisation + copy, exactly what tests/dist_worker.py does), with some stream churn in between.
-A read that differs from the first plan's factor is a late (or wrong) read.  Measured once with the plan's stream priming switched off
-by a temporary environment switch (400 iterations, 0 late reads) and once with it on (200, 0): profiles/r05_late_read_prime{0,1}.log -
-the event needs more than this (the failing process shared the GPU with three idle peer processes).
+A read that differs from the first plan's factor is a late (or wrong) read.  CAP_DMP_PRIME=0 switches the plan's stream priming off.
+Measured: priming off 400 iterations / on 200 (no peers, no second plan): 0 late reads (profiles/r05_late_read_prime{0,1}.log); priming off,
+three idle peer processes, a second live plan, 500 iterations: 0 (profiles/r05_late_read_prime0_peers3.log).  The event was not reproduced.
 
-    python tools/r05_late_read.py [iterations] [churn streams per iteration]"""
+    python tools/r05_late_read.py [iterations] [churn streams per iteration] [idle peer processes holding a context on the GPU]"""
 import ctypes as C
 import os
 import sys
@@ -17,8 +17,24 @@ import torch
 
 from capital_amd import _lib, mixed
 
+if len(sys.argv) > 1 and sys.argv[1] == "--peer":
+    # an idle peer: a context on the GPU, one kernel, one helper stream - then nothing until the parent goes away
+    import torch
+    torch.cuda.set_device(0)
+    x = torch.ones(1 << 20, device="cuda"); s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        y = x * 2
+    torch.cuda.synchronize()
+    print("peer up", flush=True)
+    sys.stdin.read()
+    sys.exit(0)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 churn = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+npeers = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+import subprocess
+peers = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--peer"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for _ in range(npeers)]
+for q in peers:
+    q.stdout.readline()
 n, nb = 2048, 256
 torch.cuda.set_device(0)
 g = np.random.default_rng(17).standard_normal((n, n))
@@ -34,7 +50,15 @@ class SelfComm:
         _lib.check(L.cap_comm_create_self(C.byref(self.handle)), "cap_comm_create_self")
 
 
+live = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+
+
 def one(sync_more=False):
+    other = None
+    if live:                                     # like the test: another plan of the process is alive and has just been used
+        so = SelfComm()
+        other = mixed.dist_plan(n, so, nb=nb, nrhs_max=5)
+        other.factor(A1); other.factor(A1); other.last_info(); other.R32_local()
     sc = SelfComm()
     p = mixed.dist_plan(n, sc, nb=nb, nrhs_max=5)
     p.factor(A1)
@@ -43,6 +67,8 @@ def one(sync_more=False):
         time.sleep(0.3); torch.cuda.synchronize()
     R = p.R32_local()
     p.close(); L.cap_comm_destroy(sc.handle)
+    if other is not None:
+        other.close(); L.cap_comm_destroy(so.handle)
     return info, R
 
 
@@ -69,4 +95,6 @@ for it in range(iters):
     if info != 0 or not d < 1e-5:
         bad += 1
         print("iteration %d: info %d, read differs from the reference factor by %.4e" % (it, info, d), flush=True)
-print("iterations=%d late_or_wrong_reads=%d (%.1f s)" % (iters, bad, time.time() - t0), flush=True)
+print("prime=%s peers=%d iterations=%d late_or_wrong_reads=%d (%.1f s)" % (os.environ.get("CAP_DMP_PRIME", "1"), npeers, iters, bad, time.time() - t0), flush=True)
+for q in peers:
+    q.stdin.close(); q.wait()
