@@ -128,6 +128,28 @@ int coop_slot(int** ctr, double** backup, int** fallbacks, hipStream_t s) {
   return CAP_OK;
 }
 
+}  // namespace
+
+// the stream is about to be destroyed: give its counter words and backup buffer back (hipFree waits for whatever still uses them)
+void cap_coop_slot_release(hipStream_t s) {
+  int dev = 0;
+  if (!s || hipGetDevice(&dev) != hipSuccess) return;
+  int* ctr = nullptr; double* backup = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    if (!g_coop_slots) return;
+    for (size_t i = 0; i < g_coop_slots->size(); i++)
+      if ((*g_coop_slots)[i].dev == dev && (*g_coop_slots)[i].s == s) {
+        ctr = (*g_coop_slots)[i].ctr; backup = (*g_coop_slots)[i].backup;
+        g_coop_slots->erase(g_coop_slots->begin() + (std::ptrdiff_t)i);
+        break;
+      }
+  }
+  if (ctr) (void)hipFree(ctr);
+  if (backup) (void)hipFree(backup);
+}
+
+namespace {
 int64_t rec_work_size(int64_t n) { return cap_round_up(std::max<int64_t>((n / 2 + 1) * (n / 2 + 1), 128 * n), 2); }
 
 // Diagonal-block fast path (n = 64 * nblk <= 1024): 64-blocked right-looking potrf with ONE fused launch per step
@@ -610,7 +632,7 @@ int ensure_sb(cap_cholinv_plan* p, int64_t NB, int64_t n) {
 
 void release_sb(cap_cholinv_plan* p) {
   if (!p->sb_ready) return;
-  (void)hipStreamSynchronize(p->s_copy); (void)hipStreamDestroy(p->s_copy);
+  (void)hipStreamSynchronize(p->s_copy); cap_stream_destroy(p->s_copy);
   (void)hipEventDestroy(p->ev_sbg); (void)hipEventDestroy(p->ev_join_cp);
   for (int i = 0; i < 4; i++) (void)hipEventDestroy(p->ev_copy[i]);
   if (p->SB) (void)hipFree(p->SB);
@@ -652,7 +674,7 @@ int inverse_after_panel(cap_cholinv_plan* p, int64_t k, int64_t cols_left, hipSt
 
 void release_inverse(cap_cholinv_plan* p) {
   if (p->inv_ready) {
-    (void)hipStreamSynchronize(p->s_inv); (void)hipStreamDestroy(p->s_inv);
+    (void)hipStreamSynchronize(p->s_inv); cap_stream_destroy(p->s_inv);
     (void)hipEventDestroy(p->ev_inv_done);
     p->inv_ready = false;
   }
@@ -662,7 +684,7 @@ void release_inverse(cap_cholinv_plan* p) {
 
 void release_split(cap_cholinv_plan* p) {
   if (!p->split_ready) return;
-  (void)hipStreamSynchronize(p->s_rest); (void)hipStreamDestroy(p->s_rest);
+  (void)hipStreamSynchronize(p->s_rest); cap_stream_destroy(p->s_rest);
   for (int i = 0; i < 2; i++) {
     (void)hipEventDestroy(p->ev_crit[i]); (void)hipEventDestroy(p->ev_near[i]);
     for (int q = 0; q < 8; q++) { (void)hipEventDestroy(p->ev_pchain[i][q]); (void)hipEventDestroy(p->ev_psolve[i][q]); }
@@ -1085,12 +1107,12 @@ int cap_cholinv_plan_destroy(cap_cholinv_plan* p) {
   if (p->work) (void)hipFree(p->work);
   if (p->info_dev) (void)hipFree(p->info_dev);
   if (p->streams_ready) {
-    (void)hipStreamDestroy(p->s_panel);
+    cap_stream_destroy(p->s_panel);
     for (int i = 0; i < 2; i++) { (void)hipEventDestroy(p->ev_panel[i]); (void)hipEventDestroy(p->ev_update[i]); }
     (void)hipEventDestroy(p->ev_fork); (void)hipEventDestroy(p->ev_join); (void)hipEventDestroy(p->ev_join_b);
   }
   if (p->bulk_ready) {
-    (void)hipStreamDestroy(p->s_bulk); (void)hipStreamDestroy(p->s_chain);
+    cap_stream_destroy(p->s_bulk); cap_stream_destroy(p->s_chain);
     for (int i = 0; i < 2; i++) (void)hipEventDestroy(p->ev_chain[i]);
     (void)hipEventDestroy(p->ev_bulk_sw);
   }
@@ -1164,8 +1186,8 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
   if (k == "reserve") {   // CUs kept free for the panel chain (multiple of 8 keeps the XCDs balanced); 0 = off
     if (value < 0 || value > 64) return CAP_ERR_ARG;
     if (p->bulk_ready) {
-      (void)hipStreamSynchronize(p->s_bulk); (void)hipStreamDestroy(p->s_bulk);
-      (void)hipStreamSynchronize(p->s_chain); (void)hipStreamDestroy(p->s_chain);
+      (void)hipStreamSynchronize(p->s_bulk); cap_stream_destroy(p->s_bulk);
+      (void)hipStreamSynchronize(p->s_chain); cap_stream_destroy(p->s_chain);
       for (int i = 0; i < 2; i++) (void)hipEventDestroy(p->ev_chain[i]);
       (void)hipEventDestroy(p->ev_bulk_sw);
       p->bulk_ready = false;

@@ -93,6 +93,17 @@ int cap_trinv_merge(const double* R, int64_t ldr, double* Ri, int64_t ldi, int64
 int cap_chain64_coop(double* R, int64_t ldr, double* Ri, int64_t ldi, int nblk, int* info, int info_base, int* ctr, int wgs, int fence,
                      int hmax, hipStream_t stream, long long* trace = nullptr, double* backup = nullptr, int* fallbacks = nullptr);
 int cap_chain64_coop_max_resident();      // workgroups of that kernel the current device holds at once (occupancy x CUs)
+// The one-launch chain keeps four counter words and a 4.25 MiB backup buffer per (device, stream) it has run on (cholinv.hip).  A plan
+// that destroys a helper stream hands them back first - they were kept for the life of the process before, one set per stream handle
+// the runtime ever returned (found by the recording stand-in of tests/hipshim: 282 live allocations after 286 plans).
+void cap_coop_slot_release(hipStream_t s);
+void cap_scratch_release(hipStream_t s);       // the split-K scratch buffer gemm.hip keeps per (device, stream): same story
+static inline void cap_stream_destroy(hipStream_t s) {
+  if (!s) return;
+  cap_coop_slot_release(s);
+  cap_scratch_release(s);
+  (void)hipStreamDestroy(s);
+}
 // resident workgroups of the one-launch diagonal-block chain (0: one launch per step) as the CALLING THREAD sees it: the process
 // default unless a CapChainScope is active; cap > 0 bounds it (CU-masked streams), also per thread
 int cap_chain_coop_swap(int wgs);         // installs wgs (-1: process default) for this thread, returns the previous value

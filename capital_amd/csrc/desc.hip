@@ -156,7 +156,7 @@ int cap_desc_destroy(cap_desc* d) {
     (void)hipStreamSynchronize(d->s_copy);
     for (int i = 0; i < 2; i++) { (void)hipHostFree(d->pin[i]); (void)hipEventDestroy(d->ev[i]); }
     (void)hipEventDestroy(d->ev_done);
-    (void)hipStreamDestroy(d->s_copy);
+    cap_stream_destroy(d->s_copy);
   }
   if (d->owns && d->data) (void)hipFree(d->data);
   delete d;

@@ -213,7 +213,7 @@ int ensure_ipc(cap_dist_plan* d, hipStream_t s) {
   if (tot != 0.0 || !ok) {
     for (int r = 0; r < P; r++) {
       for (int b = 0; b < 2; b++) if (d->peerG[r][b]) { (void)hipIpcCloseMemHandle(d->peerG[r][b]); d->peerG[r][b] = nullptr; }
-      if (d->s_peer[r]) { (void)hipStreamDestroy(d->s_peer[r]); d->s_peer[r] = nullptr; }
+      if (d->s_peer[r]) { cap_stream_destroy(d->s_peer[r]); d->s_peer[r] = nullptr; }
       if (d->ev_xr[r]) { (void)hipEventDestroy(d->ev_xr[r]); d->ev_xr[r] = nullptr; }
     }
     if (d->ev_x0) { (void)hipEventDestroy(d->ev_x0); d->ev_x0 = nullptr; }
@@ -475,7 +475,7 @@ int cap_dist_plan_destroy(cap_dist_plan* d) {
   if (d->info_dev) (void)hipFree(d->info_dev);
   if (d->info_red) (void)hipFree(d->info_red);
   for (double* q : {d->Dall, d->Ri, d->Cb[0], d->Cb[1]}) if (q) (void)hipFree(q);
-  if (d->s_inv) { (void)hipStreamSynchronize(d->s_inv); (void)hipStreamDestroy(d->s_inv); }
+  if (d->s_inv) { (void)hipStreamSynchronize(d->s_inv); cap_stream_destroy(d->s_inv); }
   for (hipEvent_t e : {d->ev_join_i, d->ev_t0, d->ev_sweep_end, d->ev_inv_end}) if (e) (void)hipEventDestroy(e);
   if (d->comm3) cap_comm_destroy(d->comm3);
   if (!d->ev_msg.empty()) {
@@ -483,13 +483,13 @@ int cap_dist_plan_destroy(cap_dist_plan* d) {
       for (auto e : *v) (void)hipEventDestroy(e);
     (void)hipEventDestroy(d->ev_init); (void)hipEventDestroy(d->ev_join_p); (void)hipEventDestroy(d->ev_join_c);
     (void)hipEventDestroy(d->ev_join_m);
-    (void)hipStreamDestroy(d->s_panel); (void)hipStreamDestroy(d->s_comm); (void)hipStreamDestroy(d->s_msg);
+    cap_stream_destroy(d->s_panel); cap_stream_destroy(d->s_comm); cap_stream_destroy(d->s_msg);
   }
   for (hipEvent_t e : d->prof_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : d->bk_ev) (void)hipEventDestroy(e);
   for (int r = 0; r < 8; r++) {
     for (int b = 0; b < 2; b++) if (d->peerG[r][b]) (void)hipIpcCloseMemHandle(d->peerG[r][b]);
-    if (d->s_peer[r]) { (void)hipStreamSynchronize(d->s_peer[r]); (void)hipStreamDestroy(d->s_peer[r]); }
+    if (d->s_peer[r]) { (void)hipStreamSynchronize(d->s_peer[r]); cap_stream_destroy(d->s_peer[r]); }
     if (d->ev_xr[r]) (void)hipEventDestroy(d->ev_xr[r]);
   }
   if (d->ev_x0) (void)hipEventDestroy(d->ev_x0);

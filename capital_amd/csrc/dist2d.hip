@@ -271,11 +271,11 @@ int ensure_ipc2d(cap_dist2d_plan* d, hipStream_t s) {
     for (int r = 0; r < 8; r++) for (int b = 0; b < 2; b++) if (d->peerA[r][b]) { (void)hipIpcCloseMemHandle(d->peerA[r][b]); d->peerA[r][b] = nullptr; }
     // ... and the copy streams / events open_all created before the failure (dist.hip's ensure_ipc does the same)
     for (int r = 0; r < 4; r++) {
-      if (d->s_pcol[r]) { (void)hipStreamDestroy(d->s_pcol[r]); d->s_pcol[r] = nullptr; }
+      if (d->s_pcol[r]) { cap_stream_destroy(d->s_pcol[r]); d->s_pcol[r] = nullptr; }
       if (d->ev_pcol[r]) { (void)hipEventDestroy(d->ev_pcol[r]); d->ev_pcol[r] = nullptr; }
     }
     for (int r = 0; r < 8; r++) {
-      if (d->s_prow[r]) { (void)hipStreamDestroy(d->s_prow[r]); d->s_prow[r] = nullptr; }
+      if (d->s_prow[r]) { cap_stream_destroy(d->s_prow[r]); d->s_prow[r] = nullptr; }
       if (d->ev_prow[r]) { (void)hipEventDestroy(d->ev_prow[r]); d->ev_prow[r] = nullptr; }
     }
     if (d->ev_px) { (void)hipEventDestroy(d->ev_px); d->ev_px = nullptr; }
@@ -434,16 +434,16 @@ int cap_dist2d_plan_destroy(cap_dist2d_plan* d) {
     for (auto* v : {&d->ev_fact, &d->ev_msg, &d->ev_rowdone, &d->ev_colb, &d->ev_inv, &d->ev_gather, &d->ev_head, &d->ev_head2, &d->ev_rest})
       for (auto e : *v) (void)hipEventDestroy(e);
     for (hipEvent_t e : {d->ev_init, d->ev_join_p, d->ev_join_c, d->ev_join_m, d->ev_join_i}) (void)hipEventDestroy(e);
-    for (hipStream_t st : {d->s_panel, d->s_comm, d->s_msg, d->s_inv}) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (hipStream_t st : {d->s_panel, d->s_comm, d->s_msg, d->s_inv}) { (void)hipStreamSynchronize(st); cap_stream_destroy(st); }
   }
   for (int r = 0; r < 4; r++) {
     for (int b = 0; b < 2; b++) if (d->peerBt[r][b]) (void)hipIpcCloseMemHandle(d->peerBt[r][b]);
-    if (d->s_pcol[r]) { (void)hipStreamSynchronize(d->s_pcol[r]); (void)hipStreamDestroy(d->s_pcol[r]); }
+    if (d->s_pcol[r]) { (void)hipStreamSynchronize(d->s_pcol[r]); cap_stream_destroy(d->s_pcol[r]); }
     if (d->ev_pcol[r]) (void)hipEventDestroy(d->ev_pcol[r]);
   }
   for (int r = 0; r < 8; r++) {
     for (int b = 0; b < 2; b++) if (d->peerA[r][b]) (void)hipIpcCloseMemHandle(d->peerA[r][b]);
-    if (d->s_prow[r]) { (void)hipStreamSynchronize(d->s_prow[r]); (void)hipStreamDestroy(d->s_prow[r]); }
+    if (d->s_prow[r]) { (void)hipStreamSynchronize(d->s_prow[r]); cap_stream_destroy(d->s_prow[r]); }
     if (d->ev_prow[r]) (void)hipEventDestroy(d->ev_prow[r]);
   }
   if (d->ev_px) (void)hipEventDestroy(d->ev_px);

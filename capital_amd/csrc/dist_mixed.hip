@@ -168,7 +168,7 @@ int cap_dmp_plan_destroy(cap_dmp_plan* d) {
     for (auto* v : {&d->ev_fact, &d->ev_msg, &d->ev_solved, &d->ev_gather, &d->ev_head, &d->ev_bulk})
       for (auto e : *v) (void)hipEventDestroy(e);
     (void)hipEventDestroy(d->ev_init); (void)hipEventDestroy(d->ev_join_p); (void)hipEventDestroy(d->ev_join_c);
-    (void)hipStreamDestroy(d->s_panel); (void)hipStreamDestroy(d->s_comm);
+    cap_stream_destroy(d->s_panel); cap_stream_destroy(d->s_comm);
   }
   delete d;
   return CAP_OK;

@@ -946,6 +946,17 @@ double* cap_scratch(int64_t elems, hipStream_t stream) {
   return b.p;
 }
 
+// the stream is about to be destroyed (cap_stream_destroy, common.h): its split-K scratch goes back to the pool, ordered behind its work
+void cap_scratch_release(hipStream_t stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  auto it = g_scratch.find(std::make_pair(dev, stream));
+  if (it == g_scratch.end()) return;
+  if (it->second.p) (void)hipFreeAsync(it->second.p, stream);
+  g_scratch.erase(it);
+}
+
 int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
                     int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri,
                     hipStream_t stream, int tag, int persist_wgs, const double* Cin, int64_t ldcin) {

@@ -616,20 +616,20 @@ int mp_ensure_reserved(cap_mpchol_plan* p) {
 }
 void mp_release_streams(cap_mpchol_plan* p) {
   if (p->split_ready) {
-    (void)hipStreamSynchronize(p->s_far); (void)hipStreamDestroy(p->s_far);
+    (void)hipStreamSynchronize(p->s_far); cap_stream_destroy(p->s_far);
     for (hipEvent_t e : {p->ev_c, p->ev_ns, p->ev_hf, p->ev_fs[0], p->ev_fs[1], p->ev_far[0], p->ev_far[1], p->ev_join2}) (void)hipEventDestroy(e);
     if (p->Tn) (void)hipFree(p->Tn);
     p->Tn = nullptr; p->split_ready = false;
   }
   if (p->streams_ready) {
-    (void)hipStreamSynchronize(p->s_panel); (void)hipStreamDestroy(p->s_panel);
+    (void)hipStreamSynchronize(p->s_panel); cap_stream_destroy(p->s_panel);
     for (int i = 0; i < 2; i++) { (void)hipEventDestroy(p->ev_rest[i]); (void)hipEventDestroy(p->ev_panel[i]); }
     (void)hipEventDestroy(p->ev_fork); (void)hipEventDestroy(p->ev_join);
     p->streams_ready = false;
   }
   if (p->res_ready) {
-    (void)hipStreamSynchronize(p->s_bulk); (void)hipStreamDestroy(p->s_bulk);
-    (void)hipStreamSynchronize(p->s_chain); (void)hipStreamDestroy(p->s_chain);
+    (void)hipStreamSynchronize(p->s_bulk); cap_stream_destroy(p->s_bulk);
+    (void)hipStreamSynchronize(p->s_chain); cap_stream_destroy(p->s_chain);
     for (hipEvent_t e : {p->ev_user, p->ev_bulk_done, p->ev_ch[0], p->ev_ch[1]}) (void)hipEventDestroy(e);
     p->res_ready = false;
   }

@@ -96,8 +96,8 @@ int cap_summa_plan_destroy(cap_summa_plan* p) {
   if (p->acc) (void)hipFree(p->acc);
   for (auto* v : {&p->ev_a, &p->ev_b, &p->ev_free, &p->ev_d}) for (auto ev : *v) if (ev) (void)hipEventDestroy(ev);
   if (p->ev_start) { (void)hipEventDestroy(p->ev_start); (void)hipEventDestroy(p->ev_join_r); (void)hipEventDestroy(p->ev_join_c); }
-  if (p->s_row) (void)hipStreamDestroy(p->s_row);
-  if (p->s_col) (void)hipStreamDestroy(p->s_col);
+  if (p->s_row) cap_stream_destroy(p->s_row);
+  if (p->s_col) cap_stream_destroy(p->s_col);
   delete p;
   return CAP_OK;
 }

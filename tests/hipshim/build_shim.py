@@ -1,0 +1,30 @@
+"""TEST INFRASTRUCTURE: links the product's own object files against the recording HIP / RCCL stand-in (hipshim.cpp) instead of
+libamdhip64 / librccl -> tests/hipshim/_build/libcapital_amd_shim.so (git-ignored).  No GPU, no HIP runtime in the process."""
+import glob
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OBJ = os.path.join(ROOT, "capital_amd", "lib", "obj")
+OUT = os.path.join(HERE, "_build")
+SHIM = os.path.join(OUT, "libhipshim.so")
+LIB = os.path.join(OUT, "libcapital_amd_shim.so")
+
+
+def build():
+    objs = sorted(glob.glob(os.path.join(OBJ, "*.o")))
+    if not objs:
+        raise RuntimeError("no object files under capital_amd/lib/obj - build the library first (python -m capital_amd.build)")
+    os.makedirs(OUT, exist_ok=True)
+    src = os.path.join(HERE, "hipshim.cpp")
+    newest = max(os.path.getmtime(f) for f in objs + [src, os.path.abspath(__file__)])
+    if os.path.exists(LIB) and os.path.exists(SHIM) and min(os.path.getmtime(LIB), os.path.getmtime(SHIM)) > newest:
+        return LIB, SHIM
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", SHIM, src])
+    subprocess.check_call(["g++", "-shared", "-fPIC", "-o", LIB] + objs + ["-L" + OUT, "-lhipshim", "-Wl,-rpath," + OUT, "-Wl,--no-undefined", "-ldl", "-lpthread"])
+    return LIB, SHIM
+
+
+if __name__ == "__main__":
+    print(build())

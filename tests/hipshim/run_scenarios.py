@@ -1,0 +1,479 @@
+"""TEST INFRASTRUCTURE: drives the library's host side (the product's object files linked against the recording HIP / RCCL stand-in,
+tests/hipshim/) through its C ABI on a machine without a GPU and checks every trace with trace_check.py.
+
+Runs in its OWN process (no torch: torch brings a real libamdhip64 into the process):
+    python tests/hipshim/run_scenarios.py out.json
+One entry per scenario: {"name", "findings": [...], "stats": {...}}.  A multi-rank plan is driven once per simulated rank with a
+callback communicator (cap_comm_create_callbacks) whose collectives are traced operations on the stream they are handed: the
+schedule a rank enqueues only depends on (rank, size), not on what its peers send."""
+import ctypes as C
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import build_shim       # noqa: E402
+import trace_check      # noqa: E402
+
+
+def signatures():
+    src = open(os.path.join(ROOT, "capital_amd", "_lib.py")).read().replace("import torch", "pass")
+    ns = {"__file__": os.path.join(ROOT, "capital_amd", "_lib.py"), "__name__": "sig"}
+    exec(compile(src, "_lib.py", "exec"), ns)
+    return ns["SIGNATURES"]
+
+
+LIBP, SHIMP = build_shim.build()
+shim = C.CDLL(SHIMP, mode=C.RTLD_GLOBAL)
+L = C.CDLL(LIBP, mode=os.RTLD_LOCAL | os.RTLD_DEEPBIND)
+for name, (res, args) in signatures().items():
+    f = getattr(L, name)
+    f.restype, f.argtypes = res, args
+shim.shim_oob.restype = C.c_longlong
+shim.shim_live_allocations.restype = C.c_longlong
+shim.shim_note_op.argtypes = [C.c_char_p, C.c_void_p]
+shim.shim_mark.argtypes = [C.c_char_p]
+shim.shim_dump.argtypes = [C.c_char_p]
+shim.shim_live_report.argtypes = [C.c_char_p]
+shim.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+shim.hipFree.argtypes = [C.c_void_p]
+shim.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+shim.hipStreamDestroy.argtypes = [C.c_void_p]
+
+_AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+_BC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+_AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+_A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64),
+                   C.POINTER(C.c_int64), C.c_void_p)
+_KEEP = []
+
+
+def ok(st, what):
+    if st != 0:
+        raise RuntimeError("%s returned %d (%s)" % (what, st, (L.cap_status_string(st) or b"?").decode()))
+
+
+class Comm:
+    """callback communicator of one simulated rank: every collective is one traced operation on its stream"""
+
+    def __init__(self, rank, size):
+        self.rank, self.size = rank, size
+        def ag_(ctx, s, r, n, st):
+            # small payloads (IPC handles, status words) are really gathered - every slot gets MY piece, so a rank "maps" its own
+            # buffers as its peers' and the IPC schedules run their real course; big payloads are only traced
+            shim.shim_note_op(b"allgather", st)
+            if 0 < n * 8 <= 4096 and s and r:
+                for q in range(size):
+                    C.memmove(r + q * n * 8, s, n * 8)
+            return 0
+        ag = _AG(ag_)
+        bc = _BC(lambda ctx, b, n, root, st: (shim.shim_note_op(b"bcast", st), 0)[1])
+        ar = _AR(lambda ctx, b, n, st: (shim.shim_note_op(b"allreduce", st), 0)[1])
+        a2a = _A2A(lambda ctx, s, sc, sd, r, rc, rd, st: (shim.shim_note_op(b"alltoallv", st), 0)[1])
+        _KEEP.extend([ag, bc, ar, a2a])
+        self.handle = C.c_void_p()
+        ok(L.cap_comm_create_callbacks(C.byref(self.handle), rank, size, ag, bc, ar, None), "cap_comm_create_callbacks")
+        ok(L.cap_comm_set_alltoallv_callback(self.handle, a2a), "cap_comm_set_alltoallv_callback")
+
+    def close(self):
+        L.cap_comm_destroy(self.handle)
+
+
+def dmalloc(nbytes):
+    p = C.c_void_p()
+    assert shim.hipMalloc(C.byref(p), max(int(nbytes), 8)) == 0
+    return p
+
+
+class Run:
+    """one scenario: a fresh trace, a user stream (0 = the NULL stream, else a non-blocking stream of the test's own), marked calls"""
+
+    def __init__(self, name, user_stream):
+        self.name = name
+        shim.shim_reset()
+        shim.shim_mark(("scenario %s" % name).encode())
+        self.stream = C.c_void_p(0)
+        if user_stream:
+            ok(shim.hipStreamCreateWithFlags(C.byref(self.stream), 1), "hipStreamCreateWithFlags")
+        self.uid = 1 if user_stream else 0          # (the stand-in numbers streams from 1 after every process start - see finish())
+
+    def call(self, what, fn, *args):
+        shim.shim_mark(("begin %s" % what).encode())
+        st = fn(*args)
+        shim.shim_mark(("end %s user=@" % what).encode())
+        return st
+
+    def finish(self):
+        path = os.path.join(build_shim.OUT, "trace_%d.txt" % os.getpid())
+        shim.shim_dump(path.encode())
+        lines = open(path).read().splitlines()
+        os.unlink(path)
+        # the user's stream is the first STREAM line of the trace when the scenario made one
+        uid = 0
+        if self.stream.value:
+            uid = int([l for l in lines if l.startswith("STREAM ")][0].split()[1])
+        lines = [l.replace("user=@", "user=%d" % uid) for l in lines]
+        findings, stats = trace_check.check(lines)
+        if self.stream.value:
+            shim.hipStreamDestroy(self.stream)
+        stats["oob"] = int(shim.shim_oob())
+        return {"name": self.name, "findings": findings, "stats": stats}
+
+
+RESULTS = []
+
+
+def scenario(name, user_stream):
+    def deco(fn):
+        r = Run(name + (" [user stream]" if user_stream else " [NULL stream]"), user_stream)
+        try:
+            fn(r)
+            out = r.finish()
+        except Exception as e:      # a refused configuration or a crash of the host side is a finding too
+            out = {"name": r.name, "findings": ["exception: %r" % (e,)], "stats": {}}
+        RESULTS.append(out)
+        return fn
+    return deco
+
+
+def cholinv_case(r, n, ci, split, bc, opts=(), reps=2, comm=None, local_cols=None):
+    plan = C.c_void_p()
+    ok(L.cap_cholinv_plan_create(C.byref(plan), n, ci, split, bc, b"U", comm), "cap_cholinv_plan_create")
+    for k, v in opts:
+        ok(L.cap_cholinv_set_option(plan, k.encode(), v), "set_option " + k)
+    cols = n if local_cols is None else max(local_cols, 1)
+    A = dmalloc(8 * n * cols); out = dmalloc(8 * n * cols)
+    info = C.c_int64(0)
+    for _ in range(reps):
+        ok(r.call("cholinv_factor", L.cap_cholinv_factor, plan, A, n, r.stream), "cap_cholinv_factor")
+    r.call("cholinv_info", L.cap_cholinv_info, plan, r.stream, C.byref(info))
+    ok(r.call("cholinv_get_R", L.cap_cholinv_get_R, plan, out, n, r.stream), "cap_cholinv_get_R")
+    if ci >= 0:
+        ok(r.call("cholinv_get_Rinv", L.cap_cholinv_get_Rinv, plan, out, n, r.stream), "cap_cholinv_get_Rinv")
+    ok(L.cap_cholinv_plan_destroy(plan), "cap_cholinv_plan_destroy")
+    shim.hipFree(A); shim.hipFree(out)
+
+
+def local_cols_1d(n, nb, P, p):
+    nblk = (n + nb - 1) // nb
+    return sum(min(nb, n - j * nb) for j in range(p, nblk, P))
+
+
+def dist_case(r, n, nb, P, p, opts=(), ci=-1):
+    comm = Comm(p, P)
+    plan = C.c_void_p()
+    ok(L.cap_dist_plan_create(C.byref(plan), n, nb, comm.handle), "cap_dist_plan_create")
+    for k, v in opts:
+        ok(L.cap_dist_set_option(plan, k.encode(), v), "dist set_option " + k)
+    if ci >= 0:
+        ok(L.cap_dist_set_option(plan, b"complete_inv", ci), "dist complete_inv")
+    lc = int(L.cap_dist_local_cols(plan))
+    A = dmalloc(8 * n * max(lc, 1)); out = dmalloc(8 * n * max(lc, 1))
+    info = C.c_int64(0)
+    for _ in range(2):
+        ok(r.call("dist_factor", L.cap_dist_factor, plan, A, n, r.stream), "cap_dist_factor")
+    r.call("dist_info", L.cap_dist_info, plan, r.stream, C.byref(info))
+    if dict(opts).get("ipc") and P > 1 and int(L.cap_dist_get_option(plan, b"ipc_active")) != 1:
+        raise RuntimeError("the IPC strip exchange was asked for but is not active (the stand-in's peer mapping failed)")
+    ok(r.call("dist_get_R", L.cap_dist_get_R, plan, out, n, r.stream), "cap_dist_get_R")
+    if ci >= 0:
+        ok(r.call("dist_get_Rinv", L.cap_dist_get_Rinv, plan, out, n, r.stream), "cap_dist_get_Rinv")
+    ok(L.cap_dist_plan_destroy(plan), "cap_dist_plan_destroy")
+    comm.close(); shim.hipFree(A); shim.hipFree(out)
+
+
+def dist2d_case(r, n, nb, Pr, Pc, pr, pc, opts=()):
+    world = Comm(pr * Pc + pc, Pr * Pc); row = Comm(pc, Pc); col = Comm(pr, Pr)
+    plan = C.c_void_p()
+    ok(L.cap_dist2d_plan_create(C.byref(plan), n, nb, world.handle, Pr, row.handle, col.handle), "cap_dist2d_plan_create")
+    for k, v in opts:
+        ok(L.cap_dist2d_set_option(plan, k.encode(), v), "dist2d set_option " + k)
+    lr, lc = int(L.cap_dist2d_get(plan, 0)), int(L.cap_dist2d_get(plan, 1))
+    A = dmalloc(8 * max(lr, 1) * max(lc, 1)); out = dmalloc(8 * max(lr, 1) * max(lc, 1))
+    info = C.c_int64(0)
+    for _ in range(2):
+        ok(r.call("dist2d_factor", L.cap_dist2d_factor, plan, A, max(lr, 1), r.stream), "cap_dist2d_factor")
+    r.call("dist2d_info", L.cap_dist2d_info, plan, r.stream, C.byref(info))
+    if dict(opts).get("ipc") and int(L.cap_dist2d_get(plan, 12)) != 1:
+        raise RuntimeError("the IPC operand moves were asked for but are not active (the stand-in's peer mapping failed)")
+    ok(r.call("dist2d_get_R", L.cap_dist2d_get_R, plan, out, max(lr, 1), r.stream), "cap_dist2d_get_R")
+    if dict(opts).get("complete_inv", -1) >= 0:
+        ok(r.call("dist2d_get_Rinv", L.cap_dist2d_get_Rinv, plan, out, max(lr, 1), r.stream), "cap_dist2d_get_Rinv")
+    ok(L.cap_dist2d_plan_destroy(plan), "cap_dist2d_plan_destroy")
+    for c in (world, row, col):
+        c.close()
+    shim.hipFree(A); shim.hipFree(out)
+
+
+def mpchol_case(r, n, nrhs, opts=()):
+    plan = C.c_void_p()
+    ok(L.cap_mpchol_plan_create(C.byref(plan), n, nrhs), "cap_mpchol_plan_create")
+    for k, v in opts:
+        ok(L.cap_mpchol_set_option(plan, k.encode(), v), "mpchol set_option " + k)
+    A = dmalloc(8 * n * n); B = dmalloc(8 * n * nrhs); X = dmalloc(8 * n * nrhs)
+    info = C.c_int64(0); it = C.c_int(0); rr = C.c_double(0)
+    for _ in range(2):
+        ok(r.call("mpchol_factor", L.cap_mpchol_factor, plan, A, n, r.stream), "cap_mpchol_factor")
+    r.call("mpchol_info", L.cap_mpchol_info, plan, r.stream, C.byref(info))
+    ok(r.call("mpchol_solve", L.cap_mpchol_solve, plan, A, n, B, n, X, n, nrhs, 3, 1e-15, C.byref(it), C.byref(rr), r.stream), "cap_mpchol_solve")
+    ok(L.cap_mpchol_plan_destroy(plan), "cap_mpchol_plan_destroy")
+    for q in (A, B, X):
+        shim.hipFree(q)
+
+
+def dmp_case(r, n, nb, P, p, nrhs=5):
+    comm = Comm(p, P)
+    plan = C.c_void_p()
+    ok(L.cap_dmp_plan_create(C.byref(plan), n, nb, nrhs, comm.handle), "cap_dmp_plan_create")
+    lc = int(L.cap_dmp_local_cols(plan))
+    A = dmalloc(8 * n * max(lc, 1)); B = dmalloc(8 * n * nrhs); X = dmalloc(8 * n * nrhs)
+    info = C.c_int64(0); it = C.c_int(0); rr = C.c_double(0)
+    ok(r.call("dmp_factor (first call of the plan)", L.cap_dmp_factor, plan, A, n, r.stream), "cap_dmp_factor")
+    r.call("dmp_info", L.cap_dmp_info, plan, r.stream, C.byref(info))
+    ok(r.call("dmp_factor", L.cap_dmp_factor, plan, A, n, r.stream), "cap_dmp_factor")
+    ok(r.call("dmp_solve", L.cap_dmp_solve, plan, A, n, B, n, X, n, nrhs, 3, 1e-15, C.byref(it), C.byref(rr), r.stream), "cap_dmp_solve")
+    ok(L.cap_dmp_plan_destroy(plan), "cap_dmp_plan_destroy")
+    comm.close()
+    for q in (A, B, X):
+        shim.hipFree(q)
+
+
+def cacqr_case(r, m, n, iters, P, p):
+    comm = Comm(p, P)
+    plan = C.c_void_p()
+    ok(L.cap_cacqr_plan_create(C.byref(plan), m, n, iters, comm.handle), "cap_cacqr_plan_create")
+    A = dmalloc(8 * m * n)
+    info = C.c_int64(0)
+    for _ in range(2):
+        ok(r.call("cacqr_factor", L.cap_cacqr_factor, plan, A, m, r.stream), "cap_cacqr_factor")
+    r.call("cacqr_info", L.cap_cacqr_info, plan, r.stream, C.byref(info))
+    ok(L.cap_cacqr_plan_destroy(plan), "cap_cacqr_plan_destroy")
+    comm.close(); shim.hipFree(A)
+
+
+def group_of(color_of, key_of, size, rank):
+    ranks = sorted((q for q in range(size) if color_of(q) == color_of(rank)), key=key_of)
+    return ranks.index(rank), len(ranks)
+
+
+class Topo:
+    """topo::square (kind 0) / topo::rect (kind 1) bundle of one simulated rank over callback communicators: the sub-groups are the
+    ones capital_amd/topo.py assembles for the host-staged runs (topology.h:16-143)"""
+
+    def __init__(self, kind, rank, size, c, num_chunks=0):
+        d, x, y, z = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        ok(L.cap_topo_coords(kind, rank, size, c, C.byref(d), C.byref(x), C.byref(y), C.byref(z)), "cap_topo_coords")
+
+        def co(q):
+            dd, xx, yy, zz = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+            L.cap_topo_coords(kind, q, size, c, C.byref(dd), C.byref(xx), C.byref(yy), C.byref(zz))
+            return xx.value, yy.value, zz.value
+        if kind == 0:
+            splits = [(lambda q: (co(q)[1], co(q)[2]), lambda q: co(q)[0]), (lambda q: (co(q)[0], co(q)[2]), lambda q: co(q)[1]),
+                      (lambda q: q // c, lambda q: q), (lambda q: co(q)[2], lambda q: q), None, None, None]
+        else:
+            cube, sl = c * c * c, c * c
+            splits = [(lambda q: (q // cube, ((q % cube) % c) + c * ((q % cube) // sl)), lambda q: q % cube), None,
+                      (lambda q: (q // cube, (q % cube) // c), lambda q: q % cube), (lambda q: q % c, lambda q: q),
+                      (lambda q: (q % sl, (q // sl) // c), lambda q: q // sl), (lambda q: (q % sl, (q // sl) % c), lambda q: q // sl),
+                      (lambda q: q // cube, lambda q: q)]
+        self.world = Comm(rank, size)
+        self.subs = []
+        arr = (C.c_void_p * 7)()
+        for i, sp in enumerate(splits):
+            if sp is None:
+                continue
+            me, n = group_of(sp[0], sp[1], size, rank)
+            cm = Comm(me, n)
+            self.subs.append(cm); arr[i] = cm.handle
+        self.handle = C.c_void_p()
+        ok(L.cap_topo_create_from(C.byref(self.handle), kind, self.world.handle, c, 0, num_chunks, arr, 7), "cap_topo_create_from")
+
+    def close(self):
+        L.cap_topo_destroy(self.handle)
+        for cm in self.subs + [self.world]:
+            cm.close()
+
+
+def summa_case(r, size, c, rank, M, N, K, chunks):
+    t = Topo(0, rank, size, c, chunks)
+    plan = C.c_void_p()
+    ok(L.cap_summa_plan_create(C.byref(plan), t.handle, M, N, K, chunks), "cap_summa_plan_create")
+    ml, nl, kl = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    L.cap_summa_local_dims(plan, C.byref(ml), C.byref(nl), C.byref(kl))
+    ml, nl, kl = max(ml.value, 1), max(nl.value, 1), max(kl.value, 1)
+    A = dmalloc(8 * ml * kl); B = dmalloc(8 * kl * nl); Cc = dmalloc(8 * ml * nl)
+    for _ in range(2):
+        ok(r.call("summa_dgemm", L.cap_summa_dgemm, plan, 1.0, A, ml, B, kl, 0.5, Cc, ml, r.stream), "cap_summa_dgemm")
+    ok(L.cap_summa_plan_destroy(plan), "cap_summa_plan_destroy")
+    if M == K:      # the TRMM overload (T m x m on the left) and the SYRK overload on plans of their own shapes
+        p2 = C.c_void_p()
+        ok(L.cap_summa_plan_create(C.byref(p2), t.handle, M, N, M, chunks), "cap_summa_plan_create")
+        T = dmalloc(8 * ml * ml); tmp = dmalloc(8 * ml * ml)
+        ok(r.call("util_transpose", L.cap_util_transpose, t.handle, T, tmp, ml * ml, r.stream), "cap_util_transpose")
+        ok(r.call("summa_dtrmm", L.cap_summa_dtrmm, p2, 0, 1, 1, 0, 1.0, T, ml, 0, B, ml, r.stream), "cap_summa_dtrmm")
+        ok(L.cap_summa_plan_destroy(p2), "cap_summa_plan_destroy")
+        p3 = C.c_void_p()
+        ok(L.cap_summa_plan_create(C.byref(p3), t.handle, N, N, K, chunks), "cap_summa_plan_create")
+        Cs = dmalloc(8 * nl * nl)
+        ok(r.call("summa_dsyrk", L.cap_summa_dsyrk, p3, 1, 1, -1.0, B, kl, 1.0, Cs, nl, 0, r.stream), "cap_summa_dsyrk")
+        ok(L.cap_summa_plan_destroy(p3), "cap_summa_plan_destroy")
+        for q in (T, tmp, Cs):
+            shim.hipFree(q)
+    t.close()
+    for q in (A, B, Cc):
+        shim.hipFree(q)
+
+
+def cacqr_grid_case(r, size, c, rank, m, n, iters):
+    t = Topo(1, rank, size, c)
+    plan = C.c_void_p()
+    ok(L.cap_cacqr_plan_create_grid(C.byref(plan), m, n, iters, t.handle), "cap_cacqr_plan_create_grid")
+    d = size // (c * c)
+    ml, nl = (m + d - 1) // d, max(n // c, 1)
+    A = dmalloc(8 * ml * nl); out = dmalloc(8 * n * n)
+    info = C.c_int64(0)
+    for _ in range(2):
+        ok(r.call("cacqr_factor (grid)", L.cap_cacqr_factor, plan, A, ml, r.stream), "cap_cacqr_factor")
+    r.call("cacqr_info", L.cap_cacqr_info, plan, r.stream, C.byref(info))
+    ok(r.call("cacqr_R_piece", L.cap_cacqr_R_piece, plan, out, max(n // c, 1), r.stream), "cap_cacqr_R_piece")
+    ok(L.cap_cacqr_plan_destroy(plan), "cap_cacqr_plan_destroy")
+    t.close(); shim.hipFree(A); shim.hipFree(out)
+
+
+def redist_case(r, n, nb, size, c, Pr, rank):
+    world = Comm(rank, size)
+    plan = C.c_void_p()
+    ok(L.cap_redist_plan_create(C.byref(plan), n, nb, world.handle, c, Pr), "cap_redist_plan_create")
+    e, lr, lc = (int(L.cap_redist_get(plan, w)) for w in (0, 1, 2))
+    piece = dmalloc(8 * max(e, 1) * max(e, 1)); bc = dmalloc(8 * max(lr, 1) * max(lc, 1))
+    ok(r.call("redistribute_cyclic_to_bc", L.cap_redistribute_cyclic_to_bc, plan, piece, max(e, 1), bc, max(lr, 1), r.stream), "cyclic_to_bc")
+    ok(r.call("redistribute_bc_to_cyclic", L.cap_redistribute_bc_to_cyclic, plan, bc, max(lr, 1), piece, max(e, 1), r.stream), "bc_to_cyclic")
+    ok(L.cap_redist_plan_destroy(plan), "cap_redist_plan_destroy")
+    world.close(); shim.hipFree(piece); shim.hipFree(bc)
+
+
+def desc_case(r, n, nb, Pr, Pc, pr, pc):
+    """host matrix -> my block-cyclic piece -> host, through the pinned staging buffers (host memory of the test: a plain bytearray)"""
+    d = C.c_void_p()
+    ok(L.cap_desc_create_bc(C.byref(d), n, n, nb, Pr, Pc, pr, pc, None, 0), "cap_desc_create_bc")
+    host = (C.c_double * (n * n))()
+    ok(r.call("desc_import_host_global", L.cap_desc_import_host_global, d, host, n, r.stream), "cap_desc_import_host_global")
+    ok(r.call("desc_export_host_global", L.cap_desc_export_host_global, d, host, n, r.stream), "cap_desc_export_host_global")
+    lr, lc = int(L.cap_desc_get(d, 3)), int(L.cap_desc_get(d, 2))
+    piece = (C.c_double * max(lr * lc, 1))()
+    ok(r.call("desc_import_host", L.cap_desc_import_host, d, piece, max(lr, 1), r.stream), "cap_desc_import_host")
+    ok(r.call("desc_export_host", L.cap_desc_export_host, d, piece, max(lr, 1), r.stream), "cap_desc_export_host")
+    ok(L.cap_desc_destroy(d), "cap_desc_destroy")
+
+
+def operators_case(r, m, n, k):
+    """the blas / lapack seam on the caller's stream (cap_dgemm .. cap_dtrtri)"""
+    A = dmalloc(8 * max(m, k) * max(m, k)); B = dmalloc(8 * max(k, m) * n); Cc = dmalloc(8 * m * max(n, m))
+    ok(r.call("dgemm NN", L.cap_dgemm, 0, 0, m, n, k, 1.0, A, m, B, k, 0.0, Cc, m, r.stream), "cap_dgemm")
+    ok(r.call("dgemm TN beta=1", L.cap_dgemm, 1, 0, m, n, k, -1.0, A, k, B, k, 1.0, Cc, m, r.stream), "cap_dgemm")
+    ok(r.call("dsyrk", L.cap_dsyrk, 1, 1, m, k, -1.0, A, k, 1.0, Cc, m, r.stream), "cap_dsyrk")
+    wt = int(L.cap_dtrmm_work_size(0, m, n)); W = dmalloc(8 * max(wt, 1))
+    ok(r.call("dtrmm", L.cap_dtrmm, 0, 1, 0, 0, m, n, 1.0, A, m, B, m, W, r.stream), "cap_dtrmm")
+    ws = int(L.cap_dtrsm_work_size(0, m, n)); W2 = dmalloc(8 * max(ws, 1))
+    ok(r.call("dtrsm", L.cap_dtrsm, 0, 1, 1, m, n, 1.0, A, m, B, m, W2, r.stream), "cap_dtrsm")
+    wp = int(L.cap_dpotrf_work_size(m)); W3 = dmalloc(8 * max(wp, 1)); info = dmalloc(8)
+    ok(r.call("dpotrf", L.cap_dpotrf, 1, m, A, m, info, W3, r.stream), "cap_dpotrf")
+    wi = int(L.cap_dtrtri_work_size(m)); W4 = dmalloc(8 * max(wi, 1))
+    ok(r.call("dtrtri", L.cap_dtrtri, 1, m, A, m, W4, r.stream), "cap_dtrtri")
+    for q in (A, B, Cc, W, W2, W3, W4, info):
+        shim.hipFree(q)
+
+
+def main(out_path, user_streams=(0, 1)):
+    for us in user_streams:
+        # ---- single-GPU Cholesky plan: the headline schedule, reference semantics, ragged sizes, schedule options
+        for (n, ci, split, bc, opts) in [
+            (4096, -1, 1, -3, ()), (8192, -1, 1, 0, ()), (4097, -1, 1, -3, ()), (1000, -1, 1, -2, ()), (64, -1, 1, 0, ()),
+            (65536, -1, 1, 0, ()),                                             # BASELINE's headline size: plan + schedule only, nothing computed
+            (32768, 0, 1, 0, ()), (16384, 1, 1, 0, ()), (4096, 0, 2, -2, ()), (4096, 1, 1, -2, (("inv_overlap", 0),)), (3000, 1, 1, -2, ()),
+            (8192, -1, 1, 0, (("use_sb", 0),)), (8192, -1, 1, 0, (("pair_rest", 0),)), (8192, -1, 1, 0, (("depth2", 0),)),
+            (8192, -1, 1, 0, (("chain_coop", 0),)), (8192, -1, 1, 0, (("inner_la", 1),)), (8192, -1, 1, 0, (("serial_m", 4096),)),
+            (8192, -1, 1, 0, (("reserve", 8),)), (16384, -1, 1, 0, (("reserve", 8), ("reserve_m", 8192))), (8192, 1, 1, 0, (("inv_fast", 0),)),
+        ]:
+            scenario("cholinv n=%d ci=%d split=%d bc=%d %s" % (n, ci, split, bc, dict(opts) or ""), us)(
+                lambda r, a=(n, ci, split, bc, opts): cholinv_case(r, *a))
+        # ---- 1 x P plan, every simulated rank
+        for (n, nb, P, opts, ci) in [(4096, 128, 4, (), -1), (4096, 128, 4, (("safe", 1),), -1), (4096, 128, 4, (("strip", 2), ("depth2", 1)), -1),
+                                     (2049, 128, 3, (), -1), (8192, 512, 8, (), -1), (2048, 128, 4, (), 1), (2048, 128, 4, (), 0), (1024, 128, 1, (), 1),
+                                     (65536, 512, 8, (), -1)]:
+            for p in range(P):
+                scenario("dist n=%d nb=%d P=%d rank=%d %s ci=%d" % (n, nb, P, p, dict(opts) or "", ci), us)(
+                    lambda r, a=(n, nb, P, p, opts, ci): dist_case(r, *a))
+        # ---- the same behind the cholinv handle (comm of size P) with the reference's element-cyclic layout
+        for p in range(8):
+            def cyc(r, p=p):
+                comm = Comm(p, 8)
+                cholinv_case(r, 1024, 1, 1, -2, (("nb", 128), ("cyclic_c", 2)), reps=1, comm=comm.handle, local_cols=512)
+                comm.close()
+            scenario("cholinv over 8 ranks, cyclic_c=2, rank=%d" % p, us)(cyc)
+        # ---- Pr x Pc plan
+        for (n, nb, Pr, Pc, opts) in [(4096, 128, 2, 2, ()), (4096, 128, 2, 4, (("strip", 1),)), (2048, 128, 2, 2, (("complete_inv", 1),)),
+                                      (1000, 128, 2, 2, ()), (4096, 128, 1, 4, (("strip", 2),)), (4096, 128, 2, 2, (("safe", 1),)),
+                                      (65536, 512, 2, 4, ())]:
+            for pr in range(Pr):
+                for pc in range(Pc):
+                    scenario("dist2d n=%d nb=%d %dx%d at (%d,%d) %s" % (n, nb, Pr, Pc, pr, pc, dict(opts) or ""), us)(
+                        lambda r, a=(n, nb, Pr, Pc, pr, pc, opts): dist2d_case(r, *a))
+        # ---- strip exchange / operand moves as IPC peer copies (the stand-in "maps" a rank's own buffers as its peers')
+        for (n, nb, P, opts) in [(4096, 128, 4, (("ipc", 1),)), (4096, 128, 4, (("ipc", 1), ("safe", 1))), (8192, 512, 8, (("ipc", 1),))]:
+            for p in range(P):
+                scenario("dist n=%d nb=%d P=%d rank=%d %s" % (n, nb, P, p, dict(opts)), us)(lambda r, a=(n, nb, P, p, opts, -1): dist_case(r, *a))
+        for (n, nb, Pr, Pc, opts) in [(2048, 128, 2, 2, (("ipc", 1),)), (4096, 128, 2, 4, (("ipc", 1),)), (2049, 256, 2, 4, (("ipc", 1), ("complete_inv", 1)))]:
+            for pr in range(Pr):
+                for pc in range(Pc):
+                    scenario("dist2d n=%d nb=%d %dx%d at (%d,%d) %s" % (n, nb, Pr, Pc, pr, pc, dict(opts)), us)(
+                        lambda r, a=(n, nb, Pr, Pc, pr, pc, opts): dist2d_case(r, *a))
+        # ---- SUMMA (GEMM, TRMM, SYRK overloads, util::transpose) on d x d x c grids; CholeskyQR on the c x d x c grid
+        for (size, c, M, N, K, chunks) in [(8, 2, 300, 300, 300, 2), (4, 1, 512, 256, 512, 0), (9, 1, 300, 300, 300, 3), (1, 1, 256, 256, 256, 0), (27, 3, 270, 270, 270, 0)]:
+            for rank in range(size):
+                scenario("summa size=%d c=%d rank=%d %dx%dx%d chunks=%d" % (size, c, rank, M, N, K, chunks), us)(
+                    lambda r, a=(size, c, rank, M, N, K, chunks): summa_case(r, *a))
+        for (size, c, m, n, iters) in [(8, 2, 4096, 128, 2), (4, 1, 4096, 64, 2), (16, 2, 8192, 256, 1)]:
+            for rank in range(size):
+                scenario("cacqr grid size=%d c=%d rank=%d m=%d n=%d iter=%d" % (size, c, rank, m, n, iters), us)(
+                    lambda r, a=(size, c, rank, m, n, iters): cacqr_grid_case(r, *a))
+        # ---- redistribution element-cyclic <-> block-cyclic, descriptors with pinned staging, the operator seam
+        for (n, nb, size, c, Pr) in [(1024, 128, 8, 2, 1), (1000, 128, 8, 2, 2), (512, 64, 4, 1, 2)]:
+            for rank in range(size):
+                scenario("redist n=%d nb=%d size=%d c=%d Pr=%d rank=%d" % (n, nb, size, c, Pr, rank), us)(
+                    lambda r, a=(n, nb, size, c, Pr, rank): redist_case(r, *a))
+        for (n, nb, Pr, Pc) in [(1000, 128, 2, 2), (2048, 256, 1, 4), (300, 128, 2, 4)]:
+            for pr in range(Pr):
+                for pc in range(Pc):
+                    scenario("desc n=%d nb=%d %dx%d at (%d,%d)" % (n, nb, Pr, Pc, pr, pc), us)(lambda r, a=(n, nb, Pr, Pc, pr, pc): desc_case(r, *a))
+        for (m, n, k) in [(1024, 1024, 1024), (1000, 777, 515), (4096, 8, 4096), (64, 64, 64), (2048, 2048, 128)]:
+            scenario("operators m=%d n=%d k=%d" % (m, n, k), us)(lambda r, a=(m, n, k): operators_case(r, *a))
+        # ---- mixed precision, one GPU and P ranks
+        for (n, nrhs, opts) in [(4096, 8, ()), (8192, 8, (("strip", 1),)), (16384, 8, (("pair_rest", 0),)), (8192, 8, (("split", 0),)), (65536, 8, ())]:
+            scenario("mpchol n=%d %s" % (n, dict(opts) or ""), us)(lambda r, a=(n, nrhs, opts): mpchol_case(r, *a))
+        for (n, nb, P) in [(2048, 256, 1), (2048, 256, 4), (1280, 256, 4), (8192, 512, 8), (1152, 256, 2)]:
+            for p in range(P):
+                scenario("dmp n=%d nb=%d P=%d rank=%d" % (n, nb, P, p), us)(lambda r, a=(n, nb, P, p): dmp_case(r, *a))
+        # ---- CholeskyQR
+        for (m, n, iters, P) in [(16384, 256, 2, 1), (16384, 128, 2, 4), (4096, 64, 1, 2), (1 << 21, 256, 2, 8)]:
+            for p in range(P):
+                scenario("cacqr m=%d n=%d iter=%d P=%d rank=%d" % (m, n, iters, P, p), us)(lambda r, a=(m, n, iters, P, p): cacqr_case(r, *a))
+    live = os.path.join(build_shim.OUT, "live_%d.txt" % os.getpid())
+    shim.shim_live_report(live.encode())
+    leaks = open(live).read().splitlines()
+    os.unlink(live)
+    json.dump({"results": RESULTS, "live_allocations_at_exit": leaks}, open(out_path, "w"), indent=1)
+    bad = [x for x in RESULTS if x["findings"]]
+    print("%d scenarios, %d with findings" % (len(RESULTS), len(bad)))
+    for x in bad[:40]:
+        print(" *", x["name"])
+        for f in x["findings"][:6]:
+            print("     ", f)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(build_shim.OUT, "scenarios.json"),
+         tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (0, 1))
