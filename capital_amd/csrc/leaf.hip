@@ -721,7 +721,12 @@ __global__ void __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2
     if (g.recover && st == 0) return;
     if (g.recover && st == 1 && threadIdx.x == 0) atomicCAS(g.ctr + 3, 1, 2);
     if ((!g.recover && st == 1) || (g.recover && st == 3)) alive = false;
-    if (alive && g.backup) {
+    // A workgroup of the PRIMARY launch that is dispatched after a peer has given up (st == 1) still saves its share: nobody got past
+    // the first meeting without it, so its blocks are untouched, and the recovery launch restores EVERY block from the backup - a share
+    // that was never saved would come back as whatever the buffer held before (round 5: seen as soon as the backup buffer was a fresh
+    // allocation per plan instead of one kept per stream handle; with the test hook the peers give up within microseconds).
+    const bool save_late = !g.recover && st == 1;
+    if ((alive || save_late) && g.backup) {
       // block q of the packed upper enumeration (column by column of blocks): workgroup 0 takes block (0, 0) - the only one that is
       // modified before the first meeting (by its own leaf) - the workers share the rest; the meeting orders save / restore before use
       const int nq = nblk * (nblk + 1) / 2;

@@ -329,7 +329,8 @@ def test_chain_that_gives_up_is_restored_and_rerun(n, nb, ci, count):
     finally:
         _lib.check(L.cap_chain_inject_timeouts(0), "cap_chain_inject_timeouts")       # (never leave a pending injection behind)
     got = [cholinv.construct_R(p1).to_numpy()] + ([cholinv.construct_Rinv(p1).to_numpy()] if ci >= 0 else [])
-    assert p1.get_option("chain_fallbacks") == before + count
+    after = p1.get_option("chain_fallbacks")
+    assert after == before + count, (before, after, count)
     for x, y in zip(ref, got):
         assert np.array_equal(x, y), float(np.abs(x - y).max())
     # and the slot is clean again: the next factorization runs undisturbed
