@@ -116,6 +116,17 @@ class Run:
             uid = int([l for l in lines if l.startswith("STREAM ")][0].split()[1])
         lines = [l.replace("user=@", "user=%d" % uid) for l in lines]
         findings, stats = trace_check.check(lines)
+        # kernel launches of the LAST marked "...factor" call, by (mangled) kernel name: compared with rocprofv3's counts of the same
+        # schedule on the GPU by tests/test_schedule_structure.py
+        hist, cur = {}, None
+        for l in lines:
+            if l.startswith("MARK begin") and "factor" in l:
+                cur = {}
+            elif l.startswith("MARK end") and cur is not None:
+                hist, cur = cur, None
+            elif cur is not None and l.startswith("K "):
+                k = l.split()[2]; cur[k] = cur.get(k, 0) + 1
+        stats["factor_kernels"] = hist
         if self.stream.value:
             shim.hipStreamDestroy(self.stream)
         stats["oob"] = int(shim.shim_oob())
@@ -393,6 +404,7 @@ def main(out_path, user_streams=(0, 1)):
         for (n, ci, split, bc, opts) in [
             (4096, -1, 1, -3, ()), (8192, -1, 1, 0, ()), (4097, -1, 1, -3, ()), (1000, -1, 1, -2, ()), (64, -1, 1, 0, ()),
             (65536, -1, 1, 0, ()),                                             # BASELINE's headline size: plan + schedule only, nothing computed
+            (65536, -1, 1, -5, ()), (32768, -1, 1, -5, ()),                    # ... with bench.py's knobs (bcMult -5): launch counts vs rocprofv3
             (32768, 0, 1, 0, ()), (16384, 1, 1, 0, ()), (4096, 0, 2, -2, ()), (4096, 1, 1, -2, (("inv_overlap", 0),)), (3000, 1, 1, -2, ()),
             (8192, -1, 1, 0, (("use_sb", 0),)), (8192, -1, 1, 0, (("pair_rest", 0),)), (8192, -1, 1, 0, (("depth2", 0),)),
             (8192, -1, 1, 0, (("chain_coop", 0),)), (8192, -1, 1, 0, (("inner_la", 1),)), (8192, -1, 1, 0, (("serial_m", 4096),)),

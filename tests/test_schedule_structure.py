@@ -51,7 +51,8 @@ def test_every_schedule_joins_its_streams_and_stays_inside_its_buffers(scenarios
     tot = {}
     for x in res:
         for k, v in x["stats"].items():
-            tot[k] = tot.get(k, 0) + v
+            if not isinstance(v, dict):
+                tot[k] = tot.get(k, 0) + v
     # the scenarios really ran the schedules: tens of thousands of launches, event edges and collectives went through the stand-in
     assert tot["kernels"] > 50000 and tot["waits"] > 50000 and tot["records"] > 50000 and tot["ops"] > 10000 and tot["oob"] == 0, tot
     names = " ".join(x["name"] for x in res)
@@ -115,3 +116,35 @@ def test_the_checker_catches_seeded_defects():
     f, _ = trace_check.check(_lines("STREAM 4 nonblocking flags\nSTREAMDESTROY 4\nMARK begin h\nK 4 x 1 1 1 0\nHOSTSYNC device\nMARK end h user=0\n"
                                     "OOB copy dst 0x10 64\nBADLAUNCH 0 k grid 0 1 1 block 256 1 1"))
     assert sum("destroyed stream" in x for x in f) == 1 and sum(x.startswith("OOB") for x in f) == 1 and sum(x.startswith("BADLAUNCH") for x in f) == 1, f
+
+
+@pytest.mark.parametrize("n,csv", [(65536, "r05_bench_n65536_kernel_stats.csv"), (32768, "r05_bench_n32768_kernel_stats.csv")])
+def test_the_recorded_schedule_is_the_one_rocprof_saw_on_the_gpu(scenarios, n, csv):
+    """The stand-in's trace of one factor call at bench.py's knobs has, kernel by kernel, the launch counts of the rocprofv3
+    --kernel-trace --stats summary of `python bench.py --size N` on the MI355X (profiles/, committed): what runs under the stand-in IS
+    the schedule that was measured."""
+    import csv as csvmod
+    import shutil
+    if not shutil.which("c++filt"):
+        pytest.skip("c++filt not available")
+    path = os.path.join(ROOT, "profiles", csv)
+    rows = {r["Name"]: int(r["Calls"]) for r in csvmod.DictReader(open(path))}
+    x = [r for r in scenarios["results"] if r["name"].startswith("cholinv n=%d ci=-1 split=1 bc=-5" % n) and "NULL" in r["name"]][0]
+    hist = x["stats"]["factor_kernels"]
+    names = sorted(hist)
+    dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.splitlines()
+    mine = {d: hist[m] for m, d in zip(names, dem)}
+    lib = {k: v for k, v in rows.items() if "(anonymous namespace)::" in k and not k.startswith("void at::")}
+    # factor calls in the profiled run = calls of the dominant kernel / its launches per factor
+    dom = [k for k in mine if "dgemm_tn_dma_kernel<1, false, 0, true, false>" in k][0]
+    assert rows[dom] % mine[dom] == 0
+    calls = rows[dom] // mine[dom]
+    assert calls >= 2
+    checked = 0
+    for k, v in mine.items():
+        if "copy_window_kernel" in k:
+            continue                                    # (the bench's own residual check uses it too)
+        assert k in lib, (k, sorted(lib)[:8])
+        assert lib[k] == calls * v, (k, lib[k], calls, v)
+        checked += 1
+    assert checked >= 4
