@@ -398,6 +398,48 @@ def operators_case(r, m, n, k):
         shim.hipFree(q)
 
 
+def lifecycle_case(r):
+    """plans that are created and destroyed without use, reconfigured between calls, refused, reused with another size of right-hand
+    sides: nothing may dangle, leak or be destroyed twice"""
+    for (n, ci) in [(2048, -1), (2048, 1), (1000, 0)]:
+        plan = C.c_void_p()
+        ok(L.cap_cholinv_plan_create(C.byref(plan), n, ci, 1, -2, b"U", None), "cap_cholinv_plan_create")
+        ok(L.cap_cholinv_plan_destroy(plan), "destroy unused")
+    plan = C.c_void_p()
+    ok(L.cap_cholinv_plan_create(C.byref(plan), 8192, 1, 1, 0, b"U", None), "cap_cholinv_plan_create")
+    A = dmalloc(8 * 8192 * 8192); out = dmalloc(8 * 8192 * 8192)
+    ok(r.call("cholinv_factor", L.cap_cholinv_factor, plan, A, 8192, r.stream), "factor")
+    for k, v in [("nb", 256), ("use_sb", 0), ("inv_overlap", 0), ("nb", 1024), ("use_sb", 1), ("reserve", 8), ("reserve", 0), ("inner_la", 1), ("inner_la", 0),
+                 ("inv_fast", 0), ("inv_fast", 1), ("chain_coop", 0), ("chain_coop", -1), ("profile", 1)]:
+        ok(L.cap_cholinv_set_option(plan, k.encode(), v), "set_option " + k)
+        ok(r.call("cholinv_factor after %s=%d" % (k, v), L.cap_cholinv_factor, plan, A, 8192, r.stream), "factor after " + k)
+        ok(r.call("cholinv_get_Rinv", L.cap_cholinv_get_Rinv, plan, out, 8192, r.stream), "get_Rinv")
+    ok(L.cap_cholinv_plan_destroy(plan), "cap_cholinv_plan_destroy")
+    # refused configurations leave nothing behind
+    bad = C.c_void_p()
+    assert L.cap_cholinv_plan_create(C.byref(bad), 1024, 1, 1, 0, b"L", None) != 0
+    assert L.cap_cholinv_plan_create(C.byref(bad), -5, 1, 1, 0, b"U", None) != 0
+    assert L.cap_mpchol_plan_create(C.byref(bad), 1000, 8) != 0                   # n % 128
+    cm = Comm(0, 4)
+    assert L.cap_dmp_plan_create(C.byref(bad), 1000, 256, 5, cm.handle) != 0
+    assert L.cap_dist2d_plan_create(C.byref(bad), 1536, 128, cm.handle, 3, None, None) != 0      # 3 does not divide 4
+    assert L.cap_dist_factor(None, A, 8192, r.stream) != 0
+    cm.close()
+    # the 1 x P plan: option changes between factor calls
+    cm = Comm(1, 4)
+    dp = C.c_void_p()
+    ok(L.cap_dist_plan_create(C.byref(dp), 4096, 128, cm.handle), "cap_dist_plan_create")
+    lc = int(L.cap_dist_local_cols(dp))
+    Al = dmalloc(8 * 4096 * lc)
+    for k, v in [("safe", 1), ("safe", 0), ("ipc", 1), ("ipc", 0), ("strip", 1), ("strip", 2), ("depth2", 0), ("complete_inv", 1), ("complete_inv", -1)]:
+        ok(L.cap_dist_set_option(dp, k.encode(), v), "dist set_option " + k)
+        ok(r.call("dist_factor after %s=%d" % (k, v), L.cap_dist_factor, dp, Al, 4096, r.stream), "dist factor after " + k)
+    ok(L.cap_dist_plan_destroy(dp), "cap_dist_plan_destroy")
+    cm.close()
+    for q in (A, out, Al):
+        shim.hipFree(q)
+
+
 def main(out_path, user_streams=(0, 1)):
     for us in user_streams:
         # ---- single-GPU Cholesky plan: the headline schedule, reference semantics, ragged sizes, schedule options
@@ -463,6 +505,7 @@ def main(out_path, user_streams=(0, 1)):
                     scenario("desc n=%d nb=%d %dx%d at (%d,%d)" % (n, nb, Pr, Pc, pr, pc), us)(lambda r, a=(n, nb, Pr, Pc, pr, pc): desc_case(r, *a))
         for (m, n, k) in [(1024, 1024, 1024), (1000, 777, 515), (4096, 8, 4096), (64, 64, 64), (2048, 2048, 128)]:
             scenario("operators m=%d n=%d k=%d" % (m, n, k), us)(lambda r, a=(m, n, k): operators_case(r, *a))
+        scenario("plan life cycles: unused, reconfigured between calls, refused", us)(lifecycle_case)
         # ---- mixed precision, one GPU and P ranks
         for (n, nrhs, opts) in [(4096, 8, ()), (8192, 8, (("strip", 1),)), (16384, 8, (("pair_rest", 0),)), (8192, 8, (("split", 0),)), (65536, 8, ())]:
             scenario("mpchol n=%d %s" % (n, dict(opts) or ""), us)(lambda r, a=(n, nrhs, opts): mpchol_case(r, *a))

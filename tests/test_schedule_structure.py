@@ -58,7 +58,7 @@ def test_every_schedule_joins_its_streams_and_stays_inside_its_buffers(scenarios
     names = " ".join(x["name"] for x in res)
     for must in ("cholinv n=65536", "dist n=65536 nb=512 P=8 rank=7", "dist2d n=65536 nb=512 2x4 at (1,3)", "mpchol n=65536", "dmp n=8192 nb=512 P=8",
                  "cacqr m=2097152 n=256 iter=2 P=8", "cyclic_c=2", "{'ipc': 1}", "summa size=27 c=3 rank=26", "cacqr grid size=16 c=2 rank=15",
-                 "redist n=1000 nb=128 size=8 c=2 Pr=2 rank=7", "desc n=300 nb=128 2x4 at (1,3)", "operators m=1000 n=777 k=515"):
+                 "redist n=1000 nb=128 size=8 c=2 Pr=2 rank=7", "desc n=300 nb=128 2x4 at (1,3)", "operators m=1000 n=777 k=515", "plan life cycles"):
         assert must in names, must
 
 
