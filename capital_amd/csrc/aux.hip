@@ -3,6 +3,7 @@
 // src/util/util.hpp:25-53,266-318.  All coalesced along the column-major fast axis.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <mutex>
 
 #include "common.h"
@@ -32,6 +33,9 @@ void cap_range_push(const char* name) {
 void cap_range_pop() {
   if (g_roctx_pop) (void)g_roctx_pop();
 }
+
+// access notes (common.h): null in the product, installed by the recording stand-in of tests/hipshim
+extern "C" { cap_access_hook_fn cap_access_hook = nullptr; }
 
 namespace {
 
@@ -181,11 +185,13 @@ int cap_copy_rect(const double* src, int64_t sld, double* dst, int64_t dld, int6
   if (rows <= 0 || cols <= 0) return CAP_OK;
   if (!(rows & 1) && !(sld & 1) && !(dld & 1) && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15) && rows * cols >= (1 << 16) && rows <= 2048 &&
       cols / 8 < 0x7fffffff) {      // (block rows of a panel; tall copies keep the element-per-thread form)
+    cap_acc_r(src, sld, rows, cols); cap_acc_w(dst, dld, rows, cols);
     hipLaunchKernelGGL(copy_rect_v2_kernel, dim3((unsigned)cap_ceil_div(cols, 8), (unsigned)cap_ceil_div(rows, 4096)), dim3(256), 0, s,
                        src, sld, dst, dld, rows, cols);
     CAP_HIP(hipGetLastError());
     return CAP_OK;
   }
+  cap_acc_r(src, sld, rows, cols); cap_acc_w(dst, dld, rows, cols);
   hipLaunchKernelGGL(copy_window_kernel, grid2d(rows, cols, 256), dim3(256), 0, s, src, 0, sld, (int64_t)0, (int64_t)0, dst,
                      0, dld, (int64_t)0, (int64_t)0, rows, cols, 0, 0);
   CAP_HIP(hipGetLastError());
@@ -194,6 +200,7 @@ int cap_copy_rect(const double* src, int64_t sld, double* dst, int64_t dld, int6
 
 int cap_zero_rect(double* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s) {
   if (rows <= 0 || cols <= 0) return CAP_OK;
+  cap_acc_w(dst, ldd, rows, cols);
   hipLaunchKernelGGL(zero_rect_kernel, grid2d(rows, cols, 256), dim3(256), 0, s, dst, ldd, rows, cols);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
@@ -209,10 +216,12 @@ int cap_fill_symmetric(double* local, int64_t ld, int64_t n_global, int64_t x, i
   if (nl > 65535) {  // column index rides in blockIdx.y only; split launches for very wide pieces
     for (int64_t c0 = 0; c0 < nl; c0 += 65535) {
       int64_t nc = nl - c0 < 65535 ? nl - c0 : 65535;
+      cap_acc_w(local + c0 * ld, ld, nl, nc);
       hipLaunchKernelGGL(fill_symmetric_kernel, dim3((unsigned)cap_ceil_div(nl, 256), (unsigned)nc), dim3(256), 0,
                          cap_stream(stream), local + c0 * ld, ld, nl, n_global, x + c0 * d, y, d, diagonally_dominant);
     }
   } else {
+    cap_acc_w(local, ld, nl, nl);
     hipLaunchKernelGGL(fill_symmetric_kernel, dim3((unsigned)cap_ceil_div(nl, 256), (unsigned)nl), dim3(256), 0,
                        cap_stream(stream), local, ld, nl, n_global, x, y, d, diagonally_dominant);
   }
@@ -229,6 +238,7 @@ int cap_fill_random(double* local, int64_t ld, int64_t m_global, int64_t n_globa
   int64_t pad_x = ((n_global % dx != 0) && ((nl - 1) * dx + x >= n_global)) ? nl - 1 : nl;
   int64_t pad_y = ((m_global % dy != 0) && ((ml - 1) * dy + y >= m_global)) ? ml - 1 : ml;
   uint64_t x0 = ((((uint64_t)key) & 0xFFFFFFFFull) << 16) | 0x330Eull;
+  cap_acc_w(local, ld, ml, nl);
   hipLaunchKernelGGL(fill_random_kernel, grid2d(ml, nl, 256), dim3(256), 0, cap_stream(stream), local, ld, ml, nl, pad_y,
                      pad_x, x0);
   CAP_HIP(hipGetLastError());
@@ -241,6 +251,17 @@ int cap_copy_window(const double* src, int src_packed, int64_t src_ld, int64_t s
   if (rows < 0 || cols < 0 || !src || !dst) return CAP_ERR_ARG;
   if (rows == 0 || cols == 0) return CAP_OK;
   if ((src_packed || dst_packed) && !tri_only) return CAP_ERR_ARG;   // packed buffers only hold the upper triangle
+  if (cap_acc_on()) {
+    // a packed operand (uppertri::_offset, structure.h:39) is noted as the contiguous range between the window's first and last element
+    auto packed = [&](int mode, const double* base, int64_t r0, int64_t c0) {
+      const int64_t lo = c0 * (c0 + 1) / 2 + r0, c1 = c0 + cols - 1, hi = c1 * (c1 + 1) / 2 + r0 + std::min(rows - 1, cols - 1);
+      cap_acc(mode, base + lo, 0, hi - lo + 1, 1);
+    };
+    if (src_packed) packed(CAP_ACC_R, src, src_row0, src_col0);
+    else cap_acc_r(src + src_row0 + src_col0 * src_ld, src_ld, rows, cols, tri_only ? 1 : 0);
+    if (dst_packed) packed(CAP_ACC_W, dst, dst_row0, dst_col0);
+    else cap_acc_w(dst + dst_row0 + dst_col0 * dst_ld, dst_ld, rows, cols, (tri_only && !zero_lower) ? 1 : 0);
+  }
   hipLaunchKernelGGL(copy_window_kernel, grid2d(rows, cols, 256), dim3(256), 0, cap_stream(stream), src, src_packed, src_ld,
                      src_row0, src_col0, dst, dst_packed, dst_ld, dst_row0, dst_col0, rows, cols, tri_only, zero_lower);
   CAP_HIP(hipGetLastError());
@@ -252,6 +273,7 @@ int cap_cyclic_import(const double* piece, int64_t ldp, double* dense, int64_t l
   if (!piece || !dense || dx <= 0 || dy <= 0 || x < 0 || y < 0 || x >= dx || y >= dy || m <= 0 || n <= 0) return CAP_ERR_ARG;
   const int64_t rl = cap_ceil_div(m, dy), cl = cap_ceil_div(n, dx);
   if (ldp < rl || ldd < m) return CAP_ERR_ARG;
+  cap_acc_r(piece, ldp, rl, cl); cap_acc_w(dense, ldd, m, n);      // (the scattered elements y + r dy, x + c dx: noted as the whole window)
   hipLaunchKernelGGL(cyclic_piece_kernel, grid2d(rl, cl, 256), dim3(256), 0, cap_stream(stream), const_cast<double*>(piece), ldp, rl, cl,
                      dense, ldd, m, n, x, y, dx, dy, 1);
   CAP_HIP(hipGetLastError());
@@ -263,6 +285,7 @@ int cap_cyclic_export(const double* dense, int64_t ldd, double* piece, int64_t l
   if (!piece || !dense || dx <= 0 || dy <= 0 || x < 0 || y < 0 || x >= dx || y >= dy || m <= 0 || n <= 0) return CAP_ERR_ARG;
   const int64_t rl = cap_ceil_div(m, dy), cl = cap_ceil_div(n, dx);
   if (ldp < rl || ldd < m) return CAP_ERR_ARG;
+  cap_acc_r(dense, ldd, m, n); cap_acc_w(piece, ldp, rl, cl);
   hipLaunchKernelGGL(cyclic_piece_kernel, grid2d(rl, cl, 256), dim3(256), 0, cap_stream(stream), piece, ldp, rl, cl,
                      const_cast<double*>(dense), ldd, m, n, x, y, dx, dy, 0);
   CAP_HIP(hipGetLastError());
@@ -273,6 +296,7 @@ int cap_remove_triangle(double* local, int64_t ld, int64_t rows_local, int64_t c
                         int dir_upper, void* stream) {
   if (!local || d <= 0) return CAP_ERR_ARG;
   if (rows_local <= 0 || cols_local <= 0) return CAP_OK;
+  cap_acc_w(local, ld, rows_local, cols_local, (d == 1 && x == 0 && y == 0) ? (dir_upper ? 2 : 1) : 0);
   hipLaunchKernelGGL(remove_triangle_kernel, grid2d(rows_local, cols_local, 256), dim3(256), 0, cap_stream(stream), local,
                      ld, rows_local, cols_local, x, y, d, dir_upper);
   CAP_HIP(hipGetLastError());
@@ -286,6 +310,7 @@ int cap_sumsq(const double* X, int64_t ldx, int64_t m, int64_t n, int sub_identi
   if (m == 0 || n == 0) return CAP_OK;
   int64_t gx = cap_ceil_div(m, 256); if (gx > 64) gx = 64;
   dim3 g = grid2d(m, n, 256); g.x = (unsigned)gx;
+  cap_acc_r(X, ldx, m, n, upper_only ? 1 : 0); cap_acc_rw(out1, 1, 1, 1);
   hipLaunchKernelGGL(sumsq_kernel, g, dim3(256), 0, cap_stream(stream), X, ldx, m, n, sub_identity, upper_only, out1);
   CAP_HIP(hipGetLastError());
   return CAP_OK;

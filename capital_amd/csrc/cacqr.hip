@@ -105,6 +105,7 @@ int sweep_grid(cap_cacqr_plan* p, const double* Qin, int64_t ldin, double* Qout,
   // dense Gram everywhere: blocks (z, x') over `row`, then (z', x') over `depth`
   CAP_TRY(cap_comm_allgather(row, p->Gblk, p->Gall + (int64_t)p->z * p->c * nl * nl, nl * nl, (void*)s));
   CAP_TRY(cap_comm_allgather(depth, p->Gall + (int64_t)p->z * p->c * nl * nl, p->Gall, p->c * nl * nl, (void*)s));
+  cap_acc_r(p->Gall, 0, (int64_t)p->c * p->c * nl * nl, 1); cap_acc_w(p->G, n, n, n);
   hipLaunchKernelGGL(blocks_to_dense_kernel, dim3((unsigned)cap_ceil_div(n, 256), (unsigned)n), dim3(256), 0, s, p->Gall, p->G, n, nl, p->c);
   CAP_HIP(hipGetLastError());
   // R = chol(G) (upper, in place), Gi = R^-1 - redundantly on every GPU

@@ -38,6 +38,26 @@ static inline bool cap_plain_device_ptr(const void* p) {
   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
   return a.type == hipMemoryTypeDevice && !a.isManaged;
 }
+// ---- access notes: what the NEXT launch / collective this host thread enqueues reads and writes, declared where the launch is made.
+// The hook is null in the product (one load + branch per note).  The recording HIP stand-in of tests/hipshim installs one, attaches
+// the notes to the launch that follows them and replays every schedule with vector clocks: two operations that touch the same bytes,
+// at least one of them writing, must be ordered by stream order, an event edge or a host synchronisation.
+// A note is a column-major window: `cols` columns of `rows` elements, ld elements apart; tri = 1 / 2 restricts it to the elements
+// with row <= col / row >= col (window-relative), the element masks of the SYRK-shaped updates and of the triangular copies.
+typedef void (*cap_access_hook_fn)(int mode, const void* base, int64_t pitch_bytes, int64_t row_bytes, int64_t cols, int tri, int elem_bytes);
+extern "C" cap_access_hook_fn cap_access_hook;
+enum { CAP_ACC_R = 1, CAP_ACC_W = 2, CAP_ACC_RW = 3, CAP_ACC_ATOMIC = 4 };      // ATOMIC: device-scope atomic read-modify-write (conflicts with R / W, not with itself)
+static inline bool cap_acc_on() { return __builtin_expect(cap_access_hook != nullptr, 0); }
+static inline void cap_acc(int mode, const void* p, int64_t ld, int64_t rows, int64_t cols, int tri = 0, int elem = 8) {
+  if (cap_acc_on() && p && rows > 0 && cols > 0) cap_access_hook(mode, p, ld * elem, rows * elem, cols, tri, elem);
+}
+static inline void cap_acc_r(const void* p, int64_t ld, int64_t rows, int64_t cols, int tri = 0, int elem = 8) { cap_acc(CAP_ACC_R, p, ld, rows, cols, tri, elem); }
+static inline void cap_acc_w(const void* p, int64_t ld, int64_t rows, int64_t cols, int tri = 0, int elem = 8) { cap_acc(CAP_ACC_W, p, ld, rows, cols, tri, elem); }
+static inline void cap_acc_rw(const void* p, int64_t ld, int64_t rows, int64_t cols, int tri = 0, int elem = 8) { cap_acc(CAP_ACC_RW, p, ld, rows, cols, tri, elem); }
+static inline void cap_acc_atomic(const void* p, int64_t count, int elem) { cap_acc(CAP_ACC_ATOMIC, p, count, count, 1, 0, elem); }
+// a launch whose accesses are all on memory no other stream can name (per-stream scratch) still says so: mode 0 = "nothing shared"
+static inline void cap_acc_none() { if (cap_acc_on()) cap_access_hook(0, nullptr, 0, 0, 0, 0, 0); }
+
 static inline int64_t cap_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t cap_round_up(int64_t a, int64_t b) { return cap_ceil_div(a, b) * b; }
 

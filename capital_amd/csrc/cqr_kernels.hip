@@ -287,7 +287,9 @@ int cap_gram256_launch(const double* Q, int64_t ld, int64_t m, double* G, int64_
   if (128 * ld * 8 >= 0xfffffff0LL) return CAP_ERR_UNSUPPORTED;
   const int64_t nslab = cap_gram256_slabs(m);
   GramArgs g{Q, ld, m, cap_round_up(cap_ceil_div(m, nslab), BK), work};
+  cap_acc_r(Q, ld, m, GN); cap_acc_w(work, 0, nslab * GN * GN, 1);
   hipLaunchKernelGGL(gram256_kernel, dim3((unsigned)nslab), dim3(512), G_STAGES * G_TILE * sizeof(double), s, g);
+  cap_acc_r(work, 0, nslab * GN * GN, 1); cap_acc_w(G, ldg, GN, GN);
   hipLaunchKernelGGL(gram256_reduce_kernel, dim3(GN), dim3(4 * GN), 0, s, work, (int)nslab, G, ldg);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
@@ -307,6 +309,7 @@ int cap_qrapply256_launch(const double* Qin, int64_t ldin, const double* Ri, dou
   static const int pipe = getenv("CAP_CQR_PIPE") ? atoi(getenv("CAP_CQR_PIPE")) : 1;
   const size_t lds = (A_NST * TA + B_NST * TB) * sizeof(double);
   const dim3 gr((unsigned)grid), bl(512);
+  cap_acc_r(Qin, ldin, m, 256); cap_acc_r(Ri, 256, 256, 256, 1); cap_acc_w(Qout, ldout, m, 256);
   if constexpr (CAP_EXPERIMENTS) {
     static const int diag = getenv("CAP_CQR_DIAG") ? atoi(getenv("CAP_CQR_DIAG")) : 0;
     if (diag == 1) hipLaunchKernelGGL((qrapply256_kernel<1, 0>), gr, bl, lds, s, g);

@@ -142,7 +142,7 @@ int jitter(cap_dist_plan* d, hipStream_t s) {
   if (d->jitter_max_us <= 0) return CAP_OK;
   d->jitter_state = d->jitter_state * 6364136223846793005ull + 1442695040888963407ull;
   const int us = (int)((d->jitter_state >> 33) % (uint64_t)(d->jitter_max_us + 1));
-  if (us > 0) { hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, us); CAP_HIP(hipGetLastError()); }
+  if (us > 0) { cap_acc_none(); hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, us); CAP_HIP(hipGetLastError()); }
   return CAP_OK;
 }
 
@@ -408,6 +408,7 @@ int cap_fill_symmetric_bc(double* local, int64_t ld, int64_t n, int64_t nb, int 
   int64_t lc = cap_bc_num_local_cols(n, nb, P, p);
   if (lc == 0) return CAP_OK;
   dim3 grid((unsigned)cap_ceil_div(n, 256), (unsigned)std::min<int64_t>(lc, 65535), (unsigned)cap_ceil_div(lc, 65535));
+  cap_acc_w(local, ld, n, lc);
   hipLaunchKernelGGL(fill_symmetric_bc_kernel, grid, dim3(256), 0, cap_stream(stream), local, ld, n, nb, P, p, diagonally_dominant, lc);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
@@ -579,9 +580,11 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
   if (d->lc_valid > 0) CAP_TRY(cap_copy_rect(Aloc, lda, d->R, ld, n, d->lc_valid, s0));
   if (npad != n && d->lc > 0) {
     // rows [n, npad) of every local column, and the padding columns of the last block on its owner
+    cap_acc_w(d->R + n, ld, npad - n, d->lc);
     hipLaunchKernelGGL(pad_identity_kernel, dim3((unsigned)cap_ceil_div(npad - n, 256), (unsigned)std::min<int64_t>(d->lc, 65535),
                                                  (unsigned)cap_ceil_div(d->lc, 65535)), dim3(256), 0, s0, d->R, ld, n,
                        npad, nb, (int)P, (int)p, n, (int64_t)0, npad - n, d->lc);
+    if (d->lc > d->lc_valid) cap_acc_w(d->R + d->lc_valid * ld, ld, npad, d->lc - d->lc_valid);
     if (d->lc > d->lc_valid)      // (at most nb columns: no grid.z folding needed, the kernel tolerates it anyway)
       hipLaunchKernelGGL(pad_identity_kernel, dim3((unsigned)cap_ceil_div(npad, 256), (unsigned)(d->lc - d->lc_valid)), dim3(256), 0, s0,
                          d->R, ld, n, npad, nb, (int)P, (int)p, (int64_t)0, d->lc_valid, npad, d->lc - d->lc_valid);
@@ -592,6 +595,7 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
     if (d->profile) CAP_HIP(hipEventRecord(d->ev_t0, s0));
     CAP_HIP(hipMemsetAsync(d->Ri, 0, sizeof(double) * d->npad * std::max<int64_t>(d->lc, 1), s0));
     if (d->lc > 0) {
+      cap_acc_w(d->Ri, npad, npad, d->lc);
       hipLaunchKernelGGL(identity_blocks_bc_kernel, dim3((unsigned)cap_ceil_div(d->lc, 256)), dim3(256), 0, s0, d->Ri, npad, nb, (int)P, (int)p, d->lc);
       CAP_HIP(hipGetLastError());
     }
@@ -747,6 +751,7 @@ int cap_dist_get_R(cap_dist_plan* d, double* out, int64_t ldo, void* stream) {
   if (!d || (d->lc_valid > 0 && (!out || ldo < d->n))) return CAP_ERR_ARG;
   if (d->lc_valid == 0) return CAP_OK;
   dim3 grid((unsigned)cap_ceil_div(d->n, 256), (unsigned)std::min<int64_t>(d->lc_valid, 65535), (unsigned)cap_ceil_div(d->lc_valid, 65535));
+  cap_acc_r(d->R, d->ld, d->n, d->lc_valid); cap_acc_w(out, ldo, d->n, d->lc_valid);
   hipLaunchKernelGGL(export_upper_bc_kernel, grid, dim3(256), 0, cap_stream(stream), d->R, d->ld, out, ldo, d->n, d->nb, d->P, d->p,
                      d->lc_valid);
   CAP_HIP(hipGetLastError());
@@ -759,6 +764,7 @@ int cap_dist_get_Rinv(cap_dist_plan* d, double* out, int64_t ldo, void* stream) 
   if (d->complete_inv < 0 || !d->Ri) return CAP_ERR_UNSUPPORTED;
   if (d->lc_valid == 0) return CAP_OK;
   dim3 grid((unsigned)cap_ceil_div(d->n, 256), (unsigned)std::min<int64_t>(d->lc_valid, 65535), (unsigned)cap_ceil_div(d->lc_valid, 65535));
+  cap_acc_r(d->Ri, d->ld, d->n, d->lc_valid); cap_acc_w(out, ldo, d->n, d->lc_valid);
   hipLaunchKernelGGL(export_upper_bc_kernel, grid, dim3(256), 0, cap_stream(stream), d->Ri, d->ld, out, ldo, d->n, d->nb, d->P, d->p,
                      d->lc_valid);
   CAP_HIP(hipGetLastError());
@@ -772,6 +778,7 @@ int cap_dist_info(cap_dist_plan* d, void* stream, int64_t* info) {
   if (!d || !info) return CAP_ERR_ARG;
   hipStream_t s = cap_stream(stream);
   double* mine = d->info_red + d->P;
+  cap_acc_r(d->info_dev, 1, 1, 1, 0, 4); cap_acc_w(mine, 1, 1, 1);
   hipLaunchKernelGGL(info_to_double, dim3(1), dim3(1), 0, s, d->info_dev, mine);
   CAP_HIP(hipGetLastError());
   CAP_TRY(cap_comm_allgather(d->comm, mine, d->info_red, 1, stream));

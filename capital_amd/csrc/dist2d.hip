@@ -337,6 +337,7 @@ int cap_fill_symmetric_bc2d(double* local, int64_t ld, int64_t n, int64_t nb, in
   const int64_t lr = valid_extent(n, nb, Pr, pr), lc = valid_extent(n, nb, Pc, pc);
   if (lr == 0 || lc == 0) return CAP_OK;
   if (ld < lr) return CAP_ERR_ARG;
+  cap_acc_w(local, ld, lr, lc);
   hipLaunchKernelGGL(fill_symmetric_bc2d_kernel, grid_cols(lr, lc), dim3(256), 0, cap_stream(stream), local, ld, n, nb, Pr, Pc, pr, pc,
                      diagonally_dominant, lr, lc);
   CAP_HIP(hipGetLastError());
@@ -492,6 +493,7 @@ int cap_dist2d_factor(cap_dist2d_plan* d, const double* Aloc, int64_t lda, void*
   d->cnt_gemm = d->cnt_chain = d->cnt_copy = d->cnt_coll = 0;
   CAP_HIP(hipMemsetAsync(d->info_dev, 0, sizeof(int), s0));
   if (d->nlr > 0 && d->nlc > 0) {
+    cap_acc_r(Aloc, lda, d->lr_valid, d->lc_valid); cap_acc_w(d->R, ld, d->nlr * nb, d->nlc * nb);
     hipLaunchKernelGGL(import_pad_2d_kernel, grid_cols(d->nlr * nb, d->nlc * nb), dim3(256), 0, s0, Aloc, lda, d->R, ld, d->n, nb, Pr, Pc, pr, pc,
                        d->nlr * nb, d->nlc * nb);
     CAP_HIP(hipGetLastError());
@@ -500,6 +502,7 @@ int cap_dist2d_factor(cap_dist2d_plan* d, const double* Aloc, int64_t lda, void*
   if (inv) {
     CAP_HIP(hipMemsetAsync(d->Ri, 0, sizeof(double) * std::max<int64_t>(ld * d->nlc * nb, 2), s0));
     if (d->nlr > 0 && d->nlc > 0) {
+      cap_acc_w(d->Ri, ld, d->nlr * nb, d->nlc * nb);
       hipLaunchKernelGGL(identity_2d_kernel, dim3((unsigned)cap_ceil_div(d->nlc * nb, 256)), dim3(256), 0, s0, d->Ri, ld, nb, Pr, Pc, pr, pc, d->nlc * nb);
       CAP_HIP(hipGetLastError());
     }
@@ -687,6 +690,7 @@ int cap_dist2d_factor(cap_dist2d_plan* d, const double* Aloc, int64_t lda, void*
     }
     const Cut2 ic = inv_cut2(d);
     if (ic.cut && ic.kcut == 0 && d->nlr > 0 && d->nlc > 0) {
+      cap_acc_w(d->Ri, ld, d->nlr * nb, d->nlc * nb);
       hipLaunchKernelGGL(zero_root_2d_kernel, grid_cols(d->nlr * nb, d->nlc * nb), dim3(256), 0, s0, d->Ri, ld, nb, Pr, Pc, pr, pc, d->nlr * nb,
                          d->nlc * nb, ic.n1);
       CAP_HIP(hipGetLastError());
@@ -700,6 +704,7 @@ int cap_dist2d_get_R(cap_dist2d_plan* d, double* out, int64_t ldo, void* stream)
   if (!d) return CAP_ERR_ARG;
   if (d->lr_valid == 0 || d->lc_valid == 0) return CAP_OK;
   if (!out || ldo < d->lr_valid) return CAP_ERR_ARG;
+  cap_acc_r(d->R, d->ld, d->lr_valid, d->lc_valid); cap_acc_w(out, ldo, d->lr_valid, d->lc_valid);
   hipLaunchKernelGGL(export_upper_2d_kernel, grid_cols(d->lr_valid, d->lc_valid), dim3(256), 0, cap_stream(stream), d->R, d->ld, out, ldo, d->nb,
                      d->Pr, d->Pc, d->pr, d->pc, d->lr_valid, d->lc_valid);
   CAP_HIP(hipGetLastError());
@@ -711,6 +716,7 @@ int cap_dist2d_info(cap_dist2d_plan* d, void* stream, int64_t* info) {
   if (!d || !info) return CAP_ERR_ARG;
   hipStream_t s = cap_stream(stream);
   double* mine = d->info_red + d->P;
+  cap_acc_r(d->info_dev, 1, 1, 1, 0, 4); cap_acc_w(mine, 1, 1, 1);
   hipLaunchKernelGGL(info_to_double2, dim3(1), dim3(1), 0, s, d->info_dev, mine);
   CAP_HIP(hipGetLastError());
   CAP_TRY(cap_comm_allgather(d->world, mine, d->info_red, 1, stream));
@@ -729,6 +735,7 @@ int cap_dist2d_get_Rinv(cap_dist2d_plan* d, double* out, int64_t ldo, void* stre
   if (d->complete_inv < 0 || !d->Ri) return CAP_ERR_UNSUPPORTED;
   if (d->lr_valid == 0 || d->lc_valid == 0) return CAP_OK;
   if (!out || ldo < d->lr_valid) return CAP_ERR_ARG;
+  cap_acc_r(d->Ri, d->ld, d->lr_valid, d->lc_valid); cap_acc_w(out, ldo, d->lr_valid, d->lc_valid);
   hipLaunchKernelGGL(export_upper_2d_kernel, grid_cols(d->lr_valid, d->lc_valid), dim3(256), 0, cap_stream(stream), d->Ri, d->ld, out, ldo, d->nb,
                      d->Pr, d->Pc, d->pr, d->pc, d->lr_valid, d->lc_valid);
   CAP_HIP(hipGetLastError());

@@ -185,6 +185,7 @@ int cap_dmp_factor(cap_dmp_plan* d, const double* Aloc, int64_t lda, void* strea
   const int64_t n = d->n, npad = d->npad, nb = d->nb, nblk = d->nblk, P = d->P, p = d->p, ld = d->ld, nb2 = nb * nb;
   CAP_HIP(hipMemsetAsync(d->info_dev, 0, sizeof(int), s0));
   if (d->lc > 0) {
+    cap_acc_r(Aloc, lda, n, d->lc_valid); cap_acc_w(d->R32, ld, npad, d->lc, 0, 4);
     hipLaunchKernelGGL(import_f32_bc_kernel, grid2(npad, d->lc), dim3(256), 0, s0, Aloc, lda, d->R32, ld, n, npad, nb, (int)P, (int)p, d->lc);
     CAP_HIP(hipGetLastError());
   }
@@ -204,10 +205,10 @@ int cap_dmp_factor(cap_dmp_plan* d, const double* Aloc, int64_t lda, void* strea
     if (p == owner) {
       CapRange range("CI::factor_diag");
       float* D32 = d->R32 + k * nb + (k / P) * nb * ld;
-      hipLaunchKernelGGL(f32_to_f64_kernel, grid2(nb, nb), dim3(256), 0, s1, D32, ld, d->D64, nb, nb, nb, 1);
+      launch_f32_to_f64(s1, D32, ld, d->D64, nb, nb, nb, 1);
       CAP_HIP(hipMemsetAsync(Dinv, 0, sizeof(double) * nb2, s1));
       CAP_TRY(cap_rec_cholinv_full(d->D64, nb, Dinv, nb, nb, d->W, d->wcap, d->info_dev, s1, k * nb));
-      hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(nb, nb), dim3(256), 0, s1, d->D64, nb, D32, ld, (__bf16*)nullptr, (int64_t)0, nb, nb, 1);
+      launch_f64_to_f32_bf16(s1, d->D64, nb, D32, ld, (__bf16*)nullptr, (int64_t)0, nb, nb, 1);
       CAP_HIP(hipGetLastError());
       CAP_HIP(hipEventRecord(d->ev_fact[k], s1));
       CAP_HIP(hipStreamWaitEvent(sc, d->ev_fact[k], 0));
@@ -222,9 +223,9 @@ int cap_dmp_factor(cap_dmp_plan* d, const double* Aloc, int64_t lda, void* strea
     if (ncols > 0) {
       CapRange range("CI::trsm");
       float* Row32 = d->R32 + k * nb + lbk * nb * ld;
-      hipLaunchKernelGGL(f32_to_f64_kernel, grid2(nb, ncols), dim3(256), 0, s1, Row32, ld, d->T64, nb, nb, ncols, 0);
+      launch_f32_to_f64(s1, Row32, ld, d->T64, nb, nb, ncols, 0);
       CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, nb, ncols, nb, 1.0, Dinv, nb, d->T64, nb, 0.0, d->S64, nb, 0, s1, 2 | 16));
-      hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(nb, ncols), dim3(256), 0, s1, d->S64, nb, Row32, ld, Pk, nb, nb, ncols, 0);
+      launch_f64_to_f32_bf16(s1, d->S64, nb, Row32, ld, Pk, nb, nb, ncols, 0);
       CAP_HIP(hipGetLastError());
     }
     CAP_HIP(hipEventRecord(d->ev_solved[k], s1));
@@ -268,7 +269,7 @@ int cap_dmp_factor(cap_dmp_plan* d, const double* Aloc, int64_t lda, void* strea
   CAP_HIP(hipStreamWaitEvent(s0, d->ev_join_c, 0));
   // fp64 promotion of my block columns for the refinement sweeps
   if (d->lc > 0) {
-    hipLaunchKernelGGL(f32_to_f64_kernel, grid2(npad, d->lc), dim3(256), 0, s0, d->R32, ld, d->R64, ld, npad, d->lc, 0);
+    launch_f32_to_f64(s0, d->R32, ld, d->R64, ld, npad, d->lc, 0);
     CAP_HIP(hipGetLastError());
   }
   d->have_r64 = true;
@@ -280,6 +281,7 @@ int cap_dmp_info(cap_dmp_plan* d, void* stream, int64_t* info) {
   if (!d || !info) return CAP_ERR_ARG;
   hipStream_t s = cap_stream(stream);
   double* mine = d->info_red + d->P;
+  cap_acc_r(d->info_dev, 1, 1, 1, 0, 4); cap_acc_w(mine, 1, 1, 1);
   hipLaunchKernelGGL(info_to_double3, dim3(1), dim3(1), 0, s, d->info_dev, mine);
   CAP_HIP(hipGetLastError());
   CAP_TRY(cap_comm_allgather(d->comm, mine, d->info_red, 1, stream));
@@ -318,6 +320,7 @@ int cap_dmp_solve(cap_dmp_plan* d, const double* Aloc, int64_t lda, const double
       const int owner = (int)(i % P);
       CAP_TRY(cap_copy_rect(d->Acc + i * nb, npad, Tmp, nb, nb, w, s));
       CAP_TRY(cap_comm_allreduce_sum(d->comm, Tmp, nb * w, (void*)s));
+      cap_acc_rw(Tmp, nb, nb, w); cap_acc_r(V + i * nb, npad, nb, w);
       hipLaunchKernelGGL(sub_from_kernel, rows_grid(nb), dim3(256), 0, s, Tmp, nb, V + i * nb, npad, nb, w);
       CAP_HIP(hipGetLastError());
       CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, nb, w, nb, 1.0, d->Dall + i * nb2, nb, Tmp, nb, 0.0, V + i * nb, npad, 0, s, 32));
@@ -341,11 +344,13 @@ int cap_dmp_solve(cap_dmp_plan* d, const double* Aloc, int64_t lda, const double
     CAP_HIP(hipMemsetAsync(d->Rw, 0, sizeof(double) * npad * w, s));
     if (d->lc_valid > 0) {
       CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, d->lc_valid, w, n, 1.0, Aloc, lda, d->V, npad, 0.0, d->Q, d->lc_valid, 0, s));
+      cap_acc_r(d->Q, d->lc_valid, d->lc_valid, w); cap_acc_w(d->Rw, npad, npad, w);       // (my rows of the replicated buffer: noted as the whole of it)
       hipLaunchKernelGGL(scatter_rows_bc_kernel, rows_grid(d->lc_valid), dim3(256), 0, s, d->Q, d->lc_valid, d->Rw, npad, nb, (int)P, (int)p,
                          d->lc_valid, w);
       CAP_HIP(hipGetLastError());
     }
     CAP_TRY(cap_comm_allreduce_sum(d->comm, d->Rw, npad * w, (void*)s));
+    cap_acc_rw(d->Rw, npad, npad, w); cap_acc_r(d->Bw, npad, npad, w);
     hipLaunchKernelGGL(sub_from_kernel, rows_grid(npad), dim3(256), 0, s, d->Rw, npad, d->Bw, npad, npad, w);     // Rw <- Bw - Rw
     CAP_HIP(hipGetLastError());
     CAP_TRY(cap_sumsq(d->Rw, npad, npad, w, 0, 0, d->norms + 1, stream));
@@ -355,6 +360,7 @@ int cap_dmp_solve(cap_dmp_plan* d, const double* Aloc, int64_t lda, const double
     if (rr <= tol || it >= max_iter || !(rr == rr) || (it >= 2 && rr > 0.5 * prev && rr < 1e-10)) break;
     prev = rr;
     CAP_TRY(apply_Ainv(d->Rw));
+    cap_acc_rw(d->V, npad, npad, w); cap_acc_r(d->Rw, npad, npad, w);
     hipLaunchKernelGGL(axpy_cols_kernel, rows_grid(npad), dim3(256), 0, s, d->V, npad, d->Rw, npad, npad, w);
     CAP_HIP(hipGetLastError());
     it++;

@@ -753,10 +753,24 @@ __global__ void __launch_bounds__(256) dgemm_small_kernel(SmallArgs g) {
   }
 }
 
+// access notes (common.h) of C = alpha op(A) op(B) + beta C [element mask tri; C input from Cin when given]
+void note_product(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda, const double* B,
+                  int64_t ldb, double beta, double* C, int64_t ldc, int tri, const double* Cin = nullptr, int64_t ldcin = 0) {
+  if (!cap_acc_on()) return;
+  if (alpha != 0.0 && k > 0) {
+    if (transa == CAP_TRANS) cap_acc_r(A, lda, k, m); else cap_acc_r(A, lda, m, k);
+    if (transb == CAP_TRANS) cap_acc_r(B, ldb, n, k); else cap_acc_r(B, ldb, k, n);
+  }
+  if (Cin && Cin != C) { cap_acc_r(Cin, ldcin, m, n, tri); cap_acc_w(C, ldc, m, n, tri); }
+  else cap_acc(beta != 0.0 ? CAP_ACC_RW : CAP_ACC_W, C, ldc, m, n, tri);
+}
+
 int launch_small(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
                  const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, int hiprio, hipStream_t stream,
                  int nbatch = 1, int64_t sa = 0, int64_t sb = 0, int64_t sc = 0) {
   SmallArgs g{A, B, C, lda, ldb, ldc, (int)m, (int)n, (int)k, alpha, beta, tri, hiprio, sa, sb, sc};
+  if (cap_acc_on())
+    for (int z = 0; z < nbatch; z++) note_product(transa, transb, m, n, k, alpha, A + z * sa, lda, B + z * sb, ldb, beta, C + z * sc, ldc, tri);
   dim3 grid((unsigned)cap_ceil_div(m, SM_T), (unsigned)cap_ceil_div(n, SM_T), (unsigned)nbatch);
   const bool ta = transa == CAP_TRANS, tb = transb == CAP_TRANS;
   const size_t lds = 2 * SM_K * SM_LD * sizeof(double);
@@ -891,9 +905,11 @@ int launch_skinny(int transa, int64_t m, int64_t n, int64_t k, double alpha, con
   SkinnyArgs g{A, B, C, lda, ldb, ldc, m, k, (int)n, alpha, beta};
   if (transa == CAP_TRANS) {
     if ((m % 16) || (lda & 1) || (ldb & 1) || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15)) return CAP_ERR_UNSUPPORTED;
+    note_product(transa, CAP_NOTRANS, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0);
     hipLaunchKernelGGL(dgemm_tn_skinny_kernel, dim3((unsigned)cap_ceil_div(m, 64)), dim3(256), 0, stream, g);
   } else {
     if (m % 64) return CAP_ERR_UNSUPPORTED;
+    note_product(transa, CAP_NOTRANS, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0);
     hipLaunchKernelGGL(dgemm_nn_skinny_kernel, dim3((unsigned)(m / 64)), dim3(256), 0, stream, g);
   }
   CAP_HIP(hipGetLastError());
@@ -969,6 +985,7 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
     if (beta == 1.0) return CAP_OK;
     dim3 grid((unsigned)cap_ceil_div(m, 256), (unsigned)n);
     if (n > 65535) return CAP_ERR_UNSUPPORTED;
+    note_product(transa, transb, m, n, 0, 0.0, A, lda, B, ldb, beta, C, ldc, tri);
     hipLaunchKernelGGL(scale_kernel, grid, dim3(256), 0, stream, C, ldc, m, n, beta, tri);
     CAP_HIP(hipGetLastError());
     return CAP_OK;
@@ -1065,6 +1082,8 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   constexpr bool use_v1 = false;       // (round 1's register-staged kernels for the aligned TN / NN forms: CAP_GEMM_V1 is gone)
   // a separate C input is only implemented in the LDS-DMA kernels' load / add / store epilogue
   if (Cin && !(a_kc && b_kc && !edge && !use_v1 && g.ksplit == 1)) return CAP_ERR_UNSUPPORTED;     // (the NN form has a_kc == false)
+  // (split-K: the product's notes ride on the first of its two launches, the partial slabs are this stream's own scratch)
+  note_product(transa, transb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, Cin, ldcin);
   if (a_kc && b_kc && !edge && !use_v1) st = (tag == 1) ? launch_tn_dma<1>(g, (int)grid, stream, persist_wgs) : launch_tn_dma<0>(g, (int)grid, stream, 0);
   else if (!a_kc && b_kc && !edge && !use_v1 && g.ksplit == 1) st = launch_nn_dma(g, (int)grid, stream);
   else if (a_kc && b_kc && tag == 1) st = launch_variant<true, true, 1>(g, edge, (int)grid, stream);
@@ -1073,6 +1092,7 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   else if (!a_kc && b_kc) st = launch_variant<false, true>(g, edge, (int)grid, stream);
   else st = launch_variant<false, false>(g, edge, (int)grid, stream);
   if (st != CAP_OK || g.ksplit == 1) return st;
+  cap_acc_none();
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cap_ceil_div(m, 256), (unsigned)n), dim3(256), 0, stream, C, ldc,
                      g.P, g.slab, g.ksplit, m, n, beta, tri);
   CAP_HIP(hipGetLastError());
@@ -1113,6 +1133,29 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   if (nsuper == 0) return CAP_OK;      // Pr > 1: every local row block may lie below every local column block (nothing to update)
   int64_t slots = nsuper * ST * ST;
   g.chunk = (int)cap_ceil_div(slots, 8);
+  if (cap_acc_on()) {
+    // access notes: per local column block J the row blocks I < J whole and I == J above the diagonal; the A operand's column chunk
+    // of every local row block that has a partner, B whole
+    const int64_t ncb = nloc / nb, nrb = m / nb;
+    const int64_t Jlast = p + (int64_t)P * (lb0 + ncb - 1);
+    for (int64_t cb = 0; cb < ncb; cb++) {
+      const int64_t J = p + (int64_t)P * (lb0 + cb);
+      int64_t full = 0; bool diag = false;
+      for (int64_t rb = 0; rb < nrb; rb++) {
+        const int64_t I = pr + (int64_t)Pr * (rlb0 + rb);
+        if (I < J) full = rb + 1; else { diag = I == J; break; }
+      }
+      cap_acc_rw(C + cb * nb * ldc, ldc, full * nb, nb);
+      if (diag) cap_acc_rw(C + full * nb + cb * nb * ldc, ldc, nb, nb, 1);
+    }
+    for (int64_t rb = 0; rb < nrb; rb++) {
+      const int64_t I = pr + (int64_t)Pr * (rlb0 + rb);
+      if (I > Jlast) break;
+      const int64_t r = (I % P) / Pr, lb = I / P - gstart[r];
+      cap_acc_r(G + r * piece + lb * nb * k, 0, k * nb, 1);
+    }
+    cap_acc_r(B, 0, k * nloc, 1);
+  }
   return launch_tn_dma<1>(g, g.chunk * 8, stream, persist_wgs);
 }
 

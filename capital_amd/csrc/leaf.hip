@@ -1031,11 +1031,24 @@ int cap_chain64_coop(double* R, int64_t ldr, double* Ri, int64_t ldi, int nblk, 
   const int useful = std::max(1, (nblk - 1) * nblk / 2);           // one workgroup per trailing block of the first step
   wgs = std::max(2, std::min(wgs, useful));
   Chain64 g{R, ldr, Ri, ldi, nblk, info, info_base, ctr, fence, hmax, trace, backup, fallbacks, 0};
+  // access notes: R's upper triangle in place, the square of Ri (diagonal 64-blocks are written whole), the stream's own counter words
+  // and backup, the device-wide fall-back counters and the pivot report (atomics)
+  auto note = [&]() {
+    if (!cap_acc_on()) return;
+    const int64_t n = (int64_t)nblk * 64;
+    cap_acc_rw(R, ldr, n, n, 1); cap_acc_rw(Ri, ldi, n, n);
+    cap_acc_rw(ctr, 4, 4, 1, 0, 4);
+    if (backup) cap_acc_rw(backup, 0, (int64_t)nblk * (nblk + 1) / 2 * 64 * 64, 1);
+    if (fallbacks) cap_acc_atomic(fallbacks, 4, 4);
+    if (info) cap_acc_atomic(info, 1, 4);
+  };
+  note();
   hipLaunchKernelGGL(chain64_coop_kernel, dim3((unsigned)wgs), dim3(LTHREADS), CHAIN_LDS_BYTES, stream, g);
   CAP_HIP(hipGetLastError());
   if (backup) {
     // the recovery launch: two workgroups that return at once unless a workgroup of the launch above gave up (ctr[3] == 1)
     g.recover = 1; g.trace = nullptr;
+    note();
     hipLaunchKernelGGL(chain64_coop_kernel, dim3(2), dim3(LTHREADS), CHAIN_LDS_BYTES, stream, g);
     CAP_HIP(hipGetLastError());
   }
@@ -1047,6 +1060,12 @@ int cap_trinv_merge(const double* R, int64_t ldr, double* Ri, int64_t ldi, int64
   if (npairs <= 0) return CAP_OK;
   const dim3 grid((unsigned)(h / 16), (unsigned)npairs);
   const size_t lds_bytes = (size_t)16 * (h + 1) * sizeof(double);
+  if (cap_acc_on() && (h == 64 || h == 128 || h == 256))
+    for (int64_t z = 0; z < npairs; z++) {
+      const int64_t o = z * 2 * h;
+      cap_acc_r(R + o + (o + h) * ldr, ldr, h, h); cap_acc_r(Ri + o + o * ldi, ldi, h, h, 1); cap_acc_r(Ri + (o + h) + (o + h) * ldi, ldi, h, h, 1);
+      cap_acc_w(Ri + o + (o + h) * ldi, ldi, h, h);
+    }
   if (h == 64) hipLaunchKernelGGL(trinv_merge_kernel<1>, grid, dim3(LTHREADS), lds_bytes, stream, R, ldr, Ri, ldi);
   else if (h == 128) hipLaunchKernelGGL(trinv_merge_kernel<2>, grid, dim3(LTHREADS), lds_bytes, stream, R, ldr, Ri, ldi);
   else if (h == 256) hipLaunchKernelGGL(trinv_merge_kernel<4>, grid, dim3(LTHREADS), lds_bytes, stream, R, ldr, Ri, ldi);
@@ -1063,6 +1082,15 @@ int cap_panel64_solve_update(double* R, int64_t ldr, const double* Dinv, int64_t
   const size_t lds_bytes = (2 * LMAX * LLD + LMAX * (LMAX + 1) / 2) * sizeof(double);
   static_assert(LMAX * (LMAX + 1) / 2 >= 2 + LMAX + 256, "the folded leaf keeps bad / dinv / rowbuf in the packed-Dinv region");
   const Panel64Fold f{Dnext, ldn, info, info_base, cj_src, cj_dst, cj_ld, cj_cols, direct};
+  if (cap_acc_on()) {
+    const int64_t o = (int64_t)(i + 1) * 64, w = (int64_t)r * 64;
+    cap_acc_r(Dinv, ldi, 64, 64, 1);
+    cap_acc(direct ? CAP_ACC_RW : CAP_ACC_R, R + (int64_t)i * 64 + o * ldr, ldr, 64, w);      // block row i right of the diagonal block
+    cap_acc_rw(R + o + o * ldr, ldr, w, w, 1);                                                  // trailing blocks (a, b), i < a <= b
+    if (!direct) cap_acc_w(Xs, 0, w * 64, 1);
+    if (Dnext) { cap_acc_w(Dnext, ldn, 64, 64); if (info) cap_acc_atomic(info, 1, 4); }
+    if (cj_cols > 0) { cap_acc_r(cj_src, 0, (int64_t)64 * cj_cols, 1); cap_acc_w(cj_dst, cj_ld, 64, cj_cols); }
+  }
   hipLaunchKernelGGL(panel64_solve_update_kernel, dim3(r * (r + 1) / 2), dim3(LTHREADS), lds_bytes, stream, R, ldr, Dinv, ldi, i, nblk,
                      Xs, f);
   CAP_HIP(hipGetLastError());
@@ -1076,6 +1104,12 @@ int cap_leaf_cholinv(double* A, int64_t lda, double* Rinv, int64_t ldr, int n, i
                      int cjob_cols) {
   if (n <= 0) return CAP_OK;
   if (n > LMAX) return CAP_ERR_ARG;
+  if (cap_acc_on()) {
+    cap_acc_rw(A, lda, n, n, 1);
+    if (Rinv) cap_acc_w(Rinv, ldr, n, n, zero_lower ? 0 : 1);
+    if (info) cap_acc_atomic(info, 1, 4);
+    if (cjob_cols > 0) { cap_acc_r(cjob_src, 0, (int64_t)64 * cjob_cols, 1); cap_acc_w(cjob_dst, cjob_ld, 64, cjob_cols); }
+  }
   hipLaunchKernelGGL(leaf_cholinv_kernel, dim3(1), dim3(LTHREADS), LEAF_LDS_BYTES, stream, A, lda, Rinv, ldr, n,
                      zero_lower, info, info_base, cjob_src, cjob_dst, cjob_ld, cjob_cols);
   CAP_HIP(hipGetLastError());
@@ -1085,6 +1119,7 @@ int cap_leaf_cholinv(double* A, int64_t lda, double* Rinv, int64_t ldr, int n, i
 int cap_leaf_trtri(const double* R, int64_t ldr, double* Rinv, int64_t ldi, int n, hipStream_t stream) {
   if (n <= 0) return CAP_OK;
   if (n > LMAX) return CAP_ERR_ARG;
+  cap_acc_r(R, ldr, n, n, 1); cap_acc_w(Rinv, ldi, n, n, 1);
   hipLaunchKernelGGL(leaf_trtri_kernel, dim3(1), dim3(LTHREADS), LEAF_LDS_BYTES, stream, R, ldr, Rinv, ldi, n);
   CAP_HIP(hipGetLastError());
   return CAP_OK;

@@ -216,6 +216,8 @@ int launch_bf16_tn(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A
     tiles = ((tri && m == n) ? nsn * (nsn + 1) / 2 : (int64_t)g.nsm * nsn) * g.st * g.st;
   }
   g.chunk = (int)cap_ceil_div(tiles, 8);
+  // access notes: C is accumulated with device-scope fp32 atomics (launches on two streams may add into the same elements)
+  cap_acc_r(A, lda, k, m, 0, 2); cap_acc_r(B, ldb, k, n, 0, 2); cap_acc(CAP_ACC_ATOMIC, C, ldc, m, n, tri ? 1 : 0, 4);
   launch_bf16_tn_kernel(g, (unsigned)(g.chunk * 8), s);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
@@ -495,6 +497,7 @@ int launch_bf16_v2(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A
   g.tpw = (int)std::max<int64_t>(1, std::min<int64_t>(g_bf16_tpw, per_xcd));
   const int64_t rounds = cap_ceil_div(per_xcd, g.tpw);
   const unsigned grid = (unsigned)(256 * rounds);
+  cap_acc_r(A, lda, k, m, 0, 2); cap_acc_r(B, ldb, k, n, 0, 2); cap_acc(CAP_ACC_ATOMIC, C, ldc, m, n, tri ? 1 : 0, 4);
   if constexpr (CAP_EXPERIMENTS) {
     switch (g_bf16_dbg) {
       case 1: return launch_bf16_v2_t<1, 1>(g, grid, s);
@@ -559,6 +562,25 @@ int cap_bf16_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const void* 
   g.stair = 1; g.sP = P; g.sp = p; g.snbT = nb / TB; g.sJ0 = J0; g.slb0 = lb0; g.gpiece = piece; g.st = 0; g.nsm = 1;
   for (int i = 0; i < 8; i++) g.gstart[i] = i < P ? gstart[i] : 0;
   g.chunk = (int)cap_ceil_div((int64_t)g.tm * g.tn, 8);       // full grid; workgroups below the staircase return at once
+  if (cap_acc_on()) {
+    // access notes (cf. cap_dist_update_launch, gemm.hip): per local column block J the row blocks I < J whole and I == J above the
+    // diagonal (fp32 atomics), the gathered operand's chunk of every row block that has a partner, my own columns whole
+    const int64_t ncb = nloc / nb, nrb = m / nb;
+    const int64_t Jlast = p + (int64_t)P * (lb0 + ncb - 1);
+    for (int64_t cb = 0; cb < ncb; cb++) {
+      const int64_t J = p + (int64_t)P * (lb0 + cb);
+      const int64_t full = std::max<int64_t>(0, std::min<int64_t>(nrb, J - J0));
+      cap_acc(CAP_ACC_ATOMIC, C + cb * nb * ldc, ldc, full * nb, nb, 0, 4);
+      if (J - J0 >= 0 && J - J0 < nrb) cap_acc(CAP_ACC_ATOMIC, C + full * nb + cb * nb * ldc, ldc, nb, nb, 1, 4);
+    }
+    for (int64_t rb = 0; rb < nrb; rb++) {
+      const int64_t I = J0 + rb;
+      if (I > Jlast) break;
+      const int64_t r = I % P, lb = I / P - gstart[r];
+      cap_acc_r((const __bf16*)G16 + r * piece + lb * nb * k, 0, k * nb, 1, 0, 2);
+    }
+    cap_acc_r(B16, 0, k * nloc, 1, 0, 2);
+  }
   launch_bf16_tn_kernel(g, (unsigned)(g.chunk * 8), s);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
@@ -728,7 +750,7 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
   p->prof_used = 0;
   if (p->prof_flops) { p->prof_flops->clear(); p->prof_bytes->clear(); }
   CAP_HIP(hipMemsetAsync(p->info_dev, 0, sizeof(int), s0));
-  hipLaunchKernelGGL(f64_to_f32_upper_kernel, grid2(n, n), dim3(256), 0, s0, A, lda, p->R32, n, n);
+  launch_f64_to_f32_upper(s0, A, lda, p->R32, n, n);
   CAP_HIP(hipGetLastError());
   CAP_HIP(hipEventRecord(p->ev_fork, s0));
   CAP_HIP(hipStreamWaitEvent(s1, p->ev_fork, 0));
@@ -769,15 +791,15 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
         // S = Dinv^T Row on the bf16 pipe with split operands (K = 3 jb): the row is split into B3 and cleared, the product is
         // accumulated straight back into it (fp32 atomics of the update kernel), then rounded into the strip buffer
         __bf16* B3 = (T == Tn) ? p->B3near : p->B3far;             // the near / far solves of a panel run side by side
-        hipLaunchKernelGGL(split3_row_kernel, grid2(jb, w), dim3(256), 0, s, Row32, n, B3, jb, w, 1);
+        launch_split3_row(s, Row32, n, B3, jb, w, 1);
         CAP_TRY(launch_bf16_update(jb, w, 3 * jb, 1.0f, p->A3[k & 1], 3 * jb, B3, 3 * jb, Row32, n, 0, s));
-        hipLaunchKernelGGL(f32_to_bf16_kernel, grid2(jb, w), dim3(256), 0, s, Row32, n, SP + roff + c0 * ldp, ldp, jb, w);
+        launch_f32_to_bf16(s, Row32, n, SP + roff + c0 * ldp, ldp, jb, w);
         CAP_HIP(hipGetLastError());
         return CAP_OK;
       }
-      hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, w), dim3(256), 0, s, Row32, n, T, jb, jb, w, 0);
+      launch_f32_to_f64(s, Row32, n, T, jb, jb, w, 0);
       CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, w, jb, 1.0, p->Inv + k * nb * nb, nb, T, jb, 0.0, S, jb, 0, s, 2 | 16));
-      hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(jb, w), dim3(256), 0, s, S, jb, Row32, n, SP + roff + c0 * ldp, ldp, jb, w, 0);
+      launch_f64_to_f32_bf16(s, S, jb, Row32, n, SP + roff + c0 * ldp, ldp, jb, w, 0);
       CAP_HIP(hipGetLastError());
       return CAP_OK;
     };
@@ -785,7 +807,7 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
       const int64_t j0 = k * nb, jb = std::min(nb, n - j0);
       float* D32 = p->R32 + j0 + j0 * n;
       double* Dinv = p->Inv + k * nb * nb;
-      hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, jb), dim3(256), 0, s1, D32, n, p->D64, jb, jb, jb, 1);
+      launch_f32_to_f64(s1, D32, n, p->D64, jb, jb, jb, 1);
       CAP_HIP(hipMemsetAsync(Dinv, 0, sizeof(double) * nb * nb, s1));
       if (p->res_ready) {           // the latency-bound launches on the reserved CUs
         CAP_HIP(hipEventRecord(p->ev_ch[0], s1));
@@ -798,8 +820,8 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
         CAP_HIP(hipStreamWaitEvent(s1, p->ev_ch[1], 0));
       } else
       CAP_TRY(cap_rec_cholinv_full(p->D64, jb, Dinv, nb, jb, p->W, p->wcap, p->info_dev, s1, j0));
-      hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(jb, jb), dim3(256), 0, s1, p->D64, jb, D32, n, (__bf16*)nullptr, (int64_t)0, jb, jb, 1);
-      if (p->solve3 && jb == nb) hipLaunchKernelGGL(split3_tri_kernel, grid2(jb, jb), dim3(256), 0, s1, Dinv, nb, p->A3[k & 1], jb);
+      launch_f64_to_f32_bf16(s1, p->D64, jb, D32, n, (__bf16*)nullptr, (int64_t)0, jb, jb, 1);
+      if (p->solve3 && jb == nb) launch_split3_tri(s1, Dinv, nb, p->A3[k & 1], jb);
       CAP_HIP(hipGetLastError());
       return CAP_OK;
     };
@@ -824,10 +846,10 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
           // fp64 promotion of the finished block row for the refinement sweeps, off the critical path (far stream) - it used to be one
           // 15 ms pass over the whole factor behind the last panel
           const int64_t j0 = k * nb, jb = std::min(nb, n - j0);
-          if (n > j1n) hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, n - j1n), dim3(256), 0, s2, p->R32 + j0 + j1n * n, n, p->R64 + j0 + j1n * n, n, jb, n - j1n, 0);
+          if (n > j1n) launch_f32_to_f64(s2, p->R32 + j0 + j1n * n, n, p->R64 + j0 + j1n * n, n, jb, n - j1n, 0);
           CAP_HIP(hipStreamWaitEvent(s2, p->ev_ns, 0));
-          hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, jb), dim3(256), 0, s2, p->R32 + j0 + j0 * n, n, p->R64 + j0 + j0 * n, n, jb, jb, 1);
-          if (j1n > j1) hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, j1n - j1), dim3(256), 0, s2, p->R32 + j0 + j1 * n, n, p->R64 + j0 + j1 * n, n, jb, j1n - j1, 0);
+          launch_f32_to_f64(s2, p->R32 + j0 + j0 * n, n, p->R64 + j0 + j0 * n, n, jb, jb, 1);
+          if (j1n > j1) launch_f32_to_f64(s2, p->R32 + j0 + j1 * n, n, p->R64 + j0 + j1 * n, n, jb, j1n - j1, 0);
           CAP_HIP(hipGetLastError());
         }
         if (k < kb) {
@@ -921,25 +943,25 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
     const int64_t j0 = k * nb, jb = std::min(nb, n - j0), j1 = j0 + jb, m = n - j1;
     float* D32 = p->R32 + j0 + j0 * n;
     double* Dinv = p->Inv + k * nb * nb;                  // kept: the diagonal-block inverse of the blocked TRSM
-    hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, jb), dim3(256), 0, s, D32, n, p->D64, jb, jb, jb, 1);
+    launch_f32_to_f64(s, D32, n, p->D64, jb, jb, jb, 1);
     CAP_HIP(hipMemsetAsync(Dinv, 0, sizeof(double) * nb * nb, s));
     CAP_TRY(cap_rec_cholinv_full(p->D64, jb, Dinv, nb, jb, p->W, p->wcap, p->info_dev, s, j0));
-    hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(jb, jb), dim3(256), 0, s, p->D64, jb, D32, n, (__bf16*)nullptr, (int64_t)0, jb, jb, 1);
+    launch_f64_to_f32_bf16(s, p->D64, jb, D32, n, (__bf16*)nullptr, (int64_t)0, jb, jb, 1);
     CAP_HIP(hipGetLastError());
     if (m > 0 && p->solve3 && jb == nb) {
       // the block-row solve on the bf16 pipe with split operands - the same three kernels, per element the same sums, as the
       // column-split schedule's solve_cols (the two schedules stay bit-identical)
       float* Row32 = p->R32 + j0 + j1 * n;
-      hipLaunchKernelGGL(split3_tri_kernel, grid2(jb, jb), dim3(256), 0, s, Dinv, nb, p->A3[k & 1], jb);
-      hipLaunchKernelGGL(split3_row_kernel, grid2(jb, m), dim3(256), 0, s, Row32, n, p->B3far, jb, m, 1);
+      launch_split3_tri(s, Dinv, nb, p->A3[k & 1], jb);
+      launch_split3_row(s, Row32, n, p->B3far, jb, m, 1);
       CAP_TRY(launch_bf16_update(jb, m, 3 * jb, 1.0f, p->A3[k & 1], 3 * jb, p->B3far, 3 * jb, Row32, n, 0, s));
-      hipLaunchKernelGGL(f32_to_bf16_kernel, grid2(jb, m), dim3(256), 0, s, Row32, n, SP + roff + j1 * ldp, ldp, jb, m);
+      launch_f32_to_bf16(s, Row32, n, SP + roff + j1 * ldp, ldp, jb, m);
       CAP_HIP(hipGetLastError());
     } else if (m > 0) {
       float* Row32 = p->R32 + j0 + j1 * n;
-      hipLaunchKernelGGL(f32_to_f64_kernel, grid2(jb, m), dim3(256), 0, s, Row32, n, p->T64, jb, jb, m, 0);
+      launch_f32_to_f64(s, Row32, n, p->T64, jb, jb, m, 0);
       CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, jb, m, jb, 1.0, Dinv, nb, p->T64, jb, 0.0, p->S64, jb, 0, s, 2 | 16));
-      hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(jb, m), dim3(256), 0, s, p->S64, jb, Row32, n, SP + roff + j1 * ldp, ldp, jb, m, 0);
+      launch_f64_to_f32_bf16(s, p->S64, jb, Row32, n, SP + roff + j1 * ldp, ldp, jb, m, 0);
       CAP_HIP(hipGetLastError());
     }
     return CAP_OK;
@@ -1001,7 +1023,7 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
   CAP_HIP(hipEventRecord(p->ev_join, s1));
   CAP_HIP(hipStreamWaitEvent(s0, p->ev_join, 0));
   // fp64 promotion of the factor for the refinement sweeps (the TRSM block inverses were stored panel by panel)
-  hipLaunchKernelGGL(f32_to_f64_kernel, grid2(n, n), dim3(256), 0, s0, p->R32, n, p->R64, n, n, n, 1);
+  launch_f32_to_f64(s0, p->R32, n, p->R64, n, n, n, 1);
   CAP_HIP(hipGetLastError());
   p->have_r64 = true;
   return CAP_OK;
@@ -1097,6 +1119,7 @@ int cap_mpchol_solve(cap_mpchol_plan* p, const double* A, int64_t lda, const dou
     if (rr <= tol || it >= max_iter || !(rr == rr) || (it >= 2 && rr > 0.5 * prev && rr < 1e-10)) break;
     prev = rr;
     CAP_TRY(apply_Ainv(p->Rw));                  // correction
+    cap_acc_rw(p->Xw, n, n, w); cap_acc_r(p->Rw, n, n, w);
     hipLaunchKernelGGL(axpy_cols_kernel, dim3((unsigned)std::min<int64_t>(cap_ceil_div(n, 256), 4096), (unsigned)w), dim3(256), 0, s, p->Xw, n,
                        p->Rw, n, n, w);
     CAP_HIP(hipGetLastError());

@@ -128,4 +128,32 @@ static __global__ void axpy_cols_kernel(double* X, int64_t ldx, const double* D,
 static inline dim3 grid2(int64_t rows, int64_t cols) {
   return dim3((unsigned)std::min<int64_t>(cap_ceil_div(rows, 1024), 4096), (unsigned)std::min<int64_t>(cols, 65535), (unsigned)cap_ceil_div(cols, 65535));
 }
+
+// launchers: the access notes of the schedule checker (common.h) next to the launch they describe
+static inline void launch_f64_to_f32_upper(hipStream_t s, const double* A, int64_t lda, float* R, int64_t ldr, int64_t n) {
+  cap_acc_r(A, lda, n, n, 1); cap_acc_w(R, ldr, n, n, 1, 4);
+  hipLaunchKernelGGL(f64_to_f32_upper_kernel, grid2(n, n), dim3(256), 0, s, A, lda, R, ldr, n);
+}
+static inline void launch_f32_to_f64(hipStream_t s, const float* S, int64_t lds_, double* D, int64_t ldd, int64_t rows, int64_t cols, int upper_only) {
+  cap_acc_r(S, lds_, rows, cols, upper_only ? 1 : 0, 4); cap_acc_w(D, ldd, rows, cols);
+  hipLaunchKernelGGL(f32_to_f64_kernel, grid2(rows, cols), dim3(256), 0, s, S, lds_, D, ldd, rows, cols, upper_only);
+}
+static inline void launch_f64_to_f32_bf16(hipStream_t s, const double* S, int64_t lds_, float* R, int64_t ldr, __bf16* P, int64_t ldp, int64_t rows,
+                                          int64_t cols, int upper_only) {
+  cap_acc_r(S, lds_, rows, cols, upper_only ? 1 : 0); cap_acc_w(R, ldr, rows, cols, 0, 4);
+  if (P) cap_acc_w(P, ldp, rows, cols, 0, 2);
+  hipLaunchKernelGGL(f64_to_f32_bf16_kernel, grid2(rows, cols), dim3(256), 0, s, S, lds_, R, ldr, P, ldp, rows, cols, upper_only);
+}
+static inline void launch_split3_row(hipStream_t s, float* S, int64_t lds_, __bf16* B3, int64_t rows, int64_t cols, int zero_src) {
+  cap_acc(zero_src ? CAP_ACC_RW : CAP_ACC_R, S, lds_, rows, cols, 0, 4); cap_acc_w(B3, 3 * rows, 3 * rows, cols, 0, 2);
+  hipLaunchKernelGGL(split3_row_kernel, grid2(rows, cols), dim3(256), 0, s, S, lds_, B3, rows, cols, zero_src);
+}
+static inline void launch_split3_tri(hipStream_t s, const double* D, int64_t ldd, __bf16* A3, int64_t n) {
+  cap_acc_r(D, ldd, n, n, 1); cap_acc_w(A3, 3 * n, 3 * n, n, 0, 2);
+  hipLaunchKernelGGL(split3_tri_kernel, grid2(n, n), dim3(256), 0, s, D, ldd, A3, n);
+}
+static inline void launch_f32_to_bf16(hipStream_t s, const float* S, int64_t lds_, __bf16* P, int64_t ldp, int64_t rows, int64_t cols) {
+  cap_acc_r(S, lds_, rows, cols, 0, 4); cap_acc_w(P, ldp, rows, cols, 0, 2);
+  hipLaunchKernelGGL(f32_to_bf16_kernel, grid2(rows, cols), dim3(256), 0, s, S, lds_, P, ldp, rows, cols);
+}
 }  // namespace

@@ -197,6 +197,7 @@ int cap_redistribute_cyclic_to_bc(cap_redist_plan* r, const double* piece, int64
     if (r->scnt[0][(size_t)t] == 0) continue;
     const int tpr = t / Pc, tpc = t % Pc;
     const int64_t nr = r->cyc_row_cnt[(size_t)tpr], nc = r->cyc_col_cnt[(size_t)tpc];
+    cap_acc_r(piece, ldp, r->pl, r->pl); cap_acc_r(r->idx, 0, r->idx_elems, 1); cap_acc_w(r->sendbuf + r->sdsp[0][(size_t)t], 0, nr * nc, 1);
     hipLaunchKernelGGL(redist_gather_kernel, rgrid(nr, nc), dim3(256), 0, s, piece, ldp, r->idx + r->cyc_row_off[(size_t)tpr], nr,
                        r->idx + r->cyc_col_off[(size_t)tpc], nc, r->sendbuf + r->sdsp[0][(size_t)t]);
   }
@@ -206,6 +207,7 @@ int cap_redistribute_cyclic_to_bc(cap_redist_plan* r, const double* piece, int64
     if (r->rcnt[0][(size_t)sr] == 0) continue;
     int sx, sy, sz; cyc_coords(sr, r->c, r->d, &sx, &sy, &sz);
     const int64_t nr = r->bc_row_cnt[(size_t)sy], nc = r->bc_col_cnt[(size_t)sx];
+    cap_acc_w(bc, ldb, r->bc_rows, r->bc_cols); cap_acc_r(r->idx, 0, r->idx_elems, 1); cap_acc_r(r->recvbuf + r->rdsp[0][(size_t)sr], 0, nr * nc, 1);
     hipLaunchKernelGGL(redist_scatter_kernel, rgrid(nr, nc), dim3(256), 0, s, bc, ldb, r->idx + r->bc_row_off[(size_t)sy], nr,
                        r->idx + r->bc_col_off[(size_t)sx], nc, r->recvbuf + r->rdsp[0][(size_t)sr]);
   }
@@ -225,6 +227,7 @@ int cap_redistribute_bc_to_cyclic(cap_redist_plan* r, const double* bc, int64_t 
     if (r->scnt[1][(size_t)t] == 0) continue;
     int sx, sy, sz; cyc_coords(t, r->c, r->d, &sx, &sy, &sz);
     const int64_t nr = r->bc_row_cnt[(size_t)sy], nc = r->bc_col_cnt[(size_t)sx];
+    cap_acc_r(bc, ldb, r->bc_rows, r->bc_cols); cap_acc_r(r->idx, 0, r->idx_elems, 1); cap_acc_w(r->sendbuf + r->sdsp[1][(size_t)t], 0, nr * nc, 1);
     hipLaunchKernelGGL(redist_gather_kernel, rgrid(nr, nc), dim3(256), 0, s, bc, ldb, r->idx + r->bc_row_off[(size_t)sy], nr,
                        r->idx + r->bc_col_off[(size_t)sx], nc, r->sendbuf + r->sdsp[1][(size_t)t]);
   }
@@ -235,6 +238,7 @@ int cap_redistribute_bc_to_cyclic(cap_redist_plan* r, const double* bc, int64_t 
     if (r->rcnt[1][(size_t)t] == 0) continue;
     const int tpr = t / Pc, tpc = t % Pc;
     const int64_t nr = r->cyc_row_cnt[(size_t)tpr], nc = r->cyc_col_cnt[(size_t)tpc];
+    cap_acc_w(piece, ldp, r->pl, r->pl); cap_acc_r(r->idx, 0, r->idx_elems, 1); cap_acc_r(r->recvbuf + r->rdsp[1][(size_t)t], 0, nr * nc, 1);
     hipLaunchKernelGGL(redist_scatter_kernel, rgrid(nr, nc), dim3(256), 0, s, piece, ldp, r->idx + r->cyc_row_off[(size_t)tpr], nr,
                        r->idx + r->cyc_col_off[(size_t)tpc], nc, r->recvbuf + r->rdsp[1][(size_t)t]);
   }

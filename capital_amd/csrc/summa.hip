@@ -224,6 +224,7 @@ int cap_summa_dgemm(cap_summa_plan* p, double alpha, const double* A, int64_t ld
   if (nl > 65535) return CAP_ERR_UNSUPPORTED;
   CAP_TRY(summa_core(p, CAP_NOTRANS, CAP_NOTRANS, Slot{A, lda, SLOT_RECT, ml, kl}, Slot{B, ldb, SLOT_RECT, kl, nl}, ml, nl, kl, alpha, 0, 1, s0));
   // C = beta C + acc (summa.hpp:32-35)
+  cap_acc(beta != 0.0 ? CAP_ACC_RW : CAP_ACC_W, C, ldc, ml, nl); cap_acc_r(p->acc, ml, ml, nl);
   hipLaunchKernelGGL(combine_kernel, dim3((unsigned)std::min<int64_t>(cap_ceil_div(ml, 256), 1024), (unsigned)nl), dim3(256), 0, s0, C, ldc,
                      p->acc, ml, ml, nl, beta);
   CAP_HIP(hipGetLastError());
@@ -264,6 +265,7 @@ int cap_summa_dtrmm(cap_summa_plan* p, int side, int uplo, int trans, int diag, 
     CAP_TRY(summa_core(p, CAP_NOTRANS, trans, Slot{B, ldb, SLOT_RECT, ml, kl}, Slot{T, ldt, tmode, kl, kl}, ml, nl, kl, alpha,
                        trans == CAP_TRANS ? 0 : 8, 0, s0));
   }
+  cap_acc_w(B, ldb, ml, nl); cap_acc_r(p->acc, ml, ml, nl);
   hipLaunchKernelGGL(combine_kernel, dim3((unsigned)std::min<int64_t>(cap_ceil_div(ml, 256), 1024), (unsigned)nl), dim3(256), 0, s0, B, ldb,
                      p->acc, ml, ml, nl, 0.0);
   CAP_HIP(hipGetLastError());
@@ -310,6 +312,8 @@ int cap_summa_dsyrk(cap_summa_plan* p, int uplo, int trans, double alpha, const 
     //                                       A[lx d + x, lk d + kp] used transposed
     CAP_TRY(summa_core(p, CAP_NOTRANS, CAP_TRANS, Slot{A, lda, SLOT_RECT, nl, kl}, Slot{p->xch[0], nl, SLOT_RECT, nl, kl}, nl, nl, kl, alpha, 0, 0, s0));
   }
+  if (c_packed) { cap_acc_rw(C, 0, nl * (nl + 1) / 2, 1); cap_acc_r(p->acc, nl, nl, nl, 1); }
+  else { cap_acc(beta != 0.0 ? CAP_ACC_RW : CAP_ACC_W, C, ldc, nl, nl); cap_acc_r(p->acc, nl, nl, nl); }
   if (c_packed) hipLaunchKernelGGL(combine_packed_kernel, dim3((unsigned)std::min<int64_t>(cap_ceil_div(nl, 256), 1024), (unsigned)nl), dim3(256), 0, s0, C, p->acc, nl, beta);
   else hipLaunchKernelGGL(combine_kernel, dim3((unsigned)std::min<int64_t>(cap_ceil_div(nl, 256), 1024), (unsigned)nl), dim3(256), 0, s0, C, ldc, p->acc, nl, nl, nl, beta);
   CAP_HIP(hipGetLastError());

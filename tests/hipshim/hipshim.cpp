@@ -8,6 +8,10 @@
 //   * every stream a call put work on is joined into the caller's stream (or waited for by the host) before the call returns;
 //   * no wait names an event that was never recorded;
 //   * every copy / memset stays inside ONE allocation (host index arithmetic at ragged sizes).
+// Access notes (capital_amd/csrc/common.h, cap_access_hook): the library declares, next to every launch, the windows the kernel reads and
+// writes; the stand-in attaches them to the launch's trace line ("A" lines: allocation serial number, offset, pitch, row bytes, columns,
+// triangle, element size) - as it does itself for copies, memsets and collectives - and trace_check.py looks for two operations that
+// touch the same bytes, one of them writing, without being ordered.  A note that leaves its allocation is an out-of-range finding.
 // Never linked into the product; nothing here computes anything.
 #include <hip/hip_runtime_api.h>
 
@@ -22,7 +26,15 @@
 #include <vector>
 
 namespace {
-struct Alloc { size_t bytes; int kind; std::string where; };   // kind 0 device, 1 pinned host; where: the last MARK before the allocation
+struct Alloc { size_t bytes; int kind; std::string where; long long id; };   // kind 0 device, 1 pinned host, 2 mapping of a peer's buffer; where: the last MARK before the allocation; id: serial number
+// IPC: hipIpcGetMemHandle writes {pointer, magic, peer tag = 0, bytes} into the handle; the test's all-gather callback tags the copy it
+// puts into slot q with q + 1 (run_scenarios.py), and hipIpcOpenMemHandle of a TAGGED handle returns a mapping of its own (a fresh
+// range of the same size, "ALIAS" line: peer, the exporter's export number, offset) - the joint replay of all ranks' traces
+// (trace_check.check_joint) resolves it to the peer's own allocation.  An untagged handle maps to the buffer itself, as before.
+constexpr unsigned long long IPC_MAGIC = 0x4c444e4148435049ull;      // "IPCHANDL"
+struct IpcHandle { void* ptr; unsigned long long magic; int tag; int export_no; unsigned long long bytes; long long off; };
+static_assert(sizeof(IpcHandle) <= sizeof(hipIpcMemHandle_t), "fits the 64-byte handle");
+long long next_export = 0;
 struct Stream { int id; unsigned flags; bool alive; };
 struct Event { int id; };
 struct Rec { std::string text; };
@@ -33,7 +45,9 @@ std::map<const void*, std::string> kernels;          // host stub -> device name
 std::vector<std::string> trace;
 std::string last_mark = "(start)";
 int next_stream = 1, next_event = 1;
-long long total_alloc = 0, oob = 0;
+long long total_alloc = 0, oob = 0, next_alloc = 1;
+struct Note { int mode; const void* base; long long pitch, row_bytes, cols; int tri, elem; };
+thread_local std::vector<Note> pending;                  // access notes waiting for the launch / collective they describe
 hipError_t last_error = hipSuccess;
 constexpr size_t TOUCH_LIMIT = 1 << 16;              // payloads up to this size are really copied / set (info words, handles); larger ones only traced
 
@@ -63,12 +77,31 @@ void check_range(const char* what, const void* p, size_t bytes) {
   if (bytes == 0) return;
   if (range_check(p, bytes) < 0) { oob++; note("OOB %s %p %zu", what, p, bytes); }
 }
+// one access line behind the operation it belongs to; memory the stand-in did not allocate (plain host arrays of a caller) is skipped
+void access_line(int mode, const void* base, long long pitch, long long row_bytes, long long cols, int tri, int elem, const char* what) {
+  if (mode == 0 || !base || row_bytes <= 0 || cols <= 0) return;
+  const uintptr_t a = (uintptr_t)base;
+  auto it = allocs.upper_bound(a);
+  if (it == allocs.begin()) return;
+  --it;
+  if (a >= it->first + it->second.bytes) return;
+  const unsigned long long span = (unsigned long long)(cols - 1) * (unsigned long long)(pitch > 0 ? pitch : 0) + (unsigned long long)row_bytes;
+  if (a + span > it->first + it->second.bytes) { oob++; note("OOB access of %s: %lld columns of %lld bytes, pitch %lld, leave the allocation of %zu bytes by %llu", what, cols, row_bytes, pitch, it->second.bytes, (unsigned long long)(a + span - it->first - it->second.bytes)); }
+  note("A %d %lld %llu %lld %lld %lld %d %d", mode, it->second.id, (unsigned long long)(a - it->first), pitch, row_bytes, cols, tri, elem);
+}
+void flush_pending(const char* what) {
+  for (const Note& n : pending) access_line(n.mode, n.base, n.pitch, n.row_bytes, n.cols, n.tri, n.elem, what);
+  pending.clear();
+}
+void orphan_check(const char* what) {
+  if (!pending.empty()) { note("ORPHAN %zu access notes in front of %s", pending.size(), what); pending.clear(); }
+}
 }  // namespace
 
 extern "C" {
 
 // ---------------------------------------------------------------- the trace, for the test
-void shim_reset() { std::lock_guard<std::mutex> lk(mu); trace.clear(); oob = 0; }
+void shim_reset() { std::lock_guard<std::mutex> lk(mu); trace.clear(); oob = 0; next_export = 0; }
 void shim_mark(const char* what) { std::lock_guard<std::mutex> lk(mu); note("MARK %s", what); last_mark = what; }
 long long shim_oob() { return oob; }
 long long shim_live_allocations() { std::lock_guard<std::mutex> lk(mu); return (long long)allocs.size(); }
@@ -95,8 +128,12 @@ int shim_dump(const char* path) {
   fclose(f);
   return 0;
 }
-// an op of the test's own making on a stream (the stand-in collectives of a callback communicator)
-void shim_note_op(const char* name, void* stream) { std::lock_guard<std::mutex> lk(mu); note("OP %d %s", sid((hipStream_t)stream), name); }
+// an op of the test's own making on a stream (the stand-in collectives of a callback communicator); its access notes come first
+void shim_note_op(const char* name, void* stream) { std::lock_guard<std::mutex> lk(mu); note("OP %d %s", sid((hipStream_t)stream), name); flush_pending(name); }
+// the library's access hook (cap_access_hook) and the tests' own way to describe a collective: the NEXT launch / op touches this window
+void shim_access_note(int mode, const void* base, long long pitch, long long row_bytes, long long cols, int tri, int elem) {
+  pending.push_back(Note{mode, base, pitch, row_bytes, cols, tri, elem});
+}
 
 // ---------------------------------------------------------------- kernel registration / launch
 void** __hipRegisterFatBinary(const void*) { static void* handle[1]; return handle; }
@@ -124,7 +161,8 @@ hipError_t hipLaunchKernel(const void* f, dim3 grid, dim3 block, void**, size_t 
     last_error = hipErrorInvalidConfiguration;
     return last_error;
   }
-  note("K %d %s %u %u %u %zu", sid(s), it == kernels.end() ? "?" : it->second.c_str(), grid.x, grid.y, grid.z, shmem);
+  note("K %d %s %u %u %u %zu %zu", sid(s), it == kernels.end() ? "?" : it->second.c_str(), grid.x, grid.y, grid.z, shmem, pending.size());
+  flush_pending(it == kernels.end() ? "?" : it->second.c_str());
   return hipSuccess;
 }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
@@ -156,7 +194,7 @@ static hipError_t alloc_(void** p, size_t bytes, int kind) {
   q = calloc((b + 255) / 256, 256);
   if (!q) { last_error = hipErrorOutOfMemory; return last_error; }
   std::lock_guard<std::mutex> lk(mu);
-  allocs[(uintptr_t)q] = Alloc{b, kind, last_mark};
+  allocs[(uintptr_t)q] = Alloc{b, kind, last_mark, next_alloc++};
   total_alloc += (long long)b;
   *p = q;
   return hipSuccess;
@@ -166,6 +204,7 @@ static hipError_t free_(void* p) {
   std::lock_guard<std::mutex> lk(mu);
   auto it = allocs.find((uintptr_t)p);
   if (it == allocs.end()) { note("BADFREE %p", p); last_error = hipErrorInvalidValue; return last_error; }
+  note("FREE %lld", it->second.id);
   allocs.erase(it);
   free(p);
   return hipSuccess;
@@ -174,21 +213,32 @@ hipError_t hipMalloc(void** p, size_t bytes) { return alloc_(p, bytes, 0); }
 hipError_t hipMallocAsync(void** p, size_t bytes, hipStream_t) { return alloc_(p, bytes, 0); }
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { return alloc_(p, bytes, 1); }
 hipError_t hipFree(void* p) { { std::lock_guard<std::mutex> lk(mu); note("HOSTSYNC device (hipFree)"); } return free_(p); }
-hipError_t hipFreeAsync(void* p, hipStream_t) { return free_(p); }
+hipError_t hipFreeAsync(void* p, hipStream_t s) {
+  if (p) {     // stream-ordered: the allocation is "written" by the free - whoever still touches it must be ordered in front of this point
+    std::lock_guard<std::mutex> lk(mu);
+    orphan_check("hipFreeAsync");
+    auto it = allocs.find((uintptr_t)p);
+    if (it != allocs.end()) { note("OP %d hipFreeAsync", sid(s)); access_line(2, p, 0, (long long)it->second.bytes, 1, 0, 1, "hipFreeAsync"); }
+  }
+  return free_(p);
+}
 hipError_t hipHostFree(void* p) { return free_(p); }
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
   std::lock_guard<std::mutex> lk(mu);
   int kind = 0;
   if (range_check(p, 1, &kind) == 0) { last_error = hipErrorInvalidValue; return last_error; }
   memset(a, 0, sizeof(*a));
-  a->type = kind == 0 ? hipMemoryTypeDevice : hipMemoryTypeHost;
+  a->type = kind == 1 ? hipMemoryTypeHost : hipMemoryTypeDevice;
   a->isManaged = 0;
   return hipSuccess;
 }
 static void copy_(void* dst, const void* src, size_t bytes, int stream, const char* what) {
   std::lock_guard<std::mutex> lk(mu);
+  orphan_check(what);
   check_range("copy dst", dst, bytes); check_range("copy src", src, bytes);
   note("%s %d %p %p %zu", what, stream, dst, src, bytes);
+  if (bytes && range_check(dst, bytes) > 0) access_line(2, dst, 0, (long long)bytes, 1, 0, 1, what);
+  if (bytes && range_check(src, bytes) > 0) access_line(1, src, 0, (long long)bytes, 1, 0, 1, what);
   if (bytes && bytes <= TOUCH_LIMIT && range_check(dst, bytes) >= 0 && range_check(src, bytes) >= 0) memmove(dst, src, bytes);
 }
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind, hipStream_t s) { copy_(dst, src, bytes, sid(s), "COPY"); return hipSuccess; }
@@ -203,15 +253,22 @@ hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t sp
     if (width > dpitch || width > spitch) { oob++; note("OOB copy2d width %zu over pitch %zu / %zu", width, dpitch, spitch); }
     check_range("copy2d dst", dst, (height - 1) * dpitch + width); check_range("copy2d src", src, (height - 1) * spitch + width);
   }
+  orphan_check("COPY2D");
   note("COPY2D %d %p %p %zu %zu", sid(s), dst, src, width, height);
+  if (width && height) {
+    if (range_check(dst, (height - 1) * dpitch + width) > 0) access_line(2, dst, (long long)dpitch, (long long)width, (long long)height, 0, 1, "COPY2D");
+    if (range_check(src, (height - 1) * spitch + width) > 0) access_line(1, src, (long long)spitch, (long long)width, (long long)height, 0, 1, "COPY2D");
+  }
   if (width * height && width * height <= TOUCH_LIMIT && range_check(dst, (height - 1) * dpitch + width) >= 0 && range_check(src, (height - 1) * spitch + width) >= 0)
     for (size_t r = 0; r < height; r++) memmove((char*)dst + r * dpitch, (const char*)src + r * spitch, width);
   return hipSuccess;
 }
 static void set_(void* p, int v, size_t bytes, int stream) {
   std::lock_guard<std::mutex> lk(mu);
+  orphan_check("memset");
   check_range("memset", p, bytes);
   note("SET %d %p %zu", stream, p, bytes);
+  if (bytes && range_check(p, bytes) > 0) access_line(2, p, 0, (long long)bytes, 1, 0, 1, "memset");
   if (bytes && bytes <= TOUCH_LIMIT && range_check(p, bytes) >= 0) memset(p, v, bytes);
 }
 hipError_t hipMemsetAsync(void* p, int v, size_t bytes, hipStream_t s) { set_(p, v, bytes, sid(s)); return hipSuccess; }
@@ -221,9 +278,37 @@ hipError_t hipMemset(void* p, int v, size_t bytes) {
   std::lock_guard<std::mutex> lk(mu); note("HOSTSYNC stream 0");
   return hipSuccess;
 }
-hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) { memset(h, 0, sizeof(*h)); memcpy(h, &p, sizeof(p)); return hipSuccess; }
-hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) { memcpy(p, &h, sizeof(*p)); return *p ? hipSuccess : hipErrorInvalidValue; }
-hipError_t hipIpcCloseMemHandle(void*) { return hipSuccess; }
+hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) {
+  memset(h, 0, sizeof(*h));
+  std::lock_guard<std::mutex> lk(mu);
+  const uintptr_t a = (uintptr_t)p;
+  auto it = allocs.upper_bound(a);
+  if (it == allocs.begin()) { last_error = hipErrorInvalidValue; return last_error; }
+  --it;
+  if (a >= it->first + it->second.bytes) { last_error = hipErrorInvalidValue; return last_error; }
+  IpcHandle q{p, IPC_MAGIC, 0, (int)next_export++, (unsigned long long)it->second.bytes, (long long)(a - it->first)};
+  memcpy(h, &q, sizeof(q));
+  note("IPCGET %d %lld %lld", q.export_no, it->second.id, q.off);
+  return hipSuccess;
+}
+hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) {
+  IpcHandle q; memcpy(&q, &h, sizeof(q));
+  if (!q.ptr) return hipErrorInvalidValue;
+  if (q.magic != IPC_MAGIC || q.tag == 0) { *p = q.ptr; return hipSuccess; }       // untagged: the buffer itself
+  void* m = calloc((q.bytes - q.off + 255) / 256 + 1, 256);
+  if (!m) return hipErrorOutOfMemory;
+  std::lock_guard<std::mutex> lk(mu);
+  allocs[(uintptr_t)m] = Alloc{(size_t)(q.bytes - q.off), 2, last_mark, next_alloc++};
+  note("ALIAS %lld %d %d %lld", allocs[(uintptr_t)m].id, q.tag - 1, q.export_no, q.off);
+  *p = m;
+  return hipSuccess;
+}
+hipError_t hipIpcCloseMemHandle(void* p) {
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = allocs.find((uintptr_t)p);
+  if (it != allocs.end() && it->second.kind == 2) { note("FREE %lld", it->second.id); allocs.erase(it); free(p); }
+  return hipSuccess;
+}
 
 // ---------------------------------------------------------------- streams and events
 static hipError_t stream_(hipStream_t* s, unsigned flags, const char* how) {
@@ -255,8 +340,8 @@ static hipError_t event_(hipEvent_t* e) {
 hipError_t hipEventCreate(hipEvent_t* e) { return event_(e); }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return event_(e); }
 hipError_t hipEventDestroy(hipEvent_t e) { std::lock_guard<std::mutex> lk(mu); note("EVENTDESTROY %d", eid(e)); return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { std::lock_guard<std::mutex> lk(mu); note("RECORD %d %d", sid(s), eid(e)); return hipSuccess; }
-hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { std::lock_guard<std::mutex> lk(mu); note("WAIT %d %d", sid(s), eid(e)); return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { std::lock_guard<std::mutex> lk(mu); orphan_check("hipEventRecord"); note("RECORD %d %d", sid(s), eid(e)); return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { std::lock_guard<std::mutex> lk(mu); orphan_check("hipStreamWaitEvent"); note("WAIT %d %d", sid(s), eid(e)); return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t e) { std::lock_guard<std::mutex> lk(mu); note("HOSTSYNC event %d", eid(e)); return hipSuccess; }
 hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 1.0f; return hipSuccess; }

@@ -41,6 +41,16 @@ shim.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
 shim.hipFree.argtypes = [C.c_void_p]
 shim.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
 shim.hipStreamDestroy.argtypes = [C.c_void_p]
+shim.shim_access_note.argtypes = [C.c_int, C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int, C.c_int]
+shim.shim_access_note.restype = None
+# the library's access hook (capital_amd/csrc/common.h): every launch now carries the windows it reads and writes into the trace
+C.c_void_p.in_dll(L, "cap_access_hook").value = C.cast(shim.shim_access_note, C.c_void_p).value
+
+
+def acc(mode, ptr, nbytes):
+    if ptr and nbytes > 0:
+        shim.shim_access_note(mode, ptr, 0, int(nbytes), 1, 0, 1)
+
 
 _AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 _BC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
@@ -55,23 +65,47 @@ def ok(st, what):
         raise RuntimeError("%s returned %d (%s)" % (what, st, (L.cap_status_string(st) or b"?").decode()))
 
 
-class Comm:
-    """callback communicator of one simulated rank: every collective is one traced operation on its stream"""
+IPC_MAGIC = (0x4c444e4148435049).to_bytes(8, "little")      # hipshim.cpp: bytes 8 .. 15 of a handle the stand-in exported
 
-    def __init__(self, rank, size):
-        self.rank, self.size = rank, size
+
+class Comm:
+    """callback communicator of one simulated rank: every collective is one traced operation on its stream, labelled with the
+    communicator it belongs to ("OP stream kind label size me count root") so that the joint replay of all ranks' traces can match
+    the k-th collective of a communicator across its ranks (trace_check.check_joint)"""
+
+    def __init__(self, rank, size, label="world", members=None):
+        """members: the WORLD ranks of this communicator's ranks, in its own order (default: it is the world)"""
+        self.rank, self.size, self.label = rank, size, label
+        members = list(members) if members is not None else list(range(size))
+
+        def op(kind, count, root, st):
+            shim.shim_note_op(("%s %s %d %d %d %d" % (kind, label, size, rank, count, root)).encode(), st)
+
         def ag_(ctx, s, r, n, st):
-            # small payloads (IPC handles, status words) are really gathered - every slot gets MY piece, so a rank "maps" its own
-            # buffers as its peers' and the IPC schedules run their real course; big payloads are only traced
-            shim.shim_note_op(b"allgather", st)
+            # small payloads (IPC handles, status words) are really gathered - every slot gets MY piece; a handle the stand-in
+            # exported is tagged with the slot it lands in, so a rank maps "the same buffer of peer q" (a range of its own in the
+            # stand-in, resolved to peer q's allocation by the joint replay) and the IPC schedules run their real course.
+            # Big payloads are only traced.
+            acc(1, s, n * 8); acc(2, r, n * 8 * size)
+            op("allgather", n, -1, st)
             if 0 < n * 8 <= 4096 and s and r:
                 for q in range(size):
                     C.memmove(r + q * n * 8, s, n * 8)
+                    for h in range(0, n * 8 - 63, 64):
+                        if C.string_at(r + q * n * 8 + h + 8, 8) == IPC_MAGIC:
+                            C.memmove(r + q * n * 8 + h + 16, (members[q] + 1).to_bytes(4, "little"), 4)
             return 0
         ag = _AG(ag_)
-        bc = _BC(lambda ctx, b, n, root, st: (shim.shim_note_op(b"bcast", st), 0)[1])
-        ar = _AR(lambda ctx, b, n, st: (shim.shim_note_op(b"allreduce", st), 0)[1])
-        a2a = _A2A(lambda ctx, s, sc, sd, r, rc, rd, st: (shim.shim_note_op(b"alltoallv", st), 0)[1])
+        bc = _BC(lambda ctx, b, n, root, st: (acc(1 if root == rank else 2, b, n * 8), op("bcast", n, root, st), 0)[2])
+        ar = _AR(lambda ctx, b, n, st: (acc(3, b, n * 8), op("allreduce", n, -1, st), 0)[2])
+
+        def a2a_(ctx, s, sc, sd, r, rc, rd, st):
+            for q in range(size):
+                acc(1, (s or 0) + 8 * sd[q] if s else None, 8 * sc[q]); acc(2, (r or 0) + 8 * rd[q] if r else None, 8 * rc[q])
+            # pairwise exchanges (ncclSend / ncclRecv pairs in the library; ranks without a partner do not call): a local operation
+            shim.shim_note_op(b"alltoallv", st)
+            return 0
+        a2a = _A2A(a2a_)
         _KEEP.extend([ag, bc, ar, a2a])
         self.handle = C.c_void_p()
         ok(L.cap_comm_create_callbacks(C.byref(self.handle), rank, size, ag, bc, ar, None), "cap_comm_create_callbacks")
@@ -115,6 +149,10 @@ class Run:
         if self.stream.value:
             uid = int([l for l in lines if l.startswith("STREAM ")][0].split()[1])
         lines = [l.replace("user=@", "user=%d" % uid) for l in lines]
+        if KEEP_TRACE:
+            os.makedirs(KEEP_TRACE, exist_ok=True)
+            open(os.path.join(KEEP_TRACE, "".join(ch if ch.isalnum() else "_" for ch in self.name)[:150] + ".txt"), "w").write("\n".join(lines) + "\n")
+        self.lines = lines
         findings, stats = trace_check.check(lines)
         # kernel launches of the LAST marked "...factor" call, by (mangled) kernel name: compared with rocprofv3's counts of the same
         # schedule on the GPU by tests/test_schedule_structure.py
@@ -134,17 +172,39 @@ class Run:
 
 
 RESULTS = []
+FILTER = os.environ.get("SHIM_FILTER", "")          # run only the scenarios whose name contains this (debugging)
+KEEP_TRACE = os.environ.get("SHIM_KEEP_TRACE", "")  # directory: keep every scenario's trace there
 
 
-def scenario(name, user_stream):
+GROUPS = {}                  # (group name, user stream) -> {rank: trace}: the ranks of one multi-rank configuration
+
+
+def scenario(name, user_stream, group=None, rank=0, nranks=1):
+    """group / rank / nranks: this scenario is rank `rank` of the `nranks` simulated ranks of configuration `group`; once all of them
+    have run, their traces are replayed TOGETHER (trace_check.check_joint: collectives matched across the ranks, peer copies of the IPC
+    exchanges checked against the peer's own kernels) and the outcome is one more result, "<group> [joint replay of N ranks]"."""
     def deco(fn):
+        if FILTER and FILTER not in name:
+            return fn
         r = Run(name + (" [user stream]" if user_stream else " [NULL stream]"), user_stream)
         try:
             fn(r)
             out = r.finish()
         except Exception as e:      # a refused configuration or a crash of the host side is a finding too
             out = {"name": r.name, "findings": ["exception: %r" % (e,)], "stats": {}}
+            r.lines = None
         RESULTS.append(out)
+        if group is not None and nranks > 1:
+            g = GROUPS.setdefault((group, user_stream), {})
+            g[rank] = r.lines
+            if len(g) == nranks:
+                nm = "%s [joint replay of %d ranks, %s]" % (group, nranks, "user stream" if user_stream else "NULL stream")
+                if any(v is None for v in g.values()):
+                    RESULTS.append({"name": nm, "findings": ["a rank's scenario did not run"], "stats": {}})
+                else:
+                    f, st = trace_check.check_joint([g[q] for q in range(nranks)])
+                    RESULTS.append({"name": nm, "findings": f, "stats": st})
+                del GROUPS[(group, user_stream)]
         return fn
     return deco
 
@@ -196,7 +256,7 @@ def dist_case(r, n, nb, P, p, opts=(), ci=-1):
 
 
 def dist2d_case(r, n, nb, Pr, Pc, pr, pc, opts=()):
-    world = Comm(pr * Pc + pc, Pr * Pc); row = Comm(pc, Pc); col = Comm(pr, Pr)
+    world = Comm(pr * Pc + pc, Pr * Pc); row = Comm(pc, Pc, "row%d" % pr, [pr * Pc + q for q in range(Pc)]); col = Comm(pr, Pr, "col%d" % pc, [q * Pc + pc for q in range(Pr)])
     plan = C.c_void_p()
     ok(L.cap_dist2d_plan_create(C.byref(plan), n, nb, world.handle, Pr, row.handle, col.handle), "cap_dist2d_plan_create")
     for k, v in opts:
@@ -266,7 +326,7 @@ def cacqr_case(r, m, n, iters, P, p):
 
 def group_of(color_of, key_of, size, rank):
     ranks = sorted((q for q in range(size) if color_of(q) == color_of(rank)), key=key_of)
-    return ranks.index(rank), len(ranks)
+    return ranks.index(rank), len(ranks), ranks
 
 
 class Topo:
@@ -296,8 +356,8 @@ class Topo:
         for i, sp in enumerate(splits):
             if sp is None:
                 continue
-            me, n = group_of(sp[0], sp[1], size, rank)
-            cm = Comm(me, n)
+            me, n, members = group_of(sp[0], sp[1], size, rank)
+            cm = Comm(me, n, "sub%d:%s" % (i, str(sp[0](rank)).replace(" ", "")), members)
             self.subs.append(cm); arr[i] = cm.handle
         self.handle = C.c_void_p()
         ok(L.cap_topo_create_from(C.byref(self.handle), kind, self.world.handle, c, 0, num_chunks, arr, 7), "cap_topo_create_from")
@@ -459,7 +519,8 @@ def main(out_path, user_streams=(0, 1)):
                                      (2049, 128, 3, (), -1), (8192, 512, 8, (), -1), (2048, 128, 4, (), 1), (2048, 128, 4, (), 0), (1024, 128, 1, (), 1),
                                      (65536, 512, 8, (), -1)]:
             for p in range(P):
-                scenario("dist n=%d nb=%d P=%d rank=%d %s ci=%d" % (n, nb, P, p, dict(opts) or "", ci), us)(
+                scenario("dist n=%d nb=%d P=%d rank=%d %s ci=%d" % (n, nb, P, p, dict(opts) or "", ci), us,
+                         "dist n=%d nb=%d P=%d %s ci=%d" % (n, nb, P, dict(opts) or "", ci), p, P)(
                     lambda r, a=(n, nb, P, p, opts, ci): dist_case(r, *a))
         # ---- the same behind the cholinv handle (comm of size P) with the reference's element-cyclic layout
         for p in range(8):
@@ -467,37 +528,43 @@ def main(out_path, user_streams=(0, 1)):
                 comm = Comm(p, 8)
                 cholinv_case(r, 1024, 1, 1, -2, (("nb", 128), ("cyclic_c", 2)), reps=1, comm=comm.handle, local_cols=512)
                 comm.close()
-            scenario("cholinv over 8 ranks, cyclic_c=2, rank=%d" % p, us)(cyc)
+            scenario("cholinv over 8 ranks, cyclic_c=2, rank=%d" % p, us, "cholinv over 8 ranks, cyclic_c=2", p, 8)(cyc)
         # ---- Pr x Pc plan
         for (n, nb, Pr, Pc, opts) in [(4096, 128, 2, 2, ()), (4096, 128, 2, 4, (("strip", 1),)), (2048, 128, 2, 2, (("complete_inv", 1),)),
                                       (1000, 128, 2, 2, ()), (4096, 128, 1, 4, (("strip", 2),)), (4096, 128, 2, 2, (("safe", 1),)),
                                       (65536, 512, 2, 4, ())]:
             for pr in range(Pr):
                 for pc in range(Pc):
-                    scenario("dist2d n=%d nb=%d %dx%d at (%d,%d) %s" % (n, nb, Pr, Pc, pr, pc, dict(opts) or ""), us)(
+                    scenario("dist2d n=%d nb=%d %dx%d at (%d,%d) %s" % (n, nb, Pr, Pc, pr, pc, dict(opts) or ""), us,
+                             "dist2d n=%d nb=%d %dx%d %s" % (n, nb, Pr, Pc, dict(opts) or ""), pr * Pc + pc, Pr * Pc)(
                         lambda r, a=(n, nb, Pr, Pc, pr, pc, opts): dist2d_case(r, *a))
         # ---- strip exchange / operand moves as IPC peer copies (the stand-in "maps" a rank's own buffers as its peers')
         for (n, nb, P, opts) in [(4096, 128, 4, (("ipc", 1),)), (4096, 128, 4, (("ipc", 1), ("safe", 1))), (8192, 512, 8, (("ipc", 1),))]:
             for p in range(P):
-                scenario("dist n=%d nb=%d P=%d rank=%d %s" % (n, nb, P, p, dict(opts)), us)(lambda r, a=(n, nb, P, p, opts, -1): dist_case(r, *a))
+                scenario("dist n=%d nb=%d P=%d rank=%d %s" % (n, nb, P, p, dict(opts)), us, "dist n=%d nb=%d P=%d %s" % (n, nb, P, dict(opts)), p, P)(
+                    lambda r, a=(n, nb, P, p, opts, -1): dist_case(r, *a))
         for (n, nb, Pr, Pc, opts) in [(2048, 128, 2, 2, (("ipc", 1),)), (4096, 128, 2, 4, (("ipc", 1),)), (2049, 256, 2, 4, (("ipc", 1), ("complete_inv", 1)))]:
             for pr in range(Pr):
                 for pc in range(Pc):
-                    scenario("dist2d n=%d nb=%d %dx%d at (%d,%d) %s" % (n, nb, Pr, Pc, pr, pc, dict(opts)), us)(
+                    scenario("dist2d n=%d nb=%d %dx%d at (%d,%d) %s" % (n, nb, Pr, Pc, pr, pc, dict(opts)), us,
+                             "dist2d n=%d nb=%d %dx%d %s" % (n, nb, Pr, Pc, dict(opts)), pr * Pc + pc, Pr * Pc)(
                         lambda r, a=(n, nb, Pr, Pc, pr, pc, opts): dist2d_case(r, *a))
         # ---- SUMMA (GEMM, TRMM, SYRK overloads, util::transpose) on d x d x c grids; CholeskyQR on the c x d x c grid
         for (size, c, M, N, K, chunks) in [(8, 2, 300, 300, 300, 2), (4, 1, 512, 256, 512, 0), (9, 1, 300, 300, 300, 3), (1, 1, 256, 256, 256, 0), (27, 3, 270, 270, 270, 0)]:
             for rank in range(size):
-                scenario("summa size=%d c=%d rank=%d %dx%dx%d chunks=%d" % (size, c, rank, M, N, K, chunks), us)(
+                scenario("summa size=%d c=%d rank=%d %dx%dx%d chunks=%d" % (size, c, rank, M, N, K, chunks), us,
+                         "summa size=%d c=%d %dx%dx%d chunks=%d" % (size, c, M, N, K, chunks), rank, size)(
                     lambda r, a=(size, c, rank, M, N, K, chunks): summa_case(r, *a))
         for (size, c, m, n, iters) in [(8, 2, 4096, 128, 2), (4, 1, 4096, 64, 2), (16, 2, 8192, 256, 1)]:
             for rank in range(size):
-                scenario("cacqr grid size=%d c=%d rank=%d m=%d n=%d iter=%d" % (size, c, rank, m, n, iters), us)(
+                scenario("cacqr grid size=%d c=%d rank=%d m=%d n=%d iter=%d" % (size, c, rank, m, n, iters), us,
+                         "cacqr grid size=%d c=%d m=%d n=%d iter=%d" % (size, c, m, n, iters), rank, size)(
                     lambda r, a=(size, c, rank, m, n, iters): cacqr_grid_case(r, *a))
         # ---- redistribution element-cyclic <-> block-cyclic, descriptors with pinned staging, the operator seam
         for (n, nb, size, c, Pr) in [(1024, 128, 8, 2, 1), (1000, 128, 8, 2, 2), (512, 64, 4, 1, 2)]:
             for rank in range(size):
-                scenario("redist n=%d nb=%d size=%d c=%d Pr=%d rank=%d" % (n, nb, size, c, Pr, rank), us)(
+                scenario("redist n=%d nb=%d size=%d c=%d Pr=%d rank=%d" % (n, nb, size, c, Pr, rank), us,
+                         "redist n=%d nb=%d size=%d c=%d Pr=%d" % (n, nb, size, c, Pr), rank, size)(
                     lambda r, a=(n, nb, size, c, Pr, rank): redist_case(r, *a))
         for (n, nb, Pr, Pc) in [(1000, 128, 2, 2), (2048, 256, 1, 4), (300, 128, 2, 4)]:
             for pr in range(Pr):
@@ -511,11 +578,12 @@ def main(out_path, user_streams=(0, 1)):
             scenario("mpchol n=%d %s" % (n, dict(opts) or ""), us)(lambda r, a=(n, nrhs, opts): mpchol_case(r, *a))
         for (n, nb, P) in [(2048, 256, 1), (2048, 256, 4), (1280, 256, 4), (8192, 512, 8), (1152, 256, 2)]:
             for p in range(P):
-                scenario("dmp n=%d nb=%d P=%d rank=%d" % (n, nb, P, p), us)(lambda r, a=(n, nb, P, p): dmp_case(r, *a))
+                scenario("dmp n=%d nb=%d P=%d rank=%d" % (n, nb, P, p), us, "dmp n=%d nb=%d P=%d" % (n, nb, P), p, P)(lambda r, a=(n, nb, P, p): dmp_case(r, *a))
         # ---- CholeskyQR
         for (m, n, iters, P) in [(16384, 256, 2, 1), (16384, 128, 2, 4), (4096, 64, 1, 2), (1 << 21, 256, 2, 8)]:
             for p in range(P):
-                scenario("cacqr m=%d n=%d iter=%d P=%d rank=%d" % (m, n, iters, P, p), us)(lambda r, a=(m, n, iters, P, p): cacqr_case(r, *a))
+                scenario("cacqr m=%d n=%d iter=%d P=%d rank=%d" % (m, n, iters, P, p), us, "cacqr m=%d n=%d iter=%d P=%d" % (m, n, iters, P), p, P)(
+                    lambda r, a=(m, n, iters, P, p): cacqr_case(r, *a))
     live = os.path.join(build_shim.OUT, "live_%d.txt" % os.getpid())
     shim.shim_live_report(live.encode())
     leaks = open(live).read().splitlines()
