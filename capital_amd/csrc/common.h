@@ -55,6 +55,9 @@ static inline void cap_acc_r(const void* p, int64_t ld, int64_t rows, int64_t co
 static inline void cap_acc_w(const void* p, int64_t ld, int64_t rows, int64_t cols, int tri = 0, int elem = 8) { cap_acc(CAP_ACC_W, p, ld, rows, cols, tri, elem); }
 static inline void cap_acc_rw(const void* p, int64_t ld, int64_t rows, int64_t cols, int tri = 0, int elem = 8) { cap_acc(CAP_ACC_RW, p, ld, rows, cols, tri, elem); }
 static inline void cap_acc_atomic(const void* p, int64_t count, int elem) { cap_acc(CAP_ACC_ATOMIC, p, count, count, 1, 0, elem); }
+// the HOST itself reads / writes a window now (pinned staging buffers): checked against the copies that are still in flight
+enum { CAP_ACC_HOST = 16 };
+static inline void cap_acc_host(int mode, const void* p, int64_t ld, int64_t rows, int64_t cols) { cap_acc(mode | CAP_ACC_HOST, p, ld, rows, cols); }
 // a launch whose accesses are all on memory no other stream can name (per-stream scratch) still says so: mode 0 = "nothing shared"
 static inline void cap_acc_none() { if (cap_acc_on()) cap_access_hook(0, nullptr, 0, 0, 0, 0, 0); }
 

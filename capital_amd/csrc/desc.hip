@@ -55,6 +55,7 @@ bool host_is_pinned(const void* p) {
 
 // copy `cols` columns of `rows` doubles between two column-major images with a few host threads
 void host_copy_cols(const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols) {
+  cap_acc_host(CAP_ACC_R, src, lds, rows, cols); cap_acc_host(CAP_ACC_W, dst, ldd, rows, cols);      // (only the pinned side is memory the checker knows)
   const int64_t bytes = rows * cols * 8;
   int nt = (int)std::min<int64_t>(8, std::max<int64_t>(1, bytes / (4 << 20)));
   nt = std::min<int>(nt, std::max(1u, std::thread::hardware_concurrency()));
@@ -89,6 +90,7 @@ inline int64_t to_global(int kind, int64_t nb, int64_t p, int64_t q, int64_t l) 
 void host_pack_cols(const cap_desc* d, const double* hostg, int64_t ldh, double* img, int64_t c0, int64_t nc, bool to_image) {
   const int64_t rows = d->ly, rl = run_len(d->kind, d->nb, d->py);
   const int64_t vrows = owned(d->kind, d->gy, d->nb, d->py, d->qy), vcols = owned(d->kind, d->gx, d->nb, d->px, d->qx);
+  cap_acc_host(to_image ? CAP_ACC_W : CAP_ACC_R, img, rows, rows, nc);
   const int64_t bytes = rows * nc * 8;
   int nt = (int)std::min<int64_t>(8, std::max<int64_t>(1, bytes / (4 << 20)));
   nt = std::min<int>(nt, std::max(1u, std::thread::hardware_concurrency()));
@@ -268,6 +270,7 @@ int cap_desc_export_host(cap_desc* d, double* host, int64_t ld_host, void* strea
         const int64_t len = std::min(d->pin_elems, rows - r0);
         CAP_HIP(hipMemcpyAsync(d->pin[0], d->data + c * d->ld + r0, len * 8, hipMemcpyDeviceToHost, d->s_copy));
         CAP_HIP(hipStreamSynchronize(d->s_copy));
+        cap_acc_host(CAP_ACC_R, d->pin[0], len, len, 1);
         memcpy(host + c * ld_host + r0, d->pin[0], (size_t)len * 8);
       }
     return CAP_OK;

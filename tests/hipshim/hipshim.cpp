@@ -132,6 +132,13 @@ int shim_dump(const char* path) {
 void shim_note_op(const char* name, void* stream) { std::lock_guard<std::mutex> lk(mu); note("OP %d %s", sid((hipStream_t)stream), name); flush_pending(name); }
 // the library's access hook (cap_access_hook) and the tests' own way to describe a collective: the NEXT launch / op touches this window
 void shim_access_note(int mode, const void* base, long long pitch, long long row_bytes, long long cols, int tri, int elem) {
+  if (mode & 16) {       // the host itself touches the window, now ("HA" line: an access of the host thread, not of a stream operation)
+    std::lock_guard<std::mutex> lk(mu);
+    const size_t before = trace.size();
+    access_line(mode & 15, base, pitch, row_bytes, cols, tri, elem, "host access");
+    for (size_t i = before; i < trace.size(); i++) if (trace[i].compare(0, 2, "A ") == 0) trace[i] = "H" + trace[i];
+    return;
+  }
   pending.push_back(Note{mode, base, pitch, row_bytes, cols, tri, elem});
 }
 

@@ -436,7 +436,9 @@ def desc_case(r, n, nb, Pr, Pc, pr, pc):
     lr, lc = int(L.cap_desc_get(d, 3)), int(L.cap_desc_get(d, 2))
     piece = (C.c_double * max(lr * lc, 1))()
     ok(r.call("desc_import_host", L.cap_desc_import_host, d, piece, max(lr, 1), r.stream), "cap_desc_import_host")
+    ok(r.call("desc_import_host (again, the first one still in flight)", L.cap_desc_import_host, d, piece, max(lr, 1), r.stream), "cap_desc_import_host")
     ok(r.call("desc_export_host", L.cap_desc_export_host, d, piece, max(lr, 1), r.stream), "cap_desc_export_host")
+    ok(r.call("desc_import_host_global (behind an export)", L.cap_desc_import_host_global, d, host, n, r.stream), "cap_desc_import_host_global")
     ok(L.cap_desc_destroy(d), "cap_desc_destroy")
 
 
@@ -511,13 +513,21 @@ def main(out_path, user_streams=(0, 1)):
             (8192, -1, 1, 0, (("use_sb", 0),)), (8192, -1, 1, 0, (("pair_rest", 0),)), (8192, -1, 1, 0, (("depth2", 0),)),
             (8192, -1, 1, 0, (("chain_coop", 0),)), (8192, -1, 1, 0, (("inner_la", 1),)), (8192, -1, 1, 0, (("serial_m", 4096),)),
             (8192, -1, 1, 0, (("reserve", 8),)), (16384, -1, 1, 0, (("reserve", 8), ("reserve_m", 8192))), (8192, 1, 1, 0, (("inv_fast", 0),)),
+            # round 5, last session: option mixes no GPU test runs - reference semantics without strip buffers / with the tree started at
+            # once / on masked streams, the paired far update at sizes where pairs and single strips alternate, ragged sizes with R^-1
+            (16384, 1, 1, 0, (("use_sb", 0),)), (16384, 0, 2, 0, (("inv_start_m", 1 << 30),)), (16384, 1, 1, 0, (("reserve", 8),)),
+            (24576, -1, 1, 0, ()), (24576, -1, 1, 0, (("use_sb", 0),)), (28672, -1, 1, 0, (("outer", 512), ("tail", 0))), (12345, 1, 1, 0, ()),
+            (16384, -1, 1, 0, (("fuse_copy", 0),)), (16384, 1, 1, 0, (("depth2", 1), ("pair_rest", 1))), (8192, 0, 1, 0, (("nb", 1024),)),
+            (8192, -1, 1, 0, (("lookahead", 0),)), (8192, -1, 1, 0, (("fastdiag", 0),)), (8192, -1, 1, 0, (("inner_la", 1), ("depth2", 1))),
         ]:
             scenario("cholinv n=%d ci=%d split=%d bc=%d %s" % (n, ci, split, bc, dict(opts) or ""), us)(
                 lambda r, a=(n, ci, split, bc, opts): cholinv_case(r, *a))
         # ---- 1 x P plan, every simulated rank
         for (n, nb, P, opts, ci) in [(4096, 128, 4, (), -1), (4096, 128, 4, (("safe", 1),), -1), (4096, 128, 4, (("strip", 2), ("depth2", 1)), -1),
                                      (2049, 128, 3, (), -1), (8192, 512, 8, (), -1), (2048, 128, 4, (), 1), (2048, 128, 4, (), 0), (1024, 128, 1, (), 1),
-                                     (65536, 512, 8, (), -1)]:
+                                     (65536, 512, 8, (), -1),
+                                     (4096, 128, 2, (), -1), (3000, 128, 8, (), 1), (4096, 256, 5, (("strip", 1),), 0), (2048, 128, 4, (("safe", 1),), 1),
+                                     (4096, 128, 7, (("depth2", 0),), -1), (1152, 128, 8, (), -1)]:
             for p in range(P):
                 scenario("dist n=%d nb=%d P=%d rank=%d %s ci=%d" % (n, nb, P, p, dict(opts) or "", ci), us,
                          "dist n=%d nb=%d P=%d %s ci=%d" % (n, nb, P, dict(opts) or "", ci), p, P)(
@@ -532,18 +542,22 @@ def main(out_path, user_streams=(0, 1)):
         # ---- Pr x Pc plan
         for (n, nb, Pr, Pc, opts) in [(4096, 128, 2, 2, ()), (4096, 128, 2, 4, (("strip", 1),)), (2048, 128, 2, 2, (("complete_inv", 1),)),
                                       (1000, 128, 2, 2, ()), (4096, 128, 1, 4, (("strip", 2),)), (4096, 128, 2, 2, (("safe", 1),)),
-                                      (65536, 512, 2, 4, ())]:
+                                      (65536, 512, 2, 4, ()),
+                                      (4096, 128, 4, 4, ()), (4096, 128, 1, 8, ()), (3000, 128, 2, 4, (("complete_inv", 0),)), (4096, 128, 4, 4, (("complete_inv", 1),)),
+                                      (2048, 128, 2, 2, (("complete_inv", 1), ("safe", 1))), (4096, 128, 2, 4, (("depth2", 0),)), (1152, 128, 4, 8, ())]:
             for pr in range(Pr):
                 for pc in range(Pc):
                     scenario("dist2d n=%d nb=%d %dx%d at (%d,%d) %s" % (n, nb, Pr, Pc, pr, pc, dict(opts) or ""), us,
                              "dist2d n=%d nb=%d %dx%d %s" % (n, nb, Pr, Pc, dict(opts) or ""), pr * Pc + pc, Pr * Pc)(
                         lambda r, a=(n, nb, Pr, Pc, pr, pc, opts): dist2d_case(r, *a))
         # ---- strip exchange / operand moves as IPC peer copies (the stand-in "maps" a rank's own buffers as its peers')
-        for (n, nb, P, opts) in [(4096, 128, 4, (("ipc", 1),)), (4096, 128, 4, (("ipc", 1), ("safe", 1))), (8192, 512, 8, (("ipc", 1),))]:
+        for (n, nb, P, opts) in [(4096, 128, 4, (("ipc", 1),)), (4096, 128, 4, (("ipc", 1), ("safe", 1))), (8192, 512, 8, (("ipc", 1),)),
+                                 (3000, 128, 3, (("ipc", 1),)), (4096, 128, 2, (("ipc", 1), ("strip", 1))), (2048, 128, 8, (("ipc", 1), ("complete_inv", 1)))]:
             for p in range(P):
                 scenario("dist n=%d nb=%d P=%d rank=%d %s" % (n, nb, P, p, dict(opts)), us, "dist n=%d nb=%d P=%d %s" % (n, nb, P, dict(opts)), p, P)(
                     lambda r, a=(n, nb, P, p, opts, -1): dist_case(r, *a))
-        for (n, nb, Pr, Pc, opts) in [(2048, 128, 2, 2, (("ipc", 1),)), (4096, 128, 2, 4, (("ipc", 1),)), (2049, 256, 2, 4, (("ipc", 1), ("complete_inv", 1)))]:
+        for (n, nb, Pr, Pc, opts) in [(2048, 128, 2, 2, (("ipc", 1),)), (4096, 128, 2, 4, (("ipc", 1),)), (2049, 256, 2, 4, (("ipc", 1), ("complete_inv", 1))),
+                                      (4096, 128, 4, 4, (("ipc", 1),)), (4096, 128, 1, 4, (("ipc", 1),)), (3000, 128, 2, 2, (("ipc", 1), ("strip", 1), ("safe", 1)))]:
             for pr in range(Pr):
                 for pc in range(Pc):
                     scenario("dist2d n=%d nb=%d %dx%d at (%d,%d) %s" % (n, nb, Pr, Pc, pr, pc, dict(opts)), us,
@@ -566,7 +580,9 @@ def main(out_path, user_streams=(0, 1)):
                 scenario("redist n=%d nb=%d size=%d c=%d Pr=%d rank=%d" % (n, nb, size, c, Pr, rank), us,
                          "redist n=%d nb=%d size=%d c=%d Pr=%d" % (n, nb, size, c, Pr), rank, size)(
                     lambda r, a=(n, nb, size, c, Pr, rank): redist_case(r, *a))
-        for (n, nb, Pr, Pc) in [(1000, 128, 2, 2), (2048, 256, 1, 4), (300, 128, 2, 4)]:
+        # (6144 on one process: a 288 MiB piece = five 64 MiB chunks through the two pinned buffers - the host refills a buffer the
+        #  copy engine may still be reading, and reads one it may still be writing: its accesses are in the trace as "HA" lines)
+        for (n, nb, Pr, Pc) in [(1000, 128, 2, 2), (2048, 256, 1, 4), (300, 128, 2, 4), (6144, 512, 1, 1)]:
             for pr in range(Pr):
                 for pc in range(Pc):
                     scenario("desc n=%d nb=%d %dx%d at (%d,%d)" % (n, nb, Pr, Pc, pr, pc), us)(lambda r, a=(n, nb, Pr, Pc, pr, pc): desc_case(r, *a))
@@ -574,9 +590,11 @@ def main(out_path, user_streams=(0, 1)):
             scenario("operators m=%d n=%d k=%d" % (m, n, k), us)(lambda r, a=(m, n, k): operators_case(r, *a))
         scenario("plan life cycles: unused, reconfigured between calls, refused", us)(lifecycle_case)
         # ---- mixed precision, one GPU and P ranks
-        for (n, nrhs, opts) in [(4096, 8, ()), (8192, 8, (("strip", 1),)), (16384, 8, (("pair_rest", 0),)), (8192, 8, (("split", 0),)), (65536, 8, ())]:
+        for (n, nrhs, opts) in [(4096, 8, ()), (8192, 8, (("strip", 1),)), (16384, 8, (("pair_rest", 0),)), (8192, 8, (("split", 0),)), (65536, 8, ()),
+                                (16384, 8, (("reserve", 8),)), (16384, 8, (("solve3", 0),)), (16384, 200, (("update_kernel", 1),)), (8192, 8, (("reserve", 16), ("split", 0))),
+                                (24576, 8, ()), (16384, 8, (("update_kernel", 0),))]:
             scenario("mpchol n=%d %s" % (n, dict(opts) or ""), us)(lambda r, a=(n, nrhs, opts): mpchol_case(r, *a))
-        for (n, nb, P) in [(2048, 256, 1), (2048, 256, 4), (1280, 256, 4), (8192, 512, 8), (1152, 256, 2)]:
+        for (n, nb, P) in [(2048, 256, 1), (2048, 256, 4), (1280, 256, 4), (8192, 512, 8), (1152, 256, 2), (4096, 128, 3), (8192, 1024, 8), (2048, 256, 7)]:
             for p in range(P):
                 scenario("dmp n=%d nb=%d P=%d rank=%d" % (n, nb, P, p), us, "dmp n=%d nb=%d P=%d" % (n, nb, P), p, P)(lambda r, a=(n, nb, P, p): dmp_case(r, *a))
         # ---- CholeskyQR

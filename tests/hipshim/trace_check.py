@@ -177,6 +177,14 @@ def _replay(rank, lines, sh, allow_unrecorded, joint):
         if k == "A":
             stats["accesses"] += 1      # (an access line without an operation in front of it: ignored)
             continue
+        if k == "HA":
+            # the host thread reads / writes a window NOW: ordered behind what the host has waited for; everything it enqueues
+            # afterwards is ordered behind this access (tick() joins the host's clock, which carries the host's own counter)
+            hk = (R, -1)
+            host[hk] = host.get(hk, 0) + 1
+            stats["accesses"] += 1
+            access(Access(*(int(x) for x in t[1:9])), hk, host, host[hk], "%shost access @line %d" % (("rank %d " % R) if joint else "", lineno + 1))
+            continue
         if k in ("K", "COPY", "COPY2D", "SET", "OP"):
             s = (R, int(t[1]))
             accs = []
