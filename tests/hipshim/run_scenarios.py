@@ -65,6 +65,7 @@ def ok(st, what):
         raise RuntimeError("%s returned %d (%s)" % (what, st, (L.cap_status_string(st) or b"?").decode()))
 
 
+ALIASING = []                # violations of the collectives' buffer-aliasing rules seen by the callbacks of the running scenario
 IPC_MAGIC = (0x4c444e4148435049).to_bytes(8, "little")      # hipshim.cpp: bytes 8 .. 15 of a handle the stand-in exported
 
 
@@ -86,6 +87,9 @@ class Comm:
             # exported is tagged with the slot it lands in, so a rank maps "the same buffer of peer q" (a range of its own in the
             # stand-in, resolved to peer q's allocation by the joint replay) and the IPC schedules run their real course.
             # Big payloads are only traced.
+            # ncclAllGather's aliasing rule: the send buffer is either disjoint from the receive buffer or exactly my slot of it
+            if s and r and n > 0 and s < r + n * 8 * size and r < s + n * 8 and s != r + rank * n * 8:
+                ALIASING.append("allgather on %s: send buffer %#x overlaps the receive buffer %#x (%d x %d bytes) but is not slot %d of it" % (label, s, r, size, n * 8, rank))
             acc(1, s, n * 8); acc(2, r, n * 8 * size)
             op("allgather", n, -1, st)
             if 0 < n * 8 <= 4096 and s and r:
@@ -102,6 +106,10 @@ class Comm:
         def a2a_(ctx, s, sc, sd, r, rc, rd, st):
             for q in range(size):
                 acc(1, (s or 0) + 8 * sd[q] if s else None, 8 * sc[q]); acc(2, (r or 0) + 8 * rd[q] if r else None, 8 * rc[q])
+                for q2 in range(size):      # no piece that is sent may overlap a piece that is received (ncclSend / ncclRecv pairs in one group)
+                    a0, a1, b0, b1 = (s or 0) + 8 * sd[q], (s or 0) + 8 * (sd[q] + sc[q]), (r or 0) + 8 * rd[q2], (r or 0) + 8 * (rd[q2] + rc[q2])
+                    if s and r and sc[q] > 0 and rc[q2] > 0 and a0 < b1 and b0 < a1:
+                        ALIASING.append("alltoallv on %s: the piece sent to %d overlaps the piece received from %d" % (label, q, q2))
             # pairwise exchanges (ncclSend / ncclRecv pairs in the library; ranks without a partner do not call): a local operation
             shim.shim_note_op(b"alltoallv", st)
             return 0
@@ -154,6 +162,8 @@ class Run:
             open(os.path.join(KEEP_TRACE, "".join(ch if ch.isalnum() else "_" for ch in self.name)[:150] + ".txt"), "w").write("\n".join(lines) + "\n")
         self.lines = lines
         findings, stats = trace_check.check(lines)
+        findings += ALIASING
+        del ALIASING[:]
         # kernel launches of the LAST marked "...factor" call, by (mangled) kernel name: compared with rocprofv3's counts of the same
         # schedule on the GPU by tests/test_schedule_structure.py
         hist, cur = {}, None
