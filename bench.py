@@ -236,16 +236,21 @@ def traffic_from_profile(n, args):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
     (profiles/rNN_traffic_bench_n65536.json, produced by tools/prof_round.sh + tools/make_traffic_json.py: FETCH_SIZE and WRITE_SIZE in
     separate runs, FETCH_SIZE doubled per the gfx950 correction).  Counters cannot be collected inside the timed run; the
-    number is only reported for the exact configuration AND library build it was measured on (newest round first), else null."""
+    number is only reported for the exact configuration AND kernel build it was measured on (same source, or same machine code of
+    gemm.hip's kernels), newest round first, else null."""
     import glob
     import hashlib
     try:
         src = b"".join(open(os.path.join(ROOT, "capital_amd", "csrc", f), "rb").read() for f in ("gemm.hip", "tile_dma.h"))
         sha = hashlib.sha256(src).hexdigest()[:16]
+        # the identity that matters is the kernel's MACHINE CODE: host-only edits of gemm.hip (a scratch-buffer release, the access
+        # notes of the schedule checker) change the source hash and not one instruction (capital_amd/build.py device_text_md5)
+        from capital_amd import build as _b
+        text = _b.device_text_md5("gemm.hip")
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_bench_n65536.json")), reverse=True):
             d = json.load(open(path))
             if (d["config"]["n"] == n and d["config"]["complete_inv"] == args.complete_inv and not (args.nb or args.outer or args.tail >= 0)
-                    and d.get("kernel_src_sha16") == sha):
+                    and (d.get("kernel_src_sha16") == sha or (text is not None and d.get("kernel_text_md5") == text))):
                 return d["traffic_bytes_per_launch"]
     except Exception:
         pass

@@ -88,6 +88,28 @@ def kernel_resources():
     return out
 
 
+def device_text_md5(source="gemm.hip"):
+    """md5 of the machine code (.text of the gfx950 code object) the last compile of `source` produced - the identity of its KERNELS:
+    host-only edits of the source leave it unchanged (the bundle around it carries a path-dependent compilation-unit id, so the object
+    file itself does not compare).  None when the object or the LLVM tools are missing."""
+    import hashlib
+    import tempfile
+    obj = os.path.join(LIBDIR, "obj", source + ".o")
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(obj) or not os.path.exists(os.path.join(tools, "clang-offload-bundler")):
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            fat, co, txt = (os.path.join(d, x) for x in ("fat.bin", "code.co", "text.bin"))
+            subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], stderr=subprocess.DEVNULL)
+            subprocess.check_call([os.path.join(tools, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], stderr=subprocess.DEVNULL)
+            subprocess.check_call([os.path.join(tools, "llvm-objcopy"), "-O", "binary", "--only-section=.text", co, txt], stderr=subprocess.DEVNULL)
+            return hashlib.md5(open(txt, "rb").read()).hexdigest()
+    except Exception:
+        return None
+
+
 def check_no_scratch():
     res = kernel_resources()
     bad = [(k, v) for k, v in res.items() if any(n in k for n in NO_SCRATCH)

@@ -4,6 +4,8 @@ import importlib.util
 import os
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -72,3 +74,21 @@ def test_self_launch_hands_the_arguments_on(monkeypatch):
     tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
     assert tail == ["--gpus", "4", "--size", "4096", "--workload", "cacqr", "--size=512"]
     assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_the_traffic_figure_follows_the_kernels_machine_code():
+    """roofline.traffic comes from committed PMC passes and is only reported for the kernel build it was measured on.  The identity is
+    the MACHINE CODE of gemm.hip's kernels (capital_amd/build.py device_text_md5), not the source text: host-only edits of gemm.hip twice
+    turned the figure into null without changing one instruction (round 5: a scratch-buffer release, the schedule checker's access notes)."""
+    import types
+    from capital_amd import build
+    build.build(verbose=False)
+    text = build.device_text_md5("gemm.hip")
+    if text is None:
+        pytest.skip("LLVM object tools not available")
+    import bench
+    args = types.SimpleNamespace(complete_inv=-1, nb=0, outer=0, tail=-1)
+    t = bench.traffic_from_profile(65536, args)
+    assert t is not None and 1e10 < t < 4e10, t                                    # the committed passes belong to THIS build's kernels
+    assert bench.traffic_from_profile(32768, args) is None                         # ... and to this configuration only
+    assert bench.traffic_from_profile(65536, types.SimpleNamespace(complete_inv=-1, nb=256, outer=0, tail=-1)) is None

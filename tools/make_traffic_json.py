@@ -49,6 +49,9 @@ out = {"command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-include-rege
        "traffic_bytes_per_launch": (2 * f + w) * 1024.0, "algorithmic_bytes_per_launch": alg, "launches_per_factor_modelled": nlaunch,
        "kernel_src_sha16": hashlib.sha256(b"".join(open(os.path.join(ROOT, "capital_amd", "csrc", f), "rb").read()
                                                     for f in ("gemm.hip", "tile_dma.h"))).hexdigest()[:16]}
+sys.path.insert(0, ROOT)
+from capital_amd import build as _build      # the machine code of gemm.hip's kernels: what the counters were really collected on
+out["kernel_text_md5"] = _build.device_text_md5("gemm.hip")
 tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 json.dump(out, open(os.path.join(ROOT, "profiles", "%s_traffic_bench_n65536.json" % tag), "w"), indent=1)
 print(out["traffic_bytes_per_launch"] / 1e9, "GB per launch,", out["traffic_bytes_per_launch"] / out["algorithmic_bytes_per_launch"], "x algorithmic")
