@@ -14,6 +14,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "kargs.h"
 #include "tile_dma.h"
 
 namespace {
@@ -24,7 +25,7 @@ constexpr int GN = 256, BK = 16;
 constexpr int G_STAGES = 4;
 constexpr int G_TILE = GN * BK;        // doubles per stage (32 KiB): [256 Q-columns][16 k], 16-byte chunks XOR-swizzled
 
-struct GramArgs { const double* Q; int64_t ld, m, chunk; double* P; };
+// struct GramArgs: csrc/kargs.h (shared with the CPU kernel models of tests/hipshim)
 
 template <int W>
 __device__ __forceinline__ void gram_wave(const GramArgs& g, double* smem, int nk, const DmaBuf& d, int half, int piece0) {
@@ -124,7 +125,7 @@ constexpr int A_NST = 4, B_NST = 3;              // 4 x 16 KiB + 3 x 32 KiB = 16
 // issues [4 pieces of B, 2 pieces of A]; vmcnt retires in order, so "tile t has landed" = at most the 8 younger pieces
 // A(t+1), B(t+1), A(t+2) outstanding.
 
-struct ApplyArgs { const double* Qin; int64_t ldin; const double* Ri; double* Qout; int64_t ldout; int ntiles; int contig; };
+// struct ApplyArgs: csrc/kargs.h (shared with the CPU kernel models of tests/hipshim)
 
 template <int DIAG, int PIPE>
 __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {

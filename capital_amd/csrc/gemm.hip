@@ -25,6 +25,8 @@
 #include <utility>
 
 #include "common.h"
+#include "kargs.h"
+#include "gemm_index.h"
 #include "tile_dma.h"
 
 namespace {
@@ -36,131 +38,10 @@ constexpr int TILE_ELEMS = 128 * LDK;  // == BK * LDO == 2304 doubles
 static_assert(128 * LDK == BK * LDO, "both LDS layouts use the same footprint");
 constexpr int ST = 8;             // supertile edge (tiles)
 
-struct GemmArgs {
-  const double* A; const double* B; double* C;
-  int64_t lda, ldb, ldc;
-  int64_t M, N, K;
-  double alpha, beta;
-  int tm, tn;       // tiles in M, N
-  int tri;          // element mask: 0 full, 1 upper (row<=col), 2 lower
-  int etri;         // tile enumeration: 0 full grid, 1/2 triangular (square tile spaces only)
-  int chunk;        // logical tiles per XCD
-  int nsm, nsn;     // supertiles in M, N
-  int st;           // supertile edge in tiles (tiles of one supertile are co-scheduled on one XCD)
-  // full-grid products whose K range depends on the tile row (aupt / aupn) or column (bupper): supertiles of stm x stn tiles
-  // (64 in all), enumerated so that every XCD's contiguous range covers ALL values of the K-determining index - a square
-  // 8 x 8 walk hands XCD 0 the short-K and XCD 7 the long-K tiles of a triangular operand (measured: the tree's R^-1
-  // products ran at the speed of the dense product).  sorder 1: supertile columns fastest.
-  int stm, stn, sorder;
-  // split-K (tall-skinny Gram / few-tile problems): blockIdx.y = K slice; partial tiles go to
-  // slab kz of P (column-major, ld = M) and a second kernel reduces them deterministically
-  int ksplit; int64_t kchunk; double* P; int64_t slab;
-  // distributed trailing update (dist.hip): C = my block-cyclic block columns (1 x P grid, block width
-  // nbT tiles), rows are global.  stair: upper mask follows the staircase  row_tile <= global tile of
-  // my local column tile;  gather: operand A is the all-gathered block row, stored as P pieces in
-  // (rank, local block) order - row tile ti lives in piece (J % P) at local block J / P - gstart[r].
-  int aupt, aupn;   // op(A) comes from an upper-triangular A (Trans / NoTrans form): see tn_dma_tile
-  int bupper;       // op(B) is upper triangular (k x n, zero for k > column): K range of a column tile stops at its diagonal
-  int* ctr;         // persistent launches: 8 per-XCD slot counters (zeroed on the stream before the launch)
-  int hiprio;       // panel-stream launches: raise the waves' issue priority (they share CUs with the bulk update)
-  int stair, gather, sP, sp, snbT, sJ0, slb0;
-  // rows of C block-cyclic over rP process rows as well (Pr x Pc layout): local row block b holds global block
-  // rp + rP (rlb0 + b).  rP = 1, rp = 0, rlb0 = sJ0 is the 1 x P layout (rows global, origin at block sJ0).
-  int rP, rp, rlb0;
-  int64_t gpiece; int gstart[8];
-  // epilogue of the beta == 1 update form as fire-and-forget fp64 atomic adds executed in L2 (global_atomic_add_f64):
-  // no C read-back into registers, no load latency on the tile's critical path.  Every C element has exactly one
-  // writer (no split-K on this path), so the result is the same single rounding fl(C + alpha*acc) as the load/add/store
-  // form and stays run-to-run deterministic.
-  int atomic_c;
-  int usebuf;       // operand rows of a tile fit a 32-bit byte offset: LDS-DMA through buffer descriptors (scalar offsets)
-  int skip;         // launch the block-skipping instantiation (triangular operands, few-tile SYRK)
-  // beta != 0 with the C input read from another matrix (C = alpha op(A) op(B) + beta Cin): the first trailing updates of a
-  // factorization read A and write R, which replaces the n x n copy in front of it.  Cin == C, ldcin == ldc otherwise.
-  const double* Cin; int64_t ldcin;
-};
+// struct GemmArgs: csrc/kargs.h (shared with the CPU kernel models of tests/hipshim)
 
-// global tile index (relative to the row origin) of local column tile tj under the staircase view
-__device__ __forceinline__ int stair_gtj(const GemmArgs& g, int tj) {
-  const int J = g.sp + g.sP * (g.slb0 + tj / g.snbT);
-  return (J - g.sJ0) * g.snbT + tj % g.snbT;
-}
-// global tile index (relative to the row origin sJ0) of local row tile ti under the staircase view
-__device__ __forceinline__ int stair_gti(const GemmArgs& g, int ti) {
-  const int I = g.rp + g.rP * (g.rlb0 + ti / g.snbT);
-  return (I - g.sJ0) * g.snbT + ti % g.snbT;
-}
-// base of A's rows for row tile ti (K-contiguous operand, lda doubles per row).  gather: global block I of the row tile
-// sits in piece (I % sP) / rP (the contributors of a process row are the columns pc' = rp mod rP, + rP, ...: all of them
-// when rP = 1) at that contributor's local block I / sP - gstart[piece]
-__device__ __forceinline__ const double* a_tile_base(const GemmArgs& g, int ti) {
-  if (!g.gather) return g.A + (int64_t)ti * 128 * g.lda;
-  const int I = g.rp + g.rP * (g.rlb0 + ti / g.snbT), r = (I % g.sP) / g.rP, lb = I / g.sP - g.gstart[r];
-  return g.A + (int64_t)r * g.gpiece + ((int64_t)(lb * g.snbT + ti % g.snbT) * 128) * g.lda;
-}
-
-// staircase enumeration (etri == 3): supertile column sj holds this many supertiles with at least one valid tile
-__host__ __device__ __forceinline__ int stair_gtj_hd(int sp, int sP, int slb0, int snbT, int sJ0, int tj) {
-  const int J = sp + sP * (slb0 + tj / snbT);
-  return (J - sJ0) * snbT + tj % snbT;
-}
-// number of LOCAL row tiles whose global tile index is <= X (rows block-cyclic over rP process rows, see GemmArgs::rP)
-__host__ __device__ __forceinline__ int stair_rows_le(int X, int snbT, int sJ0, int rP, int rp, int rlb0) {
-  if (X < 0) return 0;
-  const int Xb = X / snbT + sJ0, Xo = X % snbT;          // global block of tile X, offset inside it
-  // local blocks b >= 0 with  rp + rP (rlb0 + b) < Xb  are complete
-  int full = Xb - rp > 0 ? (Xb - rp + rP - 1) / rP - rlb0 : -rlb0;
-  if (full < 0) full = 0;
-  int cnt = full * snbT;
-  if (Xb >= rp && (Xb - rp) % rP == 0 && (Xb - rp) / rP >= rlb0) cnt += Xo + 1;     // the block of X itself is local
-  return cnt;
-}
-__host__ __device__ __forceinline__ int stair_cnt(int sj, int st, int tn, int nsm, int sp, int sP, int slb0, int snbT, int sJ0,
-                                                  int rP, int rp, int rlb0) {
-  int tjm = sj * st + st - 1;
-  if (tjm > tn - 1) tjm = tn - 1;
-  const int rows = stair_rows_le(stair_gtj_hd(sp, sP, slb0, snbT, sJ0, tjm), snbT, sJ0, rP, rp, rlb0);
-  const int c = (rows + st - 1) / st;
-  return c < nsm ? c : nsm;
-}
-
-// logical slot -> tile coordinates (returns false when the slot is empty)
-__device__ __forceinline__ bool slot_to_tile(const GemmArgs& g, int L, int& ti, int& tj) {
-  const int ST = g.st;
-  const int STM = g.stm, STN = g.stn;
-  int S = L / (STM * STN), w = L % (STM * STN);
-  int si, sj;
-  if (g.etri == 3) {  // staircase: walk the supertile columns, only supertiles that hold valid tiles are numbered
-    sj = 0;
-    for (; sj < g.nsn; sj++) {
-      const int c = stair_cnt(sj, ST, g.tn, g.nsm, g.sp, g.sP, g.slb0, g.snbT, g.sJ0, g.rP, g.rp, g.rlb0);
-      if (S < c) break;
-      S -= c;
-    }
-    si = S;
-  } else if (g.etri == 1) {  // upper triangle of supertiles, column-major: S = sj(sj+1)/2 + si
-    sj = (int)((__builtin_sqrtf(8.0f * (float)S + 1.0f) - 1.0f) * 0.5f);
-    while ((sj + 1) * (sj + 2) / 2 <= S) sj++;
-    while (sj * (sj + 1) / 2 > S) sj--;
-    si = S - sj * (sj + 1) / 2;
-  } else if (g.etri == 2) {
-    si = (int)((__builtin_sqrtf(8.0f * (float)S + 1.0f) - 1.0f) * 0.5f);
-    while ((si + 1) * (si + 2) / 2 <= S) si++;
-    while (si * (si + 1) / 2 > S) si--;
-    sj = S - si * (si + 1) / 2;
-  } else if (g.sorder) {
-    sj = S % g.nsn; si = S / g.nsn;
-  } else {
-    si = S % g.nsm; sj = S / g.nsm;
-  }
-  if (si >= g.nsm || sj >= g.nsn) return false;
-  ti = si * STM + (w % STM); tj = sj * STN + (w / STM);
-  if (ti >= g.tm || tj >= g.tn) return false;
-  if (g.stair) return stair_gti(g, ti) <= stair_gtj(g, tj);
-  if (g.tri == 1 && ti > tj) return false;
-  if (g.tri == 2 && ti < tj) return false;
-  return true;
-}
+// tile enumeration and staircase index maps (stair_*, a_tile_base, slot_to_tile): csrc/gemm_index.h - shared with the CPU kernel models
+// of tests/hipshim, which walk a launch's blocks through the very same functions
 
 // Stage one operand tile (128 outer x BK) from global into registers.
 // KC: element (o, k) at P[k + o*ld];  !KC: element (o, k) at P[o + k*ld].
@@ -655,14 +536,7 @@ int launch_variant(const GemmArgs& g, int edge, int grid, hipStream_t stream) {
 constexpr int SM_T = 64, SM_K = 64, SM_LD = SM_T + 16;
 constexpr int SM_PER_THREAD = (SM_T * SM_K) / 256;   // elements of each operand chunk staged per thread
 
-struct SmallArgs {
-  const double* A; const double* B; double* C;
-  int64_t lda, ldb, ldc;
-  int M, N, K;
-  double alpha, beta;
-  int tri, hiprio;
-  int64_t sa, sb, sc;   // batch strides (blockIdx.z)
-};
+// struct SmallArgs: csrc/kargs.h (shared with the CPU kernel models of tests/hipshim)
 
 template <bool TA, bool TB>
 __global__ void __launch_bounds__(256) dgemm_small_kernel(SmallArgs g) {
@@ -793,7 +667,7 @@ int launch_small(int transa, int transb, int64_t m, int64_t n, int64_t k, double
 //   NN (A: M x K, M-contiguous): one lane per output row, 8 accumulators, B[k, :] is wave-uniform; the four waves of a workgroup
 //      split K and meet in LDS.
 // ---------------------------------------------------------------------------------------------
-struct SkinnyArgs { const double* A; const double* B; double* C; int64_t lda, ldb, ldc; int64_t M, K; int N; double alpha, beta; };
+// struct SkinnyArgs: csrc/kargs.h (shared with the CPU kernel models of tests/hipshim)
 
 __global__ void __launch_bounds__(256) dgemm_tn_skinny_kernel(const SkinnyArgs g) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;

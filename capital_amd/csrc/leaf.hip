@@ -15,6 +15,7 @@
 // 16/32/64 with an identity tail so any size works (the reference handles ragged sizes
 // with its `span` trick, policy.h:196).
 #include "common.h"
+#include "kargs.h"
 
 namespace {
 
@@ -339,12 +340,7 @@ __global__ void __launch_bounds__(LTHREADS) leaf_trtri_kernel(const double* R, i
 // instead of two - under a concurrent bulk update every launch of the chain waits for a workgroup slot to come free.
 // The solved block row of the previous step (f.cj_*) is moved into R by the last workgroup of the launch, the solved
 // pieces of this step go to the other half of the scratch (f.direct: a single-workgroup launch writes its piece in place).
-struct Panel64Fold {
-  double* Dnext; int64_t ldn;            // Dinv_{i+1} (strictly lower part zero-filled)
-  int* info; int info_base;              // first non-positive pivot -> info_base + 1-based index
-  const double* cj_src; double* cj_dst; int64_t cj_ld; int cj_cols;
-  int direct;
-};
+// struct Panel64Fold: csrc/kargs.h (shared with the CPU kernel models of tests/hipshim)
 
 __global__ void __launch_bounds__(LTHREADS) panel64_solve_update_kernel(double* R, int64_t ldr, const double* Dinv, int64_t ldi,
                                                                        int i, int nblk, double* Xs, const Panel64Fold f) {
@@ -556,17 +552,7 @@ __global__ void __launch_bounds__(LTHREADS) trinv_merge_kernel(const double* R, 
 // through to / read from the memory side), so the barrier is just s_waitcnt vmcnt(0) + one counter - no L2 write-back or
 // invalidate, which would also hit the operand lines of the bulk update that shares the L2s.  `fence` != 0 adds the release /
 // acquire fences around the counter (A/B switch, CAP_CHAIN_FENCE).
-struct Chain64 {
-  double* R; int64_t ldr; double* Ri; int64_t ldi; int nblk; int* info; int info_base; int* ctr; int fence;
-  int hmax;             // the inverse is assembled in the same launch up to pairs of hmax x hmax blocks (0: not at all; <= 256)
-  long long* trace;     // nullptr, or [64 workgroups][32 steps][8]: 100 MHz stamps (step start, S done, released, U done, leaf done, released)
-  // recovery (round 5).  ctr[3] is the state word of the slot: 0 normal; 1 = a workgroup of the primary launch gave up waiting for its
-  // peers (every workgroup that sees it stops meeting and leaves); 2 = the recovery launch has taken over; 3 = it gave up too.  The
-  // recovery launch (recover = 1, two workgroups, enqueued behind every primary launch) returns at once if it finds 0; else it restores the block from `backup` (upper 64 x 64 blocks, packed
-  // column by column of blocks, written by the primary launch before it touched the block), clears info's -64, counts the event in
-  // fallbacks[0] and runs the same sweep.  fallbacks[1] > 0: test hook, the primary launch gives up at its first meeting.
-  double* backup; int* fallbacks; int recover;
-};
+// struct Chain64: csrc/kargs.h (shared with the CPU kernel models of tests/hipshim)
 
 __device__ __forceinline__ double gld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void gst(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

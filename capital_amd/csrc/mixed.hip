@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "common.h"
+#include "kargs.h"
 #include "mixed_kernels.h"
 #include "tile_dma.h"
 
@@ -39,23 +40,7 @@ constexpr int TB = 128;            // C tile edge
 constexpr int KB = 64;             // K tile (bf16 elements) = 128 bytes per row
 constexpr int TILE_D = 128 * 16;   // doubles per operand tile image (16 KiB)
 
-struct BfArgs {
-  const __bf16* A; const __bf16* B; float* C;
-  int64_t lda, ldb, ldc;           // elements
-  int64_t M, N, K;
-  float alpha;
-  int tri;                         // 1: only tiles / elements with row <= col (square problems)
-  int tm, tn, chunk;
-  // st > 0: tiles are enumerated supertile by supertile (st x st tiles, column-major inside and across; the upper triangle of
-  // supertiles for square tri problems), so the 64 / 32 tiles an XCD runs at a time share 2 st panel slices through its L2
-  // instead of st^2 + 1 (a plain column-major walk: every tile of a column has its own A slice); nsm = supertile rows
-  int st, nsm;
-  // distributed trailing update (dist_mixed.hip; the bf16 twin of GemmArgs::stair / gather in gemm.hip): C = my block-cyclic
-  // block columns (1 x P grid, block width snbT tiles), rows global from block sJ0 on; upper mask along the staircase
-  // row tile <= global tile of my column tile; operand A = the all-gathered bf16 block row, P pieces in (rank, local block) order
-  int stair, sP, sp, snbT, sJ0, slb0;
-  int64_t gpiece; int gstart[8];
-};
+// struct BfArgs: csrc/kargs.h (shared with the CPU kernel models of tests/hipshim)
 
 // C[M x N] += alpha * A^T B,  A: K x M, B: K x N (both K-contiguous bf16), C fp32 column-major.  M, N % 128 == 0, K % 64 == 0.
 // Epilogue: fire-and-forget fp32 atomics.  Every C tile has ONE writer per launch, so a plain read - add - write works too; round 5
@@ -241,14 +226,7 @@ int launch_bf16_tn(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A
 //     all 512 resident tiles reached their read-modify-write of C - 32 MB, an HBM-bound burst - together while the matrix pipes idled).
 //   * XCD-aware order: the 32 workgroups an XCD runs side by side work on the 4 x 8 tiles of one 1024 x 1024 supertile (4 A slices +
 //     8 B slices per K tile for 32 tiles), supertiles round-robin over the XCDs, upper-triangular enumeration for the symmetric update.
-struct Bf2Args {
-  const __bf16* A; const __bf16* B; float* C;
-  int64_t lda, ldb, ldc;                 // elements
-  int tm, tn, nk;                        // 256-row tiles, 128-column tiles, K / 64
-  int tri;                               // square problem, same origin for rows and columns: tiles / elements with row <= col only
-  int nsi, nsuper, tpw;                  // supertile rows (rectangular walk), supertiles in all, supertile steps per workgroup
-  float alpha;
-};
+// struct Bf2Args: csrc/kargs.h (shared with the CPU kernel models of tests/hipshim)
 constexpr int V2_STAGE = 49152, V2_AIMG = 32768;      // bytes: A image 256 rows x 128 B, B image 128 rows x 128 B
 
 // step i of workgroup (xcd, slot, round): which tile, if any

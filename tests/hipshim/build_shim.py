@@ -18,10 +18,14 @@ def build():
         raise RuntimeError("no object files under capital_amd/lib/obj - build the library first (python -m capital_amd.build)")
     os.makedirs(OUT, exist_ok=True)
     src = os.path.join(HERE, "hipshim.cpp")
-    newest = max(os.path.getmtime(f) for f in objs + [src, os.path.abspath(__file__)])
+    cpu = os.path.join(HERE, "kernels_cpu.cpp")          # CPU models of the kernels (compute mode), decoding the library's own argument structs
+    csrc = os.path.join(ROOT, "capital_amd", "csrc")
+    newest = max(os.path.getmtime(f) for f in objs + [src, cpu, os.path.join(csrc, "kargs.h"), os.path.join(csrc, "gemm_index.h"), os.path.abspath(__file__)])
     if os.path.exists(LIB) and os.path.exists(SHIM) and min(os.path.getmtime(LIB), os.path.getmtime(SHIM)) > newest:
         return LIB, SHIM
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", SHIM, src])
+    cpu_o = os.path.join(OUT, "kernels_cpu.o")
+    subprocess.check_call(["g++", "-std=c++17", "-O3", "-march=native", "-fPIC", "-Wall", "-Wno-unused-function", "-I" + csrc, "-c", cpu, "-o", cpu_o])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", SHIM, src, cpu_o])
     subprocess.check_call(["g++", "-shared", "-fPIC", "-o", LIB] + objs + ["-L" + OUT, "-lhipshim", "-Wl,-rpath," + OUT, "-Wl,--no-undefined", "-ldl", "-lpthread"])
     return LIB, SHIM
 

@@ -50,6 +50,10 @@ struct Note { int mode; const void* base; long long pitch, row_bytes, cols; int 
 thread_local std::vector<Note> pending;                  // access notes waiting for the launch / collective they describe
 hipError_t last_error = hipSuccess;
 constexpr size_t TOUCH_LIMIT = 1 << 16;              // payloads up to this size are really copied / set (info words, handles); larger ones only traced
+// compute mode (shim_set_compute, run_compute.py): every copy and memset is carried out, fresh allocations are filled with NaN patterns
+// (device memory is NOT zero after hipMalloc) and every launch runs the kernel's CPU model (kernels_cpu.cpp) at enqueue time
+int compute = 0;
+long long unmodelled = 0;
 
 struct PendingCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
 thread_local std::vector<PendingCfg> cfg_stack;
@@ -98,6 +102,8 @@ void orphan_check(const char* what) {
 }
 }  // namespace
 
+extern "C" int shim_cpu_kernel(const char* mangled, void** args, unsigned gx, unsigned gy, unsigned gz, unsigned bx);      // kernels_cpu.cpp
+
 extern "C" {
 
 // ---------------------------------------------------------------- the trace, for the test
@@ -128,6 +134,8 @@ int shim_dump(const char* path) {
   fclose(f);
   return 0;
 }
+void shim_set_compute(int on) { compute = on; }
+long long shim_unmodelled() { return unmodelled; }
 // an op of the test's own making on a stream (the stand-in collectives of a callback communicator); its access notes come first
 void shim_note_op(const char* name, void* stream) { std::lock_guard<std::mutex> lk(mu); note("OP %d %s", sid((hipStream_t)stream), name); flush_pending(name); }
 // the library's access hook (cap_access_hook) and the tests' own way to describe a collective: the NEXT launch / op touches this window
@@ -159,7 +167,7 @@ hipError_t __hipPopCallConfiguration(dim3* grid, dim3* block, size_t* shmem, hip
   *grid = c.grid; *block = c.block; *shmem = c.shmem; *stream = c.stream;
   return hipSuccess;
 }
-hipError_t hipLaunchKernel(const void* f, dim3 grid, dim3 block, void**, size_t shmem, hipStream_t s) {
+hipError_t hipLaunchKernel(const void* f, dim3 grid, dim3 block, void** args, size_t shmem, hipStream_t s) {
   std::lock_guard<std::mutex> lk(mu);
   auto it = kernels.find(f);
   // a launch the real runtime would refuse: empty grid / block, more than 64 KiB of LDS without the attribute is NOT modelled
@@ -170,6 +178,9 @@ hipError_t hipLaunchKernel(const void* f, dim3 grid, dim3 block, void**, size_t 
   }
   note("K %d %s %u %u %u %zu %zu", sid(s), it == kernels.end() ? "?" : it->second.c_str(), grid.x, grid.y, grid.z, shmem, pending.size());
   flush_pending(it == kernels.end() ? "?" : it->second.c_str());
+  if (compute && it != kernels.end() && !shim_cpu_kernel(it->second.c_str(), args, grid.x, grid.y, grid.z, block.x)) {
+    unmodelled++; note("UNMODELLED %s", it->second.c_str());
+  }
   return hipSuccess;
 }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
@@ -200,6 +211,7 @@ static hipError_t alloc_(void** p, size_t bytes, int kind) {
   // untouched pages of a calloc-sized mapping cost nothing: N = 65536 plans fit a small box as long as nobody writes the payload
   q = calloc((b + 255) / 256, 256);
   if (!q) { last_error = hipErrorOutOfMemory; return last_error; }
+  if (compute) memset(q, 0xff, b);
   std::lock_guard<std::mutex> lk(mu);
   allocs[(uintptr_t)q] = Alloc{b, kind, last_mark, next_alloc++};
   total_alloc += (long long)b;
@@ -246,7 +258,7 @@ static void copy_(void* dst, const void* src, size_t bytes, int stream, const ch
   note("%s %d %p %p %zu", what, stream, dst, src, bytes);
   if (bytes && range_check(dst, bytes) > 0) access_line(2, dst, 0, (long long)bytes, 1, 0, 1, what);
   if (bytes && range_check(src, bytes) > 0) access_line(1, src, 0, (long long)bytes, 1, 0, 1, what);
-  if (bytes && bytes <= TOUCH_LIMIT && range_check(dst, bytes) >= 0 && range_check(src, bytes) >= 0) memmove(dst, src, bytes);
+  if (bytes && (bytes <= TOUCH_LIMIT || compute) && range_check(dst, bytes) >= 0 && range_check(src, bytes) >= 0) memmove(dst, src, bytes);
 }
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind, hipStream_t s) { copy_(dst, src, bytes, sid(s), "COPY"); return hipSuccess; }
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) {
@@ -266,7 +278,7 @@ hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t sp
     if (range_check(dst, (height - 1) * dpitch + width) > 0) access_line(2, dst, (long long)dpitch, (long long)width, (long long)height, 0, 1, "COPY2D");
     if (range_check(src, (height - 1) * spitch + width) > 0) access_line(1, src, (long long)spitch, (long long)width, (long long)height, 0, 1, "COPY2D");
   }
-  if (width * height && width * height <= TOUCH_LIMIT && range_check(dst, (height - 1) * dpitch + width) >= 0 && range_check(src, (height - 1) * spitch + width) >= 0)
+  if (width * height && (width * height <= TOUCH_LIMIT || compute) && range_check(dst, (height - 1) * dpitch + width) >= 0 && range_check(src, (height - 1) * spitch + width) >= 0)
     for (size_t r = 0; r < height; r++) memmove((char*)dst + r * dpitch, (const char*)src + r * spitch, width);
   return hipSuccess;
 }
@@ -276,7 +288,7 @@ static void set_(void* p, int v, size_t bytes, int stream) {
   check_range("memset", p, bytes);
   note("SET %d %p %zu", stream, p, bytes);
   if (bytes && range_check(p, bytes) > 0) access_line(2, p, 0, (long long)bytes, 1, 0, 1, "memset");
-  if (bytes && bytes <= TOUCH_LIMIT && range_check(p, bytes) >= 0) memset(p, v, bytes);
+  if (bytes && (bytes <= TOUCH_LIMIT || compute) && range_check(p, bytes) >= 0) memset(p, v, bytes);
 }
 hipError_t hipMemsetAsync(void* p, int v, size_t bytes, hipStream_t s) { set_(p, v, bytes, sid(s)); return hipSuccess; }
 // (HIP's synchronous memset waits for its own fill command - unlike CUDA's, which may return early on device memory)

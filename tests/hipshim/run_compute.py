@@ -1,0 +1,197 @@
+"""TEST INFRASTRUCTURE: the library's host side computing REAL factors on a machine without a GPU.
+
+The product's object files linked against the recording stand-in (as in run_scenarios.py) with the stand-in in COMPUTE MODE: every
+launch runs a CPU model of its kernel at enqueue time (kernels_cpu.cpp - the kernels' contract incl. launch geometry: the GEMM models
+walk the launch's blocks through the library's own tile enumeration), every copy / memset is carried out, fresh "device" memory is
+filled with NaN patterns.  What comes out of a plan is compared with NumPy / the CPU oracle:
+
+    python tests/hipshim/run_compute.py out.json
+
+One entry per case: {"name", "errors": {...}, "findings": [...]}.  A finding is a result off by more than the tolerance, a NaN that
+survived (memory the schedule read before anything wrote it), a kernel without a model, an exception, or anything the structural
+replay of the same trace reports.  Its own process (no torch)."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import run_scenarios as rs          # noqa: E402  (loads the libraries, installs the access hook)
+from oracle import capital_oracle as orc   # noqa: E402  (the checker)
+
+L, shim = rs.L, rs.shim
+shim.shim_set_compute.argtypes = [C.c_int]
+shim.shim_unmodelled.restype = C.c_longlong
+RESULTS = []
+TOL = 2e-11
+
+
+def view(ptr, rows, cols, ld=None):
+    """(rows x cols) NumPy view of column-major "device" memory at ptr (leading dimension ld)"""
+    ld = ld or rows
+    a = np.ctypeslib.as_array((C.c_double * (ld * cols)).from_address(ptr.value if hasattr(ptr, "value") else ptr))
+    return a.reshape((cols, ld)).T[:rows]
+
+
+def spd(n, seed=0, cond=10.0):
+    """a well-conditioned SPD matrix that is NOT diagonally dominant: every Schur update matters"""
+    rng = np.random.default_rng(seed)
+    g = rng.standard_normal((n, n))
+    a = g @ g.T / n + (4.0 / cond) * np.eye(n)
+    return 0.5 * (a + a.T)
+
+
+def rel(x, ref):
+    d = np.linalg.norm(ref)
+    return float(np.linalg.norm(x - ref) / (d if d > 0 else 1.0))
+
+
+def case(name, user_stream=0):
+    def deco(fn):
+        if rs.FILTER and rs.FILTER not in name:
+            return fn
+        r = rs.Run(name, user_stream)
+        before = int(shim.shim_unmodelled())
+        errors, findings = {}, []
+        try:
+            fn(r, errors)
+        except Exception as e:
+            findings.append("exception: %r" % (e,))
+        out = r.finish()
+        findings += out["findings"]
+        if int(shim.shim_unmodelled()) > before:
+            findings += sorted({l for l in r.lines if l.startswith("UNMODELLED")})
+        for k, v in errors.items():
+            if not (v == v) or v > TOL:
+                findings.append("%s off by %.3e (tolerance %.1e)" % (k, v, TOL))
+        RESULTS.append({"name": name, "errors": errors, "findings": findings, "stats": {k: v for k, v in out["stats"].items() if not isinstance(v, dict)}})
+        return fn
+    return deco
+
+
+def cholinv_compute(r, errors, n, ci, split, bc, opts=(), seed=0, reps=2):
+    a = spd(n, seed)
+    plan = C.c_void_p()
+    rs.ok(L.cap_cholinv_plan_create(C.byref(plan), n, ci, split, bc, b"U", None), "cap_cholinv_plan_create")
+    for k, v in opts:
+        rs.ok(L.cap_cholinv_set_option(plan, k.encode(), v), "set_option " + k)
+    lda = n + 2
+    A = rs.dmalloc(8 * lda * n); out = rs.dmalloc(8 * n * n)
+    av = view(A, n, n, lda)
+    av[:, :] = np.triu(a) + np.tril(np.full((n, n), np.nan), -1)        # only the upper triangle may be consumed (cholinv.hpp:13)
+    info = C.c_int64(-1)
+    for _ in range(reps):                                               # the second call starts from the first one's leftovers
+        rs.ok(r.call("cholinv_factor", L.cap_cholinv_factor, plan, A, lda, r.stream), "cap_cholinv_factor")
+    r.call("cholinv_info", L.cap_cholinv_info, plan, r.stream, C.byref(info))
+    errors["info"] = float(abs(info.value))
+    rref, riref = orc.cholinv(a, max(ci, 0), split, bc)
+    rs.ok(r.call("cholinv_get_R", L.cap_cholinv_get_R, plan, out, n, r.stream), "cap_cholinv_get_R")
+    errors["R"] = rel(view(out, n, n), np.linalg.cholesky(a).T)
+    if ci >= 0:
+        rs.ok(r.call("cholinv_get_Rinv", L.cap_cholinv_get_Rinv, plan, out, n, r.stream), "cap_cholinv_get_Rinv")
+        ri = view(out, n, n).copy()
+        errors["Rinv"] = rel(ri, riref)
+        errors["Rinv_pattern"] = float(np.count_nonzero((ri != 0) != (riref != 0)))
+    rs.ok(L.cap_cholinv_plan_destroy(plan), "cap_cholinv_plan_destroy")
+    shim.hipFree(A); shim.hipFree(out)
+
+
+def operators_compute(r, errors, m, n, k, seed=1):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((m, k)); b = rng.standard_normal((k, n)); c0 = rng.standard_normal((m, n))
+    A = rs.dmalloc(8 * m * k); B = rs.dmalloc(8 * k * n); Cc = rs.dmalloc(8 * m * n)
+    view(A, m, k)[:] = a; view(B, k, n)[:] = b; view(Cc, m, n)[:] = c0
+    rs.ok(r.call("dgemm NN", L.cap_dgemm, 0, 0, m, n, k, 1.5, A, m, B, k, -0.5, Cc, m, r.stream), "cap_dgemm")
+    errors["dgemm NN"] = rel(view(Cc, m, n), 1.5 * a @ b - 0.5 * c0)
+    At = rs.dmalloc(8 * k * m); view(At, k, m)[:] = a.T
+    c1 = view(Cc, m, n).copy()
+    rs.ok(r.call("dgemm TN", L.cap_dgemm, 1, 0, m, n, k, -1.0, At, k, B, k, 1.0, Cc, m, r.stream), "cap_dgemm")
+    errors["dgemm TN beta=1"] = rel(view(Cc, m, n), c1 - a @ b)
+    Bt = rs.dmalloc(8 * n * k); view(Bt, n, k)[:] = b.T
+    rs.ok(r.call("dgemm NT", L.cap_dgemm, 0, 1, m, n, k, 1.0, A, m, Bt, n, 0.0, Cc, m, r.stream), "cap_dgemm")
+    errors["dgemm NT"] = rel(view(Cc, m, n), a @ b)
+    rs.ok(r.call("dgemm TT", L.cap_dgemm, 1, 1, m, n, k, 2.0, At, k, Bt, n, 0.0, Cc, m, r.stream), "cap_dgemm")
+    errors["dgemm TT"] = rel(view(Cc, m, n), 2.0 * a @ b)
+    # SYRK upper, trans: C = alpha A^T A + beta C on the upper triangle, the lower one untouched
+    S = rs.dmalloc(8 * m * m); s0 = rng.standard_normal((m, m)); view(S, m, m)[:] = s0
+    rs.ok(r.call("dsyrk", L.cap_dsyrk, 1, 1, m, k, -1.0, At, k, 1.0, S, m, r.stream), "cap_dsyrk")
+    errors["dsyrk"] = rel(view(S, m, m), np.triu(s0 - a @ a.T) + np.tril(s0, -1))
+    # the triangular operators on an m x m upper triangle with garbage below it
+    t = np.linalg.cholesky(spd(m, seed + 3)).T            # (a RANDOM triangle has a condition number of 1e17 at m = 1024)
+    T = rs.dmalloc(8 * m * m); view(T, m, m)[:] = t + np.tril(np.full((m, m), np.nan), -1)
+    X = rs.dmalloc(8 * m * n); x0 = rng.standard_normal((m, n))
+    for (side, trans, nm) in [(0, 0, "L N"), (0, 1, "L T")]:
+        view(X, m, n)[:] = x0
+        W = rs.dmalloc(8 * max(int(L.cap_dtrmm_work_size(side, m, n)), 1))
+        rs.ok(r.call("dtrmm " + nm, L.cap_dtrmm, side, 1, trans, 0, m, n, 0.75, T, m, X, m, W, r.stream), "cap_dtrmm")
+        errors["dtrmm " + nm] = rel(view(X, m, n), 0.75 * (t.T if trans else t) @ x0)
+        view(X, m, n)[:] = x0
+        W2 = rs.dmalloc(8 * max(int(L.cap_dtrsm_work_size(side, m, n)), 1))
+        rs.ok(r.call("dtrsm " + nm, L.cap_dtrsm, side, 1, trans, m, n, 1.25, T, m, X, m, W2, r.stream), "cap_dtrsm")
+        errors["dtrsm " + nm] = rel(view(X, m, n), np.linalg.solve(t.T if trans else t, 1.25 * x0))
+        shim.hipFree(W); shim.hipFree(W2)
+    Y = rs.dmalloc(8 * n * m); y0 = rng.standard_normal((n, m))
+    for (trans, nm) in [(0, "R N"), (1, "R T")]:
+        view(Y, n, m)[:] = y0
+        W = rs.dmalloc(8 * max(int(L.cap_dtrmm_work_size(1, n, m)), 1))
+        rs.ok(r.call("dtrmm " + nm, L.cap_dtrmm, 1, 1, trans, 0, n, m, 1.0, T, m, Y, n, W, r.stream), "cap_dtrmm")
+        errors["dtrmm " + nm] = rel(view(Y, n, m), y0 @ (t.T if trans else t))
+        view(Y, n, m)[:] = y0
+        W2 = rs.dmalloc(8 * max(int(L.cap_dtrsm_work_size(1, n, m)), 1))
+        rs.ok(r.call("dtrsm " + nm, L.cap_dtrsm, 1, 1, trans, n, m, 1.0, T, m, Y, n, W2, r.stream), "cap_dtrsm")
+        errors["dtrsm " + nm] = rel(view(Y, n, m), np.linalg.solve((t.T if trans else t).T, y0.T).T)
+        shim.hipFree(W); shim.hipFree(W2)
+    # LAPACK-shaped: potrf in place on caller memory (lower part untouched), trtri in place
+    a2 = spd(m, seed + 7)
+    P = rs.dmalloc(8 * m * m); view(P, m, m)[:] = np.triu(a2) + np.tril(np.full((m, m), 7.0), -1)
+    W3 = rs.dmalloc(8 * max(int(L.cap_dpotrf_work_size(m)), 1)); info = rs.dmalloc(8)
+    rs.ok(r.call("dpotrf", L.cap_dpotrf, 1, m, P, m, info, W3, r.stream), "cap_dpotrf")
+    rr = np.linalg.cholesky(a2).T
+    errors["dpotrf"] = rel(view(P, m, m), rr + np.tril(np.full((m, m), 7.0), -1))
+    W4 = rs.dmalloc(8 * max(int(L.cap_dtrtri_work_size(m)), 1))
+    rs.ok(r.call("dtrtri", L.cap_dtrtri, 1, m, P, m, W4, r.stream), "cap_dtrtri")
+    errors["dtrtri"] = rel(view(P, m, m), np.linalg.inv(rr) + np.tril(np.full((m, m), 7.0), -1))
+    for q in (A, B, Cc, At, Bt, S, T, X, Y, P, W3, W4, info):
+        shim.hipFree(q)
+
+
+def main(out_path):
+    shim.shim_set_compute(1)
+    for us in (0, 1):
+        tag = " [user stream]" if us else " [NULL stream]"
+        for (m, n, k) in [(256, 256, 256), (300, 200, 150), (1024, 8, 1024), (64, 64, 64), (640, 384, 128), (130, 70, 33)]:
+            case("operators m=%d n=%d k=%d%s" % (m, n, k, tag), us)(lambda r, e, a=(m, n, k): operators_compute(r, e, *a))
+        for (n, ci, split, bc, opts) in [
+            (1024, -1, 1, 0, ()), (1024, -1, 1, -3, ()), (1000, -1, 1, -2, ()), (64, -1, 1, 0, ()), (200, 1, 1, -2, ()),
+            (1024, 1, 1, 0, ()), (1024, 0, 1, 0, ()), (1024, 0, 2, -2, ()), (768, 1, 1, -2, (("inv_overlap", 0),)), (1000, 1, 1, -2, ()),
+            (1024, 1, 1, 0, (("inv_fast", 0),)), (1024, -1, 1, 0, (("nb", 128),)), (1024, -1, 1, 0, (("nb", 64), ("outer", 128), ("tail", 0))),
+            (2048, -1, 1, 0, (("nb", 128), ("outer", 256), ("tail", 256), ("depth2", 1))),
+            (2048, -1, 1, 0, (("nb", 128), ("outer", 256), ("tail", 0), ("depth2", 1), ("use_sb", 0))),
+            (2048, -1, 1, 0, (("nb", 128), ("outer", 256), ("tail", 0), ("depth2", 1), ("pair_rest", 0))),
+            (2048, -1, 1, 0, (("nb", 128), ("outer", 128), ("tail", 0), ("depth2", 0))),
+            (2048, 1, 1, 0, (("nb", 128), ("outer", 256), ("tail", 0), ("depth2", 1), ("inv_start_m", 1 << 30))),
+            (2048, 0, 1, 0, (("nb", 128), ("outer", 256), ("tail", 512), ("depth2", 1))),
+            (1536, 1, 1, 0, (("nb", 128), ("use_sb", 0))), (1536, -1, 1, 0, (("nb", 128), ("lookahead", 0))), (1536, -1, 1, 0, (("nb", 128), ("fastdiag", 0))),
+            (1536, -1, 1, 0, (("nb", 128), ("chain_coop", 0))), (1536, -1, 1, 0, (("nb", 128), ("fuse_copy", 0), ("depth2", 1))),
+            (2048, -1, 1, 0, (("nb", 128), ("outer", 256), ("inner_la", 1), ("tail", 0))), (1536, -1, 1, 0, (("nb", 128), ("serial_m", 512))),
+            (1536, -1, 1, 0, (("nb", 128), ("reserve", 8))), (1100, -1, 1, 0, (("nb", 128), ("depth2", 1), ("outer", 256), ("tail", 0))),
+            (1100, 1, 1, 0, (("nb", 128), ("depth2", 1), ("outer", 256), ("tail", 0))), (1024, 1, 1, 0, (("nb", 256), ("leaf", 32))),
+        ]:
+            case("cholinv n=%d ci=%d split=%d bc=%d %s%s" % (n, ci, split, bc, dict(opts) or "", tag), us)(
+                lambda r, e, a=(n, ci, split, bc, opts): cholinv_compute(r, e, *a))
+    json.dump({"results": RESULTS}, open(out_path, "w"), indent=1)
+    bad = [x for x in RESULTS if x["findings"]]
+    print("%d cases, %d with findings" % (len(RESULTS), len(bad)))
+    for x in bad[:40]:
+        print(" *", x["name"], {k: "%.2e" % v for k, v in x["errors"].items()})
+        for f in x["findings"][:6]:
+            print("     ", f[:300])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(rs.build_shim.OUT, "compute.json"))
