@@ -437,6 +437,118 @@ void k_chain64(void** a) {
     for (int64_t o = 0; o + 2 * h <= n; o += 2 * h) merge_pair(g.R, g.ldr, g.Ri, g.ldi, o, h);
 }
 
+
+// ------------------------------------------------------------------------------------------ dist.hip / dist2d.hip / redist.hip / summa.hip / cacqr.hip
+double sym_entry(int64_t n, int64_t grow, int64_t gcol, int dom) {
+  const int64_t hi = std::max(gcol, grow), lo = std::min(gcol, grow);
+  double v = drand48_of_seed((uint64_t)(hi + n * lo));
+  if (dom && gcol == grow) v += (double)n;
+  return v;
+}
+void k_fill_symmetric_bc(void** a) {
+  double* out = arg<double*>(a, 0); const int64_t ld = arg<int64_t>(a, 1), n = arg<int64_t>(a, 2), nb = arg<int64_t>(a, 3); const int P = arg<int>(a, 4), p = arg<int>(a, 5),
+          dom = arg<int>(a, 6); const int64_t lc = arg<int64_t>(a, 7);
+  for (int64_t l = 0; l < lc; l++) { const int64_t g = ((l / nb) * P + p) * nb + l % nb; for (int64_t r = 0; r < n; r++) out[r + l * ld] = sym_entry(n, r, g, dom); }
+}
+void k_pad_identity(void** a) {
+  double* R = arg<double*>(a, 0); const int64_t ld = arg<int64_t>(a, 1), n = arg<int64_t>(a, 2), nb = arg<int64_t>(a, 4); const int P = arg<int>(a, 5), p = arg<int>(a, 6);
+  const int64_t row0 = arg<int64_t>(a, 7), col0 = arg<int64_t>(a, 8), rows = arg<int64_t>(a, 9), cols = arg<int64_t>(a, 10);
+  for (int64_t l = col0; l < col0 + cols; l++) {
+    const int64_t g = ((l / nb) * P + p) * nb + l % nb;
+    for (int64_t r = row0; r < row0 + rows; r++) if (r >= n || g >= n) R[r + l * ld] = (r == g) ? 1.0 : 0.0;
+  }
+}
+void k_export_upper_bc(void** a) {
+  const double* R = arg<const double*>(a, 0); const int64_t ld = arg<int64_t>(a, 1); double* out = arg<double*>(a, 2); const int64_t ldo = arg<int64_t>(a, 3), n = arg<int64_t>(a, 4),
+          nb = arg<int64_t>(a, 5); const int P = arg<int>(a, 6), p = arg<int>(a, 7); const int64_t lc = arg<int64_t>(a, 8);
+  for (int64_t l = 0; l < lc; l++) { const int64_t g = ((l / nb) * P + p) * nb + l % nb; for (int64_t r = 0; r < n; r++) out[r + l * ldo] = r <= g ? R[r + l * ld] : 0.0; }
+}
+void k_info_to_double(void** a) { const int* info = arg<const int*>(a, 0); double* out = arg<double*>(a, 1); *out = (double)*info; }
+void k_identity_blocks_bc(void** a) {
+  double* X = arg<double*>(a, 0); const int64_t ld = arg<int64_t>(a, 1), nb = arg<int64_t>(a, 2); const int P = arg<int>(a, 3), p = arg<int>(a, 4); const int64_t lc = arg<int64_t>(a, 5);
+  for (int64_t l = 0; l < lc; l++) X[((l / nb) * P + p) * nb + l % nb + l * ld] = 1.0;
+}
+struct G2 { int64_t nb; int Pr, Pc, pr, pc; int64_t grow(int64_t l) const { return ((l / nb) * Pr + pr) * nb + l % nb; } int64_t gcol(int64_t l) const { return ((l / nb) * Pc + pc) * nb + l % nb; } };
+void k_fill_symmetric_bc2d(void** a) {
+  double* out = arg<double*>(a, 0); const int64_t ld = arg<int64_t>(a, 1), n = arg<int64_t>(a, 2); const G2 g{arg<int64_t>(a, 3), arg<int>(a, 4), arg<int>(a, 5), arg<int>(a, 6), arg<int>(a, 7)};
+  const int dom = arg<int>(a, 8); const int64_t lr = arg<int64_t>(a, 9), lc = arg<int64_t>(a, 10);
+  for (int64_t c = 0; c < lc; c++) for (int64_t r = 0; r < lr; r++) out[r + c * ld] = sym_entry(n, g.grow(r), g.gcol(c), dom);
+}
+void k_import_pad_2d(void** a) {
+  const double* A = arg<const double*>(a, 0); const int64_t lda = arg<int64_t>(a, 1); double* R = arg<double*>(a, 2); const int64_t ld = arg<int64_t>(a, 3), n = arg<int64_t>(a, 4);
+  const G2 g{arg<int64_t>(a, 5), arg<int>(a, 6), arg<int>(a, 7), arg<int>(a, 8), arg<int>(a, 9)}; const int64_t lr = arg<int64_t>(a, 10), lc = arg<int64_t>(a, 11);
+  for (int64_t c = 0; c < lc; c++) for (int64_t r = 0; r < lr; r++) { const int64_t gr = g.grow(r), gc = g.gcol(c); R[r + c * ld] = (gr < n && gc < n) ? A[r + c * lda] : (gr == gc ? 1.0 : 0.0); }
+}
+void k_export_upper_2d(void** a) {
+  const double* R = arg<const double*>(a, 0); const int64_t ld = arg<int64_t>(a, 1); double* out = arg<double*>(a, 2); const int64_t ldo = arg<int64_t>(a, 3);
+  const G2 g{arg<int64_t>(a, 4), arg<int>(a, 5), arg<int>(a, 6), arg<int>(a, 7), arg<int>(a, 8)}; const int64_t lr = arg<int64_t>(a, 9), lc = arg<int64_t>(a, 10);
+  for (int64_t c = 0; c < lc; c++) for (int64_t r = 0; r < lr; r++) out[r + c * ldo] = g.grow(r) <= g.gcol(c) ? R[r + c * ld] : 0.0;
+}
+void k_identity_2d(void** a) {
+  double* X = arg<double*>(a, 0); const int64_t ld = arg<int64_t>(a, 1); const G2 g{arg<int64_t>(a, 2), arg<int>(a, 3), arg<int>(a, 4), arg<int>(a, 5), arg<int>(a, 6)}; const int64_t lc = arg<int64_t>(a, 7);
+  for (int64_t l = 0; l < lc; l++) { const int64_t J = (l / g.nb) * g.Pc + g.pc; if ((int)(J % g.Pr) != g.pr) continue; X[(J / g.Pr) * g.nb + l % g.nb + l * ld] = 1.0; }
+}
+void k_zero_root_2d(void** a) {
+  double* X = arg<double*>(a, 0); const int64_t ld = arg<int64_t>(a, 1); const G2 g{arg<int64_t>(a, 2), arg<int>(a, 3), arg<int>(a, 4), arg<int>(a, 5), arg<int>(a, 6)};
+  const int64_t lr = arg<int64_t>(a, 7), lc = arg<int64_t>(a, 8), n1 = arg<int64_t>(a, 9);
+  for (int64_t c = 0; c < lc; c++) for (int64_t r = 0; r < lr; r++) if (g.grow(r) < n1 && g.gcol(c) >= n1) X[r + c * ld] = 0.0;
+}
+void k_redist(void** a, bool gather) {
+  double* mat = arg<double*>(a, 0); const int64_t ld = arg<int64_t>(a, 1); const int64_t* ri = arg<const int64_t*>(a, 2); const int64_t nr = arg<int64_t>(a, 3);
+  const int64_t* ci = arg<const int64_t*>(a, 4); const int64_t nc = arg<int64_t>(a, 5); double* buf = arg<double*>(a, 6);
+  for (int64_t j = 0; j < nc; j++) for (int64_t i = 0; i < nr; i++) { if (gather) buf[i + j * nr] = mat[ri[i] + ci[j] * ld]; else mat[ri[i] + ci[j] * ld] = buf[i + j * nr]; }
+}
+void k_combine(void** a, unsigned gy) {
+  double* C = arg<double*>(a, 0); const int64_t ldc = arg<int64_t>(a, 1); const double* acc = arg<const double*>(a, 2); const int64_t lda = arg<int64_t>(a, 3), m = arg<int64_t>(a, 4);
+  const double beta = arg<double>(a, 6);
+  for (int64_t c = 0; c < gy; c++) for (int64_t r = 0; r < m; r++) { double* p = C + r + c * ldc; const double v = acc[r + c * lda]; *p = beta == 0.0 ? v : beta * (*p) + v; }
+}
+void k_combine_packed(void** a, unsigned gy) {
+  double* Cp = arg<double*>(a, 0); const double* acc = arg<const double*>(a, 1); const int64_t n = arg<int64_t>(a, 2); const double beta = arg<double>(a, 3);
+  for (int64_t c = 0; c < gy; c++) for (int64_t r = 0; r <= c; r++) { double* q = Cp + c * (c + 1) / 2 + r; const double v = acc[r + c * n]; *q = beta == 0.0 ? v : beta * (*q) + v; }
+}
+void k_blocks_to_dense(void** a) {
+  const double* blocks = arg<const double*>(a, 0); double* dense = arg<double*>(a, 1); const int64_t n = arg<int64_t>(a, 2), nl = arg<int64_t>(a, 3); const int c = arg<int>(a, 4);
+  for (int64_t j = 0; j < n; j++) for (int64_t i = 0; i < n; i++) { const int64_t zi = i % c, aa = i / c, xj = j % c, b = j / c; dense[i + j * n] = blocks[(zi * c + xj) * nl * nl + aa + b * nl]; }
+}
+// ------------------------------------------------------------------------------------------ cqr_kernels.hip (n = 256)
+void k_gram256(void** a, unsigned gx) {
+  const GramArgs g = arg<GramArgs>(a, 0);
+  for (unsigned b = 0; b < gx; b++) {
+    const int64_t r0 = (int64_t)b * g.chunk, rows = std::max<int64_t>(0, std::min<int64_t>(g.chunk, g.m - r0)), nk = (rows / 16) * 16;
+    double* P = g.P + (int64_t)b * 256 * 256;
+    for (int c = 0; c < 256; c++)
+      for (int r = 0; r <= c; r++) {
+        const double* qr = g.Q + r0 + (int64_t)r * g.ld; const double* qc = g.Q + r0 + (int64_t)c * g.ld;
+        double s = 0.0;
+        for (int64_t k = 0; k < nk; k++) s += qr[k] * qc[k];
+        P[r + (int64_t)c * 256] = s;
+      }
+  }
+}
+void k_gram256_reduce(void** a) {
+  const double* P = arg<const double*>(a, 0); const int nslab = arg<int>(a, 1); double* G = arg<double*>(a, 2); const int64_t ldg = arg<int64_t>(a, 3);
+  for (int c = 0; c < 256; c++)
+    for (int r = 0; r < 256; r++) {
+      double s = 0.0;
+      if (r <= c) for (int z = 0; z < nslab; z++) s += P[(int64_t)z * 65536 + r + (int64_t)c * 256];
+      G[r + c * ldg] = s;
+    }
+}
+void k_qrapply256(void** a) {
+  const ApplyArgs g = arg<ApplyArgs>(a, 0);
+  const int64_t m = (int64_t)g.ntiles * 128;
+  std::vector<double> col((size_t)m);
+  std::vector<double> out((size_t)m * 256);
+  for (int c = 0; c < 256; c++) {
+    const int kmax = 16 * (c / 16 + 1);                   // Ri upper triangular: K stops at the diagonal 16-block
+    std::fill(col.begin(), col.end(), 0.0);
+    for (int k = 0; k < kmax; k++) { const double r = g.Ri[k + (int64_t)c * 256]; const double* q = g.Qin + (int64_t)k * g.ldin; for (int64_t i = 0; i < m; i++) col[i] += q[i] * r; }
+    memcpy(out.data() + (size_t)c * m, col.data(), (size_t)m * 8);
+  }
+  for (int c = 0; c < 256; c++) memcpy(g.Qout + (int64_t)c * g.ldout, out.data() + (size_t)c * m, (size_t)m * 8);
+}
+
 }  // namespace
 
 // -> 1: modelled and executed; 0: no model for this kernel (the caller reports it)
@@ -464,5 +576,23 @@ extern "C" int shim_cpu_kernel(const char* mangled, void** args, unsigned gx, un
   if (has("trinv_merge_kernel")) { k_trinv_merge(n, args, gy); return 1; }
   if (has("chain64_coop_kernel")) { k_chain64(args); return 1; }
   if (has("spin_kernel")) return 1;
+  if (has("fill_symmetric_bc2d_kernel")) { k_fill_symmetric_bc2d(args); return 1; }
+  if (has("fill_symmetric_bc_kernel")) { k_fill_symmetric_bc(args); return 1; }
+  if (has("pad_identity_kernel")) { k_pad_identity(args); return 1; }
+  if (has("export_upper_bc_kernel")) { k_export_upper_bc(args); return 1; }
+  if (has("info_to_double")) { k_info_to_double(args); return 1; }
+  if (has("identity_blocks_bc_kernel")) { k_identity_blocks_bc(args); return 1; }
+  if (has("import_pad_2d_kernel")) { k_import_pad_2d(args); return 1; }
+  if (has("export_upper_2d_kernel")) { k_export_upper_2d(args); return 1; }
+  if (has("identity_2d_kernel")) { k_identity_2d(args); return 1; }
+  if (has("zero_root_2d_kernel")) { k_zero_root_2d(args); return 1; }
+  if (has("redist_gather_kernel")) { k_redist(args, true); return 1; }
+  if (has("redist_scatter_kernel")) { k_redist(args, false); return 1; }
+  if (has("combine_packed_kernel")) { k_combine_packed(args, gy); return 1; }
+  if (has("combine_kernel")) { k_combine(args, gy); return 1; }
+  if (has("blocks_to_dense_kernel")) { k_blocks_to_dense(args); return 1; }
+  if (has("gram256_reduce_kernel")) { k_gram256_reduce(args); return 1; }
+  if (has("gram256_kernel")) { k_gram256(args, gx); return 1; }
+  if (has("qrapply256_kernel")) { k_qrapply256(args); return 1; }
   return 0;
 }

@@ -160,6 +160,259 @@ def operators_compute(r, errors, m, n, k, seed=1):
         shim.hipFree(q)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Multi-rank plans: one THREAD per rank inside this process (ctypes releases the GIL inside the library), communicators whose
+# collectives really move the data between the ranks' "device" memory and block until their partners have arrived - the way the
+# host-staged communicator of the GPU emulations does.  Every rank executes its launches at enqueue time, so by the time it enters a
+# collective everything it enqueued before has happened; the IPC exchanges copy straight into the peer's buffer (one address space: a
+# handle opens as the peer's own pointer), ordered by the token all-reduces exactly as on the GPU.
+import queue       # noqa: E402
+import threading   # noqa: E402
+
+
+class Group:
+    def __init__(self, size):
+        self.size = size
+        self.bar = threading.Barrier(size, timeout=120)
+        self.slot = [None] * size
+        self.tmp = None
+        self.mail = {}
+        self.lock = threading.Lock()
+
+    def box(self, key):
+        with self.lock:
+            return self.mail.setdefault(key, queue.Queue())
+
+
+GROUPS, GLOCK = {}, threading.Lock()
+
+
+def group(label, size):
+    with GLOCK:
+        return GROUPS.setdefault(label, Group(size))
+
+
+def dview(ptr, n):
+    return np.ctypeslib.as_array((C.c_double * n).from_address(ptr))
+
+
+class TComm:
+    """communicator of one rank thread: `me` of `size` in the group named `label` (unique per configuration and group)"""
+
+    def __init__(self, me, size, label):
+        g = group(label, size)
+        self.rank, self.size = me, size
+
+        def ag_(ctx, s, r, n, st):
+            g.slot[me] = s
+            g.bar.wait()
+            for q in range(size):
+                if n > 0:
+                    C.memmove(r + q * n * 8, g.slot[q], n * 8)
+            g.bar.wait()
+            return 0
+
+        def bc_(ctx, b, n, root, st):
+            g.slot[me] = b
+            g.bar.wait()
+            if me != root and n > 0:
+                C.memmove(b, g.slot[root], n * 8)
+            g.bar.wait()
+            return 0
+
+        def ar_(ctx, b, n, st):
+            g.slot[me] = b
+            g.bar.wait()
+            tot = dview(g.slot[0], n).copy()
+            for q in range(1, size):
+                tot += dview(g.slot[q], n)
+            g.bar.wait()
+            dview(b, n)[:] = tot
+            g.bar.wait()
+            return 0
+
+        def a2a_(ctx, s, sc, sd, r, rc, rd, st):
+            for q in range(size):
+                if sc[q] > 0:
+                    g.box(("data", me, q)).put(s + 8 * sd[q])
+            for q in range(size):
+                if rc[q] > 0:
+                    src = g.box(("data", q, me)).get(timeout=120)
+                    C.memmove(r + 8 * rd[q], src, 8 * rc[q])
+                    g.box(("ack", q, me)).put(1)
+            for q in range(size):
+                if sc[q] > 0:
+                    g.box(("ack", me, q)).get(timeout=120)
+            return 0
+        self._cb = (rs._AG(ag_), rs._BC(bc_), rs._AR(ar_), rs._A2A(a2a_))
+        rs._KEEP.extend(self._cb)
+        self.handle = C.c_void_p()
+        rs.ok(L.cap_comm_create_callbacks(C.byref(self.handle), me, size, self._cb[0], self._cb[1], self._cb[2], None), "cap_comm_create_callbacks")
+        rs.ok(L.cap_comm_set_alltoallv_callback(self.handle, self._cb[3]), "cap_comm_set_alltoallv_callback")
+
+    def close(self):
+        L.cap_comm_destroy(self.handle)
+
+
+def run_ranks(nranks, fn):
+    """fn(rank) on one thread per rank -> list of per-rank results; an exception on any rank is re-raised"""
+    out, err = [None] * nranks, []
+
+    def work(q):
+        try:
+            out[q] = fn(q)
+        except Exception as e:          # a broken barrier on the other ranks follows from the first failure
+            err.append((q, repr(e)))
+    th = [threading.Thread(target=work, args=(q,)) for q in range(nranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if err:
+        raise RuntimeError("rank failures: %s" % err[:3])
+    return out
+
+
+def bc_indices(n, nb, Q, q):
+    """global indices of the rows / columns process coordinate q of Q owns in the block-cyclic layout"""
+    idx = [j for J in range(q, (n + nb - 1) // nb, Q) for j in range(J * nb, min(n, (J + 1) * nb))]
+    return np.array(idx, dtype=np.int64)
+
+
+def ref_factors(a, ci, split):
+    """R, and R^-1 with upstream's pattern (root block empty for complete_inv = 0 unless the root is a base case)"""
+    r, ri = orc.cholinv(a, max(ci, 0), split, 0)
+    return np.linalg.cholesky(a).T, ri
+
+
+def dist_compute(r_unused, errors, n, nb, P, opts=(), ci=-1, seed=0, uid=[0]):
+    uid[0] += 1
+    a = spd(n, seed)
+    rref = np.linalg.cholesky(a).T
+    riref = np.linalg.inv(rref)
+
+    def rank(p):
+        comm = TComm(p, P, "dist%d" % uid[0])
+        plan = C.c_void_p()
+        rs.ok(L.cap_dist_plan_create(C.byref(plan), n, nb, comm.handle), "cap_dist_plan_create")
+        for k, v in opts:
+            rs.ok(L.cap_dist_set_option(plan, k.encode(), v), "dist set_option " + k)
+        if ci >= 0:
+            rs.ok(L.cap_dist_set_option(plan, b"complete_inv", ci), "dist complete_inv")
+        cols = bc_indices(n, nb, P, p)
+        lc = len(cols)
+        assert lc == int(L.cap_dist_local_cols(plan))
+        A = rs.dmalloc(8 * n * max(lc, 1)); out = rs.dmalloc(8 * n * max(lc, 1))
+        if lc:
+            view(A, n, lc)[:] = a[:, cols]
+        info = C.c_int64(-1)
+        for _ in range(2):
+            rs.ok(L.cap_dist_factor(plan, A, n, None), "cap_dist_factor")
+        L.cap_dist_info(plan, None, C.byref(info))
+        if dict(opts).get("ipc") and P > 1 and int(L.cap_dist_get_option(plan, b"ipc_active")) != 1:
+            raise RuntimeError("the IPC strip exchange is not active")
+        rs.ok(L.cap_dist_get_R(plan, out, n, None), "cap_dist_get_R")
+        R = view(out, n, lc).copy() if lc else np.zeros((n, 0))
+        Ri = None
+        if ci >= 0:
+            rs.ok(L.cap_dist_get_Rinv(plan, out, n, None), "cap_dist_get_Rinv")
+            Ri = view(out, n, lc).copy() if lc else np.zeros((n, 0))
+        rs.ok(L.cap_dist_plan_destroy(plan), "cap_dist_plan_destroy")
+        comm.close(); shim.hipFree(A); shim.hipFree(out)
+        return cols, R, Ri, info.value
+    res = run_ranks(P, rank)
+    R = np.zeros((n, n)); Ri = np.zeros((n, n))
+    for cols, Rp, Rip, info in res:
+        R[:, cols] = Rp
+        if Rip is not None:
+            Ri[:, cols] = Rip
+        errors["info"] = max(errors.get("info", 0.0), float(abs(info)))
+    errors["R"] = rel(R, rref)
+    if ci >= 0:
+        n1 = n >> 1
+        want = riref.copy()
+        if ci == 0 and 0 < n1 < n:
+            want[:n1, n1:] = 0.0                 # cholinv.hpp:147: the root block of R^-1 stays empty
+        errors["Rinv"] = rel(Ri, want)
+
+
+def dist2d_compute(r_unused, errors, n, nb, Pr, Pc, opts=(), seed=0, uid=[0]):
+    uid[0] += 1
+    a = spd(n, seed)
+    rref = np.linalg.cholesky(a).T
+    riref = np.linalg.inv(rref)
+    ci = dict(opts).get("complete_inv", -1)
+
+    def rank(q):
+        pr, pc = q // Pc, q % Pc
+        world = TComm(q, Pr * Pc, "w%d" % uid[0]); row = TComm(pc, Pc, "r%d_%d" % (uid[0], pr)); col = TComm(pr, Pr, "c%d_%d" % (uid[0], pc))
+        plan = C.c_void_p()
+        rs.ok(L.cap_dist2d_plan_create(C.byref(plan), n, nb, world.handle, Pr, row.handle, col.handle), "cap_dist2d_plan_create")
+        for k, v in opts:
+            rs.ok(L.cap_dist2d_set_option(plan, k.encode(), v), "dist2d set_option " + k)
+        rows, cols = bc_indices(n, nb, Pr, pr), bc_indices(n, nb, Pc, pc)
+        lr, lc = len(rows), len(cols)
+        assert (lr, lc) == (int(L.cap_dist2d_get(plan, 0)), int(L.cap_dist2d_get(plan, 1)))
+        A = rs.dmalloc(8 * max(lr, 1) * max(lc, 1)); out = rs.dmalloc(8 * max(lr, 1) * max(lc, 1))
+        if lr and lc:
+            view(A, lr, lc)[:] = a[np.ix_(rows, cols)]
+        info = C.c_int64(-1)
+        for _ in range(2):
+            rs.ok(L.cap_dist2d_factor(plan, A, max(lr, 1), None), "cap_dist2d_factor")
+        L.cap_dist2d_info(plan, None, C.byref(info))
+        if dict(opts).get("ipc") and int(L.cap_dist2d_get(plan, 12)) != 1:
+            raise RuntimeError("the IPC operand moves are not active")
+        rs.ok(L.cap_dist2d_get_R(plan, out, max(lr, 1), None), "cap_dist2d_get_R")
+        R = view(out, lr, lc).copy() if lr and lc else np.zeros((lr, lc))
+        Ri = None
+        if ci >= 0:
+            rs.ok(L.cap_dist2d_get_Rinv(plan, out, max(lr, 1), None), "cap_dist2d_get_Rinv")
+            Ri = view(out, lr, lc).copy() if lr and lc else np.zeros((lr, lc))
+        rs.ok(L.cap_dist2d_plan_destroy(plan), "cap_dist2d_plan_destroy")
+        for c in (world, row, col):
+            c.close()
+        shim.hipFree(A); shim.hipFree(out)
+        return rows, cols, R, Ri, info.value
+    res = run_ranks(Pr * Pc, rank)
+    R = np.zeros((n, n)); Ri = np.zeros((n, n))
+    for rows, cols, Rp, Rip, info in res:
+        if len(rows) and len(cols):
+            R[np.ix_(rows, cols)] = Rp
+            if Rip is not None:
+                Ri[np.ix_(rows, cols)] = Rip
+        errors["info"] = max(errors.get("info", 0.0), float(abs(info)))
+    errors["R"] = rel(R, rref)
+    if ci >= 0:
+        n1 = n >> 1
+        want = riref.copy()
+        if ci == 0 and 0 < n1 < n:
+            want[:n1, n1:] = 0.0
+        errors["Rinv"] = rel(Ri, want)
+
+
+def mp_case(name):
+    """a multi-rank case: no trace of its own (the ranks' threads interleave in it) - the structural checks are run_scenarios.py's"""
+    def deco(fn):
+        if rs.FILTER and rs.FILTER not in name:
+            return fn
+        shim.shim_reset()
+        before = int(shim.shim_unmodelled())
+        errors, findings = {}, []
+        try:
+            fn(None, errors)
+        except Exception as e:
+            findings.append("exception: %r" % (e,))
+        if int(shim.shim_unmodelled()) > before:
+            findings.append("kernels without a CPU model were launched")
+        for k, v in errors.items():
+            if not (v == v) or v > TOL:
+                findings.append("%s off by %.3e (tolerance %.1e)" % (k, v, TOL))
+        RESULTS.append({"name": name, "errors": errors, "findings": findings, "stats": {}})
+        shim.shim_reset()
+        return fn
+    return deco
+
+
 def main(out_path):
     shim.shim_set_compute(1)
     for us in (0, 1):
@@ -184,6 +437,16 @@ def main(out_path):
         ]:
             case("cholinv n=%d ci=%d split=%d bc=%d %s%s" % (n, ci, split, bc, dict(opts) or "", tag), us)(
                 lambda r, e, a=(n, ci, split, bc, opts): cholinv_compute(r, e, *a))
+    for (n, nb, P, opts, ci) in [(1024, 128, 1, (), -1), (1024, 128, 2, (), -1), (1024, 128, 4, (), -1), (1024, 128, 4, (("safe", 1),), -1),
+                                 (1000, 128, 3, (), -1), (1536, 128, 4, (("strip", 2), ("depth2", 1)), -1), (2048, 128, 8, (), -1), (1024, 128, 4, (), 1),
+                                 (1024, 128, 4, (), 0), (1000, 128, 3, (("safe", 1),), 1), (1024, 128, 4, (("ipc", 1),), -1), (1000, 128, 3, (("ipc", 1),), 1),
+                                 (2048, 128, 8, (("ipc", 1), ("strip", 2)), -1), (1536, 256, 5, (("strip", 1),), 0), (1152, 128, 8, (), -1)]:
+        mp_case("dist n=%d nb=%d P=%d %s ci=%d" % (n, nb, P, dict(opts) or "", ci))(lambda r, e, a=(n, nb, P, opts, ci): dist_compute(r, e, *a))
+    for (n, nb, Pr, Pc, opts) in [(1024, 128, 1, 1, ()), (1024, 128, 2, 2, ()), (1024, 128, 1, 4, ()), (1536, 128, 2, 4, ()), (1000, 128, 2, 2, ()),
+                                  (1024, 128, 2, 2, (("complete_inv", 1),)), (1000, 128, 2, 4, (("complete_inv", 0),)), (1024, 128, 2, 2, (("safe", 1), ("complete_inv", 1))),
+                                  (1024, 128, 2, 2, (("ipc", 1),)), (1536, 128, 2, 4, (("ipc", 1), ("complete_inv", 1))), (2048, 128, 4, 4, ()), (1024, 128, 4, 4, (("ipc", 1),)),
+                                  (1536, 128, 2, 4, (("strip", 1), ("depth2", 0))), (1152, 128, 4, 8, ())]:
+        mp_case("dist2d n=%d nb=%d %dx%d %s" % (n, nb, Pr, Pc, dict(opts) or ""))(lambda r, e, a=(n, nb, Pr, Pc, opts): dist2d_compute(r, e, *a))
     json.dump({"results": RESULTS}, open(out_path, "w"), indent=1)
     bad = [x for x in RESULTS if x["findings"]]
     print("%d cases, %d with findings" % (len(RESULTS), len(bad)))
