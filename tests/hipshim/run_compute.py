@@ -390,6 +390,120 @@ def dist2d_compute(r_unused, errors, n, nb, Pr, Pc, opts=(), seed=0, uid=[0]):
         errors["Rinv"] = rel(Ri, want)
 
 
+class TTopo:
+    """topo::square (kind 0) / topo::rect (kind 1) bundle of one rank thread over TComm groups (the splits of run_scenarios.Topo)"""
+
+    def __init__(self, tag, kind, rank, size, c, num_chunks=0):
+        def co(q):
+            dd, xx, yy, zz = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+            rs.ok(L.cap_topo_coords(kind, q, size, c, C.byref(dd), C.byref(xx), C.byref(yy), C.byref(zz)), "cap_topo_coords")
+            return dd.value, xx.value, yy.value, zz.value
+        self.d, self.x, self.y, self.z = co(rank)
+        if kind == 0:
+            splits = [(lambda q: (co(q)[2], co(q)[3]), lambda q: co(q)[1]), (lambda q: (co(q)[1], co(q)[3]), lambda q: co(q)[2]),
+                      (lambda q: q // c, lambda q: q), (lambda q: co(q)[3], lambda q: q), None, None, None]
+        else:
+            cube, sl = c * c * c, c * c
+            splits = [(lambda q: (q // cube, ((q % cube) % c) + c * ((q % cube) // sl)), lambda q: q % cube), None,
+                      (lambda q: (q // cube, (q % cube) // c), lambda q: q % cube), (lambda q: q % c, lambda q: q),
+                      (lambda q: (q % sl, (q // sl) // c), lambda q: q // sl), (lambda q: (q % sl, (q // sl) % c), lambda q: q // sl),
+                      (lambda q: q // cube, lambda q: q)]
+        self.world = TComm(rank, size, "%s:world" % tag)
+        self.subs = []
+        arr = (C.c_void_p * 7)()
+        for i, sp in enumerate(splits):
+            if sp is None:
+                continue
+            me, n, members = rs.group_of(sp[0], sp[1], size, rank)
+            cm = TComm(me, n, "%s:sub%d:%s" % (tag, i, str(sp[0](rank)).replace(" ", "")))
+            self.subs.append(cm); arr[i] = cm.handle
+        self.handle = C.c_void_p()
+        rs.ok(L.cap_topo_create_from(C.byref(self.handle), kind, self.world.handle, c, 0, num_chunks, arr, 7), "cap_topo_create_from")
+
+    def close(self):
+        L.cap_topo_destroy(self.handle)
+        for cm in self.subs + [self.world]:
+            cm.close()
+
+
+def cyc_piece(a, x, y, d):
+    """element-cyclic piece (x, y) of a d x d grid, ceil-sized and zero padded (matrix.hpp:8-11): piece[r, c] = a[y + r d, x + c d]"""
+    m, n = a.shape
+    out = np.zeros(((m + d - 1) // d, (n + d - 1) // d))
+    sub = a[y::d, x::d]
+    out[:sub.shape[0], :sub.shape[1]] = sub
+    return out
+
+
+def summa_compute(r_unused, errors, size, c, M, N, K, chunks, seed=2, uid=[0]):
+    uid[0] += 1
+    rng = np.random.default_rng(seed)
+    a, b, c0 = rng.standard_normal((M, K)), rng.standard_normal((K, N)), rng.standard_normal((M, N))
+    alpha, beta = 1.5, -0.5
+    want = alpha * a @ b + beta * c0
+
+    def rank(q):
+        t = TTopo("summa%d" % uid[0], 0, q, size, c, chunks)
+        plan = C.c_void_p()
+        rs.ok(L.cap_summa_plan_create(C.byref(plan), t.handle, M, N, K, chunks), "cap_summa_plan_create")
+        ml, nl, kl = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        L.cap_summa_local_dims(plan, C.byref(ml), C.byref(nl), C.byref(kl))
+        ml, nl, kl = ml.value, nl.value, kl.value
+        pa, pb, pc = cyc_piece(a, t.x, t.y, t.d), cyc_piece(b, t.x, t.y, t.d), cyc_piece(c0, t.x, t.y, t.d)
+        assert pa.shape == (ml, kl) and pb.shape == (kl, nl) and pc.shape == (ml, nl), (pa.shape, pb.shape, pc.shape, ml, nl, kl)
+        A = rs.dmalloc(8 * ml * kl); B = rs.dmalloc(8 * kl * nl); Cc = rs.dmalloc(8 * ml * nl)
+        view(A, ml, kl)[:] = pa; view(B, kl, nl)[:] = pb; view(Cc, ml, nl)[:] = pc
+        rs.ok(L.cap_summa_dgemm(plan, alpha, A, ml, B, kl, beta, Cc, ml, None), "cap_summa_dgemm")
+        got = view(Cc, ml, nl).copy()
+        rs.ok(L.cap_summa_plan_destroy(plan), "cap_summa_plan_destroy")
+        xy = (t.x, t.y, t.d)
+        t.close()
+        for z in (A, B, Cc):
+            shim.hipFree(z)
+        return xy, got
+    worst = 0.0
+    for (x, y, d), got in run_ranks(size, rank):
+        worst = max(worst, rel(got, cyc_piece(want, x, y, d)))
+    errors["C"] = worst
+
+
+def cacqr_compute(r_unused, errors, m, n, iters, P, seed=3, uid=[0]):
+    """CholeskyQR / CholeskyQR2 on the 1D grid: row-cyclic pieces of a tall matrix; Q^T Q = I, Q R = A, R upper with a positive diagonal"""
+    uid[0] += 1
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((m, n))
+    ml = m // P
+
+    def rank(p):
+        comm = TComm(p, P, "cacqr%d" % uid[0])
+        plan = C.c_void_p()
+        rs.ok(L.cap_cacqr_plan_create(C.byref(plan), ml, n, iters, comm.handle), "cap_cacqr_plan_create")
+        A = rs.dmalloc(8 * ml * n)
+        view(A, ml, n)[:] = a[p::P]
+        info = C.c_int64(-1)
+        for _ in range(2):
+            rs.ok(L.cap_cacqr_factor(plan, A, ml, None), "cap_cacqr_factor")
+        L.cap_cacqr_info(plan, None, C.byref(info))
+        ldq, ldr = C.c_int64(0), C.c_int64(0)
+        L.cap_cacqr_Q_ptr.restype = C.c_void_p; L.cap_cacqr_R_ptr.restype = C.c_void_p
+        qp = L.cap_cacqr_Q_ptr(plan, C.byref(ldq)); rp = L.cap_cacqr_R_ptr(plan, C.byref(ldr))
+        Q = view(qp, ml, n, ldq.value).copy(); R = view(rp, n, n, ldr.value).copy()
+        rs.ok(L.cap_cacqr_plan_destroy(plan), "cap_cacqr_plan_destroy")
+        comm.close(); shim.hipFree(A)
+        return Q, R, info.value
+    res = run_ranks(P, rank)
+    Q = np.zeros((m, n))
+    for p, (Qp, R, info) in enumerate(res):
+        Q[p::P] = Qp
+        errors["info"] = max(errors.get("info", 0.0), float(abs(info)))
+    R = np.triu(res[0][1])
+    errors["R replicated"] = max(rel(np.triu(x[1]), R) for x in res)
+    errors["A - QR"] = rel(Q @ R, a)
+    errors["Q^T Q - I"] = float(np.linalg.norm(Q.T @ Q - np.eye(n)) / np.sqrt(n)) if iters >= 2 else 0.0
+    qr_r = np.linalg.qr(a, mode="r")
+    errors["R vs LAPACK"] = rel(R, qr_r * np.sign(np.diag(qr_r))[:, None]) if iters >= 2 else 0.0
+
+
 def mp_case(name):
     """a multi-rank case: no trace of its own (the ranks' threads interleave in it) - the structural checks are run_scenarios.py's"""
     def deco(fn):
@@ -447,6 +561,11 @@ def main(out_path):
                                   (1024, 128, 2, 2, (("ipc", 1),)), (1536, 128, 2, 4, (("ipc", 1), ("complete_inv", 1))), (2048, 128, 4, 4, ()), (1024, 128, 4, 4, (("ipc", 1),)),
                                   (1536, 128, 2, 4, (("strip", 1), ("depth2", 0))), (1152, 128, 4, 8, ())]:
         mp_case("dist2d n=%d nb=%d %dx%d %s" % (n, nb, Pr, Pc, dict(opts) or ""))(lambda r, e, a=(n, nb, Pr, Pc, opts): dist2d_compute(r, e, *a))
+    for (size, c, M, N, K, chunks) in [(1, 1, 256, 256, 256, 0), (4, 1, 512, 256, 384, 0), (8, 2, 300, 300, 300, 2), (9, 1, 300, 270, 330, 3), (27, 3, 270, 270, 270, 0),
+                                       (4, 1, 301, 200, 257, 2), (8, 2, 256, 128, 512, 4)]:
+        mp_case("summa gemm size=%d c=%d %dx%dx%d chunks=%d" % (size, c, M, N, K, chunks))(lambda r, e, a=(size, c, M, N, K, chunks): summa_compute(r, e, *a))
+    for (m, n, iters, P) in [(4096, 256, 2, 1), (8192, 256, 2, 4), (4096, 128, 2, 4), (4096, 64, 1, 2), (6144, 256, 2, 3), (2048, 96, 2, 8)]:
+        mp_case("cacqr m=%d n=%d iter=%d P=%d" % (m, n, iters, P))(lambda r, e, a=(m, n, iters, P): cacqr_compute(r, e, *a))
     json.dump({"results": RESULTS}, open(out_path, "w"), indent=1)
     bad = [x for x in RESULTS if x["findings"]]
     print("%d cases, %d with findings" % (len(RESULTS), len(bad)))
