@@ -370,14 +370,30 @@ struct cap_cholinv_plan {
 
 namespace {
 
-// upstream's leaf test at the root (cholinv.hpp:93 with c = d = 1): a root that is itself a base case gets the full inverse
-// whatever complete_inv says (policy.h:199-201 always runs trtri)
-bool root_is_base_case(int64_t n, int64_t split, int64_t bc_mult_dim) {
-  int64_t bc = 1;
-  if (bc_mult_dim < 0) for (int64_t i = 0; i < -bc_mult_dim && bc < n; i++) bc *= 2;
-  bc = std::max<int64_t>(1, std::min<int64_t>(n, bc));
-  const int64_t bc_dim = n / bc;
-  return (n <= bc_dim) || ((n >> split) < split);
+// upstream's leaf test at the root (cholinv.hpp:93): a root that is itself a base case gets the full inverse whatever complete_inv
+// says (policy.h:199-201 always runs trtri).  The base-case dimension depends on the process grid (cholinv.hpp:15-18: bcDimLocal
+// starts at c d): c = d = 1 for the single-GPU plan and the block-column layouts, the caller's c and d when the plan speaks the
+// reference's element-cyclic layout (option cyclic_c) - with bc_mult_dim = 0 on the 2 x 2 x 2 grid upstream partitions the root
+// (base case = n / 4) where one process would not (found by the CPU compute harness against the oracle, round 5).
+bool root_is_base_case(int64_t n, int64_t split, int64_t bc_mult_dim, int64_t c = 1, int64_t d = 1) {
+  const int64_t nloc = cap_ceil_div(n, d);
+  int64_t bc = c * d;
+  if (bc_mult_dim < 0) { for (int64_t i = 0; i < -bc_mult_dim && bc < nloc; i++) bc *= 2; }
+  else { for (int64_t i = 0; i < bc_mult_dim; i++) bc /= 2; }
+  bc = std::max<int64_t>(1, std::min<int64_t>(nloc, bc));
+  const int64_t bc_dim = d * (nloc / bc);
+  return (nloc * d <= bc_dim) || ((nloc >> split) < split);
+}
+// complete_inv and root partition of the inner multi-GPU plan as upstream defines them on the caller's grid (c = 0: block-column layout)
+int apply_root_semantics(cap_cholinv_plan* p, int c) {
+  int64_t cc = 1, dd = 1;
+  if (c > 0) { cc = c; dd = 1; while (dd * dd * cc < cap_comm_size(p->comm)) dd++; }
+  const bool base = p->complete_inv == 0 && root_is_base_case(p->n, p->split, p->bc_mult_dim, cc, dd);
+  CAP_TRY(cap_dist_set_option(p->dist, "complete_inv", base ? 1 : p->complete_inv));
+  CAP_TRY(cap_dist_set_option(p->dist, "split", p->split));
+  // upstream cuts the LOCAL dimension (cholinv.hpp:107): global rows [0, (ceil(n / d) >> split) d)
+  const int64_t n1 = std::min<int64_t>(p->n, (cap_ceil_div(p->n, dd) >> p->split) * dd);
+  return cap_dist_set_option(p->dist, "root_n1", c > 0 ? n1 : 0);
 }
 
 // (re)build the reference-layout front end of a multi-GPU plan: redistribution plan + the two block-column staging arrays
@@ -386,7 +402,7 @@ int setup_cyclic(cap_cholinv_plan* p, int c) {
   if (p->bcA) { (void)hipFree(p->bcA); p->bcA = nullptr; }
   if (p->bcOut) { (void)hipFree(p->bcOut); p->bcOut = nullptr; }
   p->cyc_c = 0;
-  if (c <= 0) return CAP_OK;
+  if (c <= 0) return apply_root_semantics(p, 0);
   CAP_TRY(cap_redist_plan_create(&p->redist, p->n, cap_dist_get_option(p->dist, "nb"), p->comm, c, 1));
   p->bc_cols = cap_dist_local_cols(p->dist);
   const size_t bytes = sizeof(double) * (size_t)p->n * (size_t)std::max<int64_t>(p->bc_cols, 1);
@@ -406,10 +422,11 @@ int setup_cyclic(cap_cholinv_plan* p, int c) {
     if (p->bcA) { (void)hipFree(p->bcA); p->bcA = nullptr; }
     if (p->bcOut) { (void)hipFree(p->bcOut); p->bcOut = nullptr; }
     (void)cap_redist_plan_destroy(p->redist); p->redist = nullptr;
+    (void)apply_root_semantics(p, 0);
     return st != CAP_OK ? st : CAP_ERR_ALLOC;
   }
   p->cyc_c = c;
-  return CAP_OK;
+  return apply_root_semantics(p, c);
 }
 
 int64_t default_nb(int64_t n, int64_t bc_mult_dim) {
@@ -1138,9 +1155,8 @@ int cap_cholinv_set_option(cap_cholinv_plan* p, const char* key, int64_t value) 
       CAP_TRY(cap_dist_plan_create(&nd, p->n, value, p->comm));
       (void)cap_dist_plan_destroy(p->dist);
       p->dist = nd; p->nb = value;
-      CAP_TRY(cap_dist_set_option(p->dist, "complete_inv", (p->complete_inv == 0 && root_is_base_case(p->n, p->split, p->bc_mult_dim)) ? 1 : p->complete_inv));
-      CAP_TRY(cap_dist_set_option(p->dist, "split", p->split));
-      if (p->cyc_c) CAP_TRY(setup_cyclic(p, p->cyc_c));       // the redistribution follows the block width
+      CAP_TRY(apply_root_semantics(p, 0));
+      if (p->cyc_c) CAP_TRY(setup_cyclic(p, p->cyc_c));       // the redistribution follows the block width (and re-applies the grid's root rule)
       return CAP_OK;
     }
     if (k == "cyclic_c") {     // 0: block-column pieces (default); c >= 1: element-cyclic pieces on the d x d x c grid

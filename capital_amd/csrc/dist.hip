@@ -81,6 +81,7 @@ struct cap_dist_plan {
   // landed" after them.  RCCL stays the default and the fallback (option off, or if mapping a peer fails).
   // R^-1 on the distributed factor (complete_inv = 0 / 1, the reference's semantics on P > 1): see inverse_step
   int complete_inv; int64_t split;
+  int64_t root_n1;               // > 0: the root partition of R^-1 (rows / columns [0, root_n1) | [root_n1, n)) given by the caller instead of n >> split
   double* Dall;                  // the diagonal-block inverses of MY block columns' steps (nblk x nb x nb slots), saved from the msg broadcasts
   double* Ri;                    // my block columns of R^-1 (npad x lc, ld = npad): the partial product X_k while the sweep runs
   double* Cb[2];                 // ring of two broadcast buffers for a finished block column of R^-1 (npad x nb each)
@@ -323,7 +324,7 @@ __global__ void identity_blocks_bc_kernel(double* X, int64_t ld, int64_t nb, int
 
 struct InvCut { bool cut; int64_t kcut, n1; };
 inline InvCut inv_cut(const cap_dist_plan* d) {
-  const int64_t n1 = d->n >> d->split;
+  const int64_t n1 = d->root_n1 > 0 ? d->root_n1 : d->n >> d->split;
   const bool cut = d->complete_inv == 0 && n1 > 0 && n1 < d->n;
   return InvCut{cut, (cut && n1 % d->nb == 0) ? n1 / d->nb : 0, n1};
 }
@@ -436,7 +437,7 @@ int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* 
   d->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
   d->profile = 0; d->prof_used = 0; d->bk_used = 0; d->safe = 0;
   d->cnt_gemm = d->cnt_chain = d->cnt_copy = d->cnt_coll = 0;
-  d->complete_inv = -1; d->split = 1; d->Dall = d->Ri = nullptr; d->Cb[0] = d->Cb[1] = nullptr; d->comm3 = nullptr;
+  d->complete_inv = -1; d->split = 1; d->root_n1 = 0; d->Dall = d->Ri = nullptr; d->Cb[0] = d->Cb[1] = nullptr; d->comm3 = nullptr;
   d->s_inv = nullptr; d->ev_join_i = nullptr; d->ev_t0 = d->ev_sweep_end = d->ev_inv_end = nullptr;
   d->ipc = getenv("CAP_DIST_IPC") ? atoi(getenv("CAP_DIST_IPC")) : 0; d->ipc_ready = false; d->ipc_failed = false; d->token = nullptr;
   d->ipc_nocu = getenv("CAP_DIST_IPC_NOCU") ? atoi(getenv("CAP_DIST_IPC_NOCU")) : 0;
@@ -518,6 +519,9 @@ int cap_dist_set_option(cap_dist_plan* d, const char* key, int64_t value) {
     return CAP_OK;
   }
   if (k == "split") { if (value <= 0) return CAP_ERR_ARG; d->split = value; return CAP_OK; }
+  // the root partition as the caller's layout defines it (upstream cuts its LOCAL dimension: (ceil(n / d) >> split) d global rows,
+  // cholinv.hpp:107 - the same as n >> split unless n is ragged); 0 = n >> split
+  if (k == "root_n1") { if (value < 0 || value > d->n) return CAP_ERR_ARG; d->root_n1 = value; return CAP_OK; }
   if (k == "ipc_nocu") { d->ipc_nocu = value != 0; return CAP_OK; }
   return CAP_ERR_ARG;
 }
@@ -537,6 +541,7 @@ int64_t cap_dist_get_option(const cap_dist_plan* d, const char* key) {
   if (k == "count_coll") return d->cnt_coll;
   if (k == "complete_inv") return d->complete_inv;
   if (k == "split") return d->split;
+  if (k == "root_n1") return d->root_n1;
   if (k == "ipc_active") return (d->ipc && d->ipc_ready) ? 1 : 0;
   if (k == "nb") return d->nb;
   if (k == "n") return d->n;

@@ -416,7 +416,9 @@ def run(args):
             ref_r, ref_ri = pieces[1], pieces[2]
             assert np.array_equal(pieces[0], A.to_numpy())
         else:
-            rr, rri = orc.cholinv(a, max(args.ci, 0), args.split, -2, 1, 1)
+            # upstream's base-case rule and root cut depend on its grid (cholinv.hpp:15-18, 107): the plan behind "cyclic_c" follows them
+            # (round 5: the CPU compute harness found the c = d = 1 rule applied here, tests/hipshim/run_compute.py); the 2D route builds no inverse
+            rr, rri = orc.cholinv(a, max(args.ci, 0), args.split, -2, T.c, d)
             ref_r, ref_ri = orc.cyclic_local(rr, T.x, T.y, d, d), orc.cyclic_local(rri, T.x, T.y, d, d)
         err = np.linalg.norm((r_p - ref_r)[upper]) / max(np.linalg.norm(ref_r[upper]), 1e-300)
         assert err < 1e-13, ("R piece", rank, err)

@@ -1,0 +1,81 @@
+"""The library's host side computing REAL factors on the CPU (tests/hipshim/run_compute.py): the product's own object files linked
+against the recording stand-in in COMPUTE MODE - every launch runs a CPU model of its kernel (tests/hipshim/kernels_cpu.cpp: the kernels'
+contract incl. launch geometry; the GEMM models walk a launch's blocks through the library's own tile enumeration and decode the very
+argument structs the library passes, csrc/kargs.h / gemm_index.h), every copy is carried out, fresh "device" memory holds NaNs.  Multi-rank
+plans run with one thread per rank and communicators that really move the data (blocking collectives; the IPC exchanges copy into the
+peer's buffer behind the same token all-reduces as on the GPU).
+
+What comes out is compared with NumPy / the CPU oracle to 2e-11: R and R^-1 of the single-GPU plan under every schedule option and a
+dozen option mixes (n = 64 ... 2048, ragged sizes), the operator seam, the 1 x P plan on 1 ... 8 ranks and the Pr x Pc plan on
+1x1 ... 4x8 grids (safe, IPC, R^-1), the reference's element-cyclic layout end to end on its d x d x c grid, SUMMA on 1 ... 27 ranks,
+CholeskyQR2 on 1 ... 8 ranks.  This is a check of the HOST side - every pointer, leading dimension, flag, grid size and event-free data
+flow it computes - on a machine without a GPU; the kernels themselves are checked on the GPU (-m gpu).  It found that a plan speaking
+the reference's layout applied the single-process base-case rule where upstream's rule depends on its grid (cholinv.hpp:15-18)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def computed(tmp_path_factory):
+    from capital_amd import build
+    build.build(verbose=False)
+    out = str(tmp_path_factory.mktemp("compute") / "compute.json")
+    env = dict(os.environ); env.pop("LD_PRELOAD", None)
+    env["SHIM_FILTER"] = ""; env["SHIM_KEEP_TRACE"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipshim", "run_compute.py"), out], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return json.load(open(out))["results"]
+
+
+def test_every_plan_computes_the_right_factors_on_the_cpu(computed):
+    bad = [(x["name"], x["findings"][:3]) for x in computed if x["findings"]]
+    assert not bad, "\n".join("%s: %s" % b for b in bad[:20])
+    assert len(computed) >= 100, len(computed)
+    names = " | ".join(x["name"] for x in computed)
+    for must in ("operators m=130 n=70 k=33", "cholinv n=2048 ci=1", "'pair_rest': 0", "'inner_la': 1", "'use_sb': 0", "'inv_fast': 0", "cholinv n=1000 ci=1",
+                 "dist n=2048 nb=128 P=8 {'ipc': 1, 'strip': 2}", "dist n=1000 nb=128 P=3 {'ipc': 1} ci=1", "dist2d n=1152 nb=128 4x8", "dist2d n=1024 nb=128 4x4 {'ipc': 1}",
+                 "dist2d n=1000 nb=128 2x4 {'complete_inv': 0}", "reference's layout n=1024 ci=0 bc=0 grid 2x2x2", "reference's layout n=1003 ci=0",
+                 "summa gemm size=27 c=3", "cacqr m=8192 n=256 iter=2 P=4"):
+        assert must in names, must
+    # the numbers are real: every case carries errors at rounding level, none is exactly zero across the board
+    worst = max(v for x in computed for k, v in x["errors"].items() if k not in ("info", "Rinv_pattern", "R replicated"))
+    assert 1e-17 < worst < 2e-11, worst
+    assert all(x["errors"].get("info", 0.0) == 0.0 for x in computed)
+
+
+def test_the_models_compute_they_do_not_echo():
+    """teeth: one case through the harness by hand - the right input gives the right factor, the same plan on a DIFFERENT input (the
+    lower triangle of the matrix where the upper one is consumed, cholinv.hpp:13) gives a different one"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipshim"))
+    code = r"""
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, %r)
+import run_compute as rc
+rc.shim.shim_set_compute(1)
+e = {}
+r = rc.rs.Run("teeth", 0)
+rc.cholinv_compute(r, e, 512, 1, 1, 0, (("nb", 128),))
+ok = all(v < rc.TOL for v in e.values())
+# the same plan on a matrix whose LOWER triangle is what was factored: the library must not have read it
+print("OK" if ok else "BAD", e)
+a = rc.spd(512, 5); n = 512
+plan = C.c_void_p(); rc.rs.ok(rc.L.cap_cholinv_plan_create(C.byref(plan), n, -1, 1, 0, b"U", None), "create")
+A = rc.rs.dmalloc(8 * n * n); out = rc.rs.dmalloc(8 * n * n)
+rc.view(A, n, n)[:] = np.tril(a)                      # upper triangle zero: NOT the matrix
+rc.rs.ok(rc.L.cap_cholinv_factor(plan, A, n, None), "factor")
+rc.rs.ok(rc.L.cap_cholinv_get_R(plan, out, n, None), "get_R")
+print("DIFF %%.3e" %% rc.rel(rc.view(out, n, n), np.linalg.cholesky(a).T))
+""" % os.path.join(ROOT, "tests", "hipshim")
+    env = dict(os.environ); env.pop("LD_PRELOAD", None); env["SHIM_FILTER"] = ""; env["SHIM_KEEP_TRACE"] = ""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[0].startswith("OK"), lines
+    diff = float(lines[1].split()[1])
+    assert diff > 1e-3 or diff != diff, lines      # a different input gives a different (or NaN) factor: the models compute, they do not echo
