@@ -293,7 +293,10 @@ int cap_redistribute_bc_to_cyclic(cap_redist_plan* plan, const double* bc_local,
  * REFERENCE's layout end to end - factor's A is this rank's element-cyclic piece (ceil(n/d) x ceil(n/d), matrix.hpp:8-11),
  * get_R / get_Rinv write this rank's piece of R / R^-1 (what construct_R / construct_Rinv return on every rank of every layer,
  * cholinv.hpp:30-46; zero below the GLOBAL diagonal, i.e. already util::remove_triangle'd) - through the distributed
- * redistribution of cap_redistribute_* (one all-to-all each way).  get "piece" = the piece edge.                          */
+ * redistribution of cap_redistribute_* (one all-to-all each way).  get "piece" = the piece edge.  With it the knobs mean what they
+ * mean upstream ON THAT GRID: the base-case dimension starts at c d (cholinv.hpp:15-18: with complete_inv = 0 and bc_mult_dim = 0 the
+ * 2 x 2 x 2 grid partitions the root and leaves its block of R^-1 empty where one process would invert the whole base case), and
+ * the root partition is taken on the local dimension, (ceil(n / d) >> split) d rows (cholinv.hpp:107).                          */
 typedef struct cap_cholinv_plan cap_cholinv_plan;
 int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv, int64_t split,
                             int64_t bc_mult_dim, char dir, cap_comm* comm);
@@ -384,7 +387,9 @@ int cap_dist_info(cap_dist_plan* plan, void* stream, int64_t* info);
 /* knobs: "strip" (block rows per bulk update, 1|2), "depth2" (split bulk updates), "occ1_m" (bulk updates of at most
  * occ1_m^2 rows x local columns run one workgroup per CU), "profile", "safe" (one communicator + one communication
  * stream), "ipc" (strip exchange as IPC peer copies; get "ipc_active" tells whether the peers could be mapped),
- * "complete_inv" / "split" (R^-1, see cap_dist_get_Rinv), "jitter_us" / "jitter_seed" (stress testing: random spin kernels in
+ * "complete_inv" / "split" (R^-1, see cap_dist_get_Rinv), "root_n1" (the root partition given explicitly instead of n >> split:
+ * upstream cuts its LOCAL dimension, (ceil(n / d) >> split) d global rows on a d x d x c grid, cholinv.hpp:107 - a cholinv plan
+ * with "cyclic_c" sets it, together with the grid's base-case rule cholinv.hpp:15-18; 0 = n >> split), "jitter_us" / "jitter_seed" (stress testing: random spin kernels in
  * front of every launch group); get only: "count_gemm" / "count_chain" / "count_copy" / "count_coll" = launches and
  * collectives of the last factor call on this rank.                                                                     */
 int cap_dist_set_option(cap_dist_plan* plan, const char* key, int64_t value);
