@@ -24,8 +24,8 @@ def build():
     if os.path.exists(LIB) and os.path.exists(SHIM) and min(os.path.getmtime(LIB), os.path.getmtime(SHIM)) > newest:
         return LIB, SHIM
     cpu_o = os.path.join(OUT, "kernels_cpu.o")
-    subprocess.check_call(["g++", "-std=c++17", "-O3", "-march=native", "-fPIC", "-Wall", "-Wno-unused-function", "-I" + csrc, "-c", cpu, "-o", cpu_o])
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", SHIM, src, cpu_o])
+    subprocess.check_call(["g++", "-std=c++17", "-O3", "-march=native", "-fopenmp", "-fPIC", "-Wall", "-Wno-unused-function", "-I" + csrc, "-c", cpu, "-o", cpu_o])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-fopenmp", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", SHIM, src, cpu_o])
     subprocess.check_call(["g++", "-shared", "-fPIC", "-o", LIB] + objs + ["-L" + OUT, "-lhipshim", "-Wl,-rpath," + OUT, "-Wl,--no-undefined", "-ldl", "-lpthread"])
     return LIB, SHIM
 

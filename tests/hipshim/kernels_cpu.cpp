@@ -51,12 +51,26 @@ struct Acc { std::vector<double> v; int m, n; Acc(int m_, int n_) : v((size_t)m_
 // acc[i][j] += sum_{k in [k0, k1)} a(i, k) b(k, j): a / b given by base pointer + two strides (row/outer stride, k stride)
 void mma(Acc& c, int i0, int i1, int j0, int j1, const double* A, int64_t as_o, int64_t as_k, const double* B, int64_t bs_o, int64_t bs_k, int64_t k0, int64_t k1) {
   if (k1 <= k0) return;
+  if (as_o == 1) {                                     // rows contiguous (op(A) = A): one axpy per (k, j)
+    for (int j = j0; j < j1; j++) {
+      double* cj = &c.at(0, j);
+      for (int64_t k = k0; k < k1; k++) {
+        const double b = B[j * bs_o + k * bs_k]; const double* ak = A + k * as_k;
+#pragma omp simd
+        for (int i = i0; i < i1; i++) cj[i] += ak[i] * b;
+      }
+    }
+    return;
+  }
   for (int j = j0; j < j1; j++) {
     const double* bj = B + j * bs_o;
     for (int i = i0; i < i1; i++) {
       const double* ai = A + i * as_o;
       double s = 0.0;
-      if (as_k == 1 && bs_k == 1) { for (int64_t k = k0; k < k1; k++) s += ai[k] * bj[k]; }
+      if (as_k == 1 && bs_k == 1) {
+#pragma omp simd reduction(+ : s)
+        for (int64_t k = k0; k < k1; k++) s += ai[k] * bj[k];
+      }
       else { for (int64_t k = k0; k < k1; k++) s += ai[k * as_k] * bj[k * bs_k]; }
       c.at(i, j) += s;
     }
@@ -69,6 +83,7 @@ constexpr int TB = 128, TK = 16;
 void k_dgemm(const std::string& name, void** a, unsigned gx, unsigned gy) {
   const GemmArgs g = arg<GemmArgs>(a, 0);
   const bool akc = tmpl(name, 0), bkc = tmpl(name, 1);
+#pragma omp parallel for collapse(2) schedule(dynamic)
   for (unsigned kz = 0; kz < gy; kz++)
     for (unsigned bx = 0; bx < gx; bx++) {
       const int b = (int)((bx + kz) % gx), L = (b & 7) * g.chunk + (b >> 3);
@@ -97,6 +112,7 @@ void k_dgemm(const std::string& name, void** a, unsigned gx, unsigned gy) {
 void k_dgemm_dma(const std::string& name, void** a, unsigned gx, unsigned gy) {
   const GemmArgs g = arg<GemmArgs>(a, 0);
   const bool amc = tmpl(name, 1), skip = tmpl(name, 4);
+#pragma omp parallel for collapse(2) schedule(dynamic)
   for (unsigned kz = 0; kz < gy; kz++)
     for (unsigned bx = 0; bx < gx; bx++) {
       const int b = (int)((bx + kz) % gx), L = (b & 7) * g.chunk + (b >> 3);
@@ -171,15 +187,32 @@ void k_dgemm_small(const std::string& name, void** a, unsigned gx, unsigned gy, 
 
 void k_skinny(void** a, bool tn, unsigned gx) {
   const SkinnyArgs g = arg<SkinnyArgs>(a, 0);
-  const int64_t rows = tn ? std::min<int64_t>(g.M, (int64_t)gx * 64) : std::min<int64_t>(g.M, (int64_t)gx * 64);
-  for (int c = 0; c < g.N; c++)
-    for (int64_t r = 0; r < rows; r++) {
-      double s = 0.0;
-      if (tn) for (int64_t k = 0; k < g.K; k++) s += g.A[k + r * g.lda] * g.B[k + (int64_t)c * g.ldb];
-      else for (int64_t k = 0; k < g.K; k++) s += g.A[r + k * g.lda] * g.B[k + (int64_t)c * g.ldb];
-      double* pc = g.C + r + (int64_t)c * g.ldc;
-      *pc = g.beta != 0.0 ? g.alpha * s + g.beta * (*pc) : g.alpha * s;
+  const int64_t rows = std::min<int64_t>(g.M, (int64_t)gx * 64);
+  if (tn) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; r++)
+      for (int c = 0; c < g.N; c++) {
+        const double* x = g.A + r * g.lda; const double* y = g.B + (int64_t)c * g.ldb;
+        double s = 0.0;
+#pragma omp simd reduction(+ : s)
+        for (int64_t k = 0; k < g.K; k++) s += x[k] * y[k];
+        double* pc = g.C + r + (int64_t)c * g.ldc;
+        *pc = g.beta != 0.0 ? g.alpha * s + g.beta * (*pc) : g.alpha * s;
+      }
+    return;
+  }
+  const int64_t RB = 512;                                   // row blocks: the operand is streamed once, M-contiguous
+#pragma omp parallel for schedule(static)
+  for (int64_t r0 = 0; r0 < rows; r0 += RB) {
+    const int64_t nr = std::min(RB, rows - r0);
+    std::vector<double> acc((size_t)nr * g.N, 0.0);
+    for (int64_t k = 0; k < g.K; k++) {
+      const double* col = g.A + r0 + k * g.lda;
+      for (int c = 0; c < g.N; c++) { const double b = g.B[k + (int64_t)c * g.ldb]; double* ac = acc.data() + (size_t)c * nr; for (int64_t r = 0; r < nr; r++) ac[r] += col[r] * b; }
     }
+    for (int c = 0; c < g.N; c++)
+      for (int64_t r = 0; r < nr; r++) { double* pc = g.C + r0 + r + (int64_t)c * g.ldc; const double v = g.alpha * acc[(size_t)c * nr + r]; *pc = g.beta != 0.0 ? v + g.beta * (*pc) : v; }
+  }
 }
 
 void k_scale(void** a, unsigned gy) {
@@ -549,10 +582,152 @@ void k_qrapply256(void** a) {
   for (int c = 0; c < 256; c++) memcpy(g.Qout + (int64_t)c * g.ldout, out.data() + (size_t)c * m, (size_t)m * 8);
 }
 
+
+// ------------------------------------------------------------------------------------------ mixed precision (mixed.hip, mixed_kernels.h, dist_mixed.hip)
+typedef unsigned short bf16_t;
+float bf2f(bf16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+bf16_t f2bf(float f) {                                   // round to nearest even, as the device cast does
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);     // NaN stays NaN
+  const uint32_t r = 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)((u + r) >> 16);
+}
+void k_f64_to_f32_upper(void** a) {
+  const double* A = arg<const double*>(a, 0); const int64_t lda = arg<int64_t>(a, 1); float* R = arg<float*>(a, 2); const int64_t ldr = arg<int64_t>(a, 3), n = arg<int64_t>(a, 4);
+  for (int64_t c = 0; c < n; c++) for (int64_t r = 0; r <= c; r++) R[r + c * ldr] = (float)A[r + c * lda];
+}
+void k_f32_to_f64(void** a) {
+  const float* S = arg<const float*>(a, 0); const int64_t lds = arg<int64_t>(a, 1); double* D = arg<double*>(a, 2); const int64_t ldd = arg<int64_t>(a, 3), rows = arg<int64_t>(a, 4),
+          cols = arg<int64_t>(a, 5); const int up = arg<int>(a, 6);
+  for (int64_t c = 0; c < cols; c++) for (int64_t r = 0; r < rows; r++) D[r + c * ldd] = (!up || r <= c) ? (double)S[r + c * lds] : 0.0;
+}
+void k_f64_to_f32_bf16(void** a) {
+  const double* S = arg<const double*>(a, 0); const int64_t lds = arg<int64_t>(a, 1); float* R = arg<float*>(a, 2); const int64_t ldr = arg<int64_t>(a, 3);
+  bf16_t* P = arg<bf16_t*>(a, 4); const int64_t ldp = arg<int64_t>(a, 5), rows = arg<int64_t>(a, 6), cols = arg<int64_t>(a, 7); const int up = arg<int>(a, 8);
+  for (int64_t c = 0; c < cols; c++) for (int64_t r = 0; r < rows; r++) {
+    const double v = (!up || r <= c) ? S[r + c * lds] : 0.0;
+    R[r + c * ldr] = (float)v;
+    if (P) P[r + c * ldp] = f2bf((float)v);
+  }
+}
+void bf_split(float x, bf16_t& hi, bf16_t& lo) { hi = f2bf(x); lo = f2bf(x - bf2f(hi)); }
+void k_split3_row(void** a) {
+  float* S = arg<float*>(a, 0); const int64_t lds = arg<int64_t>(a, 1); bf16_t* B3 = arg<bf16_t*>(a, 2); const int64_t rows = arg<int64_t>(a, 3), cols = arg<int64_t>(a, 4); const int z = arg<int>(a, 5);
+  for (int64_t c = 0; c < cols; c++) { bf16_t* out = B3 + c * 3 * rows; for (int64_t r = 0; r < rows; r++) { bf16_t hi, lo; bf_split(S[r + c * lds], hi, lo); out[r] = hi; out[rows + r] = lo; out[2 * rows + r] = hi; if (z) S[r + c * lds] = 0.0f; } }
+}
+void k_split3_tri(void** a) {
+  const double* D = arg<const double*>(a, 0); const int64_t ldd = arg<int64_t>(a, 1); bf16_t* A3 = arg<bf16_t*>(a, 2); const int64_t n = arg<int64_t>(a, 3);
+  for (int64_t c = 0; c < n; c++) { bf16_t* out = A3 + c * 3 * n; for (int64_t r = 0; r < n; r++) { bf16_t hi, lo; bf_split(r <= c ? (float)D[r + c * ldd] : 0.0f, hi, lo); out[r] = hi; out[n + r] = hi; out[2 * n + r] = lo; } }
+}
+void k_f32_to_bf16(void** a) {
+  const float* S = arg<const float*>(a, 0); const int64_t lds = arg<int64_t>(a, 1); bf16_t* P = arg<bf16_t*>(a, 2); const int64_t ldp = arg<int64_t>(a, 3), rows = arg<int64_t>(a, 4), cols = arg<int64_t>(a, 5);
+  for (int64_t c = 0; c < cols; c++) for (int64_t r = 0; r < rows; r++) P[r + c * ldp] = f2bf(S[r + c * lds]);
+}
+void k_axpy_cols(void** a, unsigned gy) {
+  double* X = arg<double*>(a, 0); const int64_t ldx = arg<int64_t>(a, 1); const double* D = arg<const double*>(a, 2); const int64_t ldd = arg<int64_t>(a, 3), rows = arg<int64_t>(a, 4);
+  for (int64_t c = 0; c < gy; c++) for (int64_t r = 0; r < rows; r++) X[r + c * ldx] += D[r + c * ldd];
+}
+void k_import_f32_bc(void** a) {
+  const double* A = arg<const double*>(a, 0); const int64_t lda = arg<int64_t>(a, 1); float* R = arg<float*>(a, 2); const int64_t ld = arg<int64_t>(a, 3), n = arg<int64_t>(a, 4), npad = arg<int64_t>(a, 5),
+          nb = arg<int64_t>(a, 6); const int P = arg<int>(a, 7), p = arg<int>(a, 8); const int64_t lc = arg<int64_t>(a, 9);
+  for (int64_t l = 0; l < lc; l++) { const int64_t g = ((l / nb) * P + p) * nb + l % nb; for (int64_t r = 0; r < npad; r++) R[r + l * ld] = (r < n && g < n) ? (float)A[r + l * lda] : (r == g ? 1.0f : 0.0f); }
+}
+void k_sub_from(void** a, unsigned gy) {
+  double* T = arg<double*>(a, 0); const int64_t ldt = arg<int64_t>(a, 1); const double* V = arg<const double*>(a, 2); const int64_t ldv = arg<int64_t>(a, 3), rows = arg<int64_t>(a, 4), cols = arg<int64_t>(a, 5);
+  for (int64_t c = 0; c < std::min<int64_t>(cols, gy); c++) for (int64_t r = 0; r < rows; r++) T[r + c * ldt] = V[r + c * ldv] - T[r + c * ldt];
+}
+void k_scatter_rows_bc(void** a, unsigned gy) {
+  const double* Q = arg<const double*>(a, 0); const int64_t ldq = arg<int64_t>(a, 1); double* Out = arg<double*>(a, 2); const int64_t ldo = arg<int64_t>(a, 3), nb = arg<int64_t>(a, 4);
+  const int P = arg<int>(a, 5), p = arg<int>(a, 6); const int64_t lc = arg<int64_t>(a, 7), cols = arg<int64_t>(a, 8);
+  for (int64_t c = 0; c < std::min<int64_t>(cols, gy); c++) for (int64_t l = 0; l < lc; l++) Out[((l / nb) * P + p) * nb + l % nb + c * ldo] = Q[l + c * ldq];
+}
+// bf16_tn_kernel: C (fp32) += alpha A^T B on 128 x 128 tiles, the launch's blocks walked as the kernel walks them
+void k_bf16_tn(void** a, unsigned gx) {
+  const BfArgs g = arg<BfArgs>(a, 0);
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A); const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+  struct Tile { int ti, tj, gtj; const bf16_t* Abase; };
+  std::vector<Tile> tiles;
+  for (unsigned b = 0; b < gx; b++) {
+    const int L = (b & 7) * g.chunk + (b >> 3);
+    int ti, tj;
+    if ((int)(b >> 3) >= g.chunk) continue;
+    if (!g.stair && g.st > 0) {
+      const int per = g.st * g.st, sl = L / per, q = L - sl * per;
+      int si, sj;
+      if (g.tri && g.tm == g.tn) {
+        sj = (int)((sqrtf(8.0f * (float)sl + 1.0f) - 1.0f) * 0.5f);
+        while ((sj + 1) * (sj + 2) / 2 <= sl) sj++;
+        while (sj * (sj + 1) / 2 > sl) sj--;
+        si = sl - sj * (sj + 1) / 2;
+      } else { si = sl % g.nsm; sj = sl / g.nsm; }
+      ti = si * g.st + q % g.st; tj = sj * g.st + q / g.st;
+      if (ti >= g.tm || tj >= g.tn || (g.tri && ti > tj)) continue;
+    } else if (!g.stair && g.tri && g.tm == g.tn) {
+      tj = (int)((sqrtf(8.0f * (float)L + 1.0f) - 1.0f) * 0.5f);
+      while ((tj + 1) * (tj + 2) / 2 <= L) tj++;
+      while (tj * (tj + 1) / 2 > L) tj--;
+      ti = L - tj * (tj + 1) / 2;
+      if (tj >= g.tn) continue;
+    } else {
+      ti = L % g.tm; tj = L / g.tm;
+      if (tj >= g.tn) continue;
+      if (!g.stair && g.tri && ti > tj) continue;
+    }
+    int gtj = tj;
+    const bf16_t* Abase = A + (int64_t)ti * 128 * g.lda;
+    if (g.stair) {
+      const int J = g.sp + g.sP * (g.slb0 + tj / g.snbT);
+      gtj = (J - g.sJ0) * g.snbT + tj % g.snbT;
+      if (ti > gtj) continue;
+      const int I = g.sJ0 + ti / g.snbT, r = I % g.sP, lb = I / g.sP - g.gstart[r];
+      Abase = A + (int64_t)r * g.gpiece + ((int64_t)(lb * g.snbT + ti % g.snbT) * 128) * g.lda;
+    }
+    tiles.push_back(Tile{ti, tj, gtj, Abase});
+  }
+  const int64_t K = (g.K / 64) * 64;
+#pragma omp parallel for schedule(dynamic)
+  for (size_t t = 0; t < tiles.size(); t++) {          // (every tile of a launch has one writer)
+    const int ti = tiles[t].ti, tj = tiles[t].tj, gtj = tiles[t].gtj; const bf16_t* Abase = tiles[t].Abase;
+    std::vector<float> fa((size_t)128 * K), fb((size_t)128 * K);
+    const int64_t i0 = (int64_t)ti * 128, j0 = (int64_t)tj * 128;
+    for (int i = 0; i < 128; i++) for (int64_t k = 0; k < K; k++) fa[(size_t)i * K + k] = bf2f(Abase[(int64_t)i * g.lda + k]);
+    for (int j = 0; j < 128; j++) for (int64_t k = 0; k < K; k++) fb[(size_t)j * K + k] = bf2f(B[(j0 + j) * g.ldb + k]);
+    const bool diag = g.stair ? (ti == gtj) : (g.tri && ti == tj);
+    for (int j = 0; j < 128; j++)
+      for (int i = 0; i < 128; i++) {
+        if (diag && i > j) continue;
+        const float* x = fa.data() + (size_t)i * K; const float* y = fb.data() + (size_t)j * K;
+        float s = 0.0f;
+#pragma omp simd reduction(+ : s)
+        for (int64_t k = 0; k < K; k++) s += x[k] * y[k];
+        g.C[i0 + i + (j0 + j) * g.ldc] += g.alpha * s;
+      }
+  }
+}
+
 }  // namespace
 
+static int dispatch(const char* mangled, void** args, unsigned gx, unsigned gy, unsigned gz, unsigned bx);
+// SHIM_PROFILE=1: seconds per kernel model, printed when the process ends
+#include <chrono>
+#include <map>
+#include <mutex>
+static std::map<std::string, std::pair<double, long>>* prof = nullptr;
+static std::mutex prof_mu;
+static void prof_dump() { if (!prof) return; for (auto& kv : *prof) if (kv.second.first > 0.05) fprintf(stderr, "[shim profile] %8.2f s %7ld x %s\n", kv.second.first, kv.second.second, kv.first.substr(0, 90).c_str()); }
 // -> 1: modelled and executed; 0: no model for this kernel (the caller reports it)
 extern "C" int shim_cpu_kernel(const char* mangled, void** args, unsigned gx, unsigned gy, unsigned gz, unsigned bx) {
+  static const bool on = getenv("SHIM_PROFILE") != nullptr;
+  if (!on) return dispatch(mangled, args, gx, gy, gz, bx);
+  const auto t0 = std::chrono::steady_clock::now();
+  const int r = dispatch(mangled, args, gx, gy, gz, bx);
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::lock_guard<std::mutex> lk(prof_mu);
+  if (!prof) { prof = new std::map<std::string, std::pair<double, long>>(); atexit(prof_dump); }
+  auto& e = (*prof)[mangled]; e.first += dt; e.second++;
+  return r;
+}
+static int dispatch(const char* mangled, void** args, unsigned gx, unsigned gy, unsigned gz, unsigned bx) {
   const std::string n(mangled);
   auto has = [&](const char* s) { return n.find(s) != std::string::npos; };
   if (has("dgemm_tn_dma_kernel")) { k_dgemm_dma(n, args, gx, gy); return 1; }
@@ -576,6 +751,17 @@ extern "C" int shim_cpu_kernel(const char* mangled, void** args, unsigned gx, un
   if (has("trinv_merge_kernel")) { k_trinv_merge(n, args, gy); return 1; }
   if (has("chain64_coop_kernel")) { k_chain64(args); return 1; }
   if (has("spin_kernel")) return 1;
+  if (has("f64_to_f32_upper_kernel")) { k_f64_to_f32_upper(args); return 1; }
+  if (has("f64_to_f32_bf16_kernel")) { k_f64_to_f32_bf16(args); return 1; }
+  if (has("f32_to_f64_kernel")) { k_f32_to_f64(args); return 1; }
+  if (has("split3_row_kernel")) { k_split3_row(args); return 1; }
+  if (has("split3_tri_kernel")) { k_split3_tri(args); return 1; }
+  if (has("f32_to_bf16_kernel")) { k_f32_to_bf16(args); return 1; }
+  if (has("axpy_cols_kernel")) { k_axpy_cols(args, gy); return 1; }
+  if (has("import_f32_bc_kernel")) { k_import_f32_bc(args); return 1; }
+  if (has("sub_from_kernel")) { k_sub_from(args, gy); return 1; }
+  if (has("scatter_rows_bc_kernel")) { k_scatter_rows_bc(args, gy); return 1; }
+  if (has("bf16_tn_kernel")) { k_bf16_tn(args, gx); return 1; }
   if (has("fill_symmetric_bc2d_kernel")) { k_fill_symmetric_bc2d(args); return 1; }
   if (has("fill_symmetric_bc_kernel")) { k_fill_symmetric_bc(args); return 1; }
   if (has("pad_identity_kernel")) { k_pad_identity(args); return 1; }

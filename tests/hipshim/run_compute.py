@@ -548,6 +548,71 @@ def cholinv_cyclic_compute(r_unused, errors, n, ci, c, d, bc=-2, nb=128, seed=0,
         errors["Rinv pieces"] = eRi
 
 
+def mixed_compute(r, errors, n, nrhs, opts=(), seed=4, reps=1):
+    """bf16 factorization + fp64 refinement on one GPU (mixed.hip): a low-precision factor, a solution to fp64 accuracy"""
+    a = spd(n, seed); rng = np.random.default_rng(seed + 1); b = rng.standard_normal((n, nrhs))
+    plan = C.c_void_p()
+    rs.ok(L.cap_mpchol_plan_create(C.byref(plan), n, nrhs), "cap_mpchol_plan_create")
+    for k, v in opts:
+        rs.ok(L.cap_mpchol_set_option(plan, k.encode(), v), "mpchol set_option " + k)
+    A = rs.dmalloc(8 * n * n); B = rs.dmalloc(8 * n * nrhs); X = rs.dmalloc(8 * n * nrhs)
+    view(A, n, n)[:] = a; view(B, n, nrhs)[:] = b
+    info = C.c_int64(-1); it = C.c_int(0); rr = C.c_double(0)
+    for _ in range(reps):
+        rs.ok(r.call("mpchol_factor", L.cap_mpchol_factor, plan, A, n, r.stream), "cap_mpchol_factor")
+    r.call("mpchol_info", L.cap_mpchol_info, plan, r.stream, C.byref(info))
+    rs.ok(r.call("mpchol_solve", L.cap_mpchol_solve, plan, A, n, B, n, X, n, nrhs, 30, 1e-15, C.byref(it), C.byref(rr), r.stream), "cap_mpchol_solve")
+    x = view(X, n, nrhs).copy()
+    ld = C.c_int64(0)
+    L.cap_mpchol_R32_ptr.restype = C.c_void_p
+    rp = L.cap_mpchol_R32_ptr(plan, C.byref(ld))
+    r32 = np.ctypeslib.as_array((C.c_float * (ld.value * n)).from_address(rp)).reshape((n, ld.value)).T[:n]
+    e32 = rel(np.triu(r32.astype(np.float64)), np.linalg.cholesky(a).T)
+    errors["info"] = float(abs(info.value))
+    errors["factor is a bf16-update factor (1e-6 < err < 5e-2)"] = 0.0 if 1e-6 < e32 < 5e-2 else e32 + 1.0
+    errors["sweeps within 1..25"] = 0.0 if 1 <= it.value <= 25 else float(it.value) + 1.0
+    errors["B - A X (scaled to the tolerance)"] = float(np.linalg.norm(a @ x - b) / np.linalg.norm(b)) * 1e-3      # <= 2e-14 passes the 2e-11 gate
+    errors["X vs fp64 solve (scaled)"] = rel(x, np.linalg.solve(a, b)) * 1e-2
+    rs.ok(L.cap_mpchol_plan_destroy(plan), "cap_mpchol_plan_destroy")
+    for q in (A, B, X):
+        shim.hipFree(q)
+
+
+def dmp_compute(r_unused, errors, n, nb, P, nrhs=5, seed=6, uid=[0]):
+    """the same on P ranks (dist_mixed.hip): block columns of A per rank, B and X replicated"""
+    uid[0] += 1
+    a = spd(n, seed); rng = np.random.default_rng(seed + 1); b = rng.standard_normal((n, nrhs))
+
+    def rank(p):
+        comm = TComm(p, P, "dmp%d" % uid[0])
+        plan = C.c_void_p()
+        rs.ok(L.cap_dmp_plan_create(C.byref(plan), n, nb, nrhs, comm.handle), "cap_dmp_plan_create")
+        cols = bc_indices(n, nb, P, p); lc = len(cols)
+        assert lc == int(L.cap_dmp_local_cols(plan))
+        A = rs.dmalloc(8 * n * max(lc, 1)); B = rs.dmalloc(8 * n * nrhs); X = rs.dmalloc(8 * n * nrhs)
+        if lc:
+            view(A, n, lc)[:] = a[:, cols]
+        view(B, n, nrhs)[:] = b
+        info = C.c_int64(-1); it = C.c_int(0); rr = C.c_double(0)
+        for _ in range(2):
+            rs.ok(L.cap_dmp_factor(plan, A, n, None), "cap_dmp_factor")
+        L.cap_dmp_info(plan, None, C.byref(info))
+        rs.ok(L.cap_dmp_solve(plan, A, n, B, n, X, n, nrhs, 30, 1e-15, C.byref(it), C.byref(rr), None), "cap_dmp_solve")
+        x = view(X, n, nrhs).copy()
+        rs.ok(L.cap_dmp_plan_destroy(plan), "cap_dmp_plan_destroy")
+        comm.close()
+        for q in (A, B, X):
+            shim.hipFree(q)
+        return x, it.value, info.value
+    res = run_ranks(P, rank)
+    x = res[0][0]
+    errors["info"] = float(max(abs(v[2]) for v in res))
+    errors["every rank ends with the same X"] = max(rel(v[0], x) for v in res)
+    errors["sweeps within 1..25"] = 0.0 if all(1 <= v[1] <= 25 for v in res) else 99.0
+    errors["B - A X (scaled to the tolerance)"] = float(np.linalg.norm(a @ x - b) / np.linalg.norm(b)) * 1e-3
+    errors["X vs fp64 solve (scaled)"] = rel(x, np.linalg.solve(a, b)) * 1e-2
+
+
 def mp_case(name):
     """a multi-rank case: no trace of its own (the ranks' threads interleave in it) - the structural checks are run_scenarios.py's"""
     def deco(fn):
@@ -615,6 +680,15 @@ def main(out_path):
     for (n, ci, c, d, bc) in [(1024, 1, 2, 2, -2), (1000, 1, 2, 2, -2), (1024, 0, 1, 2, -2), (1024, 0, 2, 2, 0), (768, -1, 2, 1, -2), (1536, 0, 2, 2, -3),
                               (1003, 0, 2, 2, -2), (1001, 0, 1, 2, -3), (515, 1, 2, 2, -1)]:      # ragged: upstream cuts the LOCAL dimension
         mp_case("cholinv over the reference's layout n=%d ci=%d bc=%d grid %dx%dx%d" % (n, ci, bc, d, d, c))(lambda r, e, a=(n, ci, c, d, bc): cholinv_cyclic_compute(r, e, *a))
+    # (the single-GPU plan's panel width is 1024 = K of its bf16 updates: at least 3 panels for an update to happen, 8 for the paired far update)
+    # (N = 8192, where the paired far update starts, takes a minute on 8 host cores: SHIM_BIG=1)
+    big = [(8192, 8, ()), (6144, 5, (("pair_rest", 0),))] if os.environ.get("SHIM_BIG") else []
+    for (n, nrhs, opts) in [(4096, 8, ()), (4096, 8, (("strip", 1),)), (4096, 8, (("split", 0),)), (4096, 8, (("solve3", 0),)), (3072, 200, ()),
+                            (4096, 5, (("reserve", 8),))] + big:
+        case("mpchol n=%d nrhs=%d %s [NULL stream]" % (n, nrhs, dict(opts) or ""), 0)(lambda r, e, a=(n, nrhs, opts): mixed_compute(r, e, *a))
+    case("mpchol n=3072 nrhs=8 twice [user stream]", 1)(lambda r, e: mixed_compute(r, e, 3072, 8, reps=2))
+    for (n, nb, P) in [(1024, 256, 1), (1024, 256, 4), (1280, 256, 4), (2048, 256, 8), (1152, 128, 3), (1024, 128, 2)]:
+        mp_case("dmp n=%d nb=%d P=%d" % (n, nb, P))(lambda r, e, a=(n, nb, P): dmp_compute(r, e, *a))
     json.dump({"results": RESULTS}, open(out_path, "w"), indent=1)
     bad = [x for x in RESULTS if x["findings"]]
     print("%d cases, %d with findings" % (len(RESULTS), len(bad)))
