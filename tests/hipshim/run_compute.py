@@ -467,6 +467,98 @@ def summa_compute(r_unused, errors, size, c, M, N, K, chunks, seed=2, uid=[0]):
     errors["C"] = worst
 
 
+def desc_compute(r, errors, m, n, nb, Pr, Pc, kind, seed=8):
+    """descriptors with pinned staging: host GLOBAL matrix -> every position's piece -> back (desc.hip: pure host packing code and
+    copies - no kernel at all), for the block-cyclic kind (nb x nb blocks on Pr x Pc) and upstream's element-cyclic kind"""
+    rng = np.random.default_rng(seed)
+    g = rng.standard_normal((m, n))
+    hostg = np.asfortranarray(g)
+    back = np.zeros((m, n), order="F")
+    worst_piece = worst_local = 0.0
+    for pr in range(Pr):
+        for pc in range(Pc):
+            d = C.c_void_p()
+            if kind == 1:
+                rs.ok(L.cap_desc_create_bc(C.byref(d), n, m, nb, Pr, Pc, pr, pc, None, 0), "cap_desc_create_bc")
+                rows, cols = bc_indices(m, nb, Pr, pr), bc_indices(n, nb, Pc, pc)
+                want = g[np.ix_(rows, cols)]
+            else:
+                rs.ok(L.cap_desc_create(C.byref(d), n, m, Pc, Pr), "cap_desc_create")
+                rs.ok(L.cap_desc_set_position(d, pc, pr), "cap_desc_set_position")
+                want = np.zeros(((m + Pr - 1) // Pr, (n + Pc - 1) // Pc)); sub = g[pr::Pr, pc::Pc]; want[:sub.shape[0], :sub.shape[1]] = sub
+            lr, lc, ld = int(L.cap_desc_get(d, 3)), int(L.cap_desc_get(d, 2)), int(L.cap_desc_get(d, 4))
+            assert (lr, lc) == want.shape, ((lr, lc), want.shape)
+            rs.ok(r.call("desc_import_host_global", L.cap_desc_import_host_global, d, hostg.ctypes.data_as(C.c_void_p), m, r.stream), "import_host_global")
+            L.cap_desc_data.restype = C.c_void_p
+            if lr and lc:
+                worst_piece = max(worst_piece, rel(view(L.cap_desc_data(d), lr, lc, ld), want))
+            rs.ok(r.call("desc_export_host_global", L.cap_desc_export_host_global, d, back.ctypes.data_as(C.c_void_p), m, r.stream), "export_host_global")
+            # the local import / export pair on a compact host piece
+            loc = np.asfortranarray(rng.standard_normal((max(lr, 1), max(lc, 1)))); got = np.zeros_like(loc, order="F")
+            rs.ok(r.call("desc_import_host", L.cap_desc_import_host, d, loc.ctypes.data_as(C.c_void_p), max(lr, 1), r.stream), "import_host")
+            rs.ok(r.call("desc_export_host", L.cap_desc_export_host, d, got.ctypes.data_as(C.c_void_p), max(lr, 1), r.stream), "export_host")
+            if lr and lc:
+                worst_local = max(worst_local, rel(got[:lr, :lc], loc[:lr, :lc]))
+            rs.ok(L.cap_desc_destroy(d), "cap_desc_destroy")
+    errors["pieces"] = worst_piece
+    errors["every element comes back to its global place"] = rel(back, g)
+    errors["local round trip"] = worst_local
+
+
+def summa_tri_compute(r_unused, errors, size, c, M, N, K, chunks, seed=5, uid=[0]):
+    """matmult::summa TRMM and SYRK overloads + util::transpose on the d x d x c grid (summa.hpp:46-161, util.hpp:232-247)"""
+    uid[0] += 1
+    rng = np.random.default_rng(seed)
+    tm = np.linalg.cholesky(spd(M, seed)).T; tn = np.linalg.cholesky(spd(N, seed + 1)).T       # upper triangular, globally
+    b = rng.standard_normal((M, N)); a_t = rng.standard_normal((K, N)); a_n = rng.standard_normal((N, K))
+    c0 = rng.standard_normal((N, N)); c0 = c0 + c0.T
+    LEFT, RIGHT, UPPER, NT, TR, NONUNIT = 0, 1, 1, 0, 1, 0
+
+    def rank(q):
+        t = TTopo("stri%d" % uid[0], 0, q, size, c, chunks)
+        d, x, y = t.d, t.x, t.y
+        out = {}
+
+        def dev(piece):
+            p = rs.dmalloc(8 * max(piece.size, 1))
+            view(p, piece.shape[0], piece.shape[1])[:] = piece
+            return p
+        for (side, trans, tg, nm) in ((LEFT, NT, tm, "L N"), (LEFT, TR, tm, "L T"), (RIGHT, NT, tn, "R N"), (RIGHT, TR, tn, "R T")):
+            td = tg.shape[0]
+            tp_, bp = cyc_piece(tg, x, y, d), cyc_piece(b, x, y, d)
+            T, B = dev(tp_), dev(bp)
+            if trans == TR:                                   # upstream's call-site preparation (cholinv.hpp:115): my partner's piece
+                tmp = rs.dmalloc(8 * tp_.size)
+                rs.ok(L.cap_util_transpose(t.handle, T, tmp, tp_.size, None), "cap_util_transpose")
+                out["transpose " + nm] = rel(view(T, *tp_.shape), cyc_piece(tg, y, x, d))
+                shim.hipFree(tmp)
+            plan = C.c_void_p()
+            rs.ok(L.cap_summa_plan_create(C.byref(plan), t.handle, M, N, td, chunks), "cap_summa_plan_create")
+            rs.ok(L.cap_summa_dtrmm(plan, side, UPPER, trans, NONUNIT, 0.75, T, tp_.shape[0], 0, B, bp.shape[0], None), "cap_summa_dtrmm")
+            op = tg.T if trans == TR else tg
+            want = 0.75 * (op @ b if side == LEFT else b @ op)
+            out["trmm " + nm] = rel(view(B, *bp.shape), cyc_piece(want, x, y, d))
+            rs.ok(L.cap_summa_plan_destroy(plan), "cap_summa_plan_destroy")
+            shim.hipFree(T); shim.hipFree(B)
+        for (trans, ag, nm) in ((TR, a_t, "T"), (NT, a_n, "N")):
+            for beta in (1.0, 0.0):
+                ap, cp = cyc_piece(ag, x, y, d), cyc_piece(c0, x, y, d)
+                A, Cc = dev(ap), dev(cp)
+                plan = C.c_void_p()
+                rs.ok(L.cap_summa_plan_create(C.byref(plan), t.handle, N, N, K, chunks), "cap_summa_plan_create")
+                rs.ok(L.cap_summa_dsyrk(plan, UPPER, trans, -1.0, A, ap.shape[0], beta, Cc, cp.shape[0], 0, None), "cap_summa_dsyrk")
+                g = ag.T @ ag if trans == TR else ag @ ag.T
+                out["syrk %s beta=%g" % (nm, beta)] = rel(view(Cc, *cp.shape), cyc_piece(-g + beta * c0, x, y, d))
+                out["syrk %s: A untouched" % nm] = rel(view(A, *ap.shape), ap)
+                rs.ok(L.cap_summa_plan_destroy(plan), "cap_summa_plan_destroy")
+                shim.hipFree(A); shim.hipFree(Cc)
+        t.close()
+        return out
+    for o in run_ranks(size, rank):
+        for k, v in o.items():
+            errors[k] = max(errors.get(k, 0.0), v)
+
+
 def cacqr_compute(r_unused, errors, m, n, iters, P, seed=3, uid=[0]):
     """CholeskyQR / CholeskyQR2 on the 1D grid: row-cyclic pieces of a tall matrix; Q^T Q = I, Q R = A, R upper with a positive diagonal"""
     uid[0] += 1
@@ -675,6 +767,14 @@ def main(out_path):
     for (size, c, M, N, K, chunks) in [(1, 1, 256, 256, 256, 0), (4, 1, 512, 256, 384, 0), (8, 2, 300, 300, 300, 2), (9, 1, 300, 270, 330, 3), (27, 3, 270, 270, 270, 0),
                                        (4, 1, 301, 200, 257, 2), (8, 2, 256, 128, 512, 4)]:
         mp_case("summa gemm size=%d c=%d %dx%dx%d chunks=%d" % (size, c, M, N, K, chunks))(lambda r, e, a=(size, c, M, N, K, chunks): summa_compute(r, e, *a))
+    for (size, c, M, N, K, chunks) in [(4, 1, 256, 192, 130, 0), (8, 2, 300, 200, 153, 2), (9, 1, 270, 180, 99, 0), (1, 1, 256, 128, 64, 0)]:
+        mp_case("summa trmm / syrk / transpose size=%d c=%d m=%d n=%d k=%d chunks=%d" % (size, c, M, N, K, chunks))(
+            lambda r, e, a=(size, c, M, N, K, chunks): summa_tri_compute(r, e, *a))
+    for us in (0, 1):
+        for (m, n, nb, Pr, Pc, kind) in [(1000, 1000, 128, 2, 2, 1), (300, 520, 128, 2, 4, 1), (2048, 2048, 256, 1, 4, 1), (1000, 1000, 0, 2, 2, 0), (301, 203, 0, 3, 2, 0),
+                                         (100, 100, 128, 2, 4, 1), (3100, 2900, 512, 1, 1, 1)]:
+            case("desc %s %dx%d nb=%d grid %dx%d%s" % ("block-cyclic" if kind else "element-cyclic", m, n, nb, Pr, Pc, " [user stream]" if us else " [NULL stream]"), us)(
+                lambda r, e, a=(m, n, nb, Pr, Pc, kind): desc_compute(r, e, *a))
     for (m, n, iters, P) in [(4096, 256, 2, 1), (8192, 256, 2, 4), (4096, 128, 2, 4), (4096, 64, 1, 2), (6144, 256, 2, 3), (2048, 96, 2, 8)]:
         mp_case("cacqr m=%d n=%d iter=%d P=%d" % (m, n, iters, P))(lambda r, e, a=(m, n, iters, P): cacqr_compute(r, e, *a))
     for (n, ci, c, d, bc) in [(1024, 1, 2, 2, -2), (1000, 1, 2, 2, -2), (1024, 0, 1, 2, -2), (1024, 0, 2, 2, 0), (768, -1, 2, 1, -2), (1536, 0, 2, 2, -3),
