@@ -705,6 +705,144 @@ def dmp_compute(r_unused, errors, n, nb, P, nrhs=5, seed=6, uid=[0]):
     errors["X vs fp64 solve (scaled)"] = rel(x, np.linalg.solve(a, b)) * 1e-2
 
 
+def cacqr_grid_compute(r_unused, errors, size, c, m, n, iters=2, seed=9, uid=[0]):
+    """qr::cacqr on the c x d x c grid of a topo::rect bundle (cacqr.hpp:44-215): rows cyclic over d, columns over c, layers replicas"""
+    uid[0] += 1
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((m, n))
+    d = size // (c * c)
+
+    def rank(q):
+        t = TTopo("cqg%d" % uid[0], 1, q, size, c)
+        plan = C.c_void_p()
+        rs.ok(L.cap_cacqr_plan_create_grid(C.byref(plan), m, n, iters, t.handle), "cap_cacqr_plan_create_grid")
+        ml, nl = (m + d - 1) // d, n // c
+        pa = np.zeros((ml, nl)); sub = a[t.y::d, t.x::c]; pa[:sub.shape[0], :sub.shape[1]] = sub
+        A = rs.dmalloc(8 * ml * nl); out = rs.dmalloc(8 * n * n)
+        view(A, ml, nl)[:] = pa
+        info = C.c_int64(-1)
+        for _ in range(2):
+            rs.ok(L.cap_cacqr_factor(plan, A, ml, None), "cap_cacqr_factor")
+        L.cap_cacqr_info(plan, None, C.byref(info))
+        ldq, ldr = C.c_int64(0), C.c_int64(0)
+        L.cap_cacqr_Q_ptr.restype = C.c_void_p; L.cap_cacqr_R_ptr.restype = C.c_void_p
+        qp = L.cap_cacqr_Q_ptr(plan, C.byref(ldq)); rp = L.cap_cacqr_R_ptr(plan, C.byref(ldr))
+        Q = view(qp, ml, nl, ldq.value).copy(); R = view(rp, n, n, ldr.value).copy()
+        rs.ok(L.cap_cacqr_R_piece(plan, out, nl, None), "cap_cacqr_R_piece")
+        Rp = view(out, nl, nl).copy()
+        rs.ok(L.cap_cacqr_plan_destroy(plan), "cap_cacqr_plan_destroy")
+        xyz = (t.x, t.y, t.z)
+        t.close(); shim.hipFree(A); shim.hipFree(out)
+        return xyz, Q, R, Rp, info.value
+    res = run_ranks(size, rank)
+    Q = np.zeros((m, n)); Rg = np.zeros((n, n))
+    R = np.triu(res[0][2])
+    for (x, y, z), Qp, Rd, Rp, info in res:
+        rows = len(range(y, m, d))
+        if z == 0:
+            Q[y::d, x::c] = Qp[:rows]
+        if z == 0 and y < c:
+            Rg[y::c, x::c] = Rp
+        errors["info"] = max(errors.get("info", 0.0), float(abs(info)))
+        errors["R replicated"] = max(errors.get("R replicated", 0.0), rel(np.triu(Rd), R))
+    errors["layers are replicas"] = max(rel(Qp[:len(range(y, m, d))], Q[y::d, x::c]) for (x, y, z), Qp, _, _, _ in res)
+    errors["R pieces (c x c cyclic)"] = rel(Rg, R)
+    errors["A - QR"] = rel(Q @ R, a)
+    errors["Q^T Q - I"] = float(np.linalg.norm(Q.T @ Q - np.eye(n)) / np.sqrt(n))
+    qr_r = np.linalg.qr(a, mode="r")
+    errors["R vs LAPACK"] = rel(R, qr_r * np.sign(np.diag(qr_r))[:, None])
+
+
+def cyclic2d_compute(r_unused, errors, n, nb, size, c, Pr, seed=0, uid=[0]):
+    """a caller with the reference's element-cyclic pieces on the d x d x c grid reaches the Pr x Pc plan: redistribute (redist.hip, one
+    all-to-all), factor through the DESCRIPTOR entry points (cap_desc_create_bc view + cap_dist2d_factor_desc / get_R_desc), redistribute
+    back - the pieces of R as construct_R returns them"""
+    uid[0] += 1
+    a = spd(n, seed)
+    rref = np.linalg.cholesky(a).T
+    Pc = size // Pr
+
+    def rank(q):
+        world = TComm(q, size, "c2d%d" % uid[0])
+        rp = C.c_void_p()
+        rs.ok(L.cap_redist_plan_create(C.byref(rp), n, nb, world.handle, c, Pr), "cap_redist_plan_create")
+        e, lr, lc, d, x, y = (int(L.cap_redist_get(rp, w)) for w in (0, 1, 2, 3, 5, 6))
+        pr, pc = int(L.cap_redist_get(rp, 10)), int(L.cap_redist_get(rp, 11))
+        row = TComm(pc, Pc, "c2d%d_r%d" % (uid[0], pr)); col = TComm(pr, Pr, "c2d%d_c%d" % (uid[0], pc))
+        plan = C.c_void_p()
+        rs.ok(L.cap_dist2d_plan_create(C.byref(plan), n, nb, world.handle, Pr, row.handle, col.handle), "cap_dist2d_plan_create")
+        pa = cyc_piece(a, x, y, d)
+        assert pa.shape == (e, e)
+        P = rs.dmalloc(8 * e * e); bc = rs.dmalloc(8 * max(lr, 1) * max(lc, 1)); out = rs.dmalloc(8 * max(lr, 1) * max(lc, 1)); Pout = rs.dmalloc(8 * e * e)
+        view(P, e, e)[:] = pa
+        rs.ok(L.cap_redistribute_cyclic_to_bc(rp, P, e, bc, max(lr, 1), None), "cyclic_to_bc")
+        rows, cols = bc_indices(n, nb, Pr, pr), bc_indices(n, nb, Pc, pc)
+        e_bc = rel(view(bc, lr, lc), a[np.ix_(rows, cols)]) if lr and lc else 0.0
+        dA, dR = C.c_void_p(), C.c_void_p()
+        rs.ok(L.cap_desc_create_bc(C.byref(dA), n, n, nb, Pr, Pc, pr, pc, bc, max(lr, 1)), "cap_desc_create_bc")
+        rs.ok(L.cap_desc_create_bc(C.byref(dR), n, n, nb, Pr, Pc, pr, pc, out, max(lr, 1)), "cap_desc_create_bc")
+        rs.ok(L.cap_dist2d_factor_desc(plan, dA, None), "cap_dist2d_factor_desc")
+        info = C.c_int64(-1)
+        L.cap_dist2d_info(plan, None, C.byref(info))
+        rs.ok(L.cap_dist2d_get_R_desc(plan, dR, None), "cap_dist2d_get_R_desc")
+        rs.ok(L.cap_redistribute_bc_to_cyclic(rp, out, max(lr, 1), Pout, e, None), "bc_to_cyclic")
+        Rp = view(Pout, e, e).copy()
+        for h in (dA, dR):
+            rs.ok(L.cap_desc_destroy(h), "cap_desc_destroy")
+        rs.ok(L.cap_dist2d_plan_destroy(plan), "cap_dist2d_plan_destroy"); rs.ok(L.cap_redist_plan_destroy(rp), "cap_redist_plan_destroy")
+        for cm in (row, col, world):
+            cm.close()
+        for z in (P, bc, out, Pout):
+            shim.hipFree(z)
+        return x, y, d, Rp, e_bc, info.value
+    res = run_ranks(size, rank)
+    errors["block-cyclic pieces after the all-to-all"] = max(v[4] for v in res)
+    errors["info"] = float(max(abs(v[5]) for v in res))
+    errors["R pieces"] = max(rel(Rp, cyc_piece(rref, x, y, d)) for x, y, d, Rp, _, _ in res)
+
+
+def utils_compute(r, errors, n, seed=12):
+    """serialize (packed-upper windows), util::remove_triangle, the element-cyclic import / export, the validator's residual terms"""
+    rng = np.random.default_rng(seed)
+    a = spd(n, seed); rr = np.linalg.cholesky(a).T
+    A = rs.dmalloc(8 * n * n); R = rs.dmalloc(8 * n * n); W = rs.dmalloc(8 * n * n); out2 = rs.dmalloc(16)
+    view(A, n, n)[:] = a; view(R, n, n)[:] = rr
+    rs.ok(r.call("cholesky_residual_terms", L.cap_cholesky_residual_terms, A, n, R, n, n, W, out2, r.stream), "cap_cholesky_residual_terms")
+    t = view(out2, 2, 1)[:, 0]
+    errors["residual of the exact factor"] = float(np.sqrt(t[0] / t[1])) * 1e4          # 1e-15 passes the gate
+    view(R, n, n)[0, n - 1] += 1e-3
+    rs.ok(r.call("cholesky_residual_terms", L.cap_cholesky_residual_terms, A, n, R, n, n, W, out2, r.stream), "cap_cholesky_residual_terms")
+    t = view(out2, 2, 1)[:, 0]
+    errors["residual reacts to a perturbed factor"] = 0.0 if np.sqrt(t[0] / t[1]) > 1e-7 else 1.0
+    # packed upper storage: window (r0, c0, rows, cols) of a rect matrix -> packed -> back into a zero matrix
+    pk = rs.dmalloc(8 * n * (n + 1) // 2); Z = rs.dmalloc(8 * n * n)
+    rs.ok(r.call("copy_window rect->packed", L.cap_copy_window, A, 0, n, 0, 0, pk, 1, 0, 0, 0, n, n, 1, 0, r.stream), "cap_copy_window")
+    view(Z, n, n)[:] = 0.0
+    rs.ok(r.call("copy_window packed->rect", L.cap_copy_window, pk, 1, 0, 0, 0, Z, 0, n, 0, 0, n, n, 1, 1, r.stream), "cap_copy_window")
+    errors["packed round trip"] = rel(view(Z, n, n), np.triu(a))
+    h = n // 3
+    view(Z, n, n)[:] = 7.0
+    rs.ok(r.call("copy_window sub-window", L.cap_copy_window, A, 0, n, h, h, Z, 0, n, 2, 5, h, h + 3, 0, 0, r.stream), "cap_copy_window")
+    want = np.full((n, n), 7.0); want[2:2 + h, 5:5 + h + 3] = a[h:2 * h, h:2 * h + 3]
+    errors["window copy touches its window only"] = rel(view(Z, n, n), want)
+    view(Z, n, n)[:] = a
+    rs.ok(r.call("remove_triangle", L.cap_remove_triangle, Z, n, n, n, 0, 0, 1, 1, r.stream), "cap_remove_triangle")
+    errors["remove_triangle (upper kept)"] = rel(view(Z, n, n), np.triu(a))
+    # element-cyclic piece (x, y) of a 3 x 2 grid out of a dense matrix and back
+    dx, dy, x, y = 3, 2, 1, 1
+    pl_r, pl_c = (n + dy - 1) // dy, (n + dx - 1) // dx
+    Pm = rs.dmalloc(8 * pl_r * pl_c)
+    rs.ok(r.call("cyclic_export", L.cap_cyclic_export, A, n, Pm, pl_r, n, n, x, y, dx, dy, r.stream), "cap_cyclic_export")
+    want = np.zeros((pl_r, pl_c)); sub = a[y::dy, x::dx]; want[:sub.shape[0], :sub.shape[1]] = sub
+    errors["cyclic export"] = rel(view(Pm, pl_r, pl_c), want)
+    view(Z, n, n)[:] = 0.0
+    rs.ok(r.call("cyclic_import", L.cap_cyclic_import, Pm, pl_r, Z, n, n, n, x, y, dx, dy, r.stream), "cap_cyclic_import")
+    want = np.zeros((n, n)); want[y::dy, x::dx] = a[y::dy, x::dx]
+    errors["cyclic import"] = rel(view(Z, n, n), want)
+    for q in (A, R, W, out2, pk, Z, Pm):
+        shim.hipFree(q)
+
+
 def mp_case(name):
     """a multi-rank case: no trace of its own (the ranks' threads interleave in it) - the structural checks are run_scenarios.py's"""
     def deco(fn):
@@ -775,6 +913,13 @@ def main(out_path):
                                          (100, 100, 128, 2, 4, 1), (3100, 2900, 512, 1, 1, 1)]:
             case("desc %s %dx%d nb=%d grid %dx%d%s" % ("block-cyclic" if kind else "element-cyclic", m, n, nb, Pr, Pc, " [user stream]" if us else " [NULL stream]"), us)(
                 lambda r, e, a=(m, n, nb, Pr, Pc, kind): desc_compute(r, e, *a))
+    for (n, nb, size, c, Pr) in [(1024, 128, 8, 2, 2), (1000, 128, 4, 1, 2), (768, 128, 8, 2, 1), (1024, 128, 4, 1, 1)]:
+        mp_case("reference pieces -> %dx%d plan through descriptors -> pieces, n=%d nb=%d grid c=%d" % (Pr, size // Pr, n, nb, c))(
+            lambda r, e, a=(n, nb, size, c, Pr): cyclic2d_compute(r, e, *a))
+    for us in (0, 1):
+        case("matrix utilities n=500%s" % (" [user stream]" if us else " [NULL stream]"), us)(lambda r, e: utils_compute(r, e, 500))
+    for (size, c, m, n) in [(8, 2, 4096, 128), (4, 1, 4096, 64), (16, 2, 8192, 256), (8, 2, 1000, 64), (27, 3, 2700, 96)]:
+        mp_case("cacqr grid size=%d c=%d m=%d n=%d" % (size, c, m, n))(lambda r, e, a=(size, c, m, n): cacqr_grid_compute(r, e, *a))
     for (m, n, iters, P) in [(4096, 256, 2, 1), (8192, 256, 2, 4), (4096, 128, 2, 4), (4096, 64, 1, 2), (6144, 256, 2, 3), (2048, 96, 2, 8)]:
         mp_case("cacqr m=%d n=%d iter=%d P=%d" % (m, n, iters, P))(lambda r, e, a=(m, n, iters, P): cacqr_compute(r, e, *a))
     for (n, ci, c, d, bc) in [(1024, 1, 2, 2, -2), (1000, 1, 2, 2, -2), (1024, 0, 1, 2, -2), (1024, 0, 2, 2, 0), (768, -1, 2, 1, -2), (1536, 0, 2, 2, -3),
