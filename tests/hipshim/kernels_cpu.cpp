@@ -109,9 +109,24 @@ void k_dgemm(const std::string& name, void** a, unsigned gx, unsigned gy) {
 }
 
 // dgemm_tn_dma_kernel<TAG, A_MC, DIAG, BUF, SKIP>: the LDS-DMA kernels (aligned shapes), tile_dma semantics of gemm.hip
+// SHIM_FAULT="kind:n" (tests/test_cpu_compute.py): the n-th launch of the LDS-DMA GEMM family runs with ONE thing wrong, the way a host
+// bug would hand it over - 1: the tile grid is one tile column short, 2: B's leading dimension is two
+// elements too long, 3: a dense operand carries the "upper triangular" hint (its K range is cut at the diagonal), 4: K is one K tile short - so that the harness can be shown to notice
+static long fault_seen = 0;
 void k_dgemm_dma(const std::string& name, void** a, unsigned gx, unsigned gy) {
-  const GemmArgs g = arg<GemmArgs>(a, 0);
+  GemmArgs g = arg<GemmArgs>(a, 0);
   const bool amc = tmpl(name, 1), skip = tmpl(name, 4);
+  static const char* fault = getenv("SHIM_FAULT");
+  if (fault) {
+    const int kind = atoi(fault); const char* c = strchr(fault, ':'); const long nth = c ? atol(c + 1) : 0;
+    const bool applies = (kind == 1 && g.tn > 1) || kind == 2 || (kind == 3 && !g.aupt && !g.aupn && !g.bupper && !amc && g.K > 128) || (kind == 4 && g.K > 16);
+    if (applies && fault_seen++ == nth) {          // the n-th launch the fault makes a difference to
+      if (kind == 1) g.tn -= 1;
+      if (kind == 2) g.ldb += 2;
+      if (kind == 3) g.aupt = 1;
+      if (kind == 4) g.K -= 16;
+    }
+  }
 #pragma omp parallel for collapse(2) schedule(dynamic)
   for (unsigned kz = 0; kz < gy; kz++)
     for (unsigned bx = 0; bx < gx; bx++) {

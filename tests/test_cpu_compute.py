@@ -84,3 +84,31 @@ print("DIFF %%.3e" %% rc.rel(rc.view(out, n, n), np.linalg.cholesky(a).T))
     assert lines[0].startswith("OK"), lines
     diff = float(lines[1].split()[1])
     assert diff > 1e-3 or diff != diff, lines      # a different input gives a different (or NaN) factor: the models compute, they do not echo
+
+
+@pytest.mark.parametrize("fault,what", [("1:7", "a tile grid that is one tile column short"), ("2:20", "a leading dimension that is two elements off"),
+                                        ("3:3", "a triangular-operand hint on a dense operand"), ("4:11", "a K range that is one K tile short")])
+def test_one_wrong_launch_among_hundreds_is_noticed(fault, what):
+    """teeth: the blocked factorization of N = 2048 (nb = 128: ~110 launches, 32 of them LDS-DMA products) with ONE product handed over
+    wrong, the way a host-side bug would do it (tests/hipshim/kernels_cpu.cpp, SHIM_FAULT) - the factor must come out wrong"""
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import run_compute as rc
+rc.shim.shim_set_compute(1)
+e = {}
+r = rc.rs.Run("fault", 0)
+rc.cholinv_compute(r, e, 2048, -1, 1, 0, (("nb", 128), ("outer", 256), ("tail", 0), ("depth2", 1)), reps=1)
+print("R %%.3e" %% e["R"])
+""" % os.path.join(ROOT, "tests", "hipshim")
+    env = dict(os.environ); env.pop("LD_PRELOAD", None); env["SHIM_FILTER"] = ""; env["SHIM_KEEP_TRACE"] = ""
+    out = {}
+    for f in ("", fault):
+        env["SHIM_FAULT"] = f
+        if not f:
+            env.pop("SHIM_FAULT")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out[f] = float(r.stdout.strip().splitlines()[-1].split()[1])
+    assert out[""] < 2e-11, out
+    assert out[fault] > 1e-8 or out[fault] != out[fault], (what, out)
