@@ -722,6 +722,9 @@ void k_bf16_tn(void** a, unsigned gx) {
 
 }  // namespace
 
+#include <omp.h>
+// OpenMP threads of the CALLING thread's kernel models (a rank thread of a multi-rank case takes its share of the host cores)
+extern "C" void shim_set_threads(int n) { omp_set_num_threads(n < 1 ? 1 : n); }
 static int dispatch(const char* mangled, void** args, unsigned gx, unsigned gy, unsigned gz, unsigned bx);
 // SHIM_PROFILE=1: seconds per kernel model, printed when the process ends
 #include <chrono>

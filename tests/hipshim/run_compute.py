@@ -258,8 +258,11 @@ def run_ranks(nranks, fn):
     """fn(rank) on one thread per rank -> list of per-rank results; an exception on any rank is re-raised"""
     out, err = [None] * nranks, []
 
+    share = max(1, (os.cpu_count() or 8) // nranks)
+
     def work(q):
         try:
+            shim.shim_set_threads(share)       # the kernel models of this rank: its share of the host cores
             out[q] = fn(q)
         except Exception as e:          # a broken barrier on the other ranks follows from the first failure
             err.append((q, repr(e)))
