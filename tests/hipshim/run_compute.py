@@ -332,7 +332,7 @@ def dist_compute(r_unused, errors, n, nb, P, opts=(), ci=-1, seed=0, uid=[0]):
         errors["info"] = max(errors.get("info", 0.0), float(abs(info)))
     errors["R"] = rel(R, rref)
     if ci >= 0:
-        n1 = n >> 1
+        n1 = n >> dict(opts).get("split", 1)
         want = riref.copy()
         if ci == 0 and 0 < n1 < n:
             want[:n1, n1:] = 0.0                 # cholinv.hpp:147: the root block of R^-1 stays empty
@@ -363,7 +363,7 @@ def dist2d_compute(r_unused, errors, n, nb, Pr, Pc, opts=(), seed=0, uid=[0]):
         for _ in range(2):
             rs.ok(L.cap_dist2d_factor(plan, A, max(lr, 1), None), "cap_dist2d_factor")
         L.cap_dist2d_info(plan, None, C.byref(info))
-        if dict(opts).get("ipc") and int(L.cap_dist2d_get(plan, 12)) != 1:
+        if dict(opts).get("ipc") and Pr * Pc > 1 and int(L.cap_dist2d_get(plan, 12)) != 1:
             raise RuntimeError("the IPC operand moves are not active")
         rs.ok(L.cap_dist2d_get_R(plan, out, max(lr, 1), None), "cap_dist2d_get_R")
         R = view(out, lr, lc).copy() if lr and lc else np.zeros((lr, lc))
@@ -386,7 +386,7 @@ def dist2d_compute(r_unused, errors, n, nb, Pr, Pc, opts=(), seed=0, uid=[0]):
         errors["info"] = max(errors.get("info", 0.0), float(abs(info)))
     errors["R"] = rel(R, rref)
     if ci >= 0:
-        n1 = n >> 1
+        n1 = n >> dict(opts).get("split", 1)
         want = riref.copy()
         if ci == 0 and 0 < n1 < n:
             want[:n1, n1:] = 0.0

@@ -112,3 +112,14 @@ print("R %%.3e" %% e["R"])
         out[f] = float(r.stdout.strip().splitlines()[-1].split()[1])
     assert out[""] < 2e-11, out
     assert out[fault] > 1e-8 or out[fault] != out[fault], (what, out)
+
+
+def test_random_configurations_nobody_wrote_a_test_for():
+    """tests/hipshim/fuzz_compute.py: random sizes, block widths, grids and option mixes through the compute mode (1100 of them passed when
+    the harness was written; 40 with a fixed seed here)"""
+    env = dict(os.environ); env.pop("LD_PRELOAD", None); env["SHIM_FILTER"] = ""; env["SHIM_KEEP_TRACE"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipshim", "fuzz_compute.py"), "7", "40"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[-1] == "40 cases, 0 with findings", "\n".join(l for l in lines if not l.startswith("ok"))[-3000:]
+    assert len({l.split()[1] for l in lines if l.startswith("ok")}) >= 5           # several plan kinds came up
