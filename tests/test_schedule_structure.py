@@ -292,3 +292,14 @@ def test_removing_an_event_edge_from_a_recorded_schedule_is_noticed(tmp_path):
         assert kinds["race"] >= 0.9 * (nw - len(silent)), (f, kinds)          # ... and nearly always as a race between two named kernels
         seen += 1
     assert seen == 3
+
+
+def test_random_configurations_through_the_replay():
+    """tests/hipshim/fuzz_scenarios.py: random sizes (to N = 18000), block widths, grids and option mixes of five plan kinds through the
+    structural replay, the race check and the joint replay of all ranks (7000 scenarios passed when it was written; 60 configurations
+    with a fixed seed here)"""
+    env = dict(os.environ); env.pop("LD_PRELOAD", None); env["SHIM_FILTER"] = ""; env["SHIM_KEEP_TRACE"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipshim", "fuzz_scenarios.py"), "9", "60"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    last = [l for l in r.stdout.strip().splitlines() if "scenarios (incl. joint replays)" in l][-1]
+    assert last.endswith(" 0 with findings") and int(last.split()[0]) >= 150, r.stdout[-3000:]
