@@ -52,7 +52,7 @@ hipError_t last_error = hipSuccess;
 constexpr size_t TOUCH_LIMIT = 1 << 16;              // payloads up to this size are really copied / set (info words, handles); larger ones only traced
 // compute mode (shim_set_compute, run_compute.py): every copy and memset is carried out, fresh allocations are filled with NaN patterns
 // (device memory is NOT zero after hipMalloc) and every launch runs the kernel's CPU model (kernels_cpu.cpp) at enqueue time
-int compute = 0;
+int compute = getenv("SHIM_COMPUTE") ? atoi(getenv("SHIM_COMPUTE")) : 0;      // (a plain C program linked against the stand-in: examples/*.c)
 long long unmodelled = 0;
 
 struct PendingCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
@@ -188,6 +188,8 @@ hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int
 
 // ---------------------------------------------------------------- device
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
   *v = a == hipDeviceAttributeMultiprocessorCount ? 256 : 0;
   return hipSuccess;

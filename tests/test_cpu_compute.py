@@ -123,3 +123,38 @@ def test_random_configurations_nobody_wrote_a_test_for():
     lines = r.stdout.strip().splitlines()
     assert lines[-1] == "40 cases, 0 with findings", "\n".join(l for l in lines if not l.startswith("ok"))[-3000:]
     assert len({l.split()[1] for l in lines if l.startswith("ok")}) >= 5           # several plan kinds came up
+
+
+@pytest.mark.parametrize("name,argv,checks", [
+    ("cholinv_driver", ("2048", "-1", "1", "-3", "1", "1"), {"residual": 1e-14}),
+    ("cholinv_driver", ("1024", "1", "1", "-2", "1", "1"), {"residual": 1e-14}),
+    ("summa_driver", ("768", "512", "640", "1", "0", "2", "2", "1"), {"gemm": 1e-13, "syrk": 1e-13, "trmm": 1e-13}),
+    ("cacqr_driver", ("2", "16384", "128", "1", "1", "1", "1", "0", "0", "0", "0", "1", "1"), {"residual": 1e-13, "orthogonality": 1e-14}),
+    ("cacqr_driver", ("1", "4096", "256", "1", "1", "1", "1", "0", "0", "0", "0", "1", "1"), {"residual": 1e-13, "orthogonality": 1e-12}),
+])
+def test_the_plain_c_drivers_run_on_the_cpu(tmp_path, name, argv, checks):
+    """examples/*.c - the C forms of the reference's three bench drivers, no Python in the process - linked against the stand-in in
+    compute mode instead of libamdhip64: they run their own validation blocks (test/cholesky/validate.hpp:33-46, the three
+    summa::invoke overloads against the local operators, test/qr/validate.hpp:24-51) on a machine without a GPU.  The -m gpu suite
+    runs the same programs with the same arguments on the device."""
+    import re
+    import shutil
+    if not shutil.which("gcc") or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("gcc / ROCm headers not available")
+    from capital_amd import build
+    build.build(verbose=False)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipshim"))
+    import build_shim
+    lib, shim = build_shim.build()
+    exe = str(tmp_path / (name + ".cpu"))
+    cmd = ["gcc", "-std=c99", "-D_POSIX_C_SOURCE=199309L", "-Wall", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", name + ".c"), "-L" + os.path.dirname(lib), "-lcapital_amd_shim", "-lhipshim", "-lm", "-Wl,-rpath," + os.path.dirname(lib), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ); env.pop("LD_PRELOAD", None); env["SHIM_COMPUTE"] = "1"
+    run = subprocess.run([exe] + list(argv), capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    for word, bound in checks.items():
+        m = re.search(r"\b%s\b[^=\n]*?=?\s*([0-9.]+e[+-][0-9]+)" % word, run.stdout)
+        assert m, (word, run.stdout[-1500:])
+        assert float(m.group(1)) <= bound, (word, m.group(1), run.stdout[-1500:])
