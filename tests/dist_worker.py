@@ -370,9 +370,11 @@ def run(args):
         from capital_amd.matrix import matrix
         from tests.host_staged import HostStagedComm, grid_groups
         gold = None
+        bc_mult = -2
         if args.golden:
             gold = np.load(os.path.join(ROOT, "tests", "golden", args.golden))
             n, args.ci, args.split, args.c = int(gold["n"]), int(gold["complete_inv"]), int(gold["split"]), int(gold["c"])
+            bc_mult = int(gold["bc_mult_dim"])            # the dump's own base-case knob: on the 2 x 2 x 2 grid it decides the pattern of R^-1 ("grid8" dumps)
         T = tp.square(args.c, 0, 0, comm_factory=HostStagedComm)
         d = T.d
         a = orc.symmetric_global(n, True)
@@ -381,7 +383,7 @@ def run(args):
         assert np.array_equal(A.to_numpy(), orc.cyclic_local(a, T.x, T.y, d, d))
         ri_p = None
         if args.mode == "cyclic":
-            pack = cholinv.info(args.ci, args.split, -2, 'U')
+            pack = cholinv.info(args.ci, args.split, bc_mult, 'U')
             pack.set_option("nb", nb)
             for rep in range(2):
                 cholinv.factor(A, pack, T)

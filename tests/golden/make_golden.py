@@ -149,6 +149,12 @@ if __name__ == "__main__":
     cholinv_multirank_dump_case("cholinv_p8_n128_ci1_s1_bc-2", 128, 1, 1, -2, 1)
     cholinv_multirank_dump_case("cholinv_p8_n192_ci0_s1_bc-3", 192, 0, 1, -3, 1)
     cholinv_multirank_dump_case("cholinv_p8_n250_ci1_s1_bc-2", 250, 1, 1, -2, 2)
+    # where upstream's rules depend on its GRID (round 5; "grid8": the single-GPU plan with the same knobs gives another pattern of R^-1, so
+    # these are not among the cholinv_p8_* dumps the single-GPU tests glob): bcMult = 0 on 2 x 2 x 2 - the base case is n / 4 (bcDimLocal
+    # starts at c d, cholinv.hpp:15-18), the root IS partitioned and its block of R^-1 stays empty; a ragged n - the root partition is taken
+    # on the local dimension, (ceil(251 / 2) >> 1) 2 = 126 rows, not 251 >> 1 = 125 (cholinv.hpp:107)
+    cholinv_multirank_dump_case("cholinv_grid8_n256_ci0_s1_bc0", 256, 0, 1, 0, 1)
+    cholinv_multirank_dump_case("cholinv_grid8_n251_ci0_s1_bc-2", 251, 0, 1, -2, 1)
     cacqr_case("cacqr1_m192_n12", 1, 192, 12)
     cacqr_case("cacqr2_m256_n16", 2, 256, 16)
     cacqr_multirank_dump_case("cacqr2_p8_c1_m256_n16", 2, 256, 16, 1)     # 1D grid, 8 ranks

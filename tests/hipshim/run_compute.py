@@ -562,11 +562,11 @@ def summa_tri_compute(r_unused, errors, size, c, M, N, K, chunks, seed=5, uid=[0
             errors[k] = max(errors.get(k, 0.0), v)
 
 
-def cacqr_compute(r_unused, errors, m, n, iters, P, seed=3, uid=[0]):
+def cacqr_compute(r_unused, errors, m, n, iters, P, seed=3, uid=[0], a=None, want=None):
     """CholeskyQR / CholeskyQR2 on the 1D grid: row-cyclic pieces of a tall matrix; Q^T Q = I, Q R = A, R upper with a positive diagonal"""
     uid[0] += 1
     rng = np.random.default_rng(seed)
-    a = rng.standard_normal((m, n))
+    a = rng.standard_normal((m, n)) if a is None else a
     ml = m // P
 
     def rank(p):
@@ -597,6 +597,8 @@ def cacqr_compute(r_unused, errors, m, n, iters, P, seed=3, uid=[0]):
     errors["Q^T Q - I"] = float(np.linalg.norm(Q.T @ Q - np.eye(n)) / np.sqrt(n)) if iters >= 2 else 0.0
     qr_r = np.linalg.qr(a, mode="r")
     errors["R vs LAPACK"] = rel(R, qr_r * np.sign(np.diag(qr_r))[:, None]) if iters >= 2 else 0.0
+    if want is not None:
+        errors["Q vs the reference's"] = rel(Q, want[0]); errors["R vs the reference's"] = rel(R, np.triu(want[1]))
 
 
 def cholinv_cyclic_compute(r_unused, errors, n, ci, c, d, bc=-2, nb=128, seed=0, uid=[0]):
@@ -708,11 +710,11 @@ def dmp_compute(r_unused, errors, n, nb, P, nrhs=5, seed=6, uid=[0]):
     errors["X vs fp64 solve (scaled)"] = rel(x, np.linalg.solve(a, b)) * 1e-2
 
 
-def cacqr_grid_compute(r_unused, errors, size, c, m, n, iters=2, seed=9, uid=[0]):
+def cacqr_grid_compute(r_unused, errors, size, c, m, n, iters=2, seed=9, uid=[0], a=None, want=None):
     """qr::cacqr on the c x d x c grid of a topo::rect bundle (cacqr.hpp:44-215): rows cyclic over d, columns over c, layers replicas"""
     uid[0] += 1
     rng = np.random.default_rng(seed)
-    a = rng.standard_normal((m, n))
+    a = rng.standard_normal((m, n)) if a is None else a
     d = size // (c * c)
 
     def rank(q):
@@ -751,9 +753,12 @@ def cacqr_grid_compute(r_unused, errors, size, c, m, n, iters=2, seed=9, uid=[0]
     errors["layers are replicas"] = max(rel(Qp[:len(range(y, m, d))], Q[y::d, x::c]) for (x, y, z), Qp, _, _, _ in res)
     errors["R pieces (c x c cyclic)"] = rel(Rg, R)
     errors["A - QR"] = rel(Q @ R, a)
-    errors["Q^T Q - I"] = float(np.linalg.norm(Q.T @ Q - np.eye(n)) / np.sqrt(n))
-    qr_r = np.linalg.qr(a, mode="r")
-    errors["R vs LAPACK"] = rel(R, qr_r * np.sign(np.diag(qr_r))[:, None])
+    if iters >= 2:
+        errors["Q^T Q - I"] = float(np.linalg.norm(Q.T @ Q - np.eye(n)) / np.sqrt(n))
+        qr_r = np.linalg.qr(a, mode="r")
+        errors["R vs LAPACK"] = rel(R, qr_r * np.sign(np.diag(qr_r))[:, None])
+    if want is not None:
+        errors["Q vs the reference's"] = rel(Q, want[0]); errors["R vs the reference's"] = rel(R, np.triu(want[1]))
 
 
 def cyclic2d_compute(r_unused, errors, n, nb, size, c, Pr, seed=0, uid=[0]):
@@ -846,6 +851,83 @@ def utils_compute(r, errors, n, seed=12):
         shim.hipFree(q)
 
 
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_cholinv_1rank(r, errors, fname):
+    """the single-GPU plan against what the REAL reference left on one rank (tests/golden/*.npz, dumped by oracle/_ref)"""
+    g = np.load(os.path.join(GOLD, fname))
+    n, ci, split, bc = int(g["n"]), int(g["complete_inv"]), int(g["split"]), int(g["bc_mult_dim"])
+    a = np.array(g["A"])
+    plan = C.c_void_p()
+    rs.ok(L.cap_cholinv_plan_create(C.byref(plan), n, ci, split, bc, b"U", None), "cap_cholinv_plan_create")
+    A = rs.dmalloc(8 * n * n); out = rs.dmalloc(8 * n * n)
+    view(A, n, n)[:] = a
+    rs.ok(r.call("cholinv_factor", L.cap_cholinv_factor, plan, A, n, r.stream), "cap_cholinv_factor")
+    rs.ok(r.call("cholinv_get_R", L.cap_cholinv_get_R, plan, out, n, r.stream), "cap_cholinv_get_R")
+    errors["R vs the reference's"] = rel(view(out, n, n), np.triu(g["R"]))
+    rs.ok(r.call("cholinv_get_Rinv", L.cap_cholinv_get_Rinv, plan, out, n, r.stream), "cap_cholinv_get_Rinv")
+    ri = view(out, n, n).copy(); ref = np.triu(g["Rinv"])
+    errors["Rinv vs the reference's"] = rel(ri, ref)
+    errors["same empty block"] = float(np.count_nonzero((ri != 0) != (ref != 0)))
+    rs.ok(L.cap_cholinv_plan_destroy(plan), "cap_cholinv_plan_destroy")
+    shim.hipFree(A); shim.hipFree(out)
+
+
+def golden_cholinv_8ranks(r_unused, errors, fname, uid=[0]):
+    """8 ranks on the reference's own 2 x 2 x 2 grid: every rank's pieces of R and R^-1 against the PIECES the real reference dumped"""
+    uid[0] += 1
+    g = np.load(os.path.join(GOLD, fname))
+    n, ci, split, bc, c, d = (int(g[k]) for k in ("n", "complete_inv", "split", "bc_mult_dim", "c", "d"))
+    a = np.array(g["A"]); pieces = np.array(g["pieces"]); coords = np.array(g["rank_coords"])
+    size = c * d * d
+
+    def rank(q):
+        assert int(coords[q][0]) == q
+        x, y = int(coords[q][1]), int(coords[q][2])
+        comm = TComm(q, size, "gold%d" % uid[0])
+        plan = C.c_void_p()
+        rs.ok(L.cap_cholinv_plan_create(C.byref(plan), n, ci, split, bc, b"U", comm.handle), "cap_cholinv_plan_create")
+        rs.ok(L.cap_cholinv_set_option(plan, b"nb", 128), "nb")
+        rs.ok(L.cap_cholinv_set_option(plan, b"cyclic_c", c), "cyclic_c")
+        pa = cyc_piece(a, x, y, d); e = pa.shape[0]
+        A = rs.dmalloc(8 * e * e); out = rs.dmalloc(8 * e * e)
+        view(A, e, e)[:] = pa
+        rs.ok(L.cap_cholinv_factor(plan, A, e, None), "cap_cholinv_factor")
+        rs.ok(L.cap_cholinv_get_R(plan, out, e, None), "cap_cholinv_get_R")
+        R = view(out, e, e).copy()
+        rs.ok(L.cap_cholinv_get_Rinv(plan, out, e, None), "cap_cholinv_get_Rinv")
+        Ri = view(out, e, e).copy()
+        rs.ok(L.cap_cholinv_plan_destroy(plan), "cap_cholinv_plan_destroy")
+        comm.close(); shim.hipFree(A); shim.hipFree(out)
+        gi = np.arange(e)[:, None] * d + y; gj = np.arange(e)[None, :] * d + x
+        upper = (gi <= gj) & (gi < n) & (gj < n)               # util::remove_triangle's mask: the dump keeps the raw local triangle
+        ref_r, ref_ri = pieces[q][1], pieces[q][2]
+        return (float(np.linalg.norm((R - ref_r)[upper]) / np.linalg.norm(ref_r[upper])), float(np.linalg.norm((Ri - ref_ri)[upper]) / np.linalg.norm(ref_ri[upper])),
+                float(np.count_nonzero((Ri[upper] != 0) != (ref_ri[upper] != 0))), float(np.count_nonzero(R[~upper]) + np.count_nonzero(Ri[~upper])),
+                rel(pa, pieces[q][0]))
+    res = run_ranks(size, rank)
+    errors["R pieces vs the reference's"] = max(v[0] for v in res)
+    errors["Rinv pieces vs the reference's"] = max(v[1] for v in res)
+    errors["same empty root block, piece by piece"] = max(v[2] for v in res)
+    errors["nothing below the global diagonal"] = max(v[3] for v in res)
+    errors["same input pieces"] = max(v[4] for v in res)
+
+
+def golden_cacqr(r_unused, errors, fname, uid=[0]):
+    """CholeskyQR / CholeskyQR2 against the real reference's 8-rank runs (1D grid and the c x d x c grid)"""
+    g = np.load(os.path.join(GOLD, fname))
+    m, n, variant, c, d = (int(g[k]) for k in ("m", "n", "variant", "c", "d"))
+    a = np.array(g["A"])
+    e = {}
+    if c == 1:
+        cacqr_compute(None, e, m, n, variant, d, a=a, want=(np.array(g["Q"]), np.array(g["R"])))
+    else:
+        cacqr_grid_compute(None, e, c * c * d, c, m, n, variant, a=a, want=(np.array(g["Q"]), np.array(g["R"])))
+    for k in ("info", "Q vs the reference's", "R vs the reference's", "A - QR"):
+        errors[k] = e[k]
+
+
 def mp_case(name):
     """a multi-rank case: no trace of its own (the ranks' threads interleave in it) - the structural checks are run_scenarios.py's"""
     def deco(fn):
@@ -921,6 +1003,14 @@ def main(out_path):
             lambda r, e, a=(n, nb, size, c, Pr): cyclic2d_compute(r, e, *a))
     for us in (0, 1):
         case("matrix utilities n=500%s" % (" [user stream]" if us else " [NULL stream]"), us)(lambda r, e: utils_compute(r, e, 500))
+    # ---- against the REAL reference's dumps (tests/golden, produced by oracle/_ref): no oracle, no NumPy factorization in between
+    for f in sorted(os.listdir(GOLD)):
+        if f.startswith("cholinv_n") and f.endswith(".npz"):
+            case("golden %s [NULL stream]" % f, 0)(lambda r, e, f=f: golden_cholinv_1rank(r, e, f))
+        elif (f.startswith("cholinv_p8_n") or f.startswith("cholinv_grid8_n")) and f.endswith(".npz"):
+            mp_case("golden %s (8 ranks, pieces)" % f)(lambda r, e, f=f: golden_cholinv_8ranks(r, e, f))
+        elif f.startswith("cacqr") and "_p8_" in f and f.endswith(".npz"):
+            mp_case("golden %s (8 ranks)" % f)(lambda r, e, f=f: golden_cacqr(r, e, f))
     for (size, c, m, n) in [(8, 2, 4096, 128), (4, 1, 4096, 64), (16, 2, 8192, 256), (8, 2, 1000, 64), (27, 3, 2700, 96)]:
         mp_case("cacqr grid size=%d c=%d m=%d n=%d" % (size, c, m, n))(lambda r, e, a=(size, c, m, n): cacqr_grid_compute(r, e, *a))
     for (m, n, iters, P) in [(4096, 256, 2, 1), (8192, 256, 2, 4), (4096, 128, 2, 4), (4096, 64, 1, 2), (6144, 256, 2, 3), (2048, 96, 2, 8)]:

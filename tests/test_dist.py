@@ -510,6 +510,18 @@ def test_reference_layout_end_to_end_against_the_8rank_piece_dumps(mode, pr, nam
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cholinv_grid8_n256_ci0_s1_bc0.npz", "cholinv_grid8_n251_ci0_s1_bc-2.npz"])
+def test_reference_layout_follows_the_grids_base_case_rule_and_root_partition(name):
+    """Upstream's base-case dimension starts at c d (cholinv.hpp:15-18) and its root partition is taken on the LOCAL dimension (:107):
+    with complete_inv = 0 and bc_mult_dim = 0 the 2 x 2 x 2 grid leaves Rinv[0:128, 128:256] empty where one process would invert the
+    whole base case, and n = 251 is cut at 126, not 125.  Every rank's pieces against the REAL reference's (round 5: found on the CPU by
+    tests/hipshim/run_compute.py, which runs these two dumps as well)."""
+    r = _case(8, "cyclic", 128, 128, ("--golden", name, "--pr", 1))
+    assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    assert "CYCLIC-OK" in r.stdout and "golden=ok" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nproc,c,mode,pr,n,nb,ci", [
     (8, 2, "cyclic", 1, 2048, 128, 1), (8, 2, "cyclic", 1, 2048, 256, 0), (4, 1, "cyclic", 1, 1000, 128, 1),
     (8, 2, "cyclic2d", 2, 2048, 128, -1), (4, 1, "cyclic2d", 2, 1000, 128, -1), (8, 2, "cyclic", 1, 4096, 512, -1),
@@ -584,6 +596,7 @@ test_summa_gemm_on_process_grids._dist_case = lambda nproc, c, M, N, K, chunks: 
 test_cacqr_3d_and_tunable_grid._dist_case = lambda nproc, c, m, n: (nproc, "cacqr3d", m, n, ("--c", c))
 test_distributed_redistribution_cyclic_block_cyclic._dist_case = lambda nproc, c, pr, n, nb: (nproc, "redist", n, nb, ("--c", c, "--pr", pr))
 test_reference_layout_end_to_end_against_the_8rank_piece_dumps._dist_case = lambda mode, pr, name: (8, mode, 128, 128, ("--golden", name, "--pr", pr))
+test_reference_layout_follows_the_grids_base_case_rule_and_root_partition._dist_case = lambda name: (8, "cyclic", 128, 128, ("--golden", name, "--pr", 1))
 test_reference_layout_end_to_end_against_the_oracle._dist_case = lambda nproc, c, mode, pr, n, nb, ci: (nproc, mode, n, nb, ("--c", c, "--pr", pr, "--ci", ci))
 test_summa_trmm_and_syrk_overloads_on_process_grids._dist_case = lambda nproc, c, M, N, K, chunks: (nproc, "summa_tri", M, N, ("--c", c, "--k", K, "--chunks", chunks))
 test_reference_recursion_composed_from_the_distributed_operators._dist_case = lambda name: (8, "summa_tri", 128, 128, ("--golden", name))
