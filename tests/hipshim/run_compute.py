@@ -567,14 +567,15 @@ def cacqr_compute(r_unused, errors, m, n, iters, P, seed=3, uid=[0], a=None, wan
     uid[0] += 1
     rng = np.random.default_rng(seed)
     a = rng.standard_normal((m, n)) if a is None else a
-    ml = m // P
+    ml = (m + P - 1) // P                                     # ragged M: zero rows pad the last pieces, as upstream's generator does (structure.hpp:96-101)
 
     def rank(p):
         comm = TComm(p, P, "cacqr%d" % uid[0])
         plan = C.c_void_p()
         rs.ok(L.cap_cacqr_plan_create(C.byref(plan), ml, n, iters, comm.handle), "cap_cacqr_plan_create")
         A = rs.dmalloc(8 * ml * n)
-        view(A, ml, n)[:] = a[p::P]
+        view(A, ml, n)[:] = 0.0
+        view(A, ml, n)[:len(range(p, m, P))] = a[p::P]
         info = C.c_int64(-1)
         for _ in range(2):
             rs.ok(L.cap_cacqr_factor(plan, A, ml, None), "cap_cacqr_factor")
@@ -589,7 +590,8 @@ def cacqr_compute(r_unused, errors, m, n, iters, P, seed=3, uid=[0], a=None, wan
     res = run_ranks(P, rank)
     Q = np.zeros((m, n))
     for p, (Qp, R, info) in enumerate(res):
-        Q[p::P] = Qp
+        Q[p::P] = Qp[:len(range(p, m, P))]
+        errors["rows of padding stay zero"] = max(errors.get("rows of padding stay zero", 0.0), float(np.abs(Qp[len(range(p, m, P)):]).max(initial=0.0)))
         errors["info"] = max(errors.get("info", 0.0), float(abs(info)))
     R = np.triu(res[0][1])
     errors["R replicated"] = max(rel(np.triu(x[1]), R) for x in res)
@@ -856,7 +858,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def golden_cholinv_1rank(r, errors, fname):
     """the single-GPU plan against what the REAL reference left on one rank (tests/golden/*.npz, dumped by oracle/_ref)"""
-    g = np.load(os.path.join(GOLD, fname))
+    g = np.load(os.path.join(GOLD, fname)) if isinstance(fname, str) else fname
     n, ci, split, bc = int(g["n"]), int(g["complete_inv"]), int(g["split"]), int(g["bc_mult_dim"])
     a = np.array(g["A"])
     plan = C.c_void_p()
@@ -875,9 +877,9 @@ def golden_cholinv_1rank(r, errors, fname):
 
 
 def golden_cholinv_8ranks(r_unused, errors, fname, uid=[0]):
-    """8 ranks on the reference's own 2 x 2 x 2 grid: every rank's pieces of R and R^-1 against the PIECES the real reference dumped"""
+    """c d^2 ranks on the reference's own d x d x c grid (the committed dumps: 2 x 2 x 2): every rank's pieces of R and R^-1 against the PIECES the real reference dumped"""
     uid[0] += 1
-    g = np.load(os.path.join(GOLD, fname))
+    g = np.load(os.path.join(GOLD, fname)) if isinstance(fname, str) else fname
     n, ci, split, bc, c, d = (int(g[k]) for k in ("n", "complete_inv", "split", "bc_mult_dim", "c", "d"))
     a = np.array(g["A"]); pieces = np.array(g["pieces"]); coords = np.array(g["rank_coords"])
     size = c * d * d
@@ -903,7 +905,8 @@ def golden_cholinv_8ranks(r_unused, errors, fname, uid=[0]):
         gi = np.arange(e)[:, None] * d + y; gj = np.arange(e)[None, :] * d + x
         upper = (gi <= gj) & (gi < n) & (gj < n)               # util::remove_triangle's mask: the dump keeps the raw local triangle
         ref_r, ref_ri = pieces[q][1], pieces[q][2]
-        return (float(np.linalg.norm((R - ref_r)[upper]) / np.linalg.norm(ref_r[upper])), float(np.linalg.norm((Ri - ref_ri)[upper]) / np.linalg.norm(ref_ri[upper])),
+        tiny = 1e-300                                          # (a piece with nothing on or above the diagonal: N < d)
+        return (float(np.linalg.norm((R - ref_r)[upper]) / max(np.linalg.norm(ref_r[upper]), tiny)), float(np.linalg.norm((Ri - ref_ri)[upper]) / max(np.linalg.norm(ref_ri[upper]), tiny)),
                 float(np.count_nonzero((Ri[upper] != 0) != (ref_ri[upper] != 0))), float(np.count_nonzero(R[~upper]) + np.count_nonzero(Ri[~upper])),
                 rel(pa, pieces[q][0]))
     res = run_ranks(size, rank)
@@ -916,7 +919,7 @@ def golden_cholinv_8ranks(r_unused, errors, fname, uid=[0]):
 
 def golden_cacqr(r_unused, errors, fname, uid=[0]):
     """CholeskyQR / CholeskyQR2 against the real reference's 8-rank runs (1D grid and the c x d x c grid)"""
-    g = np.load(os.path.join(GOLD, fname))
+    g = np.load(os.path.join(GOLD, fname)) if isinstance(fname, str) else fname
     m, n, variant, c, d = (int(g[k]) for k in ("m", "n", "variant", "c", "d"))
     a = np.array(g["A"])
     e = {}

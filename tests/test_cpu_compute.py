@@ -127,6 +127,26 @@ def test_random_configurations_nobody_wrote_a_test_for():
     assert len({l.split()[1] for l in lines if l.startswith("ok")}) >= 5           # several plan kinds came up
 
 
+def test_random_configurations_against_the_real_reference_run_beside_the_library():
+    """tests/hipshim/fuzz_reference.py: the REAL reference (oracle/_ref, built from /root/reference where that exists) factors random
+    (n, complete_inv, split, bc_mult_dim) on 1 rank and on its 2 x 2 x 2 grid, random CholeskyQR / CholeskyQR2 on 1D and c x d x c grids of
+    1 ... 27 ranks; the library runs the same input through the compute mode: same R, same R^-1 pattern, same Q pieces (1750 configurations
+    agreed when this was written; 40 with a fixed seed here).  Skipped where the reference binary or an MPI launcher is missing."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipshim"))
+    import fuzz_reference
+    if not fuzz_reference.available():
+        pytest.skip("oracle/_ref (the reference built from /root/reference) or mpiexec is not here")
+    probe = subprocess.run([fuzz_reference.MPIEXEC, "-n", "1", fuzz_reference.REF, "8", "1", "1", "0", "0", "0", "0", "-", "1"], capture_output=True, text=True, timeout=120)
+    if probe.returncode != 0:
+        pytest.skip("the reference binary does not run here: " + (probe.stderr or probe.stdout)[-300:])
+    env = dict(os.environ); env.pop("LD_PRELOAD", None); env["SHIM_FILTER"] = ""; env["SHIM_KEEP_TRACE"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipshim", "fuzz_reference.py"), "21", "40"], capture_output=True, text=True, timeout=1200, env=env)
+    lines = r.stdout.strip().splitlines()
+    assert r.returncode == 0 and lines[-1] == "40 configurations, 0 with findings", "\n".join(l for l in lines if not l.startswith("ok"))[-3000:] + r.stderr[-2000:]
+    kinds = {("cacqr" if "cacqr" in l else "2x2x2" if "2x2x2" in l else "1 rank") for l in lines if l.startswith("ok")}
+    assert kinds == {"cacqr", "2x2x2", "1 rank"}
+
+
 @pytest.mark.parametrize("name,argv,checks", [
     ("cholinv_driver", ("2048", "-1", "1", "-3", "1", "1"), {"residual": 1e-14}),
     ("cholinv_driver", ("1024", "1", "1", "-2", "1", "1"), {"residual": 1e-14}),
