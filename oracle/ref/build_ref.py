@@ -8,7 +8,7 @@ __graft_entry__.smoke() and bench.py's `cpu_baseline` leg.
 What it does
 ------------
 * compiles the reference's header-only C++14 library *from where it lies* in
-  /root/reference, through two small drivers we wrote (oracle/ref/drv_*.cpp),
+  /root/reference, through three small drivers we wrote (oracle/ref/drv_*.cpp),
   against MPICH 3.3.2 + MKL 2021.4 found under /opt/conda (LP64 `libmkl_rt`);
 * the upstream tree does not compile as shipped with GCC 11 (template-parameter
   shadowing, two `static_assert(0)`, an undeclared `T`, an undeclared
@@ -24,6 +24,7 @@ What it does
 Outputs (git-ignored, NOT gpurun-ignored, so they travel to the GPU box):
   oracle/_ref/cholinv_ref   argv: N complete_inv split bcMult layout chunks policy [dump]
   oracle/_ref/cacqr_ref     argv: variant M N complete_inv split bcMult [dump]
+  oracle/_ref/summa_ref     argv: op M N K c layout num_chunks alpha beta dump   (GEMM / TRMM / SYRK overloads of matmult::summa)
 Run as: MKL_NUM_THREADS=1 /opt/conda/bin/mpiexec -n {1|8} oracle/_ref/cholinv_ref ...
 
 The reference has no build system we can use (config.mk is an empty template,
@@ -104,7 +105,7 @@ def build(verbose=True):
         shutil.copy(os.path.join(HERE, "inc", "mkl.h"), inc)
         for h in ("mpi.h", "mpio.h", "mpicxx.h"):
             shutil.copy(os.path.join(CONDA, "include", h), inc)
-        for drv, exe in (("drv_cholinv.cpp", "cholinv_ref"), ("drv_cacqr.cpp", "cacqr_ref")):
+        for drv, exe in (("drv_cholinv.cpp", "cholinv_ref"), ("drv_cacqr.cpp", "cacqr_ref"), ("drv_summa.cpp", "summa_ref")):
             cmd = ["g++", "-std=c++14", "-O2", "-fpermissive", "-w", "-DMPICH_SKIP_MPICXX",
                    "-I" + inc, "-I" + tmp, os.path.join(HERE, drv), "-o", os.path.join(OUT, exe),
                    "-L" + os.path.join(CONDA, "lib"), "-Wl,-rpath," + os.path.join(CONDA, "lib"),

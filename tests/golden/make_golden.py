@@ -138,6 +138,22 @@ def cacqr_multirank_dump_case(name, variant, m, n, c, ranks=8):
     print(name, out.strip())
 
 
+def summa_dump_case(name, op, m, n, k, c, chunks, alpha, beta):
+    """The real matmult::summa::invoke (oracle/ref/drv_summa.cpp: GEMM / TRMM / SYRK overloads, operands prepared like upstream's call sites)
+    on the c x c x c cube: every rank's pieces of the operands and of the result, as stored (packed upper triangles stay packed)."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests", "hipshim"))
+    import fuzz_reference
+    g = fuzz_reference.reference_summa(op, m, n, k, c, chunks, alpha, beta)
+    flat = {"op": op, "m": m, "n": n, "k": k, "c": c, "chunks": chunks, "alpha": alpha, "beta": beta,
+            "coords": np.array([co for co, _ in g["ranks"]], dtype=np.int64)}
+    for q, (_, arrs) in enumerate(g["ranks"]):
+        for i, (rows, cols, packed, v) in enumerate(arrs):
+            flat["shape_%d_%d" % (q, i)] = np.array([rows, cols, packed], dtype=np.int64); flat["data_%d_%d" % (q, i)] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **flat)
+    print(name, "ranks=%d" % len(g["ranks"]))
+
+
 if __name__ == "__main__":
     cholinv_case("cholinv_n64_ci0_s1_bc-2", 64, 0, 1, -2)
     cholinv_case("cholinv_n64_ci1_s1_bc-3", 64, 1, 1, -3)
@@ -160,3 +176,10 @@ if __name__ == "__main__":
     cacqr_multirank_dump_case("cacqr2_p8_c1_m256_n16", 2, 256, 16, 1)     # 1D grid, 8 ranks
     cacqr_multirank_dump_case("cacqr2_p8_c2_m256_n16", 2, 256, 16, 2)     # 3D: 2 x 2 x 2
     cacqr_multirank_dump_case("cacqr1_p8_c2_m200_n12", 1, 200, 12, 2)     # 3D, one sweep, M not a multiple of d * anything special
+    # matmult::summa's three overloads on the 2 x 2 x 2 cube (round 5), ragged sizes, chunked and unchunked
+    summa_dump_case("summa_c2_gemm_m51_n43_k35", 0, 51, 43, 35, 2, 2, 1.5, -0.5)
+    summa_dump_case("summa_c2_trmm_left_trans_m41_n30", 2, 41, 30, 0, 2, 0, 1.0, 0.0)          # cholinv.hpp:114-119
+    summa_dump_case("summa_c2_trmm_left_m40_n30", 1, 40, 30, 0, 2, 2, 1.0, 0.0)               # cholinv.hpp:149-150
+    summa_dump_case("summa_c2_trmm_right_m40_n31", 3, 40, 31, 0, 2, 0, -1.0, 0.0)             # cholinv.hpp:151-153
+    summa_dump_case("summa_c2_syrk_trans_n31_k47", 5, 0, 31, 47, 2, 0, -1.0, 1.0)             # cholinv.hpp:128-131
+    summa_dump_case("summa_c2_syrk_rect_n33_k40", 7, 0, 33, 40, 2, 2, -1.0, 0.0)

@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = os.path.join(ROOT, "oracle", "_ref", "cholinv_ref")
 CACQR = os.path.join(ROOT, "oracle", "_ref", "cacqr_ref")
+SUMMA = os.path.join(ROOT, "oracle", "_ref", "summa_ref")
 MPIEXEC = "/opt/conda/bin/mpiexec"
 
 
@@ -76,13 +77,44 @@ def reference_cacqr(variant, m, n, c, ranks):
     return {"A": a, "Q": q, "R": r, "m": m, "n": n, "variant": variant, "c": cc, "d": d}
 
 
+def reference_summa(op, m, n, k, c, chunks, alpha, beta, layout=0):
+    """the real matmult::summa::invoke (op: see oracle/ref/drv_summa.cpp) on the c x c x c cube; per rank its coordinates and its arrays
+    as (local rows, local columns, packed, the doubles as stored)"""
+    env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
+    ranks = c * c * c
+    with tempfile.TemporaryDirectory() as td:
+        dump = os.path.join(td, "s.bin")
+        subprocess.check_output([MPIEXEC, "-n", str(ranks), SUMMA, str(op), str(m), str(n), str(k), str(c), str(layout), str(chunks), repr(alpha), repr(beta), dump],
+                                env=env, stderr=subprocess.STDOUT, timeout=300)
+        out = []
+        for q in range(ranks):
+            raw = open("%s.%d" % (dump, q), "rb").read()
+            h = np.frombuffer(raw[:64], dtype=np.int64); off = 64; arrs = []
+            for _ in range(int(h[6])):
+                rows, cols, packed = (int(v) for v in np.frombuffer(raw[off:off + 24], dtype=np.int64)); off += 24
+                cnt = cols * (cols + 1) // 2 if packed else rows * cols
+                arrs.append((rows, cols, packed, np.frombuffer(raw[off:off + 8 * cnt], dtype=np.float64).copy())); off += 8 * cnt
+            out.append((tuple(int(v) for v in h[:6]), arrs))
+    return {"op": op, "m": m, "n": n, "k": k, "c": c, "chunks": chunks, "alpha": alpha, "beta": beta, "ranks": out}
+
+
 def main(seed, count):
     sys.path.insert(0, HERE)
     import run_compute as rc
     rc.shim.shim_set_compute(1)
     rng = random.Random(seed)
     for i in range(count):
-        if rng.random() < 0.3:                                  # CholeskyQR / CholeskyQR2: 1D grids of 1..8 ranks, the c x d x c grids of 8, 16 and 27
+        u = rng.random()
+        if u < 0.2 and os.path.exists(SUMMA):                   # matmult::summa's overloads on the cube (upstream's single-step SUMMA needs c == d)
+            c = rng.choice([1, 2, 2, 2, 3])
+            op = rng.randint(0, 7)
+            m, n, k = (rng.choice([rng.randint(1, 12), rng.randint(12, 150), 32 * rng.randint(1, 6)]) for _ in range(3))
+            alpha, beta = rng.choice([1.0, -1.0, 0.75]), (rng.choice([0.0, 1.0, -0.5]) if op in (0, 5, 6, 7) else 0.0)
+            chunks = rng.choice([0, 0, 1, 2, 3, 5])
+            g = reference_summa(op, m, n, k, c, chunks, alpha, beta)
+            rc.mp_case("reference vs library: summa op=%d m=%d n=%d k=%d c=%d chunks=%d alpha=%g beta=%g" % (op, m, n, k, c, chunks, alpha, beta))(
+                lambda r, e, g=g: rc.golden_summa(r, e, g))
+        elif u < 0.45:                                          # CholeskyQR / CholeskyQR2: 1D grids of 1..8 ranks, the c x d x c grids of 8, 16 and 27
             c, ranks = rng.choice([(1, 1), (1, 2), (1, 3), (1, 4), (1, 5), (1, 8), (2, 8), (2, 8), (2, 16), (3, 27)])
             variant = rng.choice([1, 2, 2])
             n = c * rng.randint(1, 48 // c)

@@ -931,6 +931,83 @@ def golden_cacqr(r_unused, errors, fname, uid=[0]):
         errors[k] = e[k]
 
 
+def golden_summa(r_unused, errors, g, uid=[0]):
+    """matmult::summa's GEMM / TRMM / SYRK overloads against the REAL reference (oracle/ref/drv_summa.cpp) on its cube: every rank gets the
+    very pieces the reference's rank at the same (x, y, z) held (the triangular operand as upstream's packed piece and, a second time, as
+    the rect piece; util::transpose first where upstream's call site has it) and must end with the pieces the reference ended with"""
+    uid[0] += 1
+    if isinstance(g, str):                                     # a committed dump (tests/golden/make_golden.py: summa_dump_case)
+        z = np.load(os.path.join(GOLD, g))
+        g = {key: (float(z[key]) if key in ("alpha", "beta") else int(z[key])) for key in ("op", "m", "n", "k", "c", "chunks", "alpha", "beta")}
+        g["ranks"] = []
+        for q, co in enumerate(z["coords"]):
+            arrs, i = [], 0
+            while "shape_%d_%d" % (q, i) in z:
+                rows, cols, packed = (int(v) for v in z["shape_%d_%d" % (q, i)])
+                arrs.append((rows, cols, packed, np.array(z["data_%d_%d" % (q, i)]))); i += 1
+            g["ranks"].append((tuple(int(v) for v in co), arrs))
+    op, m, n, k, c, chunks, alpha, beta = (g[key] for key in ("op", "m", "n", "k", "c", "chunks", "alpha", "beta"))
+    by_coord = {co[1:4]: arrs for co, arrs in g["ranks"]}
+    size = len(g["ranks"])
+    LEFT, RIGHT, UPPER, NT, TR, NONUNIT = 0, 1, 1, 0, 1, 0
+
+    def unpacked(cols, v):
+        a = np.zeros((cols, cols))
+        for j in range(cols):
+            a[:j + 1, j] = v[j * (j + 1) // 2:j * (j + 1) // 2 + j + 1]
+        return a
+
+    def rank(q):
+        t = TTopo("gsumma%d" % uid[0], 0, q, size, c, chunks)
+        arrs = by_coord[(t.x, t.y, t.z)]
+        out = {}
+
+        def dev(vec):
+            p = rs.dmalloc(8 * max(vec.size, 1))
+            np.ctypeslib.as_array((C.c_double * max(vec.size, 1)).from_address(p.value))[:vec.size] = vec
+            return p
+
+        def host(p, cnt):
+            return np.ctypeslib.as_array((C.c_double * max(cnt, 1)).from_address(p.value))[:cnt].copy()
+        plan = C.c_void_p()
+        if op == 0:
+            (ml, kl, _, va), (_, nl, _, vb), (_, _, _, vc), (_, _, _, want) = arrs
+            rs.ok(L.cap_summa_plan_create(C.byref(plan), t.handle, m, n, k, chunks), "cap_summa_plan_create")
+            A, B, Cc = dev(va), dev(vb), dev(vc)
+            rs.ok(L.cap_summa_dgemm(plan, C.c_double(alpha), A, ml, B, kl, C.c_double(beta), Cc, ml, None), "cap_summa_dgemm")
+            out["C pieces vs the reference's"] = rel(host(Cc, ml * nl), want)
+            out["operands untouched"] = rel(host(A, va.size), va) + rel(host(B, vb.size), vb)
+            bufs = [A, B, Cc]
+        elif op <= 4:
+            (_, tl, _, vt), (ml, nl, _, vb), (_, _, _, want) = arrs
+            side, trans, td = (LEFT if op <= 2 else RIGHT), (TR if op in (2, 4) else NT), (m if op <= 2 else n)
+            rs.ok(L.cap_summa_plan_create(C.byref(plan), t.handle, m, n, td, chunks), "cap_summa_plan_create")
+            bufs = []
+            for packed, vec in ((1, vt), (0, unpacked(tl, vt).T.reshape(-1))):      # (column-major image of the rect piece)
+                T, B, tmp = dev(vec), dev(vb), rs.dmalloc(8 * max(vec.size, 1))
+                if trans == TR:
+                    rs.ok(L.cap_util_transpose(t.handle, T, tmp, vec.size, None), "cap_util_transpose")
+                rs.ok(L.cap_summa_dtrmm(plan, side, UPPER, trans, NONUNIT, C.c_double(alpha), T, tl, packed, B, ml, None), "cap_summa_dtrmm")
+                out["B pieces vs the reference's (T %s)" % ("packed" if packed else "rect")] = rel(host(B, ml * nl), want)
+                bufs += [T, B, tmp]
+        else:
+            (al, ac, _, va), (_, nl, cpk, vc), (_, _, _, want) = arrs
+            rs.ok(L.cap_summa_plan_create(C.byref(plan), t.handle, n, n, k, chunks), "cap_summa_plan_create")
+            A, Cc = dev(va), dev(vc)
+            rs.ok(L.cap_summa_dsyrk(plan, UPPER, TR if op in (5, 7) else NT, C.c_double(alpha), A, al, C.c_double(beta), Cc, nl, cpk, None), "cap_summa_dsyrk")
+            out["C pieces vs the reference's"] = rel(host(Cc, want.size), want)
+            out["A untouched"] = rel(host(A, va.size), va)
+            bufs = [A, Cc]
+        rs.ok(L.cap_summa_plan_destroy(plan), "cap_summa_plan_destroy")
+        t.close()
+        for b in bufs:
+            shim.hipFree(b)
+        return out
+    for o in run_ranks(size, rank):
+        for key, v in o.items():
+            errors[key] = max(errors.get(key, 0.0), v)
+
+
 def mp_case(name):
     """a multi-rank case: no trace of its own (the ranks' threads interleave in it) - the structural checks are run_scenarios.py's"""
     def deco(fn):
@@ -1014,6 +1091,8 @@ def main(out_path):
             mp_case("golden %s (8 ranks, pieces)" % f)(lambda r, e, f=f: golden_cholinv_8ranks(r, e, f))
         elif f.startswith("cacqr") and "_p8_" in f and f.endswith(".npz"):
             mp_case("golden %s (8 ranks)" % f)(lambda r, e, f=f: golden_cacqr(r, e, f))
+        elif f.startswith("summa_c") and f.endswith(".npz"):
+            mp_case("golden %s (the cube's ranks, pieces)" % f)(lambda r, e, f=f: golden_summa(r, e, f))
     for (size, c, m, n) in [(8, 2, 4096, 128), (4, 1, 4096, 64), (16, 2, 8192, 256), (8, 2, 1000, 64), (27, 3, 2700, 96)]:
         mp_case("cacqr grid size=%d c=%d m=%d n=%d" % (size, c, m, n))(lambda r, e, a=(size, c, m, n): cacqr_grid_compute(r, e, *a))
     for (m, n, iters, P) in [(4096, 256, 2, 1), (8192, 256, 2, 4), (4096, 128, 2, 4), (4096, 64, 1, 2), (6144, 256, 2, 3), (2048, 96, 2, 8)]:

@@ -38,7 +38,7 @@ def computed(tmp_path_factory):
 def test_every_plan_computes_the_right_factors_on_the_cpu(computed):
     bad = [(x["name"], x["findings"][:3]) for x in computed if x["findings"]]
     assert not bad, "\n".join("%s: %s" % b for b in bad[:20])
-    assert len(computed) >= 165, len(computed)
+    assert len(computed) >= 171, len(computed)
     names = " | ".join(x["name"] for x in computed)
     for must in ("operators m=130 n=70 k=33", "cholinv n=2048 ci=1", "'pair_rest': 0", "'inner_la': 1", "'use_sb': 0", "'inv_fast': 0", "cholinv n=1000 ci=1",
                  "dist n=2048 nb=128 P=8 {'ipc': 1, 'strip': 2}", "dist n=1000 nb=128 P=3 {'ipc': 1} ci=1", "dist2d n=1152 nb=128 4x8", "dist2d n=1024 nb=128 4x4 {'ipc': 1}",
@@ -48,7 +48,9 @@ def test_every_plan_computes_the_right_factors_on_the_cpu(computed):
                  "summa trmm / syrk / transpose size=8 c=2", "desc block-cyclic 300x520 nb=128 grid 2x4", "desc element-cyclic 301x203",
                  "cacqr grid size=27 c=3", "reference pieces -> 2x4 plan through descriptors", "matrix utilities n=500 [user stream]",
                  "golden cholinv_grid8_n256_ci0_s1_bc0.npz (8 ranks, pieces)", "golden cholinv_grid8_n251_ci0_s1_bc-2.npz", "golden cholinv_p8_n192_ci0_s1_bc-3.npz",
-                 "golden cholinv_n100_ci0_s2_bc-4.npz", "golden cacqr2_p8_c2_m256_n16.npz", "golden cacqr1_p8_c2_m200_n12.npz"):
+                 "golden cholinv_n100_ci0_s2_bc-4.npz", "golden cacqr2_p8_c2_m256_n16.npz", "golden cacqr1_p8_c2_m200_n12.npz",
+                 "golden summa_c2_gemm_m51_n43_k35.npz", "golden summa_c2_trmm_left_trans_m41_n30.npz", "golden summa_c2_trmm_right_m40_n31.npz",
+                 "golden summa_c2_syrk_trans_n31_k47.npz", "golden summa_c2_syrk_rect_n33_k40.npz"):
         assert must in names, must
     # the numbers are real: every case carries errors at rounding level, none is exactly zero across the board
     worst = max(v for x in computed for k, v in x["errors"].items() if k in ("R", "Rinv", "C", "A - QR", "R pieces", "dpotrf", "dgemm NN"))
@@ -130,8 +132,9 @@ def test_random_configurations_nobody_wrote_a_test_for():
 def test_random_configurations_against_the_real_reference_run_beside_the_library():
     """tests/hipshim/fuzz_reference.py: the REAL reference (oracle/_ref, built from /root/reference where that exists) factors random
     (n, complete_inv, split, bc_mult_dim) on 1 rank and on its 2 x 2 x 2 grid, random CholeskyQR / CholeskyQR2 on 1D and c x d x c grids of
-    1 ... 27 ranks; the library runs the same input through the compute mode: same R, same R^-1 pattern, same Q pieces (1750 configurations
-    agreed when this was written; 40 with a fixed seed here).  Skipped where the reference binary or an MPI launcher is missing."""
+    1 ... 27 ranks, random GEMM / TRMM / SYRK calls of matmult::summa on the cubes of 1, 8, 27 ranks; the library runs the same input through
+    the compute mode: same R, same R^-1 pattern, same Q pieces, same product pieces (2700 configurations agreed when this was written; 40 with
+    a fixed seed here).  Skipped where the reference binary or an MPI launcher is missing."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "hipshim"))
     import fuzz_reference
     if not fuzz_reference.available():
@@ -143,8 +146,8 @@ def test_random_configurations_against_the_real_reference_run_beside_the_library
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipshim", "fuzz_reference.py"), "21", "40"], capture_output=True, text=True, timeout=1200, env=env)
     lines = r.stdout.strip().splitlines()
     assert r.returncode == 0 and lines[-1] == "40 configurations, 0 with findings", "\n".join(l for l in lines if not l.startswith("ok"))[-3000:] + r.stderr[-2000:]
-    kinds = {("cacqr" if "cacqr" in l else "2x2x2" if "2x2x2" in l else "1 rank") for l in lines if l.startswith("ok")}
-    assert kinds == {"cacqr", "2x2x2", "1 rank"}
+    kinds = {("summa" if "summa" in l else "cacqr" if "cacqr" in l else "2x2x2" if "2x2x2" in l else "1 rank") for l in lines if l.startswith("ok")}
+    assert kinds == {"summa", "cacqr", "2x2x2", "1 rank"}
 
 
 @pytest.mark.parametrize("name,argv,checks", [
