@@ -74,6 +74,30 @@ def build(force=False, verbose=True):
     return LIB
 
 
+CBLAS_LIB = os.path.join(LIBDIR, "libcapital_amd_cblas.so")
+CBLAS_SRC = os.path.join(CSRC, "cblas", "cblas_offload.cpp")
+CBLAS_OBJ = os.path.join(LIBDIR, "obj_cblas", "cblas_offload.o")
+
+
+def build_cblas(force=False, verbose=True):
+    """libcapital_amd_cblas.so (include/capital_amd_cblas.h): the seven CBLAS / LAPACKE symbols the reference imports, on host pointers,
+    served by libcapital_amd.so's operators through staging buffers.  Its own library: a process that also holds a CPU BLAS must not find
+    cblas_dgemm in libcapital_amd.so.  Host code only (g++; the HIP runtime API header, no device code)."""
+    build(force=False, verbose=verbose)
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    deps = [CBLAS_SRC, os.path.join(inc, "capital_amd_cblas.h"), os.path.join(inc, "capital_amd.h"), LIB]
+    if not force and os.path.exists(CBLAS_LIB) and all(os.path.getmtime(CBLAS_LIB) > os.path.getmtime(d) for d in deps):
+        return CBLAS_LIB
+    os.makedirs(os.path.dirname(CBLAS_OBJ), exist_ok=True)
+    for cmd in (["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + inc, "-c", CBLAS_SRC, "-o", CBLAS_OBJ],
+                ["g++", "-shared", "-fPIC", "-o", CBLAS_LIB, CBLAS_OBJ, "-L" + LIBDIR, "-lcapital_amd", "-L/opt/rocm/lib", "-lamdhip64",
+                 "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return CBLAS_LIB
+
+
 def kernel_resources():
     """{kernel symbol: {"VGPRs": n, "ScratchSize": bytes per lane, "VGPRs Spill": n, ...}} from the last compile of every source."""
     out, cur = {}, None
@@ -122,3 +146,4 @@ def check_no_scratch():
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print("built", LIB)
+    print("built", build_cblas(force="--force" in sys.argv))

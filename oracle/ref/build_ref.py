@@ -25,6 +25,8 @@ Outputs (git-ignored, NOT gpurun-ignored, so they travel to the GPU box):
   oracle/_ref/cholinv_ref   argv: N complete_inv split bcMult layout chunks policy [dump]
   oracle/_ref/cacqr_ref     argv: variant M N complete_inv split bcMult [dump]
   oracle/_ref/summa_ref     argv: op M N K c layout num_chunks alpha beta dump   (GEMM / TRMM / SYRK overloads of matmult::summa)
+  oracle/_ref/{cholinv,cacqr,summa}_cap   the same three drivers linked with libcapital_amd_cblas.so in MKL's place (the reference
+                            running on the product's operators; LD_LIBRARY_PATH = capital_amd/lib or tests/hipshim/_build/cblas)
 Run as: MKL_NUM_THREADS=1 /opt/conda/bin/mpiexec -n {1|8} oracle/_ref/cholinv_ref ...
 
 The reference has no build system we can use (config.mk is an empty template,
@@ -113,6 +115,17 @@ def build(verbose=True):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+            # the same driver with libcapital_amd_cblas.so (include/capital_amd_cblas.h) in MKL's place: the REAL reference, unmodified, with
+            # every BLAS / LAPACK call served by the product's operators.  No rpath to either build of that library: LD_LIBRARY_PATH picks
+            # capital_amd/lib (the GPU) or tests/hipshim/_build/cblas (the CPU stand-in); built only when the product library is
+            cap = os.path.join(REPO, "capital_amd", "lib")
+            if os.path.exists(os.path.join(cap, "libcapital_amd_cblas.so")):
+                cmd = cmd[:cmd.index("-o")] + ["-o", os.path.join(OUT, exe.replace("_ref", "_cap")), "-L" + os.path.join(CONDA, "lib"),
+                                                 "-Wl,-rpath," + os.path.join(CONDA, "lib"), "-lmpi", "-L" + cap, "-lcapital_amd_cblas",
+                                                 "-Wl,--allow-shlib-undefined", "-lpthread", "-lm", "-ldl"]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return OUT

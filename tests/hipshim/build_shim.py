@@ -30,5 +30,23 @@ def build():
     return LIB, SHIM
 
 
+def build_cblas():
+    """the CBLAS / LAPACKE offload library (include/capital_amd_cblas.h) over the stand-in: the product's own object file of it, linked
+    against libcapital_amd_shim.so instead of libcapital_amd.so + libamdhip64 -> _build/cblas/libcapital_amd_cblas.so (same soname as the
+    product's: a program linked with -lcapital_amd_cblas picks one or the other through LD_LIBRARY_PATH)"""
+    import sys
+    sys.path.insert(0, ROOT)
+    from capital_amd import build as pb
+    pb.build_cblas(verbose=False)
+    lib, shim = build()
+    out = os.path.join(OUT, "cblas")
+    os.makedirs(out, exist_ok=True)
+    dst = os.path.join(out, "libcapital_amd_cblas.so")
+    if not os.path.exists(dst) or os.path.getmtime(dst) < max(os.path.getmtime(f) for f in (pb.CBLAS_OBJ, lib, shim)):
+        subprocess.check_call(["g++", "-shared", "-fPIC", "-o", dst, pb.CBLAS_OBJ, "-L" + OUT, "-lcapital_amd_shim", "-lhipshim", "-Wl,-rpath," + OUT, "-Wl,--no-undefined"])
+    return dst
+
+
 if __name__ == "__main__":
     print(build())
+    print(build_cblas())

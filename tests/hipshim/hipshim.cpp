@@ -284,6 +284,11 @@ hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t sp
     for (size_t r = 0; r < height; r++) memmove((char*)dst + r * dpitch, (const char*)src + r * spitch, width);
   return hipSuccess;
 }
+hipError_t hipMemcpy2D(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind k) {
+  (void)hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, k, nullptr);
+  std::lock_guard<std::mutex> lk(mu); note("HOSTSYNC stream 0");
+  return hipSuccess;
+}
 static void set_(void* p, int v, size_t bytes, int stream) {
   std::lock_guard<std::mutex> lk(mu);
   orphan_check("memset");
