@@ -40,7 +40,9 @@ struct Pool {
     }
     return (double*)p[i];
   }
-  ~Pool() { for (int i = 0; i < 5; i++) if (p[i]) (void)hipFree(p[i]); }
+  // no destructor on purpose: a thread's buffers would be freed while the process (and possibly the HIP runtime) is being torn down;
+  // like a CPU BLAS's per-thread buffers they live until the process ends (capcb_release() returns the calling thread's early)
+  void release() { for (int i = 0; i < 5; i++) { if (p[i]) (void)hipFree(p[i]); p[i] = nullptr; cap[i] = 0; } }
 };
 thread_local Pool pool;
 
@@ -164,6 +166,8 @@ int LAPACKE_dorgqr(int, int, int, int, double*, int, double*) {
   fprintf(stderr, "capital_amd_cblas: LAPACKE_dorgqr has no call site in the reference and is not offloaded\n");
   return -1010;
 }
+
+void capcb_release(void) { pool.release(); }
 
 void capcb_counters(long long* calls, long long* bytes_in, long long* bytes_out) {
   if (calls) *calls = g_calls.load();

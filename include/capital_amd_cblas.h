@@ -47,6 +47,8 @@ int LAPACKE_dorgqr(int layout, int m, int n, int k, double* a, int lda, double* 
 /* calls served and bytes staged (host -> HBM, HBM -> host) by this process so far - for tests and for sizing the PCIe cost.
  * Environment CAPCB_REPORT=1 prints the same three numbers on stderr when the process ends.                                   */
 void capcb_counters(long long* calls, long long* bytes_in, long long* bytes_out);
+/* the calling thread's staging buffers back to the device allocator (they are otherwise kept, grow-only, until the process ends) */
+void capcb_release(void);
 
 #ifdef __cplusplus
 }

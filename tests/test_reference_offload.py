@@ -16,7 +16,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFDIR = os.path.join(ROOT, "oracle", "_ref")
 MPIEXEC = "/opt/conda/bin/mpiexec"
-SYMBOLS = ("cblas_dgemm", "cblas_dtrmm", "cblas_dsyrk", "LAPACKE_dpotrf", "LAPACKE_dtrtri", "LAPACKE_dgeqrf", "LAPACKE_dorgqr", "capcb_counters")
+SYMBOLS = ("cblas_dgemm", "cblas_dtrmm", "cblas_dsyrk", "LAPACKE_dpotrf", "LAPACKE_dtrtri", "LAPACKE_dgeqrf", "LAPACKE_dorgqr", "capcb_counters", "capcb_release")
 COL, NT, TR, UP, LO, NONUNIT, LEFT, RIGHT = 102, 111, 112, 121, 122, 131, 141, 142
 
 
@@ -125,6 +125,9 @@ def exercise(L, rng, sizes, every_form=True):
     calls, bi, bo = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
     L.capcb_counters(C.byref(calls), C.byref(bi), C.byref(bo))
     assert calls.value > 0 and bi.value > 0 and bo.value > 0
+    L.capcb_release()                                                   # buffers back; the next call allocates again
+    one = _f(np.array([[2.0]])); L.cblas_dgemm(COL, NT, NT, 1, 1, 1, d(1.0), _p(one), 1, _p(one), 1, d(0.0), _p(one), 1)
+    assert one[0, 0] == 4.0
     return worst
 
 
