@@ -205,6 +205,46 @@ def cpu_baseline(cpu_n, budget_s=100.0):
             "sample": "N=%d numpy.linalg.cholesky (OpenBLAS, all host threads), %.3f s" % (n, t)}
 
 
+def reference_on_operators(n=8192, iters=3, limit_s=150.0, libdirs=None, extra_env=None):
+    """The REAL reference, unmodified, with libcapital_amd_cblas.so (include/capital_amd_cblas.h) in MKL's place: its own cholinv::factor
+    on one rank (MPI singleton), every BLAS / LAPACK call staged through HBM onto this library's operators - a PCIe-INCLUSIVE figure, reported
+    next to the headline for the record and never part of it.  oracle/_ref/cholinv_cap is the checker's build of the reference
+    (oracle/ref/build_ref.py); it is timed here the way cpu_baseline times the MKL build.  Never raises, never hangs (own process group,
+    killed at `limit_s`)."""
+    import signal
+    label = ("the reference itself (unmodified sources, bench/cholesky/cholinv.cpp:39-60's protocol) with libcapital_amd_cblas.so in MKL's place: "
+             "1 rank, N=%d, complete_inv=0, bcMult=-2; every BLAS / LAPACK call crosses PCIe twice" % n)
+    exe = os.path.join(ROOT, "oracle", "_ref", "cholinv_cap")
+    if not os.path.exists(exe):
+        return {"workload": label, "value": None, "error": "oracle/_ref/cholinv_cap not built here (needs /root/reference at build time)"}
+    env = dict(os.environ, CAPCB_REPORT="1", OMP_NUM_THREADS="1")
+    env.pop("LD_PRELOAD", None)
+    env["LD_LIBRARY_PATH"] = ":".join(["/usr/lib/x86_64-linux-gnu"] + (libdirs or [os.path.join(ROOT, "capital_amd", "lib"), "/opt/rocm/lib"]))
+    env.update(extra_env or {})
+    t0 = time.time()
+    p = subprocess.Popen([exe, str(n), "0", "1", "-2", "0", "0", "0", "-", str(iters)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, start_new_session=True)
+    try:
+        so, se = p.communicate(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        p.communicate()
+        return {"workload": label, "value": None, "error": "no result within %.0f s" % limit_s}
+    mt, mr = re.search(r"time=([\d.eE+-]+)", so), re.search(r"residual=([\d.eE+-]+)", so)
+    ms = re.search(r"(\d+) calls served, (\d+) bytes host -> device, (\d+) bytes device -> host", se)
+    if p.returncode != 0 or not mt or not mr:
+        return {"workload": label, "value": None, "error": ("exit code %d: " % p.returncode) + (se or so)[-300:]}
+    sec = float(mt.group(1))
+    e = {"workload": label, "n": n, "value": n ** 3 / 3.0 / sec / 1e12, "unit": "TFLOP/s (N^3/3), PCIe-inclusive", "ms_per_step": sec * 1e3, "steps": iters,
+         "residual": float(mr.group(1)), "residual_kind": "the reference's own validator (test/cholesky/validate.hpp:33-46)", "wall_s": time.time() - t0}
+    if ms:   # whole process: generation, warm-up, `iters` timed factors and the validator's products
+        e["blas_lapack_calls_served"] = int(ms.group(1)); e["bytes_host_to_device"] = int(ms.group(2)); e["bytes_device_to_host"] = int(ms.group(3))
+    return e
+
+
 def cpu_baseline_cacqr(m, n):
     """CholeskyQR2 on the host cores: the REAL reference's cacqr (1D grid, 8 ranks) on a bounded sample of the rows."""
     exe = os.path.join(ROOT, "oracle", "_ref", "cacqr_ref")
@@ -542,6 +582,10 @@ def bench_cholesky(args, torch, L, C, rank, world, dist, emulate, timed, allredu
                           "error": o2.get("error")})
             ok = ok and k2
             torch.cuda.empty_cache()
+        try:      # informational: cannot change `ok`, cannot take the line down
+            extra.append(reference_on_operators())
+        except Exception as ex:
+            extra.append({"workload": "the reference itself on libcapital_amd_cblas.so", "value": None, "error": repr(ex)})
         out["extra_configs"] = extra
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_budget_s)
