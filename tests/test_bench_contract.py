@@ -92,3 +92,25 @@ def test_the_traffic_figure_follows_the_kernels_machine_code():
     assert t is not None and 1e10 < t < 4e10, t                                    # the committed passes belong to THIS build's kernels
     assert bench.traffic_from_profile(32768, args) is None                         # ... and to this configuration only
     assert bench.traffic_from_profile(65536, types.SimpleNamespace(complete_inv=-1, nb=256, outer=0, tail=-1)) is None
+
+
+def test_the_reference_on_the_operators_extra_is_bounded_and_cannot_raise():
+    """bench.reference_on_operators (extra_configs: the unmodified reference on libcapital_amd_cblas.so, PCIe-inclusive): on the CPU stand-in
+    it returns the reference's own residual and the staging counters; past its limit or without a device it returns an error entry"""
+    import bench
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "cholinv_cap")):
+        e = bench.reference_on_operators(512, 1, 30)
+        assert e["value"] is None and "not built" in e["error"]
+        return
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipshim"))
+    import build_shim
+    build_shim.build_cblas()
+    dirs = [os.path.join(build_shim.OUT, "cblas"), build_shim.OUT]
+    e = bench.reference_on_operators(1024, 2, 120, dirs, {"SHIM_COMPUTE": "1"})
+    assert e["value"] > 0 and e["residual"] < 1e-14 and e["blas_lapack_calls_served"] > 10 and e["bytes_host_to_device"] > 8 * 1024 * 1024, e
+    late = bench.reference_on_operators(2048, 2, 0.05, dirs, {"SHIM_COMPUTE": "1"})
+    assert late["value"] is None and "no result within" in late["error"]
+    nodev = bench.reference_on_operators(256, 1, 60)              # the product build of the library: no device here -> a loud, contained failure
+    import torch
+    if not torch.cuda.is_available():
+        assert nodev["value"] is None and "exit code" in nodev["error"]
