@@ -22,6 +22,12 @@ struct Reporter { Reporter() { const char* e = getenv("CAPCB_REPORT"); if (e && 
   fprintf(stderr, "capital_amd_cblas: %s: %s\n", fn, what);
   abort();
 }
+// an argument BLAS itself rejects (or a form this library does not take): like a CPU BLAS's xerbla - say so, do nothing, return.
+// (Upstream does issue such calls: a 0-column split piece reaches cblas_dtrmm with ldb = 0, and MKL answers "Parameter 10 was incorrect".)
+bool bad_arg(const char* fn, const char* what) {
+  fprintf(stderr, "capital_amd_cblas: %s: %s - call ignored\n", fn, what);
+  return true;
+}
 void hip_ok(hipError_t e, const char* fn) { if (e != hipSuccess) die(fn, hipGetErrorString(e)); }
 void cap_ok(int st, const char* fn) { if (st != CAP_OK) die(fn, cap_status_string(st)); }
 
@@ -68,14 +74,14 @@ extern "C" {
 void cblas_dgemm(int layout, int transa, int transb, int m, int n, int k, double alpha, const double* A, int lda, const double* B, int ldb,
                  double beta, double* C, int ldc) {
   const char* fn = "cblas_dgemm";
-  if (layout != CAPCB_COL_MAJOR) die(fn, "row-major is not taken (the reference passes AblasColumnMajor everywhere)");
-  if ((transa != CAPCB_NOTRANS && transa != CAPCB_TRANS) || (transb != CAPCB_NOTRANS && transb != CAPCB_TRANS)) die(fn, "ConjTrans is not taken");
-  if (m < 0 || n < 0 || k < 0) die(fn, "negative dimension");
-  g_calls++;
-  if (m == 0 || n == 0) return;
+  if (layout != CAPCB_COL_MAJOR && bad_arg(fn, "row-major is not taken (the reference passes AblasColumnMajor everywhere)")) return;
+  if (((transa != CAPCB_NOTRANS && transa != CAPCB_TRANS) || (transb != CAPCB_NOTRANS && transb != CAPCB_TRANS)) && bad_arg(fn, "ConjTrans is not taken")) return;
+  if ((m < 0 || n < 0 || k < 0) && bad_arg(fn, "negative dimension")) return;
   const int64_t ar = transa == CAPCB_NOTRANS ? m : k, ac = transa == CAPCB_NOTRANS ? k : m;
   const int64_t br = transb == CAPCB_NOTRANS ? k : n, bc = transb == CAPCB_NOTRANS ? n : k;
-  if (lda < ld_of(ar) || ldb < ld_of(br) || ldc < ld_of(m)) die(fn, "leading dimension smaller than the window");
+  if ((lda < ld_of(ar) || ldb < ld_of(br) || ldc < ld_of(m)) && bad_arg(fn, "leading dimension smaller than the window")) return;
+  g_calls++;
+  if (m == 0 || n == 0) return;
   double* dA = pool.get(0, (size_t)dev_ld(ar) * ac, fn); double* dB = pool.get(1, (size_t)dev_ld(br) * bc, fn); double* dC = pool.get(2, (size_t)dev_ld(m) * n, fn);
   up(dA, A, lda, ar, ac, fn); up(dB, B, ldb, br, bc, fn);
   if (beta != 0.0) up(dC, C, ldc, m, n, fn);                          // BLAS: C is not read when beta == 0
@@ -86,16 +92,16 @@ void cblas_dgemm(int layout, int transa, int transb, int m, int n, int k, double
 void cblas_dtrmm(int layout, int side, int uplo, int transa, int diag, int m, int n, double alpha, const double* A, int lda, double* B,
                  int ldb) {
   const char* fn = "cblas_dtrmm";
-  if (layout != CAPCB_COL_MAJOR) die(fn, "row-major is not taken");
-  if (side != CAPCB_LEFT && side != CAPCB_RIGHT) die(fn, "side");
-  if (uplo != CAPCB_UPPER) die(fn, "lower-triangular operands are not taken (every call site of the reference is Upper)");
-  if (diag != CAPCB_NONUNIT) die(fn, "unit-diagonal operands are not taken (every call site of the reference is NonUnit)");
-  if (transa != CAPCB_NOTRANS && transa != CAPCB_TRANS) die(fn, "ConjTrans is not taken");
-  if (m < 0 || n < 0) die(fn, "negative dimension");
+  if (layout != CAPCB_COL_MAJOR && bad_arg(fn, "row-major is not taken")) return;
+  if (side != CAPCB_LEFT && side != CAPCB_RIGHT && bad_arg(fn, "side")) return;
+  if (uplo != CAPCB_UPPER && bad_arg(fn, "lower-triangular operands are not taken (every call site of the reference is Upper)")) return;
+  if (diag != CAPCB_NONUNIT && bad_arg(fn, "unit-diagonal operands are not taken (every call site of the reference is NonUnit)")) return;
+  if (transa != CAPCB_NOTRANS && transa != CAPCB_TRANS && bad_arg(fn, "ConjTrans is not taken")) return;
+  if ((m < 0 || n < 0) && bad_arg(fn, "negative dimension")) return;
+  const int64_t t = side == CAPCB_LEFT ? m : n;
+  if ((lda < ld_of(t) || ldb < ld_of(m)) && bad_arg(fn, "leading dimension smaller than the window")) return;
   g_calls++;
   if (m == 0 || n == 0) return;
-  const int64_t t = side == CAPCB_LEFT ? m : n;
-  if (lda < t || ldb < m) die(fn, "leading dimension smaller than the window");
   const int cside = side == CAPCB_LEFT ? CAP_LEFT : CAP_RIGHT;
   double* dT = pool.get(0, (size_t)dev_ld(t) * t, fn); double* dB = pool.get(2, (size_t)dev_ld(m) * n, fn);
   double* work = pool.get(3, (size_t)cap_dtrmm_work_size(cside, m, n), fn);
@@ -106,14 +112,14 @@ void cblas_dtrmm(int layout, int side, int uplo, int transa, int diag, int m, in
 
 void cblas_dsyrk(int layout, int uplo, int trans, int n, int k, double alpha, const double* A, int lda, double beta, double* C, int ldc) {
   const char* fn = "cblas_dsyrk";
-  if (layout != CAPCB_COL_MAJOR) die(fn, "row-major is not taken");
-  if (uplo != CAPCB_UPPER && uplo != CAPCB_LOWER) die(fn, "uplo");
-  if (trans != CAPCB_NOTRANS && trans != CAPCB_TRANS) die(fn, "ConjTrans is not taken");
-  if (n < 0 || k < 0) die(fn, "negative dimension");
+  if (layout != CAPCB_COL_MAJOR && bad_arg(fn, "row-major is not taken")) return;
+  if (uplo != CAPCB_UPPER && uplo != CAPCB_LOWER && bad_arg(fn, "uplo")) return;
+  if (trans != CAPCB_NOTRANS && trans != CAPCB_TRANS && bad_arg(fn, "ConjTrans is not taken")) return;
+  if ((n < 0 || k < 0) && bad_arg(fn, "negative dimension")) return;
+  const int64_t ar = trans == CAPCB_NOTRANS ? n : k, ac = trans == CAPCB_NOTRANS ? k : n;
+  if ((lda < ld_of(ar) || ldc < ld_of(n)) && bad_arg(fn, "leading dimension smaller than the window")) return;
   g_calls++;
   if (n == 0) return;
-  const int64_t ar = trans == CAPCB_NOTRANS ? n : k, ac = trans == CAPCB_NOTRANS ? k : n;
-  if (lda < ld_of(ar) || ldc < n) die(fn, "leading dimension smaller than the window");
   double* dA = pool.get(0, (size_t)dev_ld(ar) * ac, fn); double* dC = pool.get(2, (size_t)dev_ld(n) * n, fn);
   up(dA, A, lda, ar, ac, fn);
   up(dC, C, ldc, n, n, fn);                                          // always: the other triangle of the window must come back as it was

@@ -14,7 +14,9 @@
  * Semantics kept from BLAS / LAPACK: only the `uplo` triangle of a triangular / symmetric operand is referenced or written (the other
  * triangle of the caller's window comes back untouched); C is not read when beta == 0; LAPACKE_dpotrf returns info > 0 for a
  * non-positive pivot; a negative info for an argument this library does not take (row-major, 'L', unit diagonal - none of which the
- * reference uses); the BLAS calls report the same on stderr and abort (CBLAS has no status to return).  Staging buffers are per thread
+ * reference uses); the BLAS calls answer an illegal argument the way a CPU BLAS's xerbla does - a line on stderr, the call ignored (CBLAS
+ * has no status to return; upstream does issue such calls on degenerate splits and MKL lets them pass) - and abort only when the device
+ * or the library fails underneath them.  Staging buffers are per thread
  * and grow only; everything runs on the NULL stream of the current device and has completed on return.
  * LAPACKE_dgeqrf / LAPACKE_dorgqr have no call site upstream (ArgPack_geqrf / _orgqr are never instantiated); they are exported so that
  * the reference links, and return -1010 (LAPACK_WORK_MEMORY_ERROR's slot) after a message.                                            */
