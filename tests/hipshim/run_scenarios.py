@@ -512,6 +512,35 @@ def lifecycle_case(r):
         shim.hipFree(q)
 
 
+def cblas_case(r, what, m, n, k):
+    """include/capital_amd_cblas.h over the stand-in: host memory in, staged through "device" buffers, the operator, the window back - the
+    staging copies (synchronous, NULL stream) against every stream the operator uses inside"""
+    import numpy as np
+    CB = C.CDLL(build_shim.build_cblas())
+    d = C.c_double
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    if what == "dgemm":
+        a, b, c = (np.asfortranarray(np.ones(sh)) for sh in ((m + 1, k), (k + 3, n), (m, n)))
+        for beta in (0.0, 1.0):
+            r.call("cblas_dgemm", CB.cblas_dgemm, 102, 111, 111, m, n, k, d(1.0), p(a), m + 1, p(b), k + 3, d(beta), p(c), m)
+        r.call("cblas_dgemm", CB.cblas_dgemm, 102, 112, 112, m, n, k, d(1.0), p(np.asfortranarray(np.ones((k, m)))), k, p(np.asfortranarray(np.ones((n, k)))), n, d(0.0), p(c), m)
+    elif what == "dtrmm":
+        for side, t in ((141, m), (142, n)):
+            tm, b = np.asfortranarray(np.triu(np.ones((t, t)))), np.asfortranarray(np.ones((m + 2, n)))
+            for tr in (111, 112):
+                r.call("cblas_dtrmm", CB.cblas_dtrmm, 102, side, 121, tr, 131, m, n, d(1.0), p(tm), t, p(b), m + 2)
+    elif what == "dsyrk":
+        a, c = np.asfortranarray(np.ones((k, n))), np.asfortranarray(np.ones((n, n)))
+        r.call("cblas_dsyrk", CB.cblas_dsyrk, 102, 121, 112, n, k, d(-1.0), p(a), k, d(1.0), p(c), n)
+    else:
+        a = np.asfortranarray(np.eye(n) * n + 1.0)
+        CB.LAPACKE_dpotrf.restype = C.c_int; CB.LAPACKE_dtrtri.restype = C.c_int
+        for _ in range(2):
+            r.call("LAPACKE_dpotrf", CB.LAPACKE_dpotrf, 102, C.c_char(b"U"), n, p(a), n)
+        r.call("LAPACKE_dtrtri", CB.LAPACKE_dtrtri, 102, C.c_char(b"U"), C.c_char(b"N"), min(n, 3000), p(a), n)
+    CB.capcb_release()
+
+
 def main(out_path, user_streams=(0, 1)):
     for us in user_streams:
         # ---- single-GPU Cholesky plan: the headline schedule, reference semantics, ragged sizes, schedule options
@@ -612,6 +641,11 @@ def main(out_path, user_streams=(0, 1)):
             for p in range(P):
                 scenario("cacqr m=%d n=%d iter=%d P=%d rank=%d" % (m, n, iters, P, p), us, "cacqr m=%d n=%d iter=%d P=%d" % (m, n, iters, P), p, P)(
                     lambda r, a=(m, n, iters, P, p): cacqr_case(r, *a))
+    if 0 in user_streams:
+        # ---- the CBLAS / LAPACKE offload library (always on the NULL stream): potrf at a size with look-ahead on helper streams, ragged products
+        for (what, m, n, k) in [("dpotrf", 0, 5000, 0), ("dpotrf", 0, 1000, 0), ("dgemm", 3000, 2000, 1000), ("dgemm", 129, 77, 33), ("dgemm", 4096, 4, 4096),
+                                ("dtrmm", 2048, 1000, 0), ("dsyrk", 0, 3000, 700)]:
+            scenario("cblas offload %s m=%d n=%d k=%d" % (what, m, n, k), 0)(lambda r, a=(what, m, n, k): cblas_case(r, *a))
     live = os.path.join(build_shim.OUT, "live_%d.txt" % os.getpid())
     shim.shim_live_report(live.encode())
     leaks = open(live).read().splitlines()
