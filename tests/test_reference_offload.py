@@ -27,6 +27,9 @@ def test_the_library_builds_and_exports_what_its_header_declares():
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
     assert exported == set(SYMBOLS), exported ^ set(SYMBOLS)
     header = open(os.path.join(ROOT, "include", "capital_amd_cblas.h")).read()
+    code = "import ctypes as C; L = C.CDLL(%r); [getattr(L, s) for s in %r]; print('loaded')" % (lib, SYMBOLS)     # loads (no compute call: no GPU here)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "loaded" in r.stdout, r.stderr[-2000:]
     for s in SYMBOLS:
         assert s + "(" in header, s
     # the main library does not export BLAS names: a process that also holds a CPU BLAS keeps it
