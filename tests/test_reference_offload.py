@@ -153,7 +153,19 @@ def reference_available():
 
 
 def run_reference(env, exe, ranks, argv, timeout=600):
-    r = subprocess.run([MPIEXEC, "-n", str(ranks), os.path.join(REFDIR, exe)] + [str(a) for a in argv], capture_output=True, text=True, timeout=timeout, env=env)
+    import signal
+    cmd = [MPIEXEC, "-n", str(ranks), os.path.join(REFDIR, exe)] + [str(a) for a in argv]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        so, se = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)             # the launcher AND its ranks: nothing of a stuck run stays on the device
+        except OSError:
+            pass
+        so, se = p.communicate()
+        raise AssertionError((exe, argv, "no result within %d s" % timeout, so[-1000:], se[-1000:]))
+    r = subprocess.CompletedProcess(cmd, p.returncode, so, se)
     assert r.returncode == 0, (exe, argv, r.stdout[-1500:], r.stderr[-1500:])
     run_reference.last_output = r.stdout + r.stderr
     import re

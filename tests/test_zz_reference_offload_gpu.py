@@ -43,7 +43,7 @@ def test_every_entry_point_on_the_device_against_numpy():
 def test_the_real_reference_runs_on_the_device_and_passes_its_own_validators():
     env = tro.cap_env([LIBDIR, "/opt/rocm/lib"])
     for exe, ranks, argv, checks in tro.REFERENCE_RUNS:
-        kv, served = tro.run_reference(env, exe + "_cap", ranks, list(argv) + ["-", 1], timeout=900)
+        kv, served = tro.run_reference(env, exe + "_cap", ranks, list(argv) + ["-", 1], timeout=300)
         for k, tol in checks.items():
             assert kv[k] < tol, (exe, ranks, argv, kv)
         assert len(served) == ranks and min(served) > 0, (exe, ranks, served)
