@@ -140,6 +140,32 @@ def test_every_entry_point_against_numpy_with_blas_conventions(standin):
     assert max(worst.values()) < 5e-14, worst
 
 
+def build_and_run_demo(tmp_path, libdir, run_dirs, extra_env, n):
+    """examples/cblas_offload_demo.c - a plain CBLAS / LAPACKE program (host arrays, MKL's argument lists) linked with -lcapital_amd_cblas"""
+    import re
+    exe = str(tmp_path / "cblas_offload_demo")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-O1", os.path.join(ROOT, "examples", "cblas_offload_demo.c"), "-I" + os.path.join(ROOT, "include"),
+           "-L" + libdir, "-lcapital_amd_cblas", "-Wl,--allow-shlib-undefined", "-lm", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ); env.pop("LD_PRELOAD", None); env["LD_LIBRARY_PATH"] = ":".join(run_dirs); env.update(extra_env)
+    run = subprocess.run([exe, str(n)], capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+    m = re.search(r"residual = (\S+) inverse = (\S+) calls = (\d+)", run.stdout)
+    assert m and float(m.group(1)) < 1e-14 and float(m.group(2)) < 1e-13 and int(m.group(3)) == 5, run.stdout
+
+
+def test_a_plain_cblas_program_runs_on_the_library(tmp_path):
+    import shutil
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipshim"))
+    import build_shim
+    build_shim.build_cblas()
+    d = os.path.join(build_shim.OUT, "cblas")
+    build_and_run_demo(tmp_path, d, [d, build_shim.OUT], {"SHIM_COMPUTE": "1"}, 901)
+
+
 def cap_env(libdirs):
     env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1", CAPCB_REPORT="1")
     env.pop("LD_PRELOAD", None)

@@ -39,6 +39,11 @@ def test_every_entry_point_on_the_device_against_numpy():
 
 
 @pytest.mark.gpu
+def test_a_plain_cblas_program_runs_on_the_device(tmp_path):
+    tro.build_and_run_demo(tmp_path, LIBDIR, [LIBDIR, "/opt/rocm/lib"], {}, 3001)
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif(not tro.reference_available(), reason="oracle/_ref/*_cap (the reference built from /root/reference on this library) or mpiexec is not here")
 def test_the_real_reference_runs_on_the_device_and_passes_its_own_validators():
     env = tro.cap_env([LIBDIR, "/opt/rocm/lib"])
