@@ -27,6 +27,9 @@ Outputs (git-ignored, NOT gpurun-ignored, so they travel to the GPU box):
   oracle/_ref/summa_ref     argv: op M N K c layout num_chunks alpha beta dump   (GEMM / TRMM / SYRK overloads of matmult::summa)
   oracle/_ref/{cholinv,cacqr,summa}_cap   the same three drivers linked with libcapital_amd_cblas.so in MKL's place (the reference
                             running on the product's operators; LD_LIBRARY_PATH = capital_amd/lib or tests/hipshim/_build/cblas)
+  oracle/_ref/{cholinv,cacqr,summa}_engine   the same drivers with INTEGRATION.md section A (examples/engine_binding/*.inc) pasted over
+                            upstream's double specialisations of blas::engine / lapack::engine: runs where host memory is device memory
+                            (LD_LIBRARY_PATH = tests/hipshim/_build/engine, the CPU stand-in)
 Run as: MKL_NUM_THREADS=1 /opt/conda/bin/mpiexec -n {1|8} oracle/_ref/cholinv_ref ...
 
 The reference has no build system we can use (config.mk is an empty template,
@@ -85,6 +88,29 @@ def _apply_compile_fixes(root):
          'U globalNumRows=Matrix.num_rows_global(); U globalNumColumns=Matrix.num_columns_global();')])
 
 
+def _apply_engine_binding(root):
+    """INTEGRATION.md section A made real: upstream's `double` specialisations of blas::engine / lapack::engine are cut out of the throw-away
+    copy and examples/engine_binding/*.inc (the text a maintainer would paste) put in their place; the includes the binding needs go into
+    src/util/shared.h, which every upstream header pulls in."""
+    import re
+    bind = os.path.join(REPO, "examples", "engine_binding")
+    for rel, inc, names in (("src/blas/interface.hpp", "blas_interface_double.inc", ("_gemm", "_trmm", "_syrk")),
+                            ("src/lapack/interface.hpp", "lapack_interface_double.inc", ("_potrf", "_trtri"))):
+        path = os.path.join(root, rel)
+        s = open(path).read()
+        first = None
+        for nm in names:
+            m = re.search(r"template<>\s*\nvoid engine::%s\(double\*.*?\n\}\n" % nm, s, re.S)
+            if not m:
+                raise RuntimeError("engine binding: upstream's %s specialisation not found in %s" % (nm, rel))
+            first = m.start() if first is None else min(first, m.start())
+            s = s[:m.start()] + s[m.end():]
+        s = s[:first] + open(os.path.join(bind, inc)).read() + "\n" + s[first:]
+        open(path, "w").write(s)
+    _patch(os.path.join(root, "src/util/shared.h"), [
+        ('#include "mkl.h"', '#include "mkl.h"\n#include <stdexcept>\n#include <new>\n#include <hip/hip_runtime_api.h>\n#include "capital_amd.h"')])
+
+
 def available():
     return (os.path.isdir(os.path.join(REF, "src", "alg")) and
             os.path.exists(os.path.join(CONDA, "lib", "libmkl_rt.so")) and
@@ -123,6 +149,21 @@ def build(verbose=True):
                 cmd = cmd[:cmd.index("-o")] + ["-o", os.path.join(OUT, exe.replace("_ref", "_cap")), "-L" + os.path.join(CONDA, "lib"),
                                                  "-Wl,-rpath," + os.path.join(CONDA, "lib"), "-lmpi", "-L" + cap, "-lcapital_amd_cblas",
                                                  "-Wl,--allow-shlib-undefined", "-lpthread", "-lm", "-ldl"]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
+        # the engine specialisations themselves bound to the library (examples/engine_binding/*.inc pasted over
+        # upstream's).  The matrices stay where upstream allocates them, so this build only RUNS where host memory is device memory - the CPU
+        # stand-in (tests/test_reference_offload.py); on a GPU it needs section A's other half (matrix<> on hipMalloc).  What it proves:
+        # the pasted text compiles against upstream's declarations and calls the operators with the right arguments.
+        cap = os.path.join(REPO, "capital_amd", "lib")
+        if os.path.exists(os.path.join(cap, "libcapital_amd_cblas.so")):
+            _apply_engine_binding(root)
+            for drv, exe in (("drv_cholinv.cpp", "cholinv_engine"), ("drv_cacqr.cpp", "cacqr_engine"), ("drv_summa.cpp", "summa_engine")):
+                cmd = ["g++", "-std=c++14", "-O2", "-fpermissive", "-w", "-DMPICH_SKIP_MPICXX", "-D__HIP_PLATFORM_AMD__", "-I" + inc, "-I" + tmp,
+                       "-I/opt/rocm/include", "-I" + os.path.join(REPO, "include"), os.path.join(HERE, drv), "-o", os.path.join(OUT, exe),
+                       "-L" + os.path.join(CONDA, "lib"), "-Wl,-rpath," + os.path.join(CONDA, "lib"), "-lmpi", "-L" + cap, "-lcapital_amd_cblas", "-lcapital_amd",
+                       "-L/opt/rocm/lib", "-lamdhip64", "-Wl,--allow-shlib-undefined", "-lpthread", "-lm", "-ldl"]
                 if verbose:
                     print(" ".join(cmd))
                 subprocess.check_call(cmd)

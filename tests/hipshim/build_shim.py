@@ -47,6 +47,22 @@ def build_cblas():
     return dst
 
 
+def build_engine_dir():
+    """a directory in which the PRODUCT's library names resolve to the stand-in builds (symbolic links: libcapital_amd.so -> the shim build,
+    libamdhip64.so.7 -> libhipshim.so, libcapital_amd_cblas.so -> the build over the stand-in): a program linked against the product
+    (oracle/_ref/*_engine: INTEGRATION.md section A pasted into the reference) runs on the CPU with LD_LIBRARY_PATH pointing here"""
+    cb = build_cblas()
+    d = os.path.join(OUT, "engine")
+    os.makedirs(d, exist_ok=True)
+    for name, target in (("libcapital_amd.so", LIB), ("libamdhip64.so.7", SHIM), ("libcapital_amd_cblas.so", cb)):
+        link = os.path.join(d, name)
+        if os.path.islink(link) or os.path.exists(link):
+            os.unlink(link)
+        os.symlink(target, link)
+    return d
+
+
 if __name__ == "__main__":
     print(build())
     print(build_cblas())
+    print(build_engine_dir())

@@ -296,3 +296,26 @@ def test_random_configurations_of_the_reference_on_mkl_and_on_the_library():
     lines = r.stdout.strip().splitlines()
     assert r.returncode == 0 and lines[-1] == "30 configurations, 0 with findings", "\n".join(l for l in lines if not l.startswith("ok"))[-3000:] + r.stderr[-2000:]
     assert {l.split()[1] for l in lines if l.startswith("ok")} == {"cholinv", "cacqr", "summa"}
+
+
+def test_integration_section_A_shows_the_files_that_are_compiled():
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for f in ("blas_interface_double.inc", "lapack_interface_double.inc"):
+        text = open(os.path.join(ROOT, "examples", "engine_binding", f)).read()
+        assert "```cpp\n" + text + "```" in doc, f
+
+
+@pytest.mark.skipif(not (reference_available() and os.path.exists(os.path.join(REFDIR, "cholinv_engine"))),
+                    reason="oracle/_ref/*_engine (INTEGRATION.md section A pasted into the reference) or mpiexec is not here")
+def test_integration_section_A_pasted_into_the_reference_compiles_and_runs():
+    """oracle/ref/build_ref.py cut upstream's double specialisations of blas::engine / lapack::engine out of its copy of the reference and
+    pasted examples/engine_binding/*.inc (= INTEGRATION.md section A) in their place: the reference runs on the stand-in (host memory is
+    device memory there), its validators pass, and no call went through the CBLAS library that is linked beside it"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipshim"))
+    import build_shim
+    env = cap_env([build_shim.build_engine_dir(), build_shim.OUT]); env["SHIM_COMPUTE"] = "1"
+    for exe, ranks, argv, checks in REFERENCE_RUNS:
+        kv, served = run_reference(env, exe + "_engine", ranks, list(argv) + ["-", 1])
+        for k, tol in checks.items():
+            assert kv[k] < tol, (exe, ranks, argv, kv)
+        assert served == [0] * ranks, (exe, ranks, served)
