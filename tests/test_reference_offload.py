@@ -125,6 +125,25 @@ def exercise(L, rng, sizes, every_form=True):
     assert L.LAPACKE_dtrtri(COL, C.c_char(b"U"), C.c_char(b"U"), n, _p(t), n) == -3
     L.LAPACKE_dgeqrf.restype = C.c_int
     assert L.LAPACKE_dgeqrf(COL, n, n, _p(a), n, _p(a)) == -1010
+    if every_form:
+        # BLAS's degenerate scalars: k = 0 or alpha = 0 scale C (A and B are not referenced - NaNs in them must not matter); TRMM with alpha = 0 zeroes B
+        m, n, k = 50, 40, 30
+        c0 = _f(rng.standard_normal((m, n))); nan_a, nan_b = _f(np.full((m, k), np.nan)), _f(np.full((k, n), np.nan))
+        for kk, alpha, beta in ((0, 1.0, -0.5), (0, 1.0, 0.0), (k, 0.0, 2.0)):
+            c = c0.copy(order="F")
+            L.cblas_dgemm(COL, NT, NT, m, n, kk, d(alpha), _p(nan_a), m, _p(nan_b), k, d(beta), _p(c), m)
+            assert np.array_equal(c, beta * c0), (kk, alpha, beta)
+        cs = _f(rng.standard_normal((n, n))); c = cs.copy(order="F")
+        L.cblas_dsyrk(COL, UP, TR, n, k, d(0.0), _p(nan_b), k, d(0.5), _p(c), n)
+        assert np.array_equal(np.triu(c), np.triu(0.5 * cs)) and np.array_equal(np.tril(c, -1), np.tril(cs, -1))
+        b = c0.copy(order="F")
+        L.cblas_dtrmm(COL, LEFT, UP, NT, NONUNIT, m, n, d(0.0), _p(_f(np.full((m, m), np.nan))), m, _p(b), m)
+        assert not b.any()
+        # an illegal argument: a line on stderr, the call ignored (xerbla's way) - the window stays as it was
+        c = c0.copy(order="F")
+        L.cblas_dgemm(COL, NT, NT, m, n, k, d(1.0), _p(nan_a), m - 1, _p(nan_b), k, d(0.0), _p(c), m)
+        L.cblas_dtrmm(COL, LEFT, LO, NT, NONUNIT, m, n, d(1.0), _p(nan_a), m, _p(c), m)
+        assert np.array_equal(c, c0)
     calls, bi, bo = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
     L.capcb_counters(C.byref(calls), C.byref(bi), C.byref(bo))
     assert calls.value > 0 and bi.value > 0 and bo.value > 0
