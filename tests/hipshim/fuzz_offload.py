@@ -16,6 +16,9 @@ def main(seed, count):
     import test_reference_offload as tro
     build_shim.build_cblas()
     env = tro.cap_env([os.path.join(build_shim.OUT, "cblas"), build_shim.OUT]); env["SHIM_COMPUTE"] = "1"
+    # every third configuration also through the third build: INTEGRATION.md section A pasted over upstream's engine specialisations
+    env_engine = tro.cap_env([build_shim.build_engine_dir(), build_shim.OUT]); env_engine["SHIM_COMPUTE"] = "1"
+    have_engine = os.path.exists(os.path.join(tro.REFDIR, "cholinv_engine"))
     rng = random.Random(seed)
     bad = 0
     for i in range(count):
@@ -38,6 +41,8 @@ def main(seed, count):
         try:
             # tolerance: the two builds sum in different orders; ill-conditioned random squares (M = N CholeskyQR) amplify that
             w = tro.dumps_equal(exe, ranks, argv, env, 1e-9 if exe == "cacqr" else 1e-11)
+            if have_engine and i % 3 == 0 and w is not None:
+                w = max(w, tro.dumps_equal(exe, ranks, argv, env_engine, 1e-9 if exe == "cacqr" else 1e-11, build="engine"))
             print("ok   %s ranks=%d %s  %s" % (exe, ranks, argv, "upstream's own run is not a valid one here (illegal BLAS argument / singular input)" if w is None else "%.1e" % w), flush=True)
         except AssertionError as e:
             bad += 1

@@ -260,12 +260,12 @@ def dump_arrays(exe, ranks, argv, raw):
     return out
 
 
-def dumps_equal(exe, ranks, argv, env_cap, tol):
+def dumps_equal(exe, ranks, argv, env_cap, tol, build="cap"):
     """the same run by the MKL-linked build and by the build on this library: every rank's dump file, array by array (the worst relative
     difference over the arrays: inputs must be identical, R / R^-1 / Q / the products equal to rounding)"""
     with tempfile.TemporaryDirectory() as td:
         out = {}
-        for tag, env in (("ref", dict(os.environ, MKL_NUM_THREADS="1")), ("cap", env_cap)):
+        for tag, env in (("ref", dict(os.environ, MKL_NUM_THREADS="1")), (build, env_cap)):
             dump = os.path.join(td, tag + ".bin")
             a = list(argv) + [dump] + ([1] if exe != "summa" else [])
             kv, _ = run_reference(env, exe + "_" + tag, ranks, a)
@@ -275,7 +275,7 @@ def dumps_equal(exe, ranks, argv, env_cap, tol):
             files = [dump] if os.path.exists(dump) else ["%s.%d" % (dump, q) for q in range(ranks)]
             out[tag] = [open(f, "rb").read() for f in files]
         worst = 0.0
-        for x, y in zip(out["ref"], out["cap"]):
+        for x, y in zip(out["ref"], out[build]):
             assert len(x) == len(y)
             ax, ay = dump_arrays(exe, ranks, argv, x), dump_arrays(exe, ranks, argv, y)
             assert np.array_equal(ax[0], ay[0])                                 # the input
