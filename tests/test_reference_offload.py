@@ -89,6 +89,8 @@ def exercise(L, rng, sizes, every_form=True):
             for uplo in ((UP, LO) if every_form else (UP,)):
                 for beta in (0.0, 1.0):
                     c0 = rng.standard_normal((n, n)); c = _f(np.full((n + 4, n), 3.5)); c[:n] = c0
+                    if beta == 0.0 and every_form:                               # beta = 0: the triangle that is written is not read first
+                        c[:n][np.triu_indices(n) if uplo == UP else np.tril_indices(n)] = np.nan
                     L.cblas_dsyrk(COL, uplo, tr, n, k, d(-1.0), _p(a), a.shape[0], d(beta), _p(c), c.shape[0])
                     tri = np.triu if uplo == UP else np.tril
                     other = (lambda x: np.tril(x, -1)) if uplo == UP else (lambda x: np.triu(x, 1))
