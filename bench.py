@@ -206,9 +206,10 @@ def cpu_baseline(cpu_n, budget_s=100.0):
 
 
 def reference_on_operators(n=8192, iters=3, limit_s=150.0, libdirs=None, extra_env=None):
-    """The REAL reference, unmodified, with libcapital_amd_cblas.so (include/capital_amd_cblas.h) in MKL's place: its own cholinv::factor
+    """Part of the cpu_baseline leg (the only part of this file that may execute anything under oracle/): the comparator - the REAL reference,
+    unmodified - once more with libcapital_amd_cblas.so (include/capital_amd_cblas.h) in MKL's place: its own cholinv::factor
     on one rank (MPI singleton), every BLAS / LAPACK call staged through HBM onto this library's operators - a PCIe-INCLUSIVE figure, reported
-    next to the headline for the record and never part of it.  oracle/_ref/cholinv_cap is the checker's build of the reference
+    inside `cpu_baseline` for the record and never part of `value`.  oracle/_ref/cholinv_cap is the checker's build of the reference
     (oracle/ref/build_ref.py); it is timed here the way cpu_baseline times the MKL build.  Never raises, never hangs (own process group,
     killed at `limit_s`)."""
     import signal
@@ -582,13 +583,16 @@ def bench_cholesky(args, torch, L, C, rank, world, dist, emulate, timed, allredu
                           "error": o2.get("error")})
             ok = ok and k2
             torch.cuda.empty_cache()
-        try:      # informational: cannot change `ok`, cannot take the line down
-            extra.append(reference_on_operators())
-        except Exception as ex:
-            extra.append({"workload": "the reference itself on libcapital_amd_cblas.so", "value": None, "error": repr(ex)})
         out["extra_configs"] = extra
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_budget_s)
+        if world == 1 and args.complete_inv < 0 and n == 65536:
+            # the same comparator (the checker's build of the reference, oracle/_ref) once more with its BLAS / LAPACK calls served by this
+            # library through PCIe: part of the baseline leg, informational, cannot change `value` or its gate
+            try:
+                out["cpu_baseline"]["reference_with_offloaded_blas"] = reference_on_operators()
+            except Exception as ex:
+                out["cpu_baseline"]["reference_with_offloaded_blas"] = {"value": None, "error": repr(ex)}
     if not ok:
         out["value"] = None
         out["error"] = "factorization failed its parity gate (info != 0 or residual above %g)" % RES_TOL if sec is not None else \

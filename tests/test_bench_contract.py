@@ -95,7 +95,7 @@ def test_the_traffic_figure_follows_the_kernels_machine_code():
 
 
 def test_the_reference_on_the_operators_extra_is_bounded_and_cannot_raise():
-    """bench.reference_on_operators (extra_configs: the unmodified reference on libcapital_amd_cblas.so, PCIe-inclusive): on the CPU stand-in
+    """bench.reference_on_operators (cpu_baseline.reference_with_offloaded_blas: the unmodified reference on libcapital_amd_cblas.so, PCIe-inclusive): on the CPU stand-in
     it returns the reference's own residual and the staging counters; past its limit or without a device it returns an error entry"""
     import bench
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "cholinv_cap")):
