@@ -133,7 +133,7 @@ def test_random_configurations_against_the_real_reference_run_beside_the_library
     """tests/hipshim/fuzz_reference.py: the REAL reference (oracle/_ref, built from /root/reference where that exists) factors random
     (n, complete_inv, split, bc_mult_dim) on 1 rank and on its 2 x 2 x 2 grid, random CholeskyQR / CholeskyQR2 on 1D and c x d x c grids of
     1 ... 27 ranks, random GEMM / TRMM / SYRK calls of matmult::summa on the cubes of 1, 8, 27 ranks; the library runs the same input through
-    the compute mode: same R, same R^-1 pattern, same Q pieces, same product pieces (5200 configurations agreed when this was written; 40 with
+    the compute mode: same R, same R^-1 pattern, same Q pieces, same product pieces (6800 configurations agreed when this was written; 40 with
     a fixed seed here).  Skipped where the reference binary or an MPI launcher is missing."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "hipshim"))
     import fuzz_reference
