@@ -205,7 +205,7 @@ def cpu_baseline(cpu_n, budget_s=100.0):
             "sample": "N=%d numpy.linalg.cholesky (OpenBLAS, all host threads), %.3f s" % (n, t)}
 
 
-def reference_on_operators(n=8192, iters=3, limit_s=150.0, libdirs=None, extra_env=None):
+def reference_on_operators(n=8192, iters=3, limit_s=90.0, libdirs=None, extra_env=None):
     """Part of the cpu_baseline leg (the only part of this file that may execute anything under oracle/): the comparator - the REAL reference,
     unmodified - once more with libcapital_amd_cblas.so (include/capital_amd_cblas.h) in MKL's place: its own cholinv::factor
     on one rank (MPI singleton), every BLAS / LAPACK call staged through HBM onto this library's operators - a PCIe-INCLUSIVE figure, reported
