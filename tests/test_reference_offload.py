@@ -346,7 +346,7 @@ def test_integration_section_A_pasted_into_the_reference_compiles_and_runs():
 def test_random_blas_and_lapack_calls_behave_like_mkl():
     """tests/hipshim/fuzz_cblas.py: the same random call (ragged shapes, padded leading dimensions, every transpose / side / triangle,
     alpha / beta incl. 0 and 1, NaNs wherever BLAS promises not to look, non-SPD matrices, now and then an illegal argument) through MKL and
-    through this library over the stand-in: same output window, same NaN pattern, same info (2500 calls agreed when this was written)"""
+    through this library over the stand-in: same output window, same NaN pattern, same info (5500 calls agreed when this was written)"""
     env = dict(os.environ, MKL_NUM_THREADS="1"); env.pop("LD_PRELOAD", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipshim", "fuzz_cblas.py"), "9", "250"], capture_output=True, text=True, timeout=900, env=env)
     lines = r.stdout.strip().splitlines()
