@@ -66,7 +66,8 @@ def _f(a):
 
 def exercise(L, rng, sizes, every_form=True):
     """every entry point against NumPy, on host memory with leading dimensions larger than the windows - shared with the GPU test
-    (every_form = False: SYRK only as Upper / Trans, the one form the reference and the -m gpu operator tests use)"""
+    (every_form = False: SYRK only as Upper / Trans and TRMM without Right / Trans - the forms the reference issues and the -m gpu
+    operator tests run)"""
     worst = {}
 
     def rel(x, ref):
@@ -104,6 +105,8 @@ def exercise(L, rng, sizes, every_form=True):
             tm = _f(np.full((t + 2, t), np.nan)); tv = np.linalg.cholesky(np.atleast_2d(np.cov(rng.standard_normal((t, 2 * t + 8))))).T * 3.0
             tm[:t] = tv + np.tril(np.full((t, t), np.nan), -1)                          # NaNs below the diagonal: never referenced
             for tr in (NT, TR):
+                if not every_form and side == RIGHT and tr == TR:
+                    continue                                                         # (the reference issues the other three: cholinv.hpp:114-154)
                 b = _f(np.full((m + 1, n + 3), 9.0)); b0 = rng.standard_normal((m, n)); b[:m, :n] = b0
                 L.cblas_dtrmm(COL, side, UP, tr, NONUNIT, m, n, d(0.75), _p(tm), tm.shape[0], _p(b), b.shape[0])
                 op = tv.T if tr == TR else tv
