@@ -80,7 +80,7 @@ def exercise(L, rng, sizes, every_form=True):
                 av = a[:m, :k] if ta == NT else a[:k, :m]; bv = b[:k, :n] if tb == NT else b[:n, :k]
                 av[:] = rng.standard_normal(av.shape); bv[:] = rng.standard_normal(bv.shape)
                 opa = av if ta == NT else av.T; opb = bv if tb == NT else bv.T
-                for beta in (0.0, -0.5):
+                for beta in ((0.0, -0.5, 1.0) if every_form else (0.0, 1.0)):
                     c = _f(np.full((m + 5, n + 1), 7.25)); c0 = rng.standard_normal((m, n))
                     c[:m, :n] = np.nan if beta == 0.0 else c0                        # beta = 0: C must not be read
                     L.cblas_dgemm(COL, ta, tb, m, n, k, d(1.5), _p(a), a.shape[0], _p(b), b.shape[0], d(beta), _p(c), c.shape[0])
