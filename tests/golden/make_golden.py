@@ -176,6 +176,8 @@ if __name__ == "__main__":
     cacqr_multirank_dump_case("cacqr2_p8_c1_m256_n16", 2, 256, 16, 1)     # 1D grid, 8 ranks
     cacqr_multirank_dump_case("cacqr2_p8_c2_m256_n16", 2, 256, 16, 2)     # 3D: 2 x 2 x 2
     cacqr_multirank_dump_case("cacqr1_p8_c2_m200_n12", 1, 200, 12, 2)     # 3D, one sweep, M not a multiple of d * anything special
+    cacqr_multirank_dump_case("cacqr2_p27_c3_m270_n27", 2, 270, 27, 3, ranks=27)   # the 3 x 3 x 3 cube (round 5)
+    cacqr_multirank_dump_case("cacqr2_p16_c2_m303_n28", 2, 303, 28, 2, ranks=16)   # the tunable grid c x d x c = 2 x 4 x 2 (sweep_tune), ragged M
     # matmult::summa's three overloads on the 2 x 2 x 2 cube (round 5), ragged sizes, chunked and unchunked
     summa_dump_case("summa_c2_gemm_m51_n43_k35", 0, 51, 43, 35, 2, 2, 1.5, -0.5)
     summa_dump_case("summa_c2_trmm_left_trans_m41_n30", 2, 41, 30, 0, 2, 0, 1.0, 0.0)          # cholinv.hpp:114-119

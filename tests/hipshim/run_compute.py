@@ -1089,8 +1089,8 @@ def main(out_path):
             case("golden %s [NULL stream]" % f, 0)(lambda r, e, f=f: golden_cholinv_1rank(r, e, f))
         elif (f.startswith("cholinv_p8_n") or f.startswith("cholinv_grid8_n")) and f.endswith(".npz"):
             mp_case("golden %s (8 ranks, pieces)" % f)(lambda r, e, f=f: golden_cholinv_8ranks(r, e, f))
-        elif f.startswith("cacqr") and "_p8_" in f and f.endswith(".npz"):
-            mp_case("golden %s (8 ranks)" % f)(lambda r, e, f=f: golden_cacqr(r, e, f))
+        elif f.startswith("cacqr") and ("_p8_" in f or "_p16_" in f or "_p27_" in f) and f.endswith(".npz"):
+            mp_case("golden %s (%s ranks)" % (f, f.split("_p")[1].split("_")[0]))(lambda r, e, f=f: golden_cacqr(r, e, f))
         elif f.startswith("summa_c") and f.endswith(".npz"):
             mp_case("golden %s (the cube's ranks, pieces)" % f)(lambda r, e, f=f: golden_summa(r, e, f))
     for (size, c, m, n) in [(8, 2, 4096, 128), (4, 1, 4096, 64), (16, 2, 8192, 256), (8, 2, 1000, 64), (27, 3, 2700, 96)]:
