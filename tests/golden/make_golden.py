@@ -185,3 +185,6 @@ if __name__ == "__main__":
     summa_dump_case("summa_c2_trmm_right_m40_n31", 3, 40, 31, 0, 2, 0, -1.0, 0.0)             # cholinv.hpp:151-153
     summa_dump_case("summa_c2_syrk_trans_n31_k47", 5, 0, 31, 47, 2, 0, -1.0, 1.0)             # cholinv.hpp:128-131
     summa_dump_case("summa_c2_syrk_rect_n33_k40", 7, 0, 33, 40, 2, 2, -1.0, 0.0)
+    # ... and on the 3 x 3 x 3 cube (27 ranks)
+    summa_dump_case("summa_c3_gemm_m52_n41_k37", 0, 52, 41, 37, 3, 3, -1.0, 1.0)
+    summa_dump_case("summa_c3_trmm_left_trans_m43_n29", 2, 43, 29, 0, 3, 0, 1.0, 0.0)
