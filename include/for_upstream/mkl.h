@@ -1,13 +1,13 @@
-/* include/compat/mkl.h - what the reference needs from "mkl.h" when libcapital_amd_cblas.so stands in for MKL.
+/* include/for_upstream/mkl.h - what the reference needs from "mkl.h" when libcapital_amd_cblas.so stands in for MKL.
  *
  * tbennun/capital includes "mkl.h" (src/util/shared.h:24) for exactly seven entry points and the five CBLAS enums they take
  * (blas/interface.hpp:7-41,54,74,92; lapack/interface.hpp:4-27,39,54,69,84).  This declarations-only header provides those and nothing
  * else, with MKL's LP64 types and values, so that the reference compiles on a machine without MKL:
- *     CFLAGS += -I<repo>/include/compat          LIB_PATH = -L<repo>/capital_amd/lib          LIBS = -lcapital_amd_cblas
+ *     CFLAGS += -I<repo>/include/for_upstream          LIB_PATH = -L<repo>/capital_amd/lib          LIBS = -lcapital_amd_cblas
  * (INTEGRATION.md section 0).  The functions are the ones include/capital_amd_cblas.h documents; there they are declared with plain ints
  * (the enums travel as ints), so include one header or the other in a translation unit, not both.                              */
-#ifndef CAPITAL_AMD_COMPAT_MKL_H
-#define CAPITAL_AMD_COMPAT_MKL_H
+#ifndef CAPITAL_AMD_FOR_UPSTREAM_MKL_H
+#define CAPITAL_AMD_FOR_UPSTREAM_MKL_H
 #ifdef __cplusplus
 extern "C" {
 #endif

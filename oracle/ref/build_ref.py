@@ -146,8 +146,8 @@ def build(verbose=True):
             # capital_amd/lib (the GPU) or tests/hipshim/_build/cblas (the CPU stand-in); built only when the product library is
             cap = os.path.join(REPO, "capital_amd", "lib")
             if os.path.exists(os.path.join(cap, "libcapital_amd_cblas.so")):
-                # (compiled against the PRODUCT's stand-in for mkl.h, include/compat/mkl.h, in front of the oracle's own: what INTEGRATION.md section 0 tells a maintainer to do)
-                cmd = ["-I" + os.path.join(REPO, "include", "compat") if x == "-I" + inc else x for x in cmd]
+                # (compiled against the PRODUCT's stand-in for mkl.h, include/for_upstream/mkl.h, in front of the oracle's own: what INTEGRATION.md section 0 tells a maintainer to do)
+                cmd = ["-I" + os.path.join(REPO, "include", "for_upstream") if x == "-I" + inc else x for x in cmd]
                 cmd = cmd[:cmd.index(os.path.join(HERE, drv))] + ["-I" + inc] + cmd[cmd.index(os.path.join(HERE, drv)):]      # (mpi.h still comes from the oracle's include copy)
                 cmd = cmd[:cmd.index("-o")] + ["-o", os.path.join(OUT, exe.replace("_ref", "_cap")), "-L" + os.path.join(CONDA, "lib"),
                                                  "-Wl,-rpath," + os.path.join(CONDA, "lib"), "-lmpi", "-L" + cap, "-lcapital_amd_cblas",
@@ -163,7 +163,7 @@ def build(verbose=True):
         if os.path.exists(os.path.join(cap, "libcapital_amd_cblas.so")):
             _apply_engine_binding(root)
             for drv, exe in (("drv_cholinv.cpp", "cholinv_engine"), ("drv_cacqr.cpp", "cacqr_engine"), ("drv_summa.cpp", "summa_engine")):
-                cmd = ["g++", "-std=c++14", "-O2", "-fpermissive", "-w", "-DMPICH_SKIP_MPICXX", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(REPO, "include", "compat"), "-I" + inc, "-I" + tmp,
+                cmd = ["g++", "-std=c++14", "-O2", "-fpermissive", "-w", "-DMPICH_SKIP_MPICXX", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(REPO, "include", "for_upstream"), "-I" + inc, "-I" + tmp,
                        "-I/opt/rocm/include", "-I" + os.path.join(REPO, "include"), os.path.join(HERE, drv), "-o", os.path.join(OUT, exe),
                        "-L" + os.path.join(CONDA, "lib"), "-Wl,-rpath," + os.path.join(CONDA, "lib"), "-lmpi", "-L" + cap, "-lcapital_amd_cblas", "-lcapital_amd",
                        "-L/opt/rocm/lib", "-lamdhip64", "-Wl,--allow-shlib-undefined", "-lpthread", "-lm", "-ldl"]

@@ -32,7 +32,7 @@ def test_the_library_builds_and_exports_what_its_header_declares():
     assert r.returncode == 0 and "loaded" in r.stdout, r.stderr[-2000:]
     for s in SYMBOLS:
         assert s + "(" in header, s
-    compat = open(os.path.join(ROOT, "include", "compat", "mkl.h")).read()      # the stand-in for "mkl.h" the reference is compiled against
+    compat = open(os.path.join(ROOT, "include", "for_upstream", "mkl.h")).read()      # the stand-in for "mkl.h" the reference is compiled against
     for s in SYMBOLS[:7]:
         assert s + "(" in compat, s
     # the main library does not export BLAS names: a process that also holds a CPU BLAS keeps it
