@@ -8,7 +8,7 @@
  * reserves a tag for and never defines (OffloadEachGemm, src/alg/alg.h:9-11).  The reference's own bench programs then run, unmodified,
  * every flop of cholinv / cacqr / summa on the GPU (tests: the real reference linked this way passes its own validators).
  *
- * It is the compatibility seam, not the fast path: every call pays two PCIe crossings.  The resident-matrix entry points of
+ * It is the zero-change seam, not the fast path: every call pays two PCIe crossings.  The resident-matrix entry points of
  * capital_amd.h (cap_cholinv_*, cap_cacqr_*, cap_summa_*) are the ones the headline numbers are measured on.
  *
  * Semantics kept from BLAS / LAPACK: only the `uplo` triangle of a triangular / symmetric operand is referenced or written (the other
