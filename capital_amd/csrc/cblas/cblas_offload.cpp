@@ -14,7 +14,10 @@ std::atomic<long long> g_calls{0}, g_in{0}, g_out{0};
 
 // CAPCB_REPORT=1: one line on stderr when the process ends - how many calls were served, how many bytes crossed
 void report() {
-  fprintf(stderr, "capital_amd_cblas: %lld calls served, %lld bytes host -> device, %lld bytes device -> host\n", g_calls.load(), g_in.load(), g_out.load());
+  int dev = -1;
+  (void)hipGetDevice(&dev);
+  fprintf(stderr, "capital_amd_cblas: %lld calls served, %lld bytes host -> device, %lld bytes device -> host, device %d\n", g_calls.load(), g_in.load(),
+          g_out.load(), dev);
 }
 struct Reporter { Reporter() { const char* e = getenv("CAPCB_REPORT"); if (e && *e && *e != '0') atexit(report); } } reporter;
 
@@ -31,11 +34,29 @@ bool bad_arg(const char* fn, const char* what) {
 void hip_ok(hipError_t e, const char* fn) { if (e != hipSuccess) die(fn, hipGetErrorString(e)); }
 void cap_ok(int st, const char* fn) { if (st != CAP_OK) die(fn, cap_status_string(st)); }
 
+// Which GPU: one process per GPU is the layout this library is built for, and an MPI program linked with it has no line of its own
+// that could say so.  CAPCB_DEVICE=<index> names the device; otherwise the launcher's local rank (MPICH / Open MPI / Slurm) modulo the
+// number of devices.  With one visible device (a launcher that sets ROCR_VISIBLE_DEVICES per rank, or a one-GPU box) nothing is touched.
+void choose_device_once() {
+  static thread_local bool done = false;
+  if (done) return;
+  done = true;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 1) return;
+  const char* v = getenv("CAPCB_DEVICE");
+  for (const char* name : {"MPI_LOCALRANKID", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID", "PMI_LOCAL_RANK"})
+    if (!v || !*v) v = getenv(name);
+  if (!v || !*v) return;
+  const long idx = strtol(v, nullptr, 10);
+  if (idx >= 0 && hipSetDevice((int)(idx % count)) != hipSuccess) die("device selection", "hipSetDevice failed");
+}
+
 // grow-only device buffers of this thread: three operand windows, operator scratch, the info word
 struct Pool {
   void* p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t cap[5] = {0, 0, 0, 0, 0};
   double* get(int i, size_t doubles, const char* fn) {
+    choose_device_once();
     const size_t need = (doubles ? doubles : 1) * sizeof(double);
     if (need > cap[i]) {
       if (p[i]) hip_ok(hipFree(p[i]), fn);

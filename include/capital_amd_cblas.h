@@ -17,7 +17,9 @@
  * reference uses); the BLAS calls answer an illegal argument the way a CPU BLAS's xerbla does - a line on stderr, the call ignored (CBLAS
  * has no status to return; upstream does issue such calls on degenerate splits and MKL lets them pass) - and abort only when the device
  * or the library fails underneath them.  Staging buffers are per thread
- * and grow only; everything runs on the NULL stream of the current device and has completed on return.
+ * and grow only; everything runs on the NULL stream of the thread's device and has completed on return.  The device: with more than one
+ * visible, CAPCB_DEVICE=<index>, else the launcher's local rank (MPI_LOCALRANKID, OMPI_COMM_WORLD_LOCAL_RANK, SLURM_LOCALID) modulo the
+ * device count - one process per GPU without a line of code in the MPI program; with one visible device nothing is selected.
  * LAPACKE_dgeqrf / LAPACKE_dorgqr have no call site upstream (ArgPack_geqrf / _orgqr are never instantiated); they are exported so that
  * the reference links, and return -1010 (LAPACK_WORK_MEMORY_ERROR's slot) after a message.                                            */
 #ifndef CAPITAL_AMD_CBLAS_H

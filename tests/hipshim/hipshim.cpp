@@ -187,9 +187,12 @@ hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipS
 hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 2; return hipSuccess; }
 
 // ---------------------------------------------------------------- device
-hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
-hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+// SHIM_DEVICES=N: N visible devices (default 1); the current device is per thread, as in HIP
+static int shim_device_count() { static const int n = getenv("SHIM_DEVICES") ? atoi(getenv("SHIM_DEVICES")) : 1; return n < 1 ? 1 : n; }
+static thread_local int current_device = 0;
+hipError_t hipGetDevice(int* d) { *d = current_device; return hipSuccess; }
+hipError_t hipSetDevice(int d) { if (d < 0 || d >= shim_device_count()) return hipErrorInvalidDevice; current_device = d; return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = shim_device_count(); return hipSuccess; }
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
   *v = a == hipDeviceAttributeMultiprocessorCount ? 256 : 0;
   return hipSuccess;

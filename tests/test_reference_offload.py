@@ -358,3 +358,20 @@ def test_random_blas_and_lapack_calls_behave_like_mkl():
     lines = r.stdout.strip().splitlines()
     assert r.returncode == 0 and lines[-1] == "250 calls, 0 with findings", "\n".join(l for l in lines if l.startswith("BAD"))[-3000:] + r.stderr[-1500:]
     assert {l.split()[1] for l in lines if l.startswith("ok")} >= {"dgemm", "dsyrk", "dtrmm", "potrf", "trtri"}
+
+
+@pytest.mark.skipif(not reference_available(), reason="oracle/_ref/*_cap or mpiexec is not here")
+def test_every_mpi_rank_of_the_reference_gets_a_gpu_of_its_own():
+    """one process per GPU without a line of code in the MPI program: with several devices visible (SHIM_DEVICES = 8 on the stand-in) the offload
+    library takes the launcher's local rank modulo the device count, CAPCB_DEVICE names a device, one visible device is left alone"""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipshim"))
+    import build_shim
+    build_shim.build_cblas()
+    base = cap_env([os.path.join(build_shim.OUT, "cblas"), build_shim.OUT]); base["SHIM_COMPUTE"] = "1"
+    for extra, want in (({"SHIM_DEVICES": "8"}, list(range(8))), ({"SHIM_DEVICES": "4"}, [0, 0, 1, 1, 2, 2, 3, 3]),
+                        ({"SHIM_DEVICES": "4", "CAPCB_DEVICE": "3"}, [3] * 8), ({}, [0] * 8)):
+        kv, served = run_reference(dict(base, **extra), "cholinv_cap", 8, [256, 1, 1, -2, 0, 0, 1, "-", 1])
+        assert kv["residual"] < 1e-14 and len(served) == 8
+        got = sorted(int(x) for x in re.findall(r"bytes device -> host, device (\d+)", run_reference.last_output))
+        assert got == want, (extra, got)
