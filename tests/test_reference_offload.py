@@ -171,7 +171,7 @@ def build_and_run_demo(tmp_path, libdir, run_dirs, extra_env, n):
     """examples/cblas_offload_demo.c - a plain CBLAS / LAPACKE program (host arrays, MKL's argument lists) linked with -lcapital_amd_cblas"""
     import re
     exe = str(tmp_path / "cblas_offload_demo")
-    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-O1", os.path.join(ROOT, "examples", "cblas_offload_demo.c"), "-I" + os.path.join(ROOT, "include"),
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-O1", os.path.join(ROOT, "examples", "cblas_offload_demo.c"), "-I" + os.path.join(ROOT, "include", "for_upstream"),
            "-L" + libdir, "-lcapital_amd_cblas", "-Wl,--allow-shlib-undefined", "-lm", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
