@@ -375,3 +375,19 @@ def test_every_mpi_rank_of_the_reference_gets_a_gpu_of_its_own():
         assert kv["residual"] < 1e-14 and len(served) == 8
         got = sorted(int(x) for x in re.findall(r"bytes device -> host, device (\d+)", run_reference.last_output))
         assert got == want, (extra, got)
+
+
+@pytest.mark.skipif(not reference_available(), reason="oracle/_ref or mpiexec is not here")
+def test_the_mkl_linked_reference_runs_on_the_library_when_it_is_preloaded():
+    """not even a relink: LD_PRELOAD=libcapital_amd_cblas.so in front of the build that is linked with MKL - the seven symbols resolve to this
+    library, every rank's BLAS / LAPACK calls are served by it, the reference's validator passes"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipshim"))
+    import build_shim
+    lib = build_shim.build_cblas()
+    env = cap_env([os.path.join(build_shim.OUT, "cblas"), build_shim.OUT]); env["SHIM_COMPUTE"] = "1"; env["LD_PRELOAD"] = lib
+    for exe, ranks, argv, checks in (("cholinv", 8, (512, 0, 1, -2, 0, 0, 1), {"residual": 1e-14}),
+                                     ("cacqr", 8, (2, 1024, 64, 2, 1, 1, 0), {"residual": 1e-13, "orthogonality": 1e-14})):
+        kv, served = run_reference(env, exe + "_ref", ranks, list(argv) + ["-", 1])
+        for k, tol in checks.items():
+            assert kv[k] < tol, (exe, kv)
+        assert sorted(served)[-ranks] > 0, served            # (the launcher's own processes inherit the preload and report 0 calls)
