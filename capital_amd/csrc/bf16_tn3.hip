@@ -1,0 +1,234 @@
+// bf16 trailing update, third generation (round 6): C32 += alpha A^T B on v_mfma_f32_32x32x16_bf16 with a C-STATIONARY 256 x 256 tile and a
+// plain read - add - store epilogue (every C tile has one writer per launch: no atomics).
+//
+// Why: the 128 x 128 kernel (mixed.hip, bf16_tn_kernel) pulls 1 KiB of fragments out of LDS per MFMA (64 x 64 per wave) and 64 flop per
+// byte through L2 - at the 2.5 PFLOP/s bf16 peak that is 39 TB/s of L2 -> LDS traffic, more than the chip's L2s deliver; it is LDS- and
+// L2-bound at 0.25 - 0.32 of peak (profiles/r05_pmc_cqr_bf16.txt).  The second-generation kernel (256 x 128, loader waves) halves neither
+// per compute wave and pays for its atomics.  Here:
+//   * 256 x 256 tile per 512-thread workgroup, 8 waves as 2 (rows) x 4 (columns), 128 x 64 per wave = 8 accumulators of 32 x 32 (128
+//     registers): 768 B of fragments per MFMA, 128 flop per byte through L2;
+//   * K in stages of 32 (64-byte rows: 16 KiB per operand image, 32 KiB per stage) through a ring of NST stages - 96 KiB for NST = 3, so
+//     the diagonal-block chain's 68.5 KiB workgroup never shares a CU with it and a 64 KiB head update still fits beside it;
+//   * ping-pong: the two row groups of waves (one wave of each per SIMD) run one PHASE apart.  A phase is either "load" (4 LDS-DMA
+//     pieces of the stage NST - 1 ahead + the 12 ds_read_b128 of the wave's next stage) or "compute" (16 MFMAs = 512 matrix-pipe cycles);
+//     while group 0 computes, group 1 loads, so every SIMD always has one wave feeding the matrix pipe.  One raw s_barrier per phase;
+//     LDS-DMA stays in flight across barriers (counted vmcnt, never 0 inside the loop);
+//   * LDS image: row r (64 bytes = 4 chunks of 16) stores logical chunk c at position c ^ ((r >> 2) & 3): every 16-lane group of a
+//     ds_read_b128 covers all 64 banks once.  The DMA writes lane-linear 1 KiB pieces (16 rows), so the XOR sits on the SOURCE address;
+//   * operands swapped in the MFMA (lane = C row): the epilogue's loads and stores touch 32 consecutive rows = whole 128-byte lines.
+// Same accumulation order per C element as the 128 x 128 kernel (k ascending in steps of 16, one final add into C): bit-identical results.
+#include <algorithm>
+
+#include "common.h"
+#include "kargs.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int T3 = 256;              // C tile edge
+constexpr int K3 = 32;               // K per stage (bf16 elements)
+constexpr int RB3 = 64;              // bytes per image row
+constexpr int IMG3 = T3 * RB3;       // one operand image: 16 KiB
+constexpr int STAGE3 = 2 * IMG3;     // A image + B image
+
+// vmcnt(n) with the other counters left alone / with lgkmcnt(0)
+#define CAP_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))
+#define CAP_VMCNT_LGKM0(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (0 << 8) | (((n) >> 4) << 14))
+
+template <int NST>
+__global__ void __launch_bounds__(512, 2) bf16_tn3_kernel(const BfArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  char* lds = reinterpret_cast<char*>(smem);
+  // block -> tile: XCD b % 8 walks a contiguous range of the tile list, supertile by supertile (st x st tiles; the upper triangle of
+  // supertiles for square tri problems) - the walk of bf16_tn_kernel with 256-wide tiles
+  const int b = (int)blockIdx.x;
+  if ((b >> 3) >= g.chunk) return;
+  const int L = (b & 7) * g.chunk + (b >> 3);
+  int ti, tj;
+  {
+    const int per = g.st * g.st, sl = L / per, q = L - sl * per;
+    int si, sj;
+    if (g.tri && g.tm == g.tn) {
+      sj = (int)((__builtin_sqrtf(8.0f * (float)sl + 1.0f) - 1.0f) * 0.5f);
+      while ((sj + 1) * (sj + 2) / 2 <= sl) sj++;
+      while (sj * (sj + 1) / 2 > sl) sj--;
+      si = sl - sj * (sj + 1) / 2;
+    } else {
+      si = sl % g.nsm; sj = sl / g.nsm;
+    }
+    ti = si * g.st + q % g.st; tj = sj * g.st + q / g.st;
+    if (ti >= g.tm || tj >= g.tn || (g.tri && ti > tj)) return;
+  }
+  const int64_t i0 = (int64_t)ti * T3, j0 = (int64_t)tj * T3;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wid >> 2, w4 = wid & 3;           // row group (0: rows 0-127, 1: rows 128-255), column wave (64 columns each)
+  const int r32 = lane & 31, kg = lane >> 5;
+  const int nk = (int)(g.K / K3);
+
+  // ---- LDS-DMA: group 0 moves the A image of a stage, group 1 the B image; wave w4 the pieces 4 w4 .. 4 w4 + 3 (16 rows each)
+  const __bf16* src = grp ? g.B + j0 * g.ldb : g.A + i0 * g.lda;
+  const uint32_t rowbytes = (uint32_t)((grp ? g.ldb : g.lda) * 2);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)0xffffffffu, 0x00020000);
+  const uint32_t voff = (uint32_t)(lane >> 2) * rowbytes + (uint32_t)((((lane & 3) ^ ((lane >> 4) & 3))) << 4);
+  const uint32_t piece0 = (uint32_t)(w4 * 4);
+  auto issue = [&](int st) {                         // stage st (< nk) into slot st % NST
+    char* dst = lds + (st % NST) * STAGE3 + grp * IMG3;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t p = piece0 + q;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, (int)voff,
+                                               (int)(p * 16u * rowbytes + (uint32_t)st * RB3), 0, 0);
+    }
+  };
+  // "stage v has landed" = at most the pieces of the younger stages this wave has issued are outstanding (loads retire in order)
+  auto wait_landed = [&](int younger, bool lgkm0) {
+    if (lgkm0) {
+      if (younger >= 2) CAP_VMCNT_LGKM0(8); else if (younger == 1) CAP_VMCNT_LGKM0(4); else CAP_VMCNT_LGKM0(0);
+    } else {
+      if (younger >= 2) CAP_VMCNT(8); else if (younger == 1) CAP_VMCNT(4); else CAP_VMCNT(0);
+    }
+  };
+
+  // ---- fragments: A rows grp * 128 + 32 i + r32, B rows w4 * 64 + 32 j + r32; k-step s reads logical chunk 2 s + kg
+  const int t = kg ^ ((r32 >> 2) & 3);
+  const int a_row = (grp * 128 + r32) * RB3, b_row = IMG3 + (w4 * 64 + r32) * RB3;
+  const int o0 = t << 4, o1 = (t ^ 2) << 4;
+  bf16x8 fa[2][4], fb[2][2];
+  auto read_frags = [&](int st) {
+    const char* base = lds + (st % NST) * STAGE3;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      fa[0][i] = *reinterpret_cast<const bf16x8*>(base + a_row + o0 + i * 32 * RB3);
+      fa[1][i] = *reinterpret_cast<const bf16x8*>(base + a_row + o1 + i * 32 * RB3);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      fb[0][j] = *reinterpret_cast<const bf16x8*>(base + b_row + o0 + j * 32 * RB3);
+      fb[1][j] = *reinterpret_cast<const bf16x8*>(base + b_row + o1 + j * 32 * RB3);
+    }
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+#define CAP_MMA3()                                                                                                   \
+  do {                                                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                                   \
+    _Pragma("unroll") for (int s = 0; s < 2; s++)                                                                    \
+      _Pragma("unroll") for (int i = 0; i < 4; i++)                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 2; j++)                                                                \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s][j], fa[s][i], acc[i][j], 0, 0, 0);               \
+    __builtin_amdgcn_s_setprio(0);                                                                                   \
+  } while (0)
+
+  // ---- prologue: stages 0 .. NST - 2 on their way, stage 0 landed and visible
+  const int npro = nk < NST - 1 ? nk : NST - 1;
+  for (int st = 0; st < npro; st++) issue(st);
+  wait_landed(npro - 1, false);
+  __builtin_amdgcn_s_barrier();
+  // younger stages in flight when stage t + 1 must have landed: stages t + 2 .. min(nk - 1, t + NST - 1)
+  auto younger_at = [&](int tt) { const int hi = tt + NST - 1 < nk - 1 ? tt + NST - 1 : nk - 1; return hi - (tt + 1) > 0 ? hi - (tt + 1) : 0; };
+  if (grp == 0) {
+    for (int tt = 0; tt < nk; tt++) {
+      // load phase 2 tt: the slot of stage tt - 1 was read for the last time (by group 1) before the barrier just passed
+      if (tt + NST - 1 < nk) issue(tt + NST - 1);
+      read_frags(tt);
+      CAP_VMCNT_LGKM0(63);                            // lgkmcnt(0): my reads of stage tt are done
+      __builtin_amdgcn_s_barrier();
+      // compute phase 2 tt + 1
+      CAP_MMA3();
+      wait_landed(younger_at(tt), false);             // my share of stage tt + 1 has landed
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    __builtin_amdgcn_s_barrier();                     // one phase behind group 0
+    for (int tt = 0; tt < nk; tt++) {
+      // load phase 2 tt + 1
+      if (tt + NST - 1 < nk) issue(tt + NST - 1);
+      read_frags(tt);
+      wait_landed(younger_at(tt), true);              // my reads of stage tt are done, my share of stage tt + 1 has landed
+      __builtin_amdgcn_s_barrier();
+      // compute phase 2 tt + 2
+      CAP_MMA3();
+      if (tt + 1 < nk) __builtin_amdgcn_s_barrier();
+    }
+  }
+#undef CAP_MMA3
+
+  // ---- epilogue: C += alpha * acc, plain read - add - store.  Lane holds C[i0 + grp 128 + 32 i + r32][j0 + w4 64 + 32 j + (e & 3) + 8 (e >> 2) + 4 kg]
+  const bool diag = g.tri && ti == tj;                 // wave-uniform: only these tiles mask (row <= col, tile-relative)
+  float* Cl = g.C + (i0 + grp * 128 + r32) + (j0 + w4 * 64 + 4 * kg) * g.ldc;
+  const float alpha = g.alpha;
+  // two blocks of C in flight: block b + 1 is requested before block b is added and stored
+  float cb[2][16];
+#define CAP_C3_LOAD(blk, buf)                                                                                        \
+  _Pragma("unroll") for (int e = 0; e < 16; e++)                                                                     \
+    cb[buf][e] = Cl[32 * ((blk) >> 1) + (int64_t)(32 * ((blk) & 1) + (e & 3) + 8 * (e >> 2)) * g.ldc];
+  CAP_C3_LOAD(0, 0)
+#pragma unroll
+  for (int blk = 0; blk < 8; blk++) {
+    const int i = blk >> 1, j = blk & 1;
+    if (blk + 1 < 8) { CAP_C3_LOAD(blk + 1, (blk + 1) & 1) }
+    if (!diag) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) Cl[32 * i + (int64_t)(32 * j + (e & 3) + 8 * (e >> 2)) * g.ldc] = cb[blk & 1][e] + alpha * acc[i][j][e];
+    } else {
+      const int lrow = grp * 128 + 32 * i + r32;
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int lcol = w4 * 64 + 32 * j + (e & 3) + 8 * (e >> 2) + 4 * kg;
+        if (lrow <= lcol) Cl[32 * i + (int64_t)(32 * j + (e & 3) + 8 * (e >> 2)) * g.ldc] = cb[blk & 1][e] + alpha * acc[i][j][e];
+      }
+    }
+  }
+#undef CAP_C3_LOAD
+}
+
+template <int NST>
+int launch_tn3(const BfArgs& g, unsigned grid, hipStream_t s) {
+  static bool attr_set[16] = {};                      // per device: the attribute belongs to the device's copy of the function
+  constexpr int LDS_BYTES = NST * STAGE3;
+  int dev = 0;
+  CAP_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+    CAP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_tn3_kernel<NST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    if (dev >= 0 && dev < 16) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((bf16_tn3_kernel<NST>), dim3(grid), dim3(512), LDS_BYTES, s, g);
+  CAP_HIP(hipGetLastError());
+  return CAP_OK;
+}
+
+}  // namespace
+
+bool cap_bf16_tn3_applies(int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb, int tri) {
+  return m > 0 && n > 0 && k > 0 && m % T3 == 0 && n % T3 == 0 && k % K3 == 0 && lda % 8 == 0 && ldb % 8 == 0 && (!tri || m <= n) &&
+         256 * lda * 2 + k * 2 < 0xfffffff0LL && 256 * ldb * 2 + k * 2 < 0xfffffff0LL;
+}
+
+// C32[m x n] += alpha A^T B (A: k x m, B: k x n bf16, K-contiguous), upper tiles / elements only when tri.  nst = ring depth (3: 96 KiB, 4: 128 KiB);
+// st = supertile edge in tiles.
+int cap_bf16_tn3_launch(int64_t m, int64_t n, int64_t k, float alpha, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
+                        int64_t ldc, int tri, int nst, int st, hipStream_t s) {
+  if (m <= 0 || n <= 0 || k <= 0) return CAP_OK;
+  if (!cap_bf16_tn3_applies(m, n, k, lda, ldb, tri) || st < 1) return CAP_ERR_UNSUPPORTED;
+  BfArgs g;
+  g.A = (const __bf16*)A16; g.B = (const __bf16*)B16; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.tri = tri;
+  g.stair = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0;
+  for (int i = 0; i < 8; i++) g.gstart[i] = 0;
+  g.tm = (int)(m / T3); g.tn = (int)(n / T3);
+  g.st = st; g.nsm = (int)cap_ceil_div(g.tm, st);
+  const int64_t nsn = cap_ceil_div(g.tn, st);
+  const int64_t tiles = ((tri && m == n) ? nsn * (nsn + 1) / 2 : (int64_t)g.nsm * nsn) * st * st;
+  g.chunk = (int)cap_ceil_div(tiles, 8);
+  // access notes: every C tile has one writer and is read and written in place
+  cap_acc_r(A16, lda, k, m, 0, 2); cap_acc_r(B16, ldb, k, n, 0, 2); cap_acc(CAP_ACC_RW, C, ldc, m, n, tri ? 1 : 0, 4);
+  const unsigned grid = (unsigned)(g.chunk * 8);
+  return nst >= 4 ? launch_tn3<4>(g, grid, s) : launch_tn3<3>(g, grid, s);
+}

@@ -445,6 +445,8 @@ static int g_bf16_variant = getenv("CAP_BF16_V2") ? atoi(getenv("CAP_BF16_V2")) 
 static int g_bf16_tpw = getenv("CAP_BF16_TPW") ? atoi(getenv("CAP_BF16_TPW")) : 8;
 static int64_t g_bf16_min_tiles = getenv("CAP_BF16_V2_MIN") ? atoll(getenv("CAP_BF16_V2_MIN")) : 1024;
 
+static int64_t g_bf16_v3_min = 256;      // smallest launch (in 256 x 256 tiles) the third-generation kernel takes
+static int g_bf16_v3_st = 8;             // its supertile edge in tiles
 static int g_bf16_sched = getenv("CAP_BF16_SCHED") ? atoi(getenv("CAP_BF16_SCHED")) : 1;
 static int g_bf16_dbg = 0;              // timing surgery (CAP_EXPERIMENTS builds): set through cap_bf16_update(variant = 100 + DBG)
 
@@ -501,6 +503,9 @@ int launch_bf16_update(int64_t m, int64_t n, int64_t k, float alpha, const __bf1
                    (m / 256) * (n / 128) / (tri ? 2 : 1) >= g_bf16_min_tiles &&
                    256 * lda * 2 + k * 2 < 0xfffffff0LL && 128 * ldb * 2 + k * 2 < 0xfffffff0LL;
   if (ok2) return launch_bf16_v2(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
+  // third generation (bf16_tn3.hip): whole 256 x 256 tiles and at least g_bf16_v3_min of them (below that the 128-wide tiles fill the chip better)
+  if (g_bf16_variant >= 3 && cap_bf16_tn3_applies(m, n, k, lda, ldb, tri) && (m / 256) * (n / 256) / ((tri && m == n) ? 2 : 1) >= g_bf16_v3_min)
+    return cap_bf16_tn3_launch(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, g_bf16_variant == 4 ? 4 : 3, g_bf16_v3_st, s);
   return launch_bf16_tn(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
 }
 }  // namespace
@@ -511,11 +516,13 @@ int launch_bf16_update(int64_t m, int64_t n, int64_t k, float alpha, const __bf1
 extern "C" int cap_bf16_update(int variant, int64_t m, int64_t n, int64_t k, float alpha, const void* A16, int64_t lda, const void* B16, int64_t ldb,
                                float* C, int64_t ldc, int tri, int tpw, void* stream) {
   if (!A16 || !B16 || !C || m < 0 || n < 0 || k < 0) return CAP_ERR_ARG;
-  if (tpw > 0) g_bf16_tpw = tpw;
+  if (tpw > 0 && variant != 3 && variant != 4) g_bf16_tpw = tpw;
   const __bf16* A = (const __bf16*)A16; const __bf16* B = (const __bf16*)B16;
   hipStream_t s = cap_stream(stream);
   if (variant < 0) return launch_bf16_update(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
   if (variant == 0) return launch_bf16_tn(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
+  if (variant == 3 || variant == 4)      // third generation, LDS ring of 3 / 4 stages; tpw carries the supertile edge here (0: default)
+    return cap_bf16_tn3_launch(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, variant, tpw > 0 ? tpw : g_bf16_v3_st, s);
   if (m % 256 || n % 128 || k % 64 || lda % 8 || ldb % 8 || (tri && m != n) || m == 0 || n == 0 || k == 0) return CAP_ERR_UNSUPPORTED;
   // variant 1: the production schedule; 2: without the forced read-ahead; 100 + DBG: timing surgery (experiment builds only)
   g_bf16_sched = variant == 2 ? 0 : 1;
@@ -1028,7 +1035,9 @@ int cap_mpchol_set_option(cap_mpchol_plan* p, const char* key, int64_t value) {
   if (!strcmp(key, "chain_coop")) { if (value < -1 || value > 256) return CAP_ERR_ARG; p->chain_coop = (int)value; return CAP_OK; }   // per plan, see cap_cholinv_set_option
   if (!strcmp(key, "solve3")) { p->solve3 = value != 0; return CAP_OK; }   // block-row solves on the bf16 pipe with split operands (split schedule)
   // process-wide A/B switches of the bf16 update (see launch_bf16_update): which kernel, chunk length, smallest launch for the new one
-  if (!strcmp(key, "update_kernel")) { if (value < 0 || value > 1) return CAP_ERR_ARG; g_bf16_variant = (int)value; return CAP_OK; }
+  if (!strcmp(key, "update_kernel")) { if (value < 0 || value > 4 || value == 2) return CAP_ERR_ARG; g_bf16_variant = (int)value; return CAP_OK; }
+  if (!strcmp(key, "update_v3_min_tiles")) { if (value < 0) return CAP_ERR_ARG; g_bf16_v3_min = value; return CAP_OK; }
+  if (!strcmp(key, "update_v3_st")) { if (value < 1 || value > 64) return CAP_ERR_ARG; g_bf16_v3_st = (int)value; return CAP_OK; }
   if (!strcmp(key, "update_tpw")) { if (value < 1 || value > 64) return CAP_ERR_ARG; g_bf16_tpw = (int)value; return CAP_OK; }
   if (!strcmp(key, "update_min_tiles")) { if (value < 0) return CAP_ERR_ARG; g_bf16_min_tiles = value; return CAP_OK; }
   if (!strcmp(key, "strip")) { if (value < 1 || value > 2) return CAP_ERR_ARG; p->strip = value; return CAP_OK; }   // panels per bf16 update

@@ -657,7 +657,7 @@ void k_scatter_rows_bc(void** a, unsigned gy) {
   for (int64_t c = 0; c < std::min<int64_t>(cols, gy); c++) for (int64_t l = 0; l < lc; l++) Out[((l / nb) * P + p) * nb + l % nb + c * ldo] = Q[l + c * ldq];
 }
 // bf16_tn_kernel: C (fp32) += alpha A^T B on 128 x 128 tiles, the launch's blocks walked as the kernel walks them
-void k_bf16_tn(void** a, unsigned gx) {
+void k_bf16_tn(void** a, unsigned gx, const int TB = 128, const int KG = 64) {
   const BfArgs g = arg<BfArgs>(a, 0);
   const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A); const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
   struct Tile { int ti, tj, gtj; const bf16_t* Abase; };
@@ -689,27 +689,27 @@ void k_bf16_tn(void** a, unsigned gx) {
       if (!g.stair && g.tri && ti > tj) continue;
     }
     int gtj = tj;
-    const bf16_t* Abase = A + (int64_t)ti * 128 * g.lda;
+    const bf16_t* Abase = A + (int64_t)ti * TB * g.lda;
     if (g.stair) {
       const int J = g.sp + g.sP * (g.slb0 + tj / g.snbT);
       gtj = (J - g.sJ0) * g.snbT + tj % g.snbT;
       if (ti > gtj) continue;
       const int I = g.sJ0 + ti / g.snbT, r = I % g.sP, lb = I / g.sP - g.gstart[r];
-      Abase = A + (int64_t)r * g.gpiece + ((int64_t)(lb * g.snbT + ti % g.snbT) * 128) * g.lda;
+      Abase = A + (int64_t)r * g.gpiece + ((int64_t)(lb * g.snbT + ti % g.snbT) * TB) * g.lda;
     }
     tiles.push_back(Tile{ti, tj, gtj, Abase});
   }
-  const int64_t K = (g.K / 64) * 64;
+  const int64_t K = (g.K / KG) * KG;
 #pragma omp parallel for schedule(dynamic)
   for (size_t t = 0; t < tiles.size(); t++) {          // (every tile of a launch has one writer)
     const int ti = tiles[t].ti, tj = tiles[t].tj, gtj = tiles[t].gtj; const bf16_t* Abase = tiles[t].Abase;
-    std::vector<float> fa((size_t)128 * K), fb((size_t)128 * K);
-    const int64_t i0 = (int64_t)ti * 128, j0 = (int64_t)tj * 128;
-    for (int i = 0; i < 128; i++) for (int64_t k = 0; k < K; k++) fa[(size_t)i * K + k] = bf2f(Abase[(int64_t)i * g.lda + k]);
-    for (int j = 0; j < 128; j++) for (int64_t k = 0; k < K; k++) fb[(size_t)j * K + k] = bf2f(B[(j0 + j) * g.ldb + k]);
+    std::vector<float> fa((size_t)TB * K), fb((size_t)TB * K);
+    const int64_t i0 = (int64_t)ti * TB, j0 = (int64_t)tj * TB;
+    for (int i = 0; i < TB; i++) for (int64_t k = 0; k < K; k++) fa[(size_t)i * K + k] = bf2f(Abase[(int64_t)i * g.lda + k]);
+    for (int j = 0; j < TB; j++) for (int64_t k = 0; k < K; k++) fb[(size_t)j * K + k] = bf2f(B[(j0 + j) * g.ldb + k]);
     const bool diag = g.stair ? (ti == gtj) : (g.tri && ti == tj);
-    for (int j = 0; j < 128; j++)
-      for (int i = 0; i < 128; i++) {
+    for (int j = 0; j < TB; j++)
+      for (int i = 0; i < TB; i++) {
         if (diag && i > j) continue;
         const float* x = fa.data() + (size_t)i * K; const float* y = fb.data() + (size_t)j * K;
         float s = 0.0f;
@@ -780,6 +780,7 @@ static int dispatch(const char* mangled, void** args, unsigned gx, unsigned gy, 
   if (has("sub_from_kernel")) { k_sub_from(args, gy); return 1; }
   if (has("scatter_rows_bc_kernel")) { k_scatter_rows_bc(args, gy); return 1; }
   if (has("bf16_tn_kernel")) { k_bf16_tn(args, gx); return 1; }
+  if (has("bf16_tn3_kernel")) { k_bf16_tn(args, gx, 256, 32); return 1; }      // third generation: the same walk on 256 x 256 tiles, K in stages of 32
   if (has("fill_symmetric_bc2d_kernel")) { k_fill_symmetric_bc2d(args); return 1; }
   if (has("fill_symmetric_bc_kernel")) { k_fill_symmetric_bc(args); return 1; }
   if (has("pad_identity_kernel")) { k_pad_identity(args); return 1; }

@@ -196,6 +196,53 @@ def test_bf16_update_kernels_against_torch(m, n, k, tri, tpw):
         assert float((outs[0] - outs[1])[mask].abs().max()) / scale < 8e-6 * (k / 64.0) ** 0.5
 
 
+@pytest.mark.parametrize("m,n,k,tri,st", [(256, 256, 32, 0, 8), (256, 256, 64, 1, 8), (512, 768, 96, 0, 1), (1024, 1024, 160, 1, 2), (2304, 2304, 64, 1, 8),
+                                          (2048, 2048, 512, 1, 8), (1280, 4352, 320, 0, 3), (4096, 4096, 2048, 1, 8), (3072, 3072, 4096, 1, 4), (768, 2048, 224, 1, 8)])
+def test_bf16_update_third_generation(m, n, k, tri, st):
+    """The C-stationary 256 x 256 kernel (csrc/bf16_tn3.hip; LDS rings of 3 and 4 stages) against torch's fp32 matmul of the same bf16
+    operands and BIT FOR BIT against the 128 x 128 kernel where both apply (same k order per element, one final add into C): 1 .. 128
+    stages (ring fills, wraps and drains; the tail's vmcnt counts), supertile edges 1 .. 8, diagonal tiles, strips of a triangular
+    update (m < n), untouched strictly-lower part and leading-dimension padding."""
+    g = torch.Generator(device="cuda"); g.manual_seed(3 * m + n + k)
+    lda = k + 64
+    abuf = torch.randn(max(m, n) if tri else m, lda, device="cuda", generator=g).to(torch.bfloat16)
+    if tri:
+        a16 = abuf[:m, :k]; b16 = abuf[:n, :k]                    # C = rows [0, m) x columns [0, n) of a symmetric update
+    else:
+        a16 = abuf[:, :k]
+        bbuf = torch.randn(n, lda, device="cuda", generator=g).to(torch.bfloat16); b16 = bbuf[:, :k]
+    c0 = torch.randn(n, m + 32, device="cuda", generator=g)
+    ref = c0[:, :m].t().double() - 0.5 * (a16.double() @ b16.double().t())
+    mask = torch.triu(torch.ones(m, n, dtype=torch.bool, device="cuda")) if tri else torch.ones(m, n, dtype=torch.bool, device="cuda")
+    scale = float(ref.abs().max())
+    outs = {}
+    for variant in (0, 3, 4):
+        c = c0.clone()
+        rc = _bf16_update(variant, a16, b16, c, -0.5, tri, st if variant else 0)
+        if variant == 0 and rc != 0:
+            assert k % 64, rc
+            continue
+        assert rc == 0, (variant, rc)
+        torch.cuda.synchronize()
+        got = c[:, :m].t()
+        err = float((got.double() - ref)[mask].abs().max()) / scale
+        assert err < 4e-6 * (k / 64.0) ** 0.5 + 1e-7, (variant, err)
+        if tri:
+            assert torch.equal(got[~mask], c0[:, :m].t()[~mask]), "entries below the diagonal must not be touched"
+        assert torch.equal(c[:, m:], c0[:, m:]), "padding of the leading dimension must not be touched"
+        outs[variant] = got.clone()
+    assert torch.equal(outs[3][mask], outs[4][mask])
+    if 0 in outs:
+        assert torch.equal(outs[0][mask], outs[3][mask]), "same k order, one final add: the generations must agree bit for bit"
+
+
+def test_bf16_update_third_generation_refusals():
+    a16 = torch.zeros(384, 64, device="cuda", dtype=torch.bfloat16); c = torch.zeros(384, 384, device="cuda")
+    assert _bf16_update(3, a16, a16, c, 1.0, 1) != 0             # 384 is no multiple of 256
+    a16 = torch.zeros(256, 48, device="cuda", dtype=torch.bfloat16); c = torch.zeros(256, 256, device="cuda")
+    assert _bf16_update(3, a16, a16, c, 1.0, 1) != 0             # K = 48 is no multiple of 32
+
+
 def test_bf16_update_dispatcher_and_refusals():
     """variant 1 refuses shapes outside whole 256 x 128 x 64 tiles (the dispatcher then takes the 128-tile kernel); the factorization
     gives the same factor (to fp32 rounding of a different summation order) with either kernel forced for every big update."""

@@ -16,7 +16,7 @@ for m in sizes:
     a16 = torch.randn(m, K, device="cuda").to(torch.bfloat16)
     c = torch.zeros(m, m, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
-    variants = [(0, 0, "v1 128x128"), (1, 8, "v2 tpw=8"), (116, 8, "v2 pfC/2"), (117, 8, "v2 pfC/4"), (118, 8, "v2 pfC/8"), (104, 8, "v2 -mfma"),
+    variants = [(0, 0, "v1 128x128"), (1, 8, "v2 tpw=8"), (3, 8, "v3 nst=3 st=8"), (4, 8, "v3 nst=4 st=8"), (3, 4, "v3 nst=3 st=4"), (116, 8, "v2 pfC/2"), (117, 8, "v2 pfC/4"), (118, 8, "v2 pfC/8"), (104, 8, "v2 -mfma"),
                 (120, 8, "v2 pfC/4 -mfma"), (101, 8, "v2 -atomics")]
     if os.environ.get("BF16_PLAIN"):
         variants = [v for v in variants if v[0] < 100]
