@@ -83,10 +83,11 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
                     int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri,
                     hipStream_t stream, int tag = 0, int persist_wgs = 0, const double* Cin = nullptr, int64_t ldcin = 0);
 
-// bf16_tn3.hip: third-generation bf16 trailing update (256 x 256 C-stationary tile, read - add - store epilogue); nst = LDS ring depth (3 / 4)
-bool cap_bf16_tn3_applies(int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb, int tri);
+// bf16_tn3.hip: third-generation bf16 trailing update (256 x 256 C-stationary tile, read - add - store epilogue); nst = 3 / 4: LDS ring of
+// 3 / 4 stages of 32 k, 5: two stages of 64 k
+bool cap_bf16_tn3_applies(int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb, int tri, int nst);
 int cap_bf16_tn3_launch(int64_t m, int64_t n, int64_t k, float alpha, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
-                        int64_t ldc, int tri, int nst, int st, hipStream_t s);
+                        int64_t ldc, int tri, int nst, int st, hipStream_t s, int dbg = 0);
 
 // leaf.hip: in-LDS cholinv (potrf + trtri) / trtri of one n <= 64 block
 constexpr int CAP_LEAF_MAX = 64;

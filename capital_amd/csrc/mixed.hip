@@ -441,12 +441,13 @@ __global__ void __launch_bounds__(512, 2) bf16_tn_v2_kernel(const Bf2Args g) {
 // against 630 for the old one, but its workgroups hold 145 KiB of LDS for a whole chunk, the diagonal-block chain finds no CU to
 // start on, and the factorization - bound by that chain (panel stream) at every strip - gets 5 % SLOWER (211 vs 199 ms).  Stand-alone
 // (update-bound callers, K >= 2048) it is the faster kernel: 855 vs 770 TF at K = 2048, 1017 vs 894 at K = 4096.
-static int g_bf16_variant = getenv("CAP_BF16_V2") ? atoi(getenv("CAP_BF16_V2")) : 0;
+static int g_bf16_variant = getenv("CAP_BF16_V2") ? atoi(getenv("CAP_BF16_V2")) : 5;
 static int g_bf16_tpw = getenv("CAP_BF16_TPW") ? atoi(getenv("CAP_BF16_TPW")) : 8;
 static int64_t g_bf16_min_tiles = getenv("CAP_BF16_V2_MIN") ? atoll(getenv("CAP_BF16_V2_MIN")) : 1024;
 
-static int64_t g_bf16_v3_min = 256;      // smallest launch (in 256 x 256 tiles) the third-generation kernel takes
-static int g_bf16_v3_st = 8;             // its supertile edge in tiles
+static int64_t g_bf16_v3_min = 64;      // smallest launch (in 256 x 256 tiles) the third-generation kernel takes
+static int64_t g_bf16_head_min = 32;     // smallest panel-stream update it takes (-1: none, the 128-tile kernel)
+static int g_bf16_v3_st = 4;             // its supertile edge in tiles
 static int g_bf16_sched = getenv("CAP_BF16_SCHED") ? atoi(getenv("CAP_BF16_SCHED")) : 1;
 static int g_bf16_dbg = 0;              // timing surgery (CAP_EXPERIMENTS builds): set through cap_bf16_update(variant = 100 + DBG)
 
@@ -504,8 +505,16 @@ int launch_bf16_update(int64_t m, int64_t n, int64_t k, float alpha, const __bf1
                    256 * lda * 2 + k * 2 < 0xfffffff0LL && 128 * ldb * 2 + k * 2 < 0xfffffff0LL;
   if (ok2) return launch_bf16_v2(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
   // third generation (bf16_tn3.hip): whole 256 x 256 tiles and at least g_bf16_v3_min of them (below that the 128-wide tiles fill the chip better)
-  if (g_bf16_variant >= 3 && cap_bf16_tn3_applies(m, n, k, lda, ldb, tri) && (m / 256) * (n / 256) / ((tri && m == n) ? 2 : 1) >= g_bf16_v3_min)
-    return cap_bf16_tn3_launch(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, g_bf16_variant == 4 ? 4 : 3, g_bf16_v3_st, s);
+  if (g_bf16_variant >= 3 && cap_bf16_tn3_applies(m, n, k, lda, ldb, tri, g_bf16_variant) && (m / 256) * (n / 256) / ((tri && m == n) ? 2 : 1) >= g_bf16_v3_min)
+    return cap_bf16_tn3_launch(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, g_bf16_variant, g_bf16_v3_st, s);
+  return launch_bf16_tn(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
+}
+// the panel-stream updates (heads, in-strip updates): the same dispatcher with its own threshold (g_bf16_head_min tiles of 256 x 256)
+int launch_bf16_head(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A, int64_t lda, const __bf16* B, int64_t ldb, float* C,
+                     int64_t ldc, int tri, hipStream_t s) {
+  if (g_bf16_variant >= 3 && g_bf16_head_min >= 0 && cap_bf16_tn3_applies(m, n, k, lda, ldb, tri, g_bf16_variant) &&
+      (m / 256) * (n / 256) / ((tri && m == n) ? 2 : 1) >= g_bf16_head_min)
+    return cap_bf16_tn3_launch(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, g_bf16_variant, g_bf16_v3_st, s);
   return launch_bf16_tn(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
 }
 }  // namespace
@@ -516,13 +525,17 @@ int launch_bf16_update(int64_t m, int64_t n, int64_t k, float alpha, const __bf1
 extern "C" int cap_bf16_update(int variant, int64_t m, int64_t n, int64_t k, float alpha, const void* A16, int64_t lda, const void* B16, int64_t ldb,
                                float* C, int64_t ldc, int tri, int tpw, void* stream) {
   if (!A16 || !B16 || !C || m < 0 || n < 0 || k < 0) return CAP_ERR_ARG;
-  if (tpw > 0 && variant != 3 && variant != 4) g_bf16_tpw = tpw;
+  if (tpw > 0 && (variant < 3 || (variant > 5 && variant < 300))) g_bf16_tpw = tpw;
   const __bf16* A = (const __bf16*)A16; const __bf16* B = (const __bf16*)B16;
   hipStream_t s = cap_stream(stream);
   if (variant < 0) return launch_bf16_update(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
   if (variant == 0) return launch_bf16_tn(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
-  if (variant == 3 || variant == 4)      // third generation, LDS ring of 3 / 4 stages; tpw carries the supertile edge here (0: default)
+  if (variant >= 3 && variant <= 5)      // third generation: LDS ring of 3 / 4 stages of 32 k, 5 = two stages of 64 k; tpw carries the supertile edge here (0: default)
     return cap_bf16_tn3_launch(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, variant, tpw > 0 ? tpw : g_bf16_v3_st, s);
+  if (variant >= 300 && variant < 316)   // timing surgery on the third generation (experiment builds only): 300 + DBG; 500 + DBG: wide staging
+    return cap_bf16_tn3_launch(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, 3, tpw > 0 ? tpw : g_bf16_v3_st, s, variant - 300);
+  if (variant >= 500 && variant < 516)
+    return cap_bf16_tn3_launch(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, 5, tpw > 0 ? tpw : g_bf16_v3_st, s, variant - 500);
   if (m % 256 || n % 128 || k % 64 || lda % 8 || ldb % 8 || (tri && m != n) || m == 0 || n == 0 || k == 0) return CAP_ERR_UNSUPPORTED;
   // variant 1: the production schedule; 2: without the forced read-ahead; 100 + DBG: timing surgery (experiment builds only)
   g_bf16_sched = variant == 2 ? 0 : 1;
@@ -841,9 +854,9 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
           // head of panel a inside the strip: rows of panel b.  near = its diagonal block, far = the rectangle to the right
           const int64_t rb = j1n - j1;
           const __bf16* Pa = SP + roff;                                    // this panel's rows of the strip buffer, column c at c * ldp
-          CAP_TRY(launch_bf16_tn(rb, rb, nb, -1.0f, Pa + j1 * ldp, ldp, Pa + j1 * ldp, ldp, p->R32 + j1 + j1 * n, n, 1, s1));
+          CAP_TRY(launch_bf16_head(rb, rb, nb, -1.0f, Pa + j1 * ldp, ldp, Pa + j1 * ldp, ldp, p->R32 + j1 + j1 * n, n, 1, s1));
           CAP_HIP(hipStreamWaitEvent(s2, p->ev_ns, 0));
-          if (n > j1n) CAP_TRY(launch_bf16_tn(rb, n - j1n, nb, -1.0f, Pa + j1 * ldp, ldp, Pa + j1n * ldp, ldp, p->R32 + j1 + j1n * n, n, 0, s2));
+          if (n > j1n) CAP_TRY(launch_bf16_head(rb, n - j1n, nb, -1.0f, Pa + j1 * ldp, ldp, Pa + j1n * ldp, ldp, p->R32 + j1 + j1n * n, n, 0, s2));
           CAP_HIP(hipEventRecord(p->ev_hf, s2)); have_hf = true;
         }
       }
@@ -858,11 +871,11 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
       // waits for nothing else); far: the rest of those rows.  Both wait for rest(t-1), which touched the same rows.
       if (t > 0) { CAP_HIP(hipStreamWaitEvent(s1, p->ev_rest[(t - 1) & 1], 0)); CAP_HIP(hipStreamWaitEvent(s2, p->ev_rest[(t - 1) & 1], 0)); }
       if (kb > ka) CAP_HIP(hipStreamWaitEvent(s1, p->ev_fs[ka & 1], 0));    // the first panel's rows at these columns come from its FAR solve
-      CAP_TRY(launch_bf16_tn(ra, ra, K, -1.0f, S, ldp, S, ldp, p->R32 + Js + Js * n, n, 1, s1));
+      CAP_TRY(launch_bf16_head(ra, ra, K, -1.0f, S, ldp, S, ldp, p->R32 + Js + Js * n, n, 1, s1));
       CAP_HIP(hipStreamWaitEvent(s2, p->ev_ns, 0));                         // the last panel's rows at the near columns (A operand of rows a')
       if (m > ra) {
-        CAP_TRY(launch_bf16_tn(ra, m - ra, K, -1.0f, S, ldp, S + ra * ldp, ldp, p->R32 + Js + (Js + ra) * n, n, 0, s2));
-        if (rbn > 0) CAP_TRY(launch_bf16_tn(rbn, m - ra, K, -1.0f, S + ra * ldp, ldp, S + ra * ldp, ldp, p->R32 + (Js + ra) * (n + 1), n, 1, s2));
+        CAP_TRY(launch_bf16_head(ra, m - ra, K, -1.0f, S, ldp, S + ra * ldp, ldp, p->R32 + Js + (Js + ra) * n, n, 0, s2));
+        if (rbn > 0) CAP_TRY(launch_bf16_head(rbn, m - ra, K, -1.0f, S + ra * ldp, ldp, S + ra * ldp, ldp, p->R32 + (Js + ra) * (n + 1), n, 1, s2));
       }
       CAP_HIP(hipEventRecord(p->ev_hf, s2)); have_hf = true;
       // rest: rows below the next strip, caller's stream
@@ -892,14 +905,14 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
           // the factorization gained nothing from a bulk that ran 15 % faster (profiles/r05_mixed_pair_first.log)
           Kr = K + 2 * nb; Sr = p->P16[(t >> 1) & 1] + J3 * ldp;
           const int64_t hh = std::min<int64_t>(2 * nb, m3);
-          CAP_TRY(launch_bf16_tn(hh, m3, Kr, -1.0f, Sr, ldp, Sr, ldp, p->R32 + J3 * (n + 1), n, 1, s0));
+          CAP_TRY(launch_bf16_head(hh, m3, Kr, -1.0f, Sr, ldp, Sr, ldp, p->R32 + J3 * (n + 1), n, 1, s0));
           CAP_HIP(hipEventRecord(p->ev_rest[t & 1], s0)); rest_recorded = true;
           launch_rest = false;
           if (m3 > hh) CAP_TRY(launch_bf16_update(m3 - hh, m3 - hh, Kr, -1.0f, Sr + hh * ldp, ldp, Sr + hh * ldp, ldp, p->R32 + (J3 + hh) * (n + 1), n, 1, s0));
           deferred = false; p->cnt_paired++;
         } else if (p->pair_rest && (t & 1) == 0 && K == 2 * nb && hb == 2 * nb && m3 > 2 * nb) {
           // head of strip t on strip t + 2's rows; the region below waits for strip t + 1
-          CAP_TRY(launch_bf16_tn(2 * nb, m3, K, -1.0f, Sr, ldp, Sr, ldp, p->R32 + J3 * (n + 1), n, 1, s0));
+          CAP_TRY(launch_bf16_head(2 * nb, m3, K, -1.0f, Sr, ldp, Sr, ldp, p->R32 + J3 * (n + 1), n, 1, s0));
           deferred = true; launch_rest = false; head_only = true;
         }
         if (launch_rest) CAP_TRY(launch_bf16_update(m3, m3, Kr, -1.0f, Sr, ldp, Sr, ldp, p->R32 + J3 * (n + 1), n, 1, s0));
@@ -960,7 +973,7 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
       const int64_t j1 = std::min(n, (k + 1) * nb), rows_left = Jend - j1;
       if (rows_left > 0) {         // rows of the strip below panel k, all columns to their right: K = nb, this panel's rows of SP
         const __bf16* Pk = SP + (k - k0) * nb + j1 * ldp;
-        CAP_TRY(launch_bf16_tn(rows_left, n - j1, nb, -1.0f, Pk, ldp, Pk, ldp, p->R32 + j1 + j1 * n, n, 1, s));
+        CAP_TRY(launch_bf16_head(rows_left, n - j1, nb, -1.0f, Pk, ldp, Pk, ldp, p->R32 + j1 + j1 * n, n, 1, s));
       }
     }
     return CAP_OK;
@@ -979,7 +992,7 @@ static int mp_factor_impl(cap_mpchol_plan* p, const double* A, int64_t lda, hipS
     const __bf16* S = p->P16[t & 1] + Js * ldp;
     const int64_t hb = std::min(sp * nb, m);              // rows of the next strip
     if (t > 0) CAP_HIP(hipStreamWaitEvent(s1, p->ev_rest[(t - 1) & 1], 0));
-    CAP_TRY(launch_bf16_tn(hb, m, K, -1.0f, S, ldp, S, ldp, p->R32 + Js + Js * n, n, 1, s1));
+    CAP_TRY(launch_bf16_head(hb, m, K, -1.0f, S, ldp, S, ldp, p->R32 + Js + Js * n, n, 1, s1));
     CAP_HIP(hipStreamWaitEvent(s0, p->ev_panel[t & 1], 0));
     if (m > hb) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1035,8 +1048,9 @@ int cap_mpchol_set_option(cap_mpchol_plan* p, const char* key, int64_t value) {
   if (!strcmp(key, "chain_coop")) { if (value < -1 || value > 256) return CAP_ERR_ARG; p->chain_coop = (int)value; return CAP_OK; }   // per plan, see cap_cholinv_set_option
   if (!strcmp(key, "solve3")) { p->solve3 = value != 0; return CAP_OK; }   // block-row solves on the bf16 pipe with split operands (split schedule)
   // process-wide A/B switches of the bf16 update (see launch_bf16_update): which kernel, chunk length, smallest launch for the new one
-  if (!strcmp(key, "update_kernel")) { if (value < 0 || value > 4 || value == 2) return CAP_ERR_ARG; g_bf16_variant = (int)value; return CAP_OK; }
+  if (!strcmp(key, "update_kernel")) { if (value < 0 || value > 5 || value == 2) return CAP_ERR_ARG; g_bf16_variant = (int)value; return CAP_OK; }
   if (!strcmp(key, "update_v3_min_tiles")) { if (value < 0) return CAP_ERR_ARG; g_bf16_v3_min = value; return CAP_OK; }
+  if (!strcmp(key, "update_v3_head_min_tiles")) { if (value < -1) return CAP_ERR_ARG; g_bf16_head_min = value; return CAP_OK; }
   if (!strcmp(key, "update_v3_st")) { if (value < 1 || value > 64) return CAP_ERR_ARG; g_bf16_v3_st = (int)value; return CAP_OK; }
   if (!strcmp(key, "update_tpw")) { if (value < 1 || value > 64) return CAP_ERR_ARG; g_bf16_tpw = (int)value; return CAP_OK; }
   if (!strcmp(key, "update_min_tiles")) { if (value < 0) return CAP_ERR_ARG; g_bf16_min_tiles = value; return CAP_OK; }

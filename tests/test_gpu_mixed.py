@@ -197,7 +197,7 @@ def test_bf16_update_kernels_against_torch(m, n, k, tri, tpw):
 
 
 @pytest.mark.parametrize("m,n,k,tri,st", [(256, 256, 32, 0, 8), (256, 256, 64, 1, 8), (512, 768, 96, 0, 1), (1024, 1024, 160, 1, 2), (2304, 2304, 64, 1, 8),
-                                          (2048, 2048, 512, 1, 8), (1280, 4352, 320, 0, 3), (4096, 4096, 2048, 1, 8), (3072, 3072, 4096, 1, 4), (768, 2048, 224, 1, 8)])
+                                          (2048, 2048, 512, 1, 8), (1280, 4352, 320, 0, 3), (4096, 4096, 2048, 1, 8), (3072, 3072, 4096, 1, 4), (768, 2048, 224, 1, 8), (512, 512, 128, 1, 8), (1024, 768, 192, 0, 2)])
 def test_bf16_update_third_generation(m, n, k, tri, st):
     """The C-stationary 256 x 256 kernel (csrc/bf16_tn3.hip; LDS rings of 3 and 4 stages) against torch's fp32 matmul of the same bf16
     operands and BIT FOR BIT against the 128 x 128 kernel where both apply (same k order per element, one final add into C): 1 .. 128
@@ -216,11 +216,11 @@ def test_bf16_update_third_generation(m, n, k, tri, st):
     mask = torch.triu(torch.ones(m, n, dtype=torch.bool, device="cuda")) if tri else torch.ones(m, n, dtype=torch.bool, device="cuda")
     scale = float(ref.abs().max())
     outs = {}
-    for variant in (0, 3, 4):
+    for variant in (0, 3, 4, 5):
         c = c0.clone()
         rc = _bf16_update(variant, a16, b16, c, -0.5, tri, st if variant else 0)
-        if variant == 0 and rc != 0:
-            assert k % 64, rc
+        if variant in (0, 5) and rc != 0:
+            assert k % 64, rc                                  # the 128-tile kernel and the wide staging take K in steps of 64
             continue
         assert rc == 0, (variant, rc)
         torch.cuda.synchronize()
@@ -234,6 +234,7 @@ def test_bf16_update_third_generation(m, n, k, tri, st):
     assert torch.equal(outs[3][mask], outs[4][mask])
     if 0 in outs:
         assert torch.equal(outs[0][mask], outs[3][mask]), "same k order, one final add: the generations must agree bit for bit"
+        assert torch.equal(outs[5][mask], outs[3][mask])
 
 
 def test_bf16_update_third_generation_refusals():
