@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 3 factorizations; 20 for the 10 ms CholeskyQR2 step)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cholesky", choices=["cholesky", "cacqr", "mixed"])
+    ap.add_argument("--workload", default="cholesky", choices=["cholesky", "cacqr", "mixed", "summa"])
     ap.add_argument("--n", "--size", dest="n", type=int, default=65536,
                     help="matrix dimension (BASELINE metric: 65536); use --size under torch.distributed.run, whose own parser trips over --n")
     ap.add_argument("--nb", type=int, default=0, help="panel width override (0 = library default)")
@@ -73,6 +73,12 @@ def parse():
                     help="-1 blocked Cholesky (headline), 0/1 reference cholinv semantics (R and R^-1)")
     ap.add_argument("--qr-rows", type=int, default=1 << 21, help="cacqr: rows per GPU")
     ap.add_argument("--qr-cols", type=int, default=256, help="cacqr: columns")
+    ap.add_argument("--replay-rank", type=int, default=None,
+                    help="PROJECTION, not a multi-GPU measurement: replay rank r (-1: every rank) of the --of P rank 1 x P schedule on THIS GPU "
+                         "(tools/replay.py: the peers' data comes out of a finished factor behind a link model) and print the per-rank timeline")
+    ap.add_argument("--of", type=int, default=8, help="--replay-rank: ranks of the replayed schedule")
+    ap.add_argument("--link-gbps", type=float, default=100.0, help="--replay-rank: modelled bandwidth per xGMI link")
+    ap.add_argument("--lat-us", type=float, default=10.0, help="--replay-rank: modelled latency per collective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs runs")
     ap.add_argument("--no-check", action="store_true", help="skip the residual checks (profiling runs)")
@@ -81,7 +87,7 @@ def parse():
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the residual is always computed)")
     args = ap.parse_args()
     if args.steps <= 0:
-        args.steps = 20 if args.workload == "cacqr" else 3      # a CholeskyQR2 step is 10 ms: average over more of them
+        args.steps = 20 if args.workload == "cacqr" else (5 if args.workload == "summa" else 3)      # a CholeskyQR2 step is 10 ms: average over more of them
     return args
 
 
@@ -367,6 +373,25 @@ def main():
     L = _lib.lib()     # fails loudly if the HIP library is missing
     import ctypes as C
 
+    if args.replay_rank is not None:
+        # one rank's real schedule at full speed on the one GPU there is; everything it prints is labelled a projection
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import replay
+        ranks = None if args.replay_rank < 0 else [args.replay_rank]
+        res = replay.run(args.n, args.of, ranks, 512, args.steps or 3, args.warmup, args.link_gbps, args.lat_us, "auto",
+                         args.occ1_m if args.occ1_m >= 0 else None, args.strip or None)
+        print(json.dumps({
+            "metric": "PROJECTED fp64 Cholesky TFLOP/s on %d MI355X (max over the replayed ranks of N^3/3 per second of one rank's schedule on ONE GPU; "
+                      "peers' data from a finished factor behind a link model) - not a multi-GPU measurement" % args.of,
+            "value": res["projected_tf_whole_job"], "unit": "TFLOP/s", "n_gpus": 1, "projection_of_gpus": args.of, "steps": args.steps or 3, "warmup": args.warmup,
+            "ms_per_step": res["projected_ms_max_over_ranks"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "N=%d fp64 Cholesky, rank(s) %s of the 1 x %d block-column-cyclic plan replayed on one GPU (tools/replay.py)" % (
+                args.n, "all" if ranks is None else ranks, args.of), "link_GBps_per_link": args.link_gbps, "lat_us": args.lat_us,
+                "projected_frac_of_node_fp64_mfma_peak": res["projected_frac_of_P_gpu_peak"], "projected_speedup_vs_1gpu": res["projected_speedup_vs_1gpu"],
+                "single_gpu_tf_same_box": res["single_gpu_tf"]},
+            "ranks": res["ranks"]}))
+        return
+
     # N > 1: the control plane (barriers, max over ranks) runs over a gloo group on the HOST and GPU completion is POLLED, so a
     # collective that never completes (first contact with multi-rank RCCL) cannot block the bench: after `watchdog_s` without
     # completion every rank reports, rank 0 prints a JSON line with value null + the error, and the processes leave without
@@ -433,6 +458,10 @@ def main():
         out, ok = bench_cacqr(args, torch, L, C, rank, world, dist, emulate, timed, allreduce_sum)
     elif args.workload == "mixed":
         out, ok = bench_mixed(args, torch, L, C, rank, world, timed)
+    elif args.workload == "summa":
+        if world != 1:
+            raise SystemExit("bench.py --workload summa runs on one GPU (the multi-rank driver is tools/summa_bench.py / examples/summa_driver.c)")
+        out, ok = bench_summa(args, torch, L, C, rank, world, timed)
     else:
         out, ok = bench_cholesky(args, torch, L, C, rank, world, dist, emulate, timed, allreduce_sum)
     if rank == 0:
@@ -566,13 +595,17 @@ def bench_cholesky(args, torch, L, C, rank, world, dist, emulate, timed, allredu
         # BASELINE configs[3] (per-GPU shape) and configs[4]'s method on one GPU, each with its own roofline and residual
         class _Sub:
             pass
-        for wl in ("cacqr", "mixed"):
+        for wl in ("cacqr", "mixed", "summa"):
             sub = _Sub(); sub.__dict__.update(vars(args))
             sub.no_cpu_baseline = True; sub.warmup = 1
             try:
                 if wl == "cacqr":
                     sub.steps = 20
+                    sub.no_cpu_baseline = args.no_cpu_baseline      # config 4's CPU comparator (the real reference's cacqr on 8 ranks, bounded sample) rides along
                     o2, k2 = bench_cacqr(sub, torch, L, C, rank, world, dist, emulate, timed, allreduce_sum)
+                elif wl == "summa":
+                    sub.steps = 5
+                    o2, k2 = bench_summa(sub, torch, L, C, rank, world, timed)
                 else:
                     sub.steps = 2
                     o2, k2 = bench_mixed(sub, torch, L, C, rank, world, timed)
@@ -580,7 +613,7 @@ def bench_cholesky(args, torch, L, C, rank, world, dist, emulate, timed, allredu
                 o2, k2 = {"metric": wl, "value": None, "error": repr(ex)}, False
             extra.append({"workload": o2.get("metric"), "value": o2.get("value"), "unit": o2.get("unit"), "ms_per_step": o2.get("ms_per_step"),
                           "steps": o2.get("steps"), "dtype": o2.get("dtype"), "config": o2.get("config"), "roofline": o2.get("roofline"),
-                          "error": o2.get("error")})
+                          "cpu_baseline": o2.get("cpu_baseline"), "error": o2.get("error")})
             ok = ok and k2
             torch.cuda.empty_cache()
         out["extra_configs"] = extra
@@ -930,6 +963,65 @@ def bench_mixed_dist(args, torch, L, C, rank, world, timed):
     p.close()
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_budget_s)     # the reference has no solve path: its fp64 factor is the comparator
+    return out, ok
+
+
+def bench_summa(args, torch, L, C, rank, world, timed):
+    """SUMMA on one GPU (d = c = 1: the carrier's plan, streams and events around the local MFMA products) - the reference's
+    bench/matmult/summa_gemm.cpp:7-55 protocol (warm call, timed calls) for its GEMM overload (NoTrans x NoTrans, the only form that
+    bench runs), the SYRK overload in its Trans form (C = A^T A, summa.hpp:98-161: the TN product of the Cholesky update) and a tall-K
+    GEMM, each with its own roofline and a check against torch's fp64 matmul on a probe."""
+    from capital_amd import blas, summa, topo
+    from capital_amd.matrix import matrix
+    T = topo.square(1, 0, 4)
+    forms, ok = [], True
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    steps = args.steps or 5
+    for (name, kind, M, N, K) in (("GEMM NN 8192^3", "gemm", 8192, 8192, 8192), ("SYRK Trans (TN) n=8192 k=8192", "syrk", 8192, 8192, 8192),
+                                  ("GEMM NN tall-K 4096 x 4096 x 65536", "gemm", 4096, 4096, 65536)):
+        if kind == "gemm":
+            A = matrix(K, M, 1, 1); B = matrix(N, K, 1, 1); Cm = matrix(N, M, 1, 1)
+            A.distribute_random(0, 0, 1, 1, 0); B.distribute_random(0, 0, 1, 1, 1000)
+            pack = blas.ArgPack_gemm(blas.Order.AblasColumnMajor, blas.Transpose.AblasNoTrans, blas.Transpose.AblasNoTrans, 1.0, 0.0)
+            run = lambda: summa.invoke(A, B, Cm, T, pack)
+            flops = 2.0 * M * N * K
+        else:
+            A = matrix(N, K, 1, 1); Cm = matrix(N, N, 1, 1)            # A: K x N, C = A^T A (upper)
+            A.distribute_random(0, 0, 1, 1, 0)
+            pack = blas.ArgPack_syrk(blas.Order.AblasColumnMajor, blas.UpLo.AblasUpper, blas.Transpose.AblasTrans, 1.0, 0.0)
+            run = lambda: summa.invoke(A, Cm, T, pack)
+            flops = 1.0 * N * (N + 1) * K
+        sec = timed(run, steps, args.warmup)
+        tf = flops / sec / 1e12
+        err = None
+        if not args.no_check:
+            # probe: a 256 x 256 block of C (inside the upper triangle for SYRK) against torch's fp64 matmul of the operand slices
+            r0, c0 = 128, N - 512
+            Cv = Cm.view()[r0:r0 + 256, c0:c0 + 256]
+            if kind == "gemm":
+                ref = A.view()[r0:r0 + 256, :] @ B.view()[:, c0:c0 + 256]
+            else:
+                ref = A.view()[:, r0:r0 + 256].t() @ A.view()[:, c0:c0 + 256]
+            err = float((Cv - ref).norm() / ref.norm())
+            ok = ok and err == err and err <= 1e-13
+        forms.append({"form": name, "M": M, "N": N, "K": K, "value": tf, "unit": "TFLOP/s", "ms_per_step": sec * 1e3, "steps": steps, "probe_rel_err": err,
+                      "roofline": {"bound": "mfma", "kernel": "dgemm_tn_dma_kernel (%s)" % ("A_MC: M-contiguous A" if kind == "gemm" else "K-contiguous operands, upper tiles"),
+                                   "achieved": tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TF, "traffic": None,
+                                   "algorithmic_flops_per_step": flops}})
+        del A, Cm
+        if kind == "gemm": del B
+        summa.release(T)
+        torch.cuda.empty_cache()
+    T.close()
+    best = forms[0]
+    out = {"metric": "fp64 SUMMA GEMM TFLOP/s (2 M N K per wall-second of one warm summa::invoke, bench/matmult/summa_gemm.cpp:39-52), 8192^3 on 1 GPU",
+           "value": best["value"], "unit": "TFLOP/s", "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": best["ms_per_step"],
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "SUMMA (matmult::summa::invoke) on the 1 x 1 x 1 grid: GEMM NN 8192^3 (headline of this line), SYRK Trans 8192 x 8192 x 8192, "
+                                  "GEMM NN 4096 x 4096 x 65536; upstream distribute_random operands generated on the GPU", "forms": forms},
+           "roofline": best["roofline"]}
+    if not ok:
+        out["value"] = None; out["error"] = "a SUMMA form failed its probe against torch's fp64 matmul"
     return out, ok
 
 

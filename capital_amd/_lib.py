@@ -111,6 +111,7 @@ SIGNATURES = {
     "cap_dist_get_option": (i64, [ptr, C.c_char_p]),
     "cap_dist_profile": (cint, [ptr, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]),
     "cap_dist_profile_streams": (cint, [ptr, C.POINTER(dbl)]),
+    "cap_dist_profile_launches": (cint, [ptr, C.POINTER(dbl), C.POINTER(dbl), i64, C.POINTER(i64)]),
     "cap_dist_progress": (cint, [ptr, C.POINTER(i64)]),
     "cap_dist_profile_inverse": (cint, [ptr, C.POINTER(dbl)]),
     "cap_fill_symmetric_bc": (cint, [ptr, i64, i64, i64, cint, cint, cint, ptr]),

@@ -20,7 +20,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # Kernels of the hot path that must live in registers: a silent scratch allocation (seen once: accumulators captured by a
 # lambda) costs 5-7x and nothing else reports it.  Checked after every build against the compiler's own resource remarks.
 NO_SCRATCH = ("dgemm_tn_dma_kernel", "gram256_kernel", "qrapply256_kernel", "bf16_tn_kernel", "bf16_tn_v2_kernel", "bf16_tn3_kernel", "bf16_tn3w_kernel", "leaf_cholinv_kernel",
-              "panel64_solve_update_kernel")
+              "panel64_solve_update_kernel", "chain64_coop_kernel")
 
 
 def sources():
@@ -98,6 +98,25 @@ def build_cblas(force=False, verbose=True):
     return CBLAS_LIB
 
 
+REPLAY_LIB = os.path.join(LIBDIR, "libcap_replay.so")
+REPLAY_SRC = os.path.join(CSRC, "replay", "replay_comm.hip")
+
+
+def build_replay(force=False, verbose=True):
+    """libcap_replay.so (csrc/replay/replay_comm.hip): the replay communicator of tools/replay.py / bench.py --replay-rank - a measurement
+    harness ABOVE the C ABI (it only calls cap_comm_create_callbacks), kept out of libcapital_amd.so."""
+    build(force=False, verbose=verbose)
+    deps = [REPLAY_SRC, os.path.join(os.path.dirname(HERE), "include", "capital_amd.h"), LIB]
+    if not force and os.path.exists(REPLAY_LIB) and all(os.path.getmtime(REPLAY_LIB) > os.path.getmtime(d) for d in deps):
+        return REPLAY_LIB
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", REPLAY_LIB, REPLAY_SRC, "-L" + LIBDIR, "-lcapital_amd",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return REPLAY_LIB
+
+
 def kernel_resources():
     """{kernel symbol: {"VGPRs": n, "ScratchSize": bytes per lane, "VGPRs Spill": n, ...}} from the last compile of every source."""
     out, cur = {}, None
@@ -147,3 +166,4 @@ if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print("built", LIB)
     print("built", build_cblas(force="--force" in sys.argv))
+    print("built", build_replay(force="--force" in sys.argv))

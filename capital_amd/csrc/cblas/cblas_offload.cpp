@@ -31,6 +31,14 @@ bool bad_arg(const char* fn, const char* what) {
   fprintf(stderr, "capital_amd_cblas: %s: %s - call ignored\n", fn, what);
   return true;
 }
+// a LEGAL BLAS form this library does not implement (row-major, ConjTrans, Lower / Unit triangular operands: none has a call site in the
+// reference): returning would leave the caller's output buffer as it was and the program computing on with wrong numbers - a library that
+// stands in for MKL must not do that silently.  Abort with the reason.
+[[noreturn]] bool unsupported(const char* fn, const char* what) {
+  fprintf(stderr, "capital_amd_cblas: %s: %s - a legal BLAS form this offload library does not implement; aborting instead of returning wrong numbers\n", fn, what);
+  abort();
+}
+bool valid_trans(int t) { return t == CAPCB_NOTRANS || t == CAPCB_TRANS || t == CAPCB_CONJTRANS; }
 void hip_ok(hipError_t e, const char* fn) { if (e != hipSuccess) die(fn, hipGetErrorString(e)); }
 void cap_ok(int st, const char* fn) { if (st != CAP_OK) die(fn, cap_status_string(st)); }
 
@@ -95,8 +103,11 @@ extern "C" {
 void cblas_dgemm(int layout, int transa, int transb, int m, int n, int k, double alpha, const double* A, int lda, const double* B, int ldb,
                  double beta, double* C, int ldc) {
   const char* fn = "cblas_dgemm";
-  if (layout != CAPCB_COL_MAJOR && bad_arg(fn, "row-major is not taken (the reference passes AblasColumnMajor everywhere)")) return;
-  if (((transa != CAPCB_NOTRANS && transa != CAPCB_TRANS) || (transb != CAPCB_NOTRANS && transb != CAPCB_TRANS)) && bad_arg(fn, "ConjTrans is not taken")) return;
+  if (layout != CAPCB_COL_MAJOR && layout != CAPCB_ROW_MAJOR && bad_arg(fn, "layout")) return;
+  if (layout != CAPCB_COL_MAJOR) unsupported(fn, "row-major (the reference passes AblasColumnMajor everywhere)");
+  if ((!valid_trans(transa) || !valid_trans(transb)) && bad_arg(fn, "transpose flag")) return;
+  if (transa == CAPCB_CONJTRANS) transa = CAPCB_TRANS;              // real arithmetic: the conjugate transpose IS the transpose
+  if (transb == CAPCB_CONJTRANS) transb = CAPCB_TRANS;
   if ((m < 0 || n < 0 || k < 0) && bad_arg(fn, "negative dimension")) return;
   const int64_t ar = transa == CAPCB_NOTRANS ? m : k, ac = transa == CAPCB_NOTRANS ? k : m;
   const int64_t br = transb == CAPCB_NOTRANS ? k : n, bc = transb == CAPCB_NOTRANS ? n : k;
@@ -113,11 +124,15 @@ void cblas_dgemm(int layout, int transa, int transb, int m, int n, int k, double
 void cblas_dtrmm(int layout, int side, int uplo, int transa, int diag, int m, int n, double alpha, const double* A, int lda, double* B,
                  int ldb) {
   const char* fn = "cblas_dtrmm";
-  if (layout != CAPCB_COL_MAJOR && bad_arg(fn, "row-major is not taken")) return;
+  if (layout != CAPCB_COL_MAJOR && layout != CAPCB_ROW_MAJOR && bad_arg(fn, "layout")) return;
   if (side != CAPCB_LEFT && side != CAPCB_RIGHT && bad_arg(fn, "side")) return;
-  if (uplo != CAPCB_UPPER && bad_arg(fn, "lower-triangular operands are not taken (every call site of the reference is Upper)")) return;
-  if (diag != CAPCB_NONUNIT && bad_arg(fn, "unit-diagonal operands are not taken (every call site of the reference is NonUnit)")) return;
-  if (transa != CAPCB_NOTRANS && transa != CAPCB_TRANS && bad_arg(fn, "ConjTrans is not taken")) return;
+  if (uplo != CAPCB_UPPER && uplo != CAPCB_LOWER && bad_arg(fn, "uplo")) return;
+  if (diag != CAPCB_NONUNIT && diag != CAPCB_UNIT && bad_arg(fn, "diag")) return;
+  if (!valid_trans(transa) && bad_arg(fn, "transpose flag")) return;
+  if (layout != CAPCB_COL_MAJOR) unsupported(fn, "row-major");
+  if (uplo != CAPCB_UPPER) unsupported(fn, "lower-triangular operand (every call site of the reference is Upper)");
+  if (diag != CAPCB_NONUNIT) unsupported(fn, "unit-diagonal operand (every call site of the reference is NonUnit)");
+  if (transa == CAPCB_CONJTRANS) transa = CAPCB_TRANS;
   if ((m < 0 || n < 0) && bad_arg(fn, "negative dimension")) return;
   const int64_t t = side == CAPCB_LEFT ? m : n;
   if ((lda < ld_of(t) || ldb < ld_of(m)) && bad_arg(fn, "leading dimension smaller than the window")) return;
@@ -133,9 +148,11 @@ void cblas_dtrmm(int layout, int side, int uplo, int transa, int diag, int m, in
 
 void cblas_dsyrk(int layout, int uplo, int trans, int n, int k, double alpha, const double* A, int lda, double beta, double* C, int ldc) {
   const char* fn = "cblas_dsyrk";
-  if (layout != CAPCB_COL_MAJOR && bad_arg(fn, "row-major is not taken")) return;
+  if (layout != CAPCB_COL_MAJOR && layout != CAPCB_ROW_MAJOR && bad_arg(fn, "layout")) return;
   if (uplo != CAPCB_UPPER && uplo != CAPCB_LOWER && bad_arg(fn, "uplo")) return;
-  if (trans != CAPCB_NOTRANS && trans != CAPCB_TRANS && bad_arg(fn, "ConjTrans is not taken")) return;
+  if (!valid_trans(trans) && bad_arg(fn, "transpose flag")) return;
+  if (layout != CAPCB_COL_MAJOR) unsupported(fn, "row-major");
+  if (trans == CAPCB_CONJTRANS) trans = CAPCB_TRANS;
   if ((n < 0 || k < 0) && bad_arg(fn, "negative dimension")) return;
   const int64_t ar = trans == CAPCB_NOTRANS ? n : k, ac = trans == CAPCB_NOTRANS ? k : n;
   if ((lda < ld_of(ar) || ldc < ld_of(n)) && bad_arg(fn, "leading dimension smaller than the window")) return;

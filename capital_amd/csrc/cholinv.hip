@@ -98,14 +98,18 @@ thread_local int tl_coop_cap = 0;
 // apart but ran together).
 constexpr int COOP_MAX_NBLK = 16;
 constexpr size_t COOP_BACKUP_DOUBLES = (size_t)COOP_MAX_NBLK * (COOP_MAX_NBLK + 1) / 2 * 64 * 64;
-struct CoopSlot { int dev; hipStream_t s; int* ctr; double* backup; hipEvent_t ready; };
+struct CoopSlot { int dev; hipStream_t s; int* ctr; double* backup; };
 std::mutex g_coop_mu;
 std::vector<CoopSlot>* g_coop_slots = nullptr;
 int* g_coop_fallbacks[16] = {};           // per device: how many chains were re-run after a workgroup gave up waiting (device word)
+hipEvent_t g_coop_fb_zeroed[16] = {};     // recorded behind the one memset that zeroes those words
 long long* g_coop_trace = nullptr;
 int64_t g_coop_trace_at = -1;
 // (no host synchronisation in here: the first chain of a rank is enqueued in the middle of a multi-stream, multi-rank schedule, and a
-// host that waits for its device there waits for collectives whose partners may not have been enqueued yet)
+// host that waits for its device there waits for collectives whose partners may not have been enqueued yet.)  The fallback words of a
+// device are zeroed ONCE, on the stream that asks first; every stream that is handed them - this one included, through stream order -
+// waits for that memset's event when its slot is created (chains on other streams read fallbacks[1] with no ordering
+// against the memset; hipMalloc does not zero).  A failing memset leaves nothing published.
 int coop_slot(int** ctr, double** backup, int** fallbacks, hipStream_t s) {
   int dev = 0;
   CAP_HIP(hipGetDevice(&dev));
@@ -113,16 +117,33 @@ int coop_slot(int** ctr, double** backup, int** fallbacks, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_coop_mu);
   if (!g_coop_slots) g_coop_slots = new std::vector<CoopSlot>();
   if (!g_coop_fallbacks[dev]) {
-    CAP_HIP(hipMalloc((void**)&g_coop_fallbacks[dev], 4 * sizeof(int)));
-    CAP_HIP(hipMemsetAsync(g_coop_fallbacks[dev], 0, 4 * sizeof(int), s));    // (first use below is stream-ordered behind the slot's event)
+    int* fb = nullptr; hipEvent_t ev = nullptr;
+    CAP_HIP(hipMalloc((void**)&fb, 4 * sizeof(int)));
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipMemsetAsync(fb, 0, 4 * sizeof(int), s) != hipSuccess ||
+        hipEventRecord(ev, s) != hipSuccess) {
+      (void)hipGetLastError();
+      if (ev) (void)hipEventDestroy(ev);
+      (void)hipFree(fb);
+      return CAP_ERR_HIP;
+    }
+    g_coop_fallbacks[dev] = fb; g_coop_fb_zeroed[dev] = ev;
   }
   *fallbacks = g_coop_fallbacks[dev];
   for (const CoopSlot& c : *g_coop_slots)
     if (c.dev == dev && c.s == s) { *ctr = c.ctr; *backup = c.backup; return CAP_OK; }
-  CoopSlot c{dev, s, nullptr, nullptr, nullptr};
+  // first chain of this stream: behind the zeroing of the device's fallback words (no event: cap_chain_inject_timeouts zeroed them synchronously)
+  if (g_coop_fb_zeroed[dev]) {
+    const hipError_t q = hipEventQuery(g_coop_fb_zeroed[dev]);          // long complete for every stream but the first few: then there is nothing to wait for
+    if (q == hipErrorNotReady) { (void)hipGetLastError(); CAP_HIP(hipStreamWaitEvent(s, g_coop_fb_zeroed[dev], 0)); }
+    else if (q != hipSuccess) CAP_HIP(q);
+  }
+  CoopSlot c{dev, s, nullptr, nullptr};
   CAP_HIP(hipMalloc((void**)&c.ctr, 4 * sizeof(int)));
   if (hipMalloc((void**)&c.backup, COOP_BACKUP_DOUBLES * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); c.backup = nullptr; }   // no backup: no recovery
-  CAP_HIP(hipMemsetAsync(c.ctr, 0, 4 * sizeof(int), s));
+  if (hipMemsetAsync(c.ctr, 0, 4 * sizeof(int), s) != hipSuccess) {
+    (void)hipGetLastError(); (void)hipFree(c.ctr); if (c.backup) (void)hipFree(c.backup);
+    return CAP_ERR_HIP;
+  }
   g_coop_slots->push_back(c);
   *ctr = c.ctr; *backup = c.backup;
   return CAP_OK;
@@ -130,21 +151,24 @@ int coop_slot(int** ctr, double** backup, int** fallbacks, hipStream_t s) {
 
 }  // namespace
 
-// the stream is about to be destroyed: give its counter words and backup buffer back (hipFree waits for whatever still uses them)
+// the stream is about to be destroyed: give its counter words and backup buffer back.  The slot is found by the stream HANDLE alone (a
+// plan may be destroyed while another device is current - ADVICE round 5: the per-device lookup leaked it then) and the buffers are freed
+// after the stream itself has drained, so that nothing of this stream can still be using them.
 void cap_coop_slot_release(hipStream_t s) {
-  int dev = 0;
-  if (!s || hipGetDevice(&dev) != hipSuccess) return;
+  if (!s) return;
   int* ctr = nullptr; double* backup = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_coop_mu);
     if (!g_coop_slots) return;
     for (size_t i = 0; i < g_coop_slots->size(); i++)
-      if ((*g_coop_slots)[i].dev == dev && (*g_coop_slots)[i].s == s) {
+      if ((*g_coop_slots)[i].s == s) {
         ctr = (*g_coop_slots)[i].ctr; backup = (*g_coop_slots)[i].backup;
         g_coop_slots->erase(g_coop_slots->begin() + (std::ptrdiff_t)i);
         break;
       }
   }
+  if (!ctr && !backup) return;
+  (void)hipStreamSynchronize(s);
   if (ctr) (void)hipFree(ctr);
   if (backup) (void)hipFree(backup);
 }
@@ -1356,6 +1380,7 @@ int cap_cholinv_get_Rinv_desc(cap_cholinv_plan* p, cap_desc* Rinv, void* stream)
 int cap_cholinv_info(cap_cholinv_plan* p, void* stream, int64_t* info) {
   if (!p || !info) return CAP_ERR_ARG;
   if (p->dist) return cap_dist_info(p->dist, stream, info);
+  CAP_TRY(cap_drain_streams({p->s_panel, p->s_bulk, p->s_chain, p->s_rest, p->s_copy, p->s_inv}));
   int h = 0;
   CAP_HIP(hipMemcpyAsync(&h, p->info_dev, sizeof(int), hipMemcpyDeviceToHost, cap_stream(stream)));
   CAP_HIP(hipStreamSynchronize(cap_stream(stream)));

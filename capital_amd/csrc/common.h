@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <initializer_list>
+
 #include "../../include/capital_amd.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -60,6 +62,15 @@ enum { CAP_ACC_HOST = 16 };
 static inline void cap_acc_host(int mode, const void* p, int64_t ld, int64_t rows, int64_t cols) { cap_acc(mode | CAP_ACC_HOST, p, ld, rows, cols); }
 // a launch whose accesses are all on memory no other stream can name (per-stream scratch) still says so: mode 0 = "nothing shared"
 static inline void cap_acc_none() { if (cap_acc_on()) cap_access_hook(0, nullptr, 0, 0, 0, 0, 0); }
+
+// Every status / result query of a plan drains the plan's OWN helper streams before it reads (round 6, after round 5's one late read of a
+// factor that cap_dmp_info + a device synchronisation had both declared finished): the join of the helper streams into the caller's stream
+// by events is what the schedule relies on, this is the belt to those braces - a query is a host synchronisation point anyway.
+static inline int cap_drain_streams(std::initializer_list<hipStream_t> streams) {
+  for (hipStream_t s : streams)
+    if (s && hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return CAP_ERR_HIP; }
+  return CAP_OK;
+}
 
 static inline int64_t cap_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t cap_round_up(int64_t a, int64_t b) { return cap_ceil_div(a, b) * b; }

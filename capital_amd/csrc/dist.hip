@@ -61,6 +61,7 @@ struct cap_dist_plan {
   int64_t occ1_m;                // bulk updates with rows x local columns <= occ1_m^2 run one workgroup per CU (cholinv.hip, occ1_m)
   // stress testing: random spin kernels in front of every launch group (exposes missing event edges)
   uint64_t jitter_state; int jitter_max_us;
+  int remote_chain_us;           // replay aid: a foreign owner's message arrives this long after my panel stream reached the block row (0: off)
   // live profile of the bulk update (HIP events on its stream)
   int profile; std::vector<hipEvent_t> prof_ev; std::vector<double> prof_flops; int prof_used;
   // profile mode also brackets the other launch groups: busy ms per stream role (cap_dist_profile_streams)
@@ -433,8 +434,11 @@ int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* 
   for (int i = 0; i < 4; i++) d->msg[i] = nullptr;
   d->s_panel = d->s_comm = d->s_msg = nullptr;
   d->strip = d->nblk >= 8 ? 2 : 1; d->depth2 = 1;
-  d->jitter_state = 0x9E3779B97F4A7C15ull * (uint64_t)(d->p + 1); d->jitter_max_us = 0;
-  d->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
+  d->jitter_state = 0x9E3779B97F4A7C15ull * (uint64_t)(d->p + 1); d->jitter_max_us = 0; d->remote_chain_us = 0;
+  // one bulk workgroup per CU while rows x local columns <= occ1_m^2.  On P ranks a rank waits for EVERY diagonal-block chain (its own and, through
+  // the broadcasts, the peers') while its bulk work per strip is 1 / P of the single-GPU plan's: the threshold grows with P (single-GPU replay of
+  // one rank at N = 65536, tools/replay.py: P = 8 slowest rank 286 -> 258 ms, P = 4 445 -> 418, P = 2 755 -> 752; always-on LOSES at P = 2: 771)
+  d->occ1_m = 16384 * (int64_t)(d->P > 1 ? d->P : 1);
   d->profile = 0; d->prof_used = 0; d->bk_used = 0; d->safe = 0;
   d->cnt_gemm = d->cnt_chain = d->cnt_copy = d->cnt_coll = 0;
   d->complete_inv = -1; d->split = 1; d->root_n1 = 0; d->Dall = d->Ri = nullptr; d->Cb[0] = d->Cb[1] = nullptr; d->comm3 = nullptr;
@@ -464,6 +468,8 @@ int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* 
   if (e == hipSuccess) e = hipMalloc((void**)&d->info_dev, sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&d->info_red, sizeof(double) * (d->P + 1));
   if (e != hipSuccess) { cap_dist_plan_destroy(d); return CAP_ERR_ALLOC; }
+  // helper streams and events exist from here on (round 6: never created inside the first factor call)
+  { const int st = ensure_events(d); if (st != CAP_OK) { cap_dist_plan_destroy(d); return st; } }
   *plan = d;
   return CAP_OK;
 }
@@ -508,6 +514,7 @@ int cap_dist_set_option(cap_dist_plan* d, const char* key, int64_t value) {
   if (k == "depth2") { d->depth2 = value != 0; return CAP_OK; }
   if (k == "occ1_m") { if (value < 0) return CAP_ERR_ARG; d->occ1_m = value; return CAP_OK; }
   if (k == "jitter_us") { if (value < 0 || value > 100000) return CAP_ERR_ARG; d->jitter_max_us = (int)value; return CAP_OK; }
+  if (k == "remote_chain_us") { if (value < 0 || value > 1000000) return CAP_ERR_ARG; d->remote_chain_us = (int)value; return CAP_OK; }
   if (k == "jitter_seed") { d->jitter_state = 0x9E3779B97F4A7C15ull * (uint64_t)(value + 1) + (uint64_t)d->p; return CAP_OK; }
   if (k == "profile") { d->profile = value != 0; return CAP_OK; }
   if (k == "safe") { d->safe = value != 0; return CAP_OK; }
@@ -533,6 +540,7 @@ int64_t cap_dist_get_option(const cap_dist_plan* d, const char* key) {
   if (k == "depth2") return d->depth2;
   if (k == "occ1_m") return d->occ1_m;
   if (k == "jitter_us") return d->jitter_max_us;
+  if (k == "remote_chain_us") return d->remote_chain_us;
   if (k == "safe") return d->safe;
   if (k == "ipc") return d->ipc;
   if (k == "count_gemm") return d->cnt_gemm;
@@ -644,8 +652,16 @@ int cap_dist_factor(cap_dist_plan* d, const double* Aloc, int64_t lda, void* str
         if (r == 1) { CAP_TRY(cap_copy_rect(S + (k / P - lbS) * nb * ldS, ldS, mb, nb, nb, nb, s1)); d->cnt_copy++; }   // R(a,b) rides along
         CAP_HIP(hipEventRecord(d->ev_fact[k], s1));
         CAP_HIP(hipStreamWaitEvent(sm, d->ev_fact[k], 0));
-      } else if (k >= 4) {
-        CAP_HIP(hipStreamWaitEvent(sm, d->ev_rowdone[k - 4], 0));   // the broadcast overwrites the buffer block row k-4 read
+      } else {
+        if (k >= 4) CAP_HIP(hipStreamWaitEvent(sm, d->ev_rowdone[k - 4], 0));   // the broadcast overwrites the buffer block row k-4 read
+        if (d->remote_chain_us > 0) {
+          // single-GPU replay of one rank (tools/replay.py): the owner's diagonal-block chain is not run here, so the message would
+          // arrive the moment it is asked for.  Model: the owner reaches this point when I do (symmetric ranks) and then needs
+          // remote_chain_us for its chain - a spin kernel on the message stream behind my own panel stream's position
+          CAP_HIP(hipEventRecord(d->ev_fact[k], s1));
+          CAP_HIP(hipStreamWaitEvent(sm, d->ev_fact[k], 0));
+          cap_acc_none(); hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, sm, d->remote_chain_us); CAP_HIP(hipGetLastError());
+        }
       }
       // ---- msg: msg(k) = [ R(k-1,k) | Dinv(k) ] from the owner, on the small-message communicator
       CAP_TRY(jitter(d, sm));
@@ -782,6 +798,8 @@ double* cap_dist_Rinv_ptr(cap_dist_plan* d, int64_t* ld) { if (!d || !d->Ri) ret
 int cap_dist_info(cap_dist_plan* d, void* stream, int64_t* info) {
   if (!d || !info) return CAP_ERR_ARG;
   hipStream_t s = cap_stream(stream);
+  CAP_TRY(cap_drain_streams({d->s_panel, d->s_comm, d->s_msg, d->s_inv}));
+  for (int r = 0; r < 8; r++) CAP_TRY(cap_drain_streams({d->s_peer[r]}));
   double* mine = d->info_red + d->P;
   cap_acc_r(d->info_dev, 1, 1, 1, 0, 4); cap_acc_w(mine, 1, 1, 1);
   hipLaunchKernelGGL(info_to_double, dim3(1), dim3(1), 0, s, d->info_dev, mine);
@@ -805,6 +823,19 @@ int cap_dist_profile(cap_dist_plan* d, int64_t* launches, double* ms_total, doub
     float ms = 0;
     CAP_HIP(hipEventElapsedTime(&ms, d->prof_ev[i], d->prof_ev[i + 1]));
     *ms_total += ms; *flops_total += d->prof_flops[i / 2]; (*launches)++;
+  }
+  return CAP_OK;
+}
+
+// the same per launch: up to `cap` entries of (ms, flops) in launch order; returns the number of launches through *count
+int cap_dist_profile_launches(cap_dist_plan* d, double* ms_out, double* flops_out, int64_t cap, int64_t* count) {
+  if (!d || !count || (cap > 0 && (!ms_out || !flops_out))) return CAP_ERR_ARG;
+  *count = d->prof_used / 2;
+  for (int i = 0; i + 1 < d->prof_used && i / 2 < cap; i += 2) {
+    CAP_HIP(hipEventSynchronize(d->prof_ev[(size_t)i + 1]));
+    float ms = 0;
+    CAP_HIP(hipEventElapsedTime(&ms, d->prof_ev[(size_t)i], d->prof_ev[(size_t)i + 1]));
+    ms_out[i / 2] = ms; flops_out[i / 2] = d->prof_flops[(size_t)i / 2];
   }
   return CAP_OK;
 }

@@ -367,7 +367,7 @@ int cap_dist2d_plan_create(cap_dist2d_plan** plan, int64_t n, int64_t nb, cap_co
   for (int i = 0; i < 4; i++) d->msg[i] = nullptr;
   d->Ri = d->Dall = nullptr;
   d->s_panel = d->s_comm = d->s_msg = d->s_inv = nullptr;
-  d->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
+  d->occ1_m = 16384 * (int64_t)(P > 1 ? P : 1);        // grows with the rank count like the 1 x P plan's (dist.hip: measured by the single-GPU replay)
   d->strip = d->nblk >= 8 ? 2 : 1; d->depth2 = 1; d->safe = 0; d->complete_inv = -1; d->split = 1;
   d->ipc = 0; d->ipc_ready = d->ipc_failed = false; d->tok = nullptr; d->ev_px = nullptr;
   for (int r = 0; r < 4; r++) { d->peerBt[r][0] = d->peerBt[r][1] = nullptr; d->s_pcol[r] = nullptr; d->ev_pcol[r] = nullptr; }
@@ -421,6 +421,8 @@ int cap_dist2d_plan_create(cap_dist2d_plan** plan, int64_t n, int64_t nb, cap_co
   if (e == hipSuccess) e = hipMalloc((void**)&d->tok, sizeof(double) * tok_elems);
   if (e == hipSuccess) e = hipMemset(d->tok, 0, sizeof(double) * tok_elems);
   if (e != hipSuccess) { cap_dist2d_plan_destroy(d); return CAP_ERR_ALLOC; }
+  // helper streams and events exist from here on (round 6: never created inside the first factor call)
+  { const int st = ensure_events2(d); if (st != CAP_OK) { cap_dist2d_plan_destroy(d); return st; } }
   *plan = d;
   return CAP_OK;
 }
@@ -715,6 +717,7 @@ int cap_dist2d_get_R(cap_dist2d_plan* d, double* out, int64_t ldo, void* stream)
 int cap_dist2d_info(cap_dist2d_plan* d, void* stream, int64_t* info) {
   if (!d || !info) return CAP_ERR_ARG;
   hipStream_t s = cap_stream(stream);
+  CAP_TRY(cap_drain_streams({d->s_panel, d->s_comm, d->s_msg, d->s_inv}));
   double* mine = d->info_red + d->P;
   cap_acc_r(d->info_dev, 1, 1, 1, 0, 4); cap_acc_w(mine, 1, 1, 1);
   hipLaunchKernelGGL(info_to_double2, dim3(1), dim3(1), 0, s, d->info_dev, mine);

@@ -104,8 +104,7 @@ int ensure_events3(cap_dmp_plan* d) {
   // while the plan's streams were still in their first step (tests/dist_worker.py, profiles/r05_flake_forensics.txt) - the
   // hardware queue behind a stream is created lazily with its first command.  Private streams with one 8-byte memset each: nothing
   // another rank could be waiting for.
-  static const bool prime = getenv("CAP_DMP_PRIME") ? atoi(getenv("CAP_DMP_PRIME")) != 0 : true;     // (0: the A/B runs of tools/r05_late_read.py)
-  if (prime) {
+  {
     CAP_HIP(hipMemsetAsync(d->info_red, 0, sizeof(double), d->s_panel));
     CAP_HIP(hipStreamSynchronize(d->s_panel));
     CAP_HIP(hipMemsetAsync(d->info_red, 0, sizeof(double), d->s_comm));
@@ -155,6 +154,8 @@ int cap_dmp_plan_create(cap_dmp_plan** plan, int64_t n, int64_t nb, int64_t nrhs
   d->T64 = d->D64 + nb * nb; d->S64 = d->T64 + nb * cols; d->W = d->S64 + nb * cols;
   d->Rw = d->V + npad * w; d->Bw = d->Rw + npad * w; d->Acc = d->Bw + npad * w; d->Tmp = d->Acc + npad * w;
   d->Q = d->Tmp + 2 * nb * w; d->norms = d->Q + std::max<int64_t>(cols, 128) * w;
+  // helper streams and events exist from here on (round 6: never created inside the first factor call)
+  { const int st = ensure_events3(d); if (st != CAP_OK) { cap_dmp_plan_destroy(d); return st; } }
   *plan = d;
   return CAP_OK;
 }
@@ -280,6 +281,7 @@ int cap_dmp_factor(cap_dmp_plan* d, const double* Aloc, int64_t lda, void* strea
 int cap_dmp_info(cap_dmp_plan* d, void* stream, int64_t* info) {
   if (!d || !info) return CAP_ERR_ARG;
   hipStream_t s = cap_stream(stream);
+  CAP_TRY(cap_drain_streams({d->s_panel, d->s_comm}));
   double* mine = d->info_red + d->P;
   cap_acc_r(d->info_dev, 1, 1, 1, 0, 4); cap_acc_w(mine, 1, 1, 1);
   hipLaunchKernelGGL(info_to_double3, dim3(1), dim3(1), 0, s, d->info_dev, mine);

@@ -838,13 +838,14 @@ double* cap_scratch(int64_t elems, hipStream_t stream) {
 
 // the stream is about to be destroyed (cap_stream_destroy, common.h): its split-K scratch goes back to the pool, ordered behind its work
 void cap_scratch_release(hipStream_t stream) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return;
+  // found by the stream HANDLE alone: a plan may be destroyed while another device is current (the (device, stream) lookup leaked it then)
   std::lock_guard<std::mutex> lock(g_scratch_mu);
-  auto it = g_scratch.find(std::make_pair(dev, stream));
-  if (it == g_scratch.end()) return;
-  if (it->second.p) (void)hipFreeAsync(it->second.p, stream);
-  g_scratch.erase(it);
+  for (auto it = g_scratch.begin(); it != g_scratch.end(); ++it)
+    if (it->first.second == stream) {
+      if (it->second.p) (void)hipFreeAsync(it->second.p, stream);
+      g_scratch.erase(it);
+      return;
+    }
 }
 
 int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
@@ -989,7 +990,9 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   g.M = m; g.N = nloc; g.K = k; g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.etri = 0;
   g.tm = (int)(m / BM); g.tn = (int)(nloc / BN);
   g.st = ST; g.stm = ST; g.stn = ST; g.sorder = 0;
-  g.nsm = (int)cap_ceil_div(g.tm, ST); g.nsn = (int)cap_ceil_div(g.tn, ST);
+  // block-column-shaped supertiles where the staircase is steep (1 x P with P >= 4: P row tiles per local column tile), see stair_cnt
+  if (Pr == 1 && P >= 4 && nb / 128 >= 2 && nb / 128 <= 8 && (ST * ST) % (nb / 128) == 0) { g.stn = nb / 128; g.stm = ST * ST / g.stn; }
+  g.nsm = (int)cap_ceil_div(g.tm, g.stm); g.nsn = (int)cap_ceil_div(g.tn, g.stn);
   g.ksplit = 1; g.kchunk = k; g.P = nullptr; g.slab = 0;
   g.hiprio = 0; g.ctr = nullptr; g.bupper = 0; g.aupt = 0; g.aupn = 0;
   {
@@ -1003,9 +1006,9 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   // only supertiles under the staircase are enumerated, so the 8 XCD ranges carry equal work
   g.etri = 3;
   int64_t nsuper = 0;
-  for (int sj = 0; sj < g.nsn; sj++) nsuper += stair_cnt(sj, ST, g.tn, g.nsm, p, P, lb0, nb / 128, J0, Pr, pr, rlb0);
+  for (int sj = 0; sj < g.nsn; sj++) nsuper += stair_cnt(sj, g.stm, g.stn, g.tn, g.nsm, p, P, lb0, nb / 128, J0, Pr, pr, rlb0);
   if (nsuper == 0) return CAP_OK;      // Pr > 1: every local row block may lie below every local column block (nothing to update)
-  int64_t slots = nsuper * ST * ST;
+  int64_t slots = nsuper * g.stm * g.stn;
   g.chunk = (int)cap_ceil_div(slots, 8);
   if (cap_acc_on()) {
     // access notes: per local column block J the row blocks I < J whole and I == J above the diagonal; the A operand's column chunk

@@ -46,25 +46,27 @@ CAP_HD int stair_rows_le(int X, int snbT, int sJ0, int rP, int rp, int rlb0) {
   if (Xb >= rp && (Xb - rp) % rP == 0 && (Xb - rp) / rP >= rlb0) cnt += Xo + 1;     // the block of X itself is local
   return cnt;
 }
-CAP_HD int stair_cnt(int sj, int st, int tn, int nsm, int sp, int sP, int slb0, int snbT, int sJ0,
+// (supertiles of stm x stn tiles: on a 1 x P layout the staircase climbs P row tiles per local column tile, so a supertile ONE block
+//  column wide and 64 / snbT tiles tall leaves one partial supertile per block column where a square one leaves ~ P of them - the XCDs'
+//  contiguous slot ranges then carry equal work)
+CAP_HD int stair_cnt(int sj, int stm, int stn, int tn, int nsm, int sp, int sP, int slb0, int snbT, int sJ0,
                                                   int rP, int rp, int rlb0) {
-  int tjm = sj * st + st - 1;
+  int tjm = sj * stn + stn - 1;
   if (tjm > tn - 1) tjm = tn - 1;
   const int rows = stair_rows_le(stair_gtj_hd(sp, sP, slb0, snbT, sJ0, tjm), snbT, sJ0, rP, rp, rlb0);
-  const int c = (rows + st - 1) / st;
+  const int c = (rows + stm - 1) / stm;
   return c < nsm ? c : nsm;
 }
 
 // logical slot -> tile coordinates (returns false when the slot is empty)
 CAP_HD bool slot_to_tile(const GemmArgs& g, int L, int& ti, int& tj) {
-  const int ST = g.st;
   const int STM = g.stm, STN = g.stn;
   int S = L / (STM * STN), w = L % (STM * STN);
   int si, sj;
   if (g.etri == 3) {  // staircase: walk the supertile columns, only supertiles that hold valid tiles are numbered
     sj = 0;
     for (; sj < g.nsn; sj++) {
-      const int c = stair_cnt(sj, ST, g.tn, g.nsm, g.sp, g.sP, g.slb0, g.snbT, g.sJ0, g.rP, g.rp, g.rlb0);
+      const int c = stair_cnt(sj, STM, STN, g.tn, g.nsm, g.sp, g.sP, g.slb0, g.snbT, g.sJ0, g.rP, g.rp, g.rlb0);
       if (S < c) break;
       S -= c;
     }

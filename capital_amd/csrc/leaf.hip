@@ -573,9 +573,11 @@ __device__ __forceinline__ bool chain_wait(int* ctr, int target, int fence, int*
   if (threadIdx.x == 0) {
     int polls = 0;
     bool ok = true;
+    // the recovery launch (gave_up == 3) is the last resort - a slow, time-sliced device must not end in info = -64: it waits 8 x longer
+    const int limit = gave_up == 3 ? (CHAIN_POLLS << 3) : CHAIN_POLLS;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
-      if (++polls >= CHAIN_POLLS || ((polls & 63) == 0 && __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gave_up)) { ok = false; break; }
+      if (++polls >= limit || ((polls & 63) == 0 && __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gave_up)) { ok = false; break; }
     }
     if (fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     *lds_flag = ok;

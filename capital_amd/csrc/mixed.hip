@@ -1078,6 +1078,7 @@ float* cap_mpchol_R32_ptr(cap_mpchol_plan* p, int64_t* ld) { if (!p) return null
 
 int cap_mpchol_info(cap_mpchol_plan* p, void* stream, int64_t* info) {
   if (!p || !info) return CAP_ERR_ARG;
+  CAP_TRY(cap_drain_streams({p->s_panel, p->s_far, p->s_bulk, p->s_chain}));
   int h = 0;
   CAP_HIP(hipMemcpyAsync(&h, p->info_dev, sizeof(int), hipMemcpyDeviceToHost, cap_stream(stream)));
   CAP_HIP(hipStreamSynchronize(cap_stream(stream)));

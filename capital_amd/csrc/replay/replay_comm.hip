@@ -1,0 +1,135 @@
+// Replay communicator (measurement harness, NOT part of libcapital_amd.so): lets ONE GPU run the real schedule of rank `rank` of a
+// P-rank 1 x P Cholesky plan (csrc/dist.hip, safe mode: one communicator, collectives in program order) at full speed.  The peers'
+// contributions are not computed but COPIED out of a finished factor R of the same matrix (single-GPU plan), through the callback
+// constructor of the product's communicator (cap_comm_create_callbacks, include/capital_amd.h):
+//   broadcast k   (msg(k) = [ R(k-1,k) | Dinv(k) ], 2 nb^2 doubles, root = k % P)  foreign root: the two blocks are copied from R / the
+//                 table of diagonal-block inverses, behind a spin of  lat_us + bytes / link_GBps
+//   all-gather t  (the solved strip right of itself, q nb x cols per rank)          every peer's piece is gathered from R's rows of the
+//                 strip, behind ONE spin of  lat_us + piece bytes / link_GBps (xGMI is point-to-point: each peer's piece has a link
+//                 of its own); my own piece is the one I computed
+//   all-reduce    not used by safe mode without the IPC exchange: identity
+// What the replay measures is rank `rank`'s OWN timeline - its kernels at full speed, what its streams wait for - with peers that
+// are never late beyond the link model and the owner's chain model (dist.hip option remote_chain_us).  It is a projection of the
+// P-GPU run from one GPU, not a measurement of it: RCCL's kernels, their CU share and real arrival skew are absent.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <new>
+
+#include "../../../include/capital_amd.h"
+
+namespace {
+struct ReplayCtx {
+  int rank, size;
+  const double* R; int64_t ldr, n, nb, nblk; int strip;
+  const double* Dinv;                         // nblk blocks of nb x nb (ld nb): inverses of R's diagonal blocks
+  double link_GBps, lat_us;
+  int64_t nbcast, ngather;                    // position in the factor call's sequence
+  int64_t bytes_in; double model_us; int64_t calls;   // totals since the last reset (what the link model charged)
+};
+
+inline int64_t lbfirst(int64_t r, int64_t k, int64_t P) { return k >= r ? (k - r) / P + 1 : 0; }
+inline int64_t nblocks_of(int64_t r, int64_t nblk, int64_t P) { return r < nblk ? (nblk - 1 - r) / P + 1 : 0; }
+
+__global__ void replay_spin_kernel(int us) {
+  const uint64_t t0 = wall_clock64();
+  while (wall_clock64() - t0 < (uint64_t)us * 100ull) __builtin_amdgcn_s_sleep(32);
+}
+// dst (ld ldd) = src (ld lds): rows x cols, 2 doubles per lane
+__global__ void replay_copy_kernel(const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows, int64_t cols) {
+  const int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 2, c = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (r >= rows || c >= cols) return;
+  if (r + 1 < rows) *reinterpret_cast<double2*>(dst + r + c * ldd) = *reinterpret_cast<const double2*>(src + r + c * lds_);
+  else dst[r + c * ldd] = src[r + c * lds_];
+}
+// one peer's piece of a strip exchange: local blocks lb0 .. lb0 + nbl - 1 of rank r (global block lb P + r), rows [row0, row0 + ldS)
+__global__ void replay_gather_kernel(const double* R, int64_t ldr, double* piece, int64_t ldS, int64_t row0, int64_t nb, int P, int r, int64_t lb0) {
+  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 2, c = blockIdx.y, lb = blockIdx.z;
+  if (i >= ldS) return;
+  const int64_t gcol = ((lb0 + lb) * P + r) * nb + c;
+  *reinterpret_cast<double2*>(piece + i + (lb * nb + c) * ldS) = *reinterpret_cast<const double2*>(R + row0 + i + gcol * ldr);
+}
+__global__ void replay_fill1_kernel(double* recv, const double* send, int P) { if ((int)threadIdx.x < P) recv[threadIdx.x] = send[0]; }
+
+int spin(ReplayCtx* c, double bytes, hipStream_t s) {
+  const double us = c->lat_us + (c->link_GBps > 0 ? bytes / (c->link_GBps * 1e3) : 0.0);
+  c->model_us += us; c->calls++;
+  if (us >= 1.0) hipLaunchKernelGGL(replay_spin_kernel, dim3(1), dim3(64), 0, s, (int)(us + 0.5));
+  return 0;
+}
+
+int cb_bcast(void* ctx, double* buf, int64_t count, int root, void* stream) {
+  ReplayCtx* c = (ReplayCtx*)ctx;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nb2 = c->nb * c->nb;
+  if (count != 2 * nb2) { fprintf(stderr, "replay: unexpected broadcast of %lld doubles\n", (long long)count); return 1; }
+  const int64_t k = c->nbcast++;
+  if (k >= c->nblk || root != (int)(k % c->size)) { fprintf(stderr, "replay: broadcast %lld out of sequence (root %d)\n", (long long)k, root); return 1; }
+  if (root != c->rank) {
+    spin(c, (double)count * 8.0, s);
+    c->bytes_in += count * 8;
+    const dim3 grid((unsigned)((c->nb / 2 + 255) / 256), (unsigned)c->nb);
+    if (c->strip == 2 && (k & 1) && k >= 1)      // second block row of a strip: R(a, b) rides along
+      hipLaunchKernelGGL(replay_copy_kernel, grid, dim3(256), 0, s, c->R + (k - 1) * c->nb + k * c->nb * c->ldr, c->ldr, buf, c->nb, c->nb, c->nb);
+    hipLaunchKernelGGL(replay_copy_kernel, grid, dim3(256), 0, s, c->Dinv + k * nb2, c->nb, buf + nb2, c->nb, c->nb, c->nb);
+  }
+  if (c->nbcast == c->nblk) { c->nbcast = 0; c->ngather = 0; }      // the factor call is complete: the next one starts over
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int cb_allgather(void* ctx, const double* send, double* recv, int64_t cpr, void* stream) {
+  ReplayCtx* c = (ReplayCtx*)ctx;
+  hipStream_t s = (hipStream_t)stream;
+  const int P = c->size;
+  if (cpr == 1) {                                // cap_dist_info: every peer reports what I report
+    hipLaunchKernelGGL(replay_fill1_kernel, dim3(1), dim3(64), 0, s, recv, send, P);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+  }
+  const int64_t t = c->ngather++;
+  const int64_t a = t * c->strip, q = c->strip < c->nblk - a ? c->strip : c->nblk - a, b = a + q - 1, ldS = q * c->nb;
+  int64_t nmax = 0;
+  for (int r = 0; r < P; r++) { const int64_t w = (nblocks_of(r, c->nblk, P) - lbfirst(r, b, P)) * c->nb; if (w > nmax) nmax = w; }
+  if (a >= c->nblk || cpr != ldS * nmax) { fprintf(stderr, "replay: all-gather %lld out of sequence (%lld doubles per rank, expected %lld)\n", (long long)t, (long long)cpr, (long long)(ldS * nmax)); return 1; }
+  spin(c, (double)cpr * 8.0, s);                 // every peer's piece on its own link, all at once
+  for (int r = 0; r < P; r++) {
+    if (r == c->rank) continue;
+    const int64_t lb0 = lbfirst(r, b, P), nbl = nblocks_of(r, c->nblk, P) - lb0;
+    if (nbl <= 0) continue;
+    c->bytes_in += nbl * c->nb * ldS * 8;
+    hipLaunchKernelGGL(replay_gather_kernel, dim3((unsigned)((ldS / 2 + 255) / 256), (unsigned)c->nb, (unsigned)nbl), dim3(256), 0, s, c->R, c->ldr,
+                       recv + (int64_t)r * cpr, ldS, a * c->nb, c->nb, P, r, lb0);
+  }
+  if (send != recv + (int64_t)c->rank * cpr) (void)hipMemcpyAsync(recv + (int64_t)c->rank * cpr, send, sizeof(double) * cpr, hipMemcpyDeviceToDevice, s);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int cb_allreduce(void*, double*, int64_t, void*) { return 0; }
+}  // namespace
+
+extern "C" {
+// R: the finished n x n factor (column-major, ld ldr, n % nb == 0); Dinv: nblk blocks nb x nb, the inverses of R's diagonal blocks (upper).
+// strip = the plan's block rows per strip (cap_dist_get_option "strip").  *ctx_out is owned by the caller (cap_replay_destroy).
+int cap_replay_create(cap_comm** comm, void** ctx_out, int rank, int size, const double* R, int64_t ldr, int64_t n, int64_t nb, int strip,
+                      const double* Dinv, double link_GBps, double lat_us) {
+  if (!comm || !ctx_out || !R || !Dinv || size < 1 || size > 8 || rank < 0 || rank >= size || n <= 0 || nb <= 0 || n % nb || (strip != 1 && strip != 2)) return CAP_ERR_ARG;
+  ReplayCtx* c = new (std::nothrow) ReplayCtx();
+  if (!c) return CAP_ERR_ALLOC;
+  c->rank = rank; c->size = size; c->R = R; c->ldr = ldr; c->n = n; c->nb = nb; c->nblk = n / nb; c->strip = strip; c->Dinv = Dinv;
+  c->link_GBps = link_GBps; c->lat_us = lat_us; c->nbcast = c->ngather = 0; c->bytes_in = 0; c->model_us = 0; c->calls = 0;
+  const int st = cap_comm_create_callbacks(comm, rank, size, cb_allgather, cb_bcast, cb_allreduce, c);
+  if (st != CAP_OK) { delete c; return st; }
+  *ctx_out = c;
+  return CAP_OK;
+}
+// out3 = bytes the peers "sent" since the last reset, microseconds the link model charged, collectives it charged; resets the totals
+int cap_replay_stats(void* ctx, double* out3) {
+  ReplayCtx* c = (ReplayCtx*)ctx;
+  if (!c || !out3) return CAP_ERR_ARG;
+  out3[0] = (double)c->bytes_in; out3[1] = c->model_us; out3[2] = (double)c->calls;
+  c->bytes_in = 0; c->model_us = 0; c->calls = 0;
+  return CAP_OK;
+}
+int cap_replay_set_strip(void* ctx, int strip) { ReplayCtx* c = (ReplayCtx*)ctx; if (!c || (strip != 1 && strip != 2)) return CAP_ERR_ARG; c->strip = strip; c->nbcast = c->ngather = 0; return CAP_OK; }
+void cap_replay_destroy(void* ctx) { delete (ReplayCtx*)ctx; }
+}

@@ -398,6 +398,8 @@ int cap_dist_profile(cap_dist_plan* plan, int64_t* launches, double* ms_total, d
 /* profile mode, per stream role: out6 = busy ms of the diagonal-block chains, block-row solves, HEAD updates (panel stream),
  * message broadcasts, strip exchanges (communication streams) and bulk updates (caller's stream) of the LAST factor call. */
 int cap_dist_profile_streams(cap_dist_plan* plan, double* out6);
+/* the bulk updates of the LAST factor call in profile mode, one by one: up to cap entries of (ms, algorithmic flops); *count = launches */
+int cap_dist_profile_launches(cap_dist_plan* plan, double* ms_out, double* flops_out, int64_t cap, int64_t* count);
 /* profile mode, complete_inv >= 0: out3 = busy ms of the streamed inverse's launch groups, ms of it left after the sweep's join
  * (what the overlap did not hide), ms of the whole factor call.                                                          */
 int cap_dist_profile_inverse(cap_dist_plan* plan, double* out3);
