@@ -1004,7 +1004,10 @@ def bench_summa(args, torch, L, C, rank, world, timed):
                 ref = A.view()[:, r0:r0 + 256].t() @ A.view()[:, c0:c0 + 256]
             err = float((Cv - ref).norm() / ref.norm())
             ok = ok and err == err and err <= 1e-13
-        forms.append({"form": name, "M": M, "N": N, "K": K, "value": tf, "unit": "TFLOP/s", "ms_per_step": sec * 1e3, "steps": steps, "probe_rel_err": err,
+        extra_f = {} if kind == "gemm" else {"executed_tflops": 2.0 * N * N * K / sec / 1e12,
+                                             "note": "like upstream's SYRK overload (summa.hpp:98-161) the carrier forms the full product A^T A: 2 n^2 k flops are executed, "
+                                                     "n (n + 1) k are counted in `value`"}
+        forms.append({"form": name, "M": M, "N": N, "K": K, "value": tf, **extra_f, "unit": "TFLOP/s", "ms_per_step": sec * 1e3, "steps": steps, "probe_rel_err": err,
                       "roofline": {"bound": "mfma", "kernel": "dgemm_tn_dma_kernel (%s)" % ("A_MC: M-contiguous A" if kind == "gemm" else "K-contiguous operands, upper tiles"),
                                    "achieved": tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TF, "traffic": None,
                                    "algorithmic_flops_per_step": flops}})

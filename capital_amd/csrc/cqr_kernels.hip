@@ -141,13 +141,6 @@ __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {
   const int nmine = g.contig ? max(0, min(per, g.ntiles - t0)) : (b < g.ntiles ? (g.ntiles - 1 - b) / G + 1 : 0);
   const int U = nmine * 16;                                    // pipeline steps: (my row tile, K tile)
   if (U == 0) return;
-  // A row tile's 16 K steps carry equal memory traffic (16 KiB in, 16 KiB out) but MFMA work that falls from 16 block columns to 1: workgroups
-  // that start together move through "MFMA-bound" and "HBM-bound" steps together and the two times ADD.  Started (b % 16) sixteenths of a
-  // row tile apart - and every row tile takes the same time, so they stay apart - the chip sees the average demand of both at every moment.
-  if (g.stagger > 0) {
-    const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)(b & 15) * (unsigned)g.stagger;
-    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-  }
   // column wave wn owns the block columns wn, wn + 4, wn + 8, wn + 12 (cyclic: at K tile kt only block columns >= kt are
   // non-zero in an upper-triangular Rinv, so every wave loses work at the same pace); waves w and w + 4 share a SIMD:
   // pairing column waves (0, 3) and (1, 2) there evens out the remaining +-1 block
@@ -276,6 +269,9 @@ __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {
 #undef CQR_STORE_COL
 }
 
+// (Round 6: starting the workgroups (b % 16) sixteenths of a row tile apart - so that the chip sees the AVERAGE of the MFMA-heavy early and the
+// HBM-heavy late K steps of a row tile instead of all workgroups moving through them together - changes nothing: 2.96 ms with any stagger between
+// 0 and 6 us per sixteenth, 3.0 - 3.05 ms beyond; profiles/r06_experiments.md.)
 // (A variant that handled the K tiles (s, 15 - s) of a row tile in one step - 17 block columns of work in every step, half the barriers -
 // was built and measured in round 4: 4 % SLOWER on the whole CholeskyQR2 call, its hand-over sits at the top of a step where this kernel
 // hides it between the two k-halves of a tile; profiles/r04_experiments.log section 5.  Removed in round 5.)
@@ -311,8 +307,7 @@ int cap_qrapply256_launch(const double* Qin, int64_t ldin, const double* Ri, dou
   CAP_HIP(hipGetDevice(&dev));
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   static const int contig = getenv("CAP_CQR_CONTIG") ? atoi(getenv("CAP_CQR_CONTIG")) : 1;
-  static const int stagger = getenv("CAP_CQR_STAGGER") ? atoi(getenv("CAP_CQR_STAGGER")) : 0;
-  ApplyArgs g{Qin, ldin, Ri, Qout, ldout, (int)(m / 128), contig, stagger};
+  ApplyArgs g{Qin, ldin, Ri, Qout, ldout, (int)(m / 128), contig};
   const int grid = (int)std::min<int64_t>(cus, g.ntiles);
   // CAP_CQR_DIAG is timing surgery only (1 = no stores, 2 = no MFMA: results are wrong); CAP_CQR_PIPE picks the loop form
   static const int pipe = getenv("CAP_CQR_PIPE") ? atoi(getenv("CAP_CQR_PIPE")) : 1;

@@ -121,7 +121,6 @@ struct Bf2Args {
 struct GramArgs { const double* Q; int64_t ld, m, chunk; double* P; };
 
 // ---- cqr_kernels.hip
-struct ApplyArgs { const double* Qin; int64_t ldin; const double* Ri; double* Qout; int64_t ldout; int ntiles; int contig;
-                   int stagger; };   // stagger: workgroup b starts (b % 16) * stagger ticks of 10 ns late (0: all together)
+struct ApplyArgs { const double* Qin; int64_t ldin; const double* Ri; double* Qout; int64_t ldout; int ntiles; int contig; };
 
 }  // namespace
