@@ -58,7 +58,7 @@ int sweep(cap_cacqr_plan* p, const double* Qin, int64_t ldin, double* Qout, hipS
   const int64_t m = p->m, n = p->n;
   // Gram: upper triangle of Q^T Q (cacqr.hpp:15), full square zero-initialised so the all-reduce moves
   // a dense n x n block like NoSerialize::compute_gram (policy.h:22)
-  static const bool k256_env = getenv("CAP_CQR256") ? atoi(getenv("CAP_CQR256")) != 0 : true;
+  static const bool k256_env = CAP_ENV("CAP_CQR256") ? atoi(CAP_ENV("CAP_CQR256")) != 0 : true;
   const bool k256 = k256_env && p->gram_work && n == 256 && m % 128 == 0 && !(ldin & 1) && 128 * ldin * 8 < 0xfffffff0LL && !((uintptr_t)Qin & 15);
   {
     CapRange range("CQR::gram");                  // cacqr.hpp:83-101

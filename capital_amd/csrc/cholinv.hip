@@ -88,7 +88,7 @@ int rec_cholinv(const RecCtx& c, int64_t off, int64_t n, bool is_root, int64_t i
 // that was given its own value (option "chain_coop") installs it for the duration of ITS factor call on the calling host thread
 // (CapChainScope), and a caller that launches on a CU-masked stream bounds the count the same way (cap_chain_coop_cap) - both are
 // thread_local: two host threads / two plans never see each other's settings (they were process globals in round 4).
-const int g_coop_default = getenv("CAP_CHAIN_COOP") ? atoi(getenv("CAP_CHAIN_COOP")) : 32;
+const int g_coop_default = CAP_ENV("CAP_CHAIN_COOP") ? atoi(CAP_ENV("CAP_CHAIN_COOP")) : 32;
 thread_local int tl_coop_wgs = -1;        // -1: the process default
 thread_local int tl_coop_cap = 0;
 // Per (device, stream): four counter words (end-of-step meetings, exit count, mid-step meetings, state: 0 / 1 = a workgroup gave up
@@ -185,7 +185,7 @@ int blocked_cholinv(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, 
                     int64_t info_base, hipStream_t s) {
   const int nblk = (int)(n / 64);
   if (128 * n > wcap) return CAP_ERR_ALLOC;
-  static const bool fold = getenv("CAP_FOLD_LEAF") ? atoi(getenv("CAP_FOLD_LEAF")) != 0 : true;
+  static const bool fold = CAP_ENV("CAP_FOLD_LEAF") ? atoi(CAP_ENV("CAP_FOLD_LEAF")) != 0 : true;
   int coop = cap_chain_coop_get();
   if (tl_coop_cap > 0) coop = std::min(coop, tl_coop_cap);
   coop = std::min(coop, cap_chain64_coop_max_resident());      // never more workgroups than the device can hold at once
@@ -197,10 +197,10 @@ int blocked_cholinv(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, 
     if (nblk > COOP_MAX_NBLK) backup = nullptr;
     // release / acquire fences around the meeting counter: on by default since round 5 (the relaxed protocol relies on behaviour the
     // AMDGPU memory model does not promise; measured cost in profiles/r05_experiments.log), CAP_CHAIN_FENCE=0 for the A/B run
-    static const int fence = getenv("CAP_CHAIN_FENCE") ? atoi(getenv("CAP_CHAIN_FENCE")) : 1;
+    static const int fence = CAP_ENV("CAP_CHAIN_FENCE") ? atoi(CAP_ENV("CAP_CHAIN_FENCE")) : 1;
     long long* trace = nullptr;
     if (g_coop_trace && g_coop_trace_at-- == 0) trace = g_coop_trace;       // instrumentation of ONE launch (cap_chain_trace_arm)
-    static const int merge_env = getenv("CAP_CHAIN_MERGE") ? atoi(getenv("CAP_CHAIN_MERGE")) : 256;   // inverse levels done in the same launch
+    static const int merge_env = CAP_ENV("CAP_CHAIN_MERGE") ? atoi(CAP_ENV("CAP_CHAIN_MERGE")) : 256;   // inverse levels done in the same launch
     merged = std::min<int64_t>(merge_env, n / 2);
     CAP_TRY(cap_chain64_coop(R, ldr, Ri, ldi, nblk, info, (int)info_base, ctr, coop, fence, (int)merged, s, trace, backup, fallbacks));
   } else if (fold) {
@@ -232,7 +232,7 @@ int blocked_cholinv(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, 
     const int npairs = (int)(n / (2 * h));
     if (h <= merged) continue;
     if (h * h * npairs > wcap) return CAP_ERR_ALLOC;
-    static const bool merge1 = getenv("CAP_TRINV_MERGE") ? atoi(getenv("CAP_TRINV_MERGE")) != 0 : true;
+    static const bool merge1 = CAP_ENV("CAP_TRINV_MERGE") ? atoi(CAP_ENV("CAP_TRINV_MERGE")) != 0 : true;
     if (merge1 && h <= 256) {
       CAP_TRY(cap_trinv_merge(R, ldr, Ri, ldi, h, npairs, s));     // both products of the level in one launch (leaf.hip)
     } else if (h <= 256) {
@@ -1110,27 +1110,27 @@ int cap_cholinv_plan_create(cap_cholinv_plan** plan, int64_t n, int complete_inv
   // two-level blocking defaults (tools/sweep.sh on MI355X): K = 2 nb bulk updates while the trailing matrix is
   // large, nb-wide strips for the last n/8 columns where the strip chain could no longer hide
   p->outer = n >= 8192 ? 2 * p->nb : p->nb; p->tail = n >= 8192 ? n / 8 : 0;
-  p->reserve = getenv("CAP_RESERVE") ? atoll(getenv("CAP_RESERVE")) : 0;
-  p->reserve_m = getenv("CAP_RESERVE_M") ? atoll(getenv("CAP_RESERVE_M")) : 0; p->chain_masked = false;
-  p->srcA = nullptr; p->src_lda = 0; p->fuse_copy = getenv("CAP_FUSE_COPY") ? atoi(getenv("CAP_FUSE_COPY")) : 1;
+  p->reserve = CAP_ENV("CAP_RESERVE") ? atoll(CAP_ENV("CAP_RESERVE")) : 0;
+  p->reserve_m = CAP_ENV("CAP_RESERVE_M") ? atoll(CAP_ENV("CAP_RESERVE_M")) : 0; p->chain_masked = false;
+  p->srcA = nullptr; p->src_lda = 0; p->fuse_copy = CAP_ENV("CAP_FUSE_COPY") ? atoi(CAP_ENV("CAP_FUSE_COPY")) : 1;
   // fused 64-blocked diagonal-block path (11 dependent launches per 512 panel instead of 43; N = 8192 alone, first version:
   // 20.8 -> 15.5 ms).  Its workgroups use 84 KiB of LDS so that they fit into ONE slot vacated by a bulk
   // workgroup - a first 135 KiB version needed a fully idle CU and lost 4 % under a concurrent bulk update.
-  p->fastdiag = getenv("CAP_FASTDIAG") ? atoi(getenv("CAP_FASTDIAG")) : 1;
+  p->fastdiag = CAP_ENV("CAP_FASTDIAG") ? atoi(CAP_ENV("CAP_FASTDIAG")) : 1;
   p->serial_m = 0;
-  p->inner_la = getenv("CAP_INNER_LA") ? atoi(getenv("CAP_INNER_LA")) : 0;
+  p->inner_la = CAP_ENV("CAP_INNER_LA") ? atoi(CAP_ENV("CAP_INNER_LA")) : 0;
   // below ~16K remaining columns a step's chain (2 x 512 diagonal blocks, ~4 ms next to the bulk update) outlasts its bulk
   // update (m^2 x 1024 flops): from there on the bulk runs one workgroup per CU (N = 32768: 59.3 -> 61.2 TF, 16384: 34.4 -> 37.1)
-  p->occ1_m = getenv("CAP_OCC1_M") ? atoll(getenv("CAP_OCC1_M")) : 16384;
+  p->occ1_m = CAP_ENV("CAP_OCC1_M") ? atoll(CAP_ENV("CAP_OCC1_M")) : 16384;
   p->chain_coop = -1;
-  p->pair_rest = getenv("CAP_PAIR_REST") ? atoi(getenv("CAP_PAIR_REST")) : 1;
+  p->pair_rest = CAP_ENV("CAP_PAIR_REST") ? atoi(CAP_ENV("CAP_PAIR_REST")) : 1;
   p->cnt_paired = 0;
   p->depth2 = n >= 24576;     // look-ahead depth 2 pays once a bulk update is long enough to split (+2 % at N = 32768)
   // reference semantics (R and R^-1): blocked factorization + inverse tree; the tree starts once the sweep is chain-bound
-  p->use_sb = getenv("CAP_USE_SB") ? atoi(getenv("CAP_USE_SB")) : 1;
-  p->inv_fast = getenv("CAP_INV_FAST") ? atoi(getenv("CAP_INV_FAST")) : 1;
-  p->inv_overlap = getenv("CAP_INV_OVERLAP") ? atoi(getenv("CAP_INV_OVERLAP")) : 1;
-  p->inv_start_m = getenv("CAP_INV_START_M") ? atoll(getenv("CAP_INV_START_M")) : std::max<int64_t>(16384, n / 2);
+  p->use_sb = CAP_ENV("CAP_USE_SB") ? atoi(CAP_ENV("CAP_USE_SB")) : 1;
+  p->inv_fast = CAP_ENV("CAP_INV_FAST") ? atoi(CAP_ENV("CAP_INV_FAST")) : 1;
+  p->inv_overlap = CAP_ENV("CAP_INV_OVERLAP") ? atoi(CAP_ENV("CAP_INV_OVERLAP")) : 1;
+  p->inv_start_m = CAP_ENV("CAP_INV_START_M") ? atoll(CAP_ENV("CAP_INV_START_M")) : std::max<int64_t>(16384, n / 2);
   int st = plan_alloc(p);
   if (st != CAP_OK) { cap_cholinv_plan_destroy(p); return st; }
   *plan = p;
@@ -1640,7 +1640,7 @@ extern "C" int cap_chain_trace_read(int64_t* out) {
 // used by cacqr.hip: full cholinv (R in place, Ri = R^-1) of an n x n block on one stream
 int cap_rec_cholinv_full(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, double* W, int64_t wcap, int* info,
                          hipStream_t s, int64_t info_base) {
-  static const bool fast = getenv("CAP_FASTDIAG") ? atoi(getenv("CAP_FASTDIAG")) != 0 : true;   // see cap_cholinv_plan::fastdiag
+  static const bool fast = CAP_ENV("CAP_FASTDIAG") ? atoi(CAP_ENV("CAP_FASTDIAG")) != 0 : true;   // see cap_cholinv_plan::fastdiag
   if (fast && n % 64 == 0 && n >= 128 && n <= 1024 && (n & (n - 1)) == 0) return blocked_cholinv(R, ldr, Ri, ldi, n, W, wcap, info, info_base, s);
   RecCtx c{R, ldr, Ri, ldi, W, wcap, info, CAP_LEAF_MAX, 1, 1, s};
   return rec_cholinv(c, 0, n, false, info_base);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <initializer_list>
 
@@ -31,6 +32,15 @@ static inline hipStream_t cap_stream(void* s) { return (hipStream_t)s; }
 // Timing-surgery kernel variants (CAP_DIAG, CAP_CQR_DIAG: results are WRONG by construction) are only compiled into
 // experiment builds: set this to true, rebuild, measure, set it back.  Release libraries cannot be switched into them.
 constexpr bool CAP_EXPERIMENTS = false;
+// The A/B switches of the experiment logs (CAP_USE_SB, CAP_CHAIN_COOP, CAP_BF16_V2, ... - profiles/HISTORY.md lists them) are read from the
+// environment ONLY in experiment builds.  A release library ignores every CAP_* variable: a stray one in a caller's environment cannot change
+// the product's code path (round 5 review).  What a caller may choose is a per-plan option (cap_*_set_option).  The expression folds to a
+// null pointer at compile time, so the variable names are not even in the release binary (tests/test_abi.py checks that).
+static inline const char* cap_env_(const char* name) {
+  if constexpr (CAP_EXPERIMENTS) return getenv(name);
+  else return nullptr;
+}
+#define CAP_ENV(name) cap_env_(name)
 // tag bit of cap_gemm_launch: C is caller-supplied memory that has not been verified to be plain device memory -
 // the fire-and-forget atomic epilogue (hardware fp64 atomics are dropped on fine-grained / host-mapped memory) is off
 constexpr int CAP_TAG_NO_ATOMIC = 64;

@@ -306,16 +306,16 @@ int cap_qrapply256_launch(const double* Qin, int64_t ldin, const double* Ri, dou
   int dev = 0, cus = 256;
   CAP_HIP(hipGetDevice(&dev));
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  static const int contig = getenv("CAP_CQR_CONTIG") ? atoi(getenv("CAP_CQR_CONTIG")) : 1;
+  static const int contig = CAP_ENV("CAP_CQR_CONTIG") ? atoi(CAP_ENV("CAP_CQR_CONTIG")) : 1;
   ApplyArgs g{Qin, ldin, Ri, Qout, ldout, (int)(m / 128), contig};
   const int grid = (int)std::min<int64_t>(cus, g.ntiles);
   // CAP_CQR_DIAG is timing surgery only (1 = no stores, 2 = no MFMA: results are wrong); CAP_CQR_PIPE picks the loop form
-  static const int pipe = getenv("CAP_CQR_PIPE") ? atoi(getenv("CAP_CQR_PIPE")) : 1;
+  static const int pipe = CAP_ENV("CAP_CQR_PIPE") ? atoi(CAP_ENV("CAP_CQR_PIPE")) : 1;
   const size_t lds = (A_NST * TA + B_NST * TB) * sizeof(double);
   const dim3 gr((unsigned)grid), bl(512);
   cap_acc_r(Qin, ldin, m, 256); cap_acc_r(Ri, 256, 256, 256, 1); cap_acc_w(Qout, ldout, m, 256);
   if constexpr (CAP_EXPERIMENTS) {
-    static const int diag = getenv("CAP_CQR_DIAG") ? atoi(getenv("CAP_CQR_DIAG")) : 0;
+    static const int diag = CAP_ENV("CAP_CQR_DIAG") ? atoi(CAP_ENV("CAP_CQR_DIAG")) : 0;
     if (diag == 1) hipLaunchKernelGGL((qrapply256_kernel<1, 0>), gr, bl, lds, s, g);
     else if (diag == 2) hipLaunchKernelGGL((qrapply256_kernel<2, 0>), gr, bl, lds, s, g);
     else if (diag == 3) hipLaunchKernelGGL((qrapply256_kernel<3, 0>), gr, bl, lds, s, g);

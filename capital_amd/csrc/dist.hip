@@ -443,8 +443,8 @@ int cap_dist_plan_create(cap_dist_plan** plan, int64_t n, int64_t nb, cap_comm* 
   d->cnt_gemm = d->cnt_chain = d->cnt_copy = d->cnt_coll = 0;
   d->complete_inv = -1; d->split = 1; d->root_n1 = 0; d->Dall = d->Ri = nullptr; d->Cb[0] = d->Cb[1] = nullptr; d->comm3 = nullptr;
   d->s_inv = nullptr; d->ev_join_i = nullptr; d->ev_t0 = d->ev_sweep_end = d->ev_inv_end = nullptr;
-  d->ipc = getenv("CAP_DIST_IPC") ? atoi(getenv("CAP_DIST_IPC")) : 0; d->ipc_ready = false; d->ipc_failed = false; d->token = nullptr;
-  d->ipc_nocu = getenv("CAP_DIST_IPC_NOCU") ? atoi(getenv("CAP_DIST_IPC_NOCU")) : 0;
+  d->ipc = CAP_ENV("CAP_DIST_IPC") ? atoi(CAP_ENV("CAP_DIST_IPC")) : 0; d->ipc_ready = false; d->ipc_failed = false; d->token = nullptr;
+  d->ipc_nocu = CAP_ENV("CAP_DIST_IPC_NOCU") ? atoi(CAP_ENV("CAP_DIST_IPC_NOCU")) : 0;
   for (int r = 0; r < 8; r++) { d->peerG[r][0] = d->peerG[r][1] = nullptr; d->s_peer[r] = nullptr; d->ev_xr[r] = nullptr; }
   d->ev_x0 = nullptr;
   d->wcap = cap_rec_work_size(nb);

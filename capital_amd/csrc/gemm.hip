@@ -495,10 +495,10 @@ int launch_tn_dma(GemmArgs g, int grid, hipStream_t stream, int persist_wgs = 0)
   // tail (cholinv.hip, option occ1_m).  Round 5 measured why this works (profiles/r05_chain_fp64_occ1_lds{96,88}.log): the chain only
   // reaches its isolated speed (0.31 ms per 512-block) on CUs it has to itself - next to one bulk workgroup every fp64 VALU operation of
   // its leaf waits for the fp64 matrix pipe (1.9 ms per block at 88 KiB, where the two co-reside; N = 32768: 61.7 TF against 63.4).
-  static const size_t occ1_lds = (size_t)(getenv("CAP_OCC1_LDS_KB") ? atoi(getenv("CAP_OCC1_LDS_KB")) : 96) * 1024;
+  static const size_t occ1_lds = (size_t)(CAP_ENV("CAP_OCC1_LDS_KB") ? atoi(CAP_ENV("CAP_OCC1_LDS_KB")) : 96) * 1024;
   size_t lds = persist_wgs == -1 ? std::max<size_t>(occ1_lds, 4 * DMA_TILE * sizeof(double)) : 4 * DMA_TILE * sizeof(double);
   if constexpr (CAP_EXPERIMENTS && TAG == 0) {                       // timing experiments only (results are wrong)
-    static const int diag_env = getenv("CAP_DIAG") ? atoi(getenv("CAP_DIAG")) : 0;
+    static const int diag_env = CAP_ENV("CAP_DIAG") ? atoi(CAP_ENV("CAP_DIAG")) : 0;
     if (diag_env == 1) {
       hipLaunchKernelGGL((dgemm_tn_dma_kernel<0, false, 1, true>), dim3(grid, g.ksplit), dim3(NTHREADS), lds, stream, g);
       CAP_HIP(hipGetLastError());
@@ -774,7 +774,7 @@ __global__ void __launch_bounds__(256) dgemm_nn_skinny_kernel(const SkinnyArgs g
 // returns CAP_ERR_UNSUPPORTED when the shape does not qualify (the caller then takes the tile kernels)
 int launch_skinny(int transa, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda, const double* B, int64_t ldb,
                   double beta, double* C, int64_t ldc, hipStream_t stream) {
-  static const int on = getenv("CAP_SKINNY") ? atoi(getenv("CAP_SKINNY")) : 1;
+  static const int on = CAP_ENV("CAP_SKINNY") ? atoi(CAP_ENV("CAP_SKINNY")) : 1;
   if (!on || n < 1 || n > 8 || m < 64 || k < 8 || (k % 8)) return CAP_ERR_UNSUPPORTED;
   SkinnyArgs g{A, B, C, lda, ldb, ldc, m, k, (int)n, alpha, beta};
   if (transa == CAP_TRANS) {
@@ -891,12 +891,12 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   g.stair = 0; g.gather = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0; g.rP = 1; g.rp = 0; g.rlb0 = 0;
   for (int i = 0; i < 8; i++) g.gstart[i] = 0;
   g.tm = (int)cap_ceil_div(m, BM); g.tn = (int)cap_ceil_div(n, BN);
-  static const int st_env = getenv("CAP_ST") ? atoi(getenv("CAP_ST")) : ST;
+  static const int st_env = CAP_ENV("CAP_ST") ? atoi(CAP_ENV("CAP_ST")) : ST;
   g.st = st_env; g.stm = g.st; g.stn = g.st; g.sorder = 0;
   g.nsm = (int)cap_ceil_div(g.tm, g.st); g.nsn = (int)cap_ceil_div(g.tn, g.st);
   int64_t nsuper;
   g.etri = (tri != 0 && g.nsm == g.nsn) ? tri : 0;
-  static const int xbal_env = getenv("CAP_XCD_BALANCE") ? atoi(getenv("CAP_XCD_BALANCE")) : 1;
+  static const int xbal_env = CAP_ENV("CAP_XCD_BALANCE") ? atoi(CAP_ENV("CAP_XCD_BALANCE")) : 1;
   if (g.etri == 0 && xbal_env && g.st == 8 && (g.bupper || g.aupt || g.aupn) && g.tm * g.tn >= 64) {
     // triangular operand: make the K-determining tile index the one every XCD's range walks completely (see GemmArgs::stm)
     if (g.bupper && !(g.aupt || g.aupn)) {            // K range grows with the column tile: XCD x = a band of tile rows, all columns
@@ -933,11 +933,11 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   }
 
   {
-    static const int atomic_env = getenv("CAP_ATOMIC_C") ? atoi(getenv("CAP_ATOMIC_C")) : 1;
+    static const int atomic_env = CAP_ENV("CAP_ATOMIC_C") ? atoi(CAP_ENV("CAP_ATOMIC_C")) : 1;
     g.atomic_c = (atomic_env && !no_atomic && beta == 1.0 && g.ksplit == 1) ? 1 : 0;
-    static const int skip_env = getenv("CAP_SKIP") ? atoi(getenv("CAP_SKIP")) : 1;
+    static const int skip_env = CAP_ENV("CAP_SKIP") ? atoi(CAP_ENV("CAP_SKIP")) : 1;
     g.skip = (skip_env && tag != 1 && (g.bupper || g.aupt || g.aupn || (tri == 1 && g.tm <= 8))) ? 1 : 0;
-    static const int buf_env = getenv("CAP_DMA_BUF") ? atoi(getenv("CAP_DMA_BUF")) : 1;
+    static const int buf_env = CAP_ENV("CAP_DMA_BUF") ? atoi(CAP_ENV("CAP_DMA_BUF")) : 1;
     g.usebuf = (buf_env && 128 * lda * 8 + k * 8 < 0xfffffff0LL && 128 * ldb * 8 + k * 8 < 0xfffffff0LL) ? 1 : 0;
   }
   const bool a_kc = (transa == CAP_TRANS);   // op(A)=A^T: k contiguous
@@ -996,7 +996,7 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   g.ksplit = 1; g.kchunk = k; g.P = nullptr; g.slab = 0;
   g.hiprio = 0; g.ctr = nullptr; g.bupper = 0; g.aupt = 0; g.aupn = 0;
   {
-    static const int atomic_env = getenv("CAP_ATOMIC_C") ? atoi(getenv("CAP_ATOMIC_C")) : 1;
+    static const int atomic_env = CAP_ENV("CAP_ATOMIC_C") ? atoi(CAP_ENV("CAP_ATOMIC_C")) : 1;
     g.atomic_c = atomic_env ? 1 : 0;
     g.usebuf = (128 * k * 8 + k * 8 < 0x7fffffffLL) ? 1 : 0; g.skip = 0; g.Cin = C; g.ldcin = ldc;
   }

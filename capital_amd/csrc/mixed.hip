@@ -191,7 +191,7 @@ int launch_bf16_tn(int64_t m, int64_t n, int64_t k, float alpha, const __bf16* A
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.tri = tri;
   g.stair = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0;
   for (int i = 0; i < 8; i++) g.gstart[i] = 0;
-  static const int st_env = getenv("CAP_BF16_ST") ? atoi(getenv("CAP_BF16_ST")) : 8;     // supertile edge (BfArgs::st), 0 = column-major walk
+  static const int st_env = CAP_ENV("CAP_BF16_ST") ? atoi(CAP_ENV("CAP_BF16_ST")) : 8;     // supertile edge (BfArgs::st), 0 = column-major walk
   g.st = 0; g.nsm = 1;
   g.tm = (int)(m / TB); g.tn = (int)(n / TB);
   int64_t tiles = (tri && m == n) ? (int64_t)g.tn * (g.tn + 1) / 2 : (int64_t)g.tm * g.tn;
@@ -441,14 +441,14 @@ __global__ void __launch_bounds__(512, 2) bf16_tn_v2_kernel(const Bf2Args g) {
 // against 630 for the old one, but its workgroups hold 145 KiB of LDS for a whole chunk, the diagonal-block chain finds no CU to
 // start on, and the factorization - bound by that chain (panel stream) at every strip - gets 5 % SLOWER (211 vs 199 ms).  Stand-alone
 // (update-bound callers, K >= 2048) it is the faster kernel: 855 vs 770 TF at K = 2048, 1017 vs 894 at K = 4096.
-static int g_bf16_variant = getenv("CAP_BF16_V2") ? atoi(getenv("CAP_BF16_V2")) : 5;
-static int g_bf16_tpw = getenv("CAP_BF16_TPW") ? atoi(getenv("CAP_BF16_TPW")) : 8;
-static int64_t g_bf16_min_tiles = getenv("CAP_BF16_V2_MIN") ? atoll(getenv("CAP_BF16_V2_MIN")) : 1024;
+static int g_bf16_variant = CAP_ENV("CAP_BF16_V2") ? atoi(CAP_ENV("CAP_BF16_V2")) : 5;
+static int g_bf16_tpw = CAP_ENV("CAP_BF16_TPW") ? atoi(CAP_ENV("CAP_BF16_TPW")) : 8;
+static int64_t g_bf16_min_tiles = CAP_ENV("CAP_BF16_V2_MIN") ? atoll(CAP_ENV("CAP_BF16_V2_MIN")) : 1024;
 
 static int64_t g_bf16_v3_min = 64;      // smallest launch (in 256 x 256 tiles) the third-generation kernel takes
 static int64_t g_bf16_head_min = 32;     // smallest panel-stream update it takes (-1: none, the 128-tile kernel)
 static int g_bf16_v3_st = 4;             // its supertile edge in tiles
-static int g_bf16_sched = getenv("CAP_BF16_SCHED") ? atoi(getenv("CAP_BF16_SCHED")) : 1;
+static int g_bf16_sched = CAP_ENV("CAP_BF16_SCHED") ? atoi(CAP_ENV("CAP_BF16_SCHED")) : 1;
 static int g_bf16_dbg = 0;              // timing surgery (CAP_EXPERIMENTS builds): set through cap_bf16_update(variant = 100 + DBG)
 
 template <int SCHED, int DBG, int PFI = 0>
@@ -667,12 +667,12 @@ int cap_mpchol_plan_create(cap_mpchol_plan** plan, int64_t n, int64_t nrhs_max) 
   if (!p) return CAP_ERR_ALLOC;
   memset(p, 0, sizeof(*p));
   p->n = n; p->nb = 1024; p->nrhs_cap = cap_round_up(nrhs_max, 128);
-  p->strip = getenv("CAP_MP_STRIP") ? atoll(getenv("CAP_MP_STRIP")) : 2;
-  p->split = getenv("CAP_MP_SPLIT") ? atoi(getenv("CAP_MP_SPLIT")) : 1;
-  p->solve3 = getenv("CAP_MP_SOLVE3") ? atoi(getenv("CAP_MP_SOLVE3")) : 1;
-  p->reserve = getenv("CAP_MP_RESERVE") ? atoi(getenv("CAP_MP_RESERVE")) : 0;
+  p->strip = CAP_ENV("CAP_MP_STRIP") ? atoll(CAP_ENV("CAP_MP_STRIP")) : 2;
+  p->split = CAP_ENV("CAP_MP_SPLIT") ? atoi(CAP_ENV("CAP_MP_SPLIT")) : 1;
+  p->solve3 = CAP_ENV("CAP_MP_SOLVE3") ? atoi(CAP_ENV("CAP_MP_SOLVE3")) : 1;
+  p->reserve = CAP_ENV("CAP_MP_RESERVE") ? atoi(CAP_ENV("CAP_MP_RESERVE")) : 0;
   p->chain_coop = -1;
-  p->pair_rest = getenv("CAP_MP_PAIR_REST") ? atoi(getenv("CAP_MP_PAIR_REST")) : 1;
+  p->pair_rest = CAP_ENV("CAP_MP_PAIR_REST") ? atoi(CAP_ENV("CAP_MP_PAIR_REST")) : 1;
   p->cnt_paired = 0;
   // largest power of two <= min(n, 1024) (>= 128 because n % 128 == 0): the fused diagonal-block chain and the bf16 tile
   // kernel (k % 64, m % 128) need it; the last panel of a non-power-of-two n is a shorter multiple of 128

@@ -160,6 +160,27 @@ def test_plain_c_host_compiles_against_the_header(built, tmp_path, name):
     assert exe.exists()
 
 
+def test_release_library_reads_no_experiment_switch_from_the_environment(built):
+    """Round 5 review: ~40 CAP_* environment switches were live in the release library - a stray variable in a caller's environment silently
+    changed the product's code path.  They are read through CAP_ENV now, which is getenv only in experiment builds (csrc/common.h:
+    CAP_EXPERIMENTS, false in the tree) and folds to a null pointer otherwise: the names must not even be IN the release binary, and no
+    plain getenv of a CAP_ name may be left in the sources.  (libcapital_amd_cblas.so keeps CAPCB_REPORT / CAPCB_DEVICE: a report and the
+    device choice of an MPI program that has no line of its own to make it - not code-path switches.)"""
+    import glob
+    csrc = os.path.join(ROOT, "capital_amd", "csrc")
+    common = open(os.path.join(csrc, "common.h")).read()
+    assert "constexpr bool CAP_EXPERIMENTS = false;" in common, "the tree must hold a release configuration"
+    names = set()
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
+        src = open(f).read()
+        assert not re.search(r'(?<![A-Za-z_])getenv\("CAP_', src.replace("CAP_ENV", "")), "plain getenv of a CAP_ switch in " + f
+        names.update(re.findall(r'CAP_ENV\("(CAP_[A-Z0-9_]+)"\)', src))
+    assert len(names) >= 30, names
+    blob = open(built, "rb").read()
+    left = sorted(n for n in names if n.encode() + b"\0" in blob)
+    assert not left, "experiment switches present in the release library: %s" % left
+
+
 def test_integration_md_snippets_are_the_compiled_ones():
     """Every cap_* call line inside INTEGRATION.md's C / C++ code blocks of section B appears verbatim (modulo whitespace) in
     examples/integration_snippets.c - the file the test above compiles."""

@@ -150,8 +150,12 @@ def exercise(L, rng, sizes, every_form=True):
         # an illegal argument: a line on stderr, the call ignored (xerbla's way) - the window stays as it was
         c = c0.copy(order="F")
         L.cblas_dgemm(COL, NT, NT, m, n, k, d(1.0), _p(nan_a), m - 1, _p(nan_b), k, d(0.0), _p(c), m)
-        L.cblas_dtrmm(COL, LEFT, LO, NT, NONUNIT, m, n, d(1.0), _p(nan_a), m, _p(c), m)
+        L.cblas_dtrmm(COL, LEFT, 99, NT, NONUNIT, m, n, d(1.0), _p(nan_a), m, _p(c), m)        # uplo = 99 is no BLAS value at all
         assert np.array_equal(c, c0)
+        # ConjTrans is Trans in real arithmetic
+        a2, b2 = _f(rng.standard_normal((k, m))), _f(rng.standard_normal((k, n))); c = c0.copy(order="F")
+        L.cblas_dgemm(COL, 113, NT, m, n, k, d(1.0), _p(a2), k, _p(b2), k, d(0.0), _p(c), m)
+        assert np.linalg.norm(c - a2.T @ b2) <= 1e-13 * np.linalg.norm(c)
     calls, bi, bo = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
     L.capcb_counters(C.byref(calls), C.byref(bi), C.byref(bo))
     assert calls.value > 0 and bi.value > 0 and bo.value > 0
@@ -165,6 +169,27 @@ def test_every_entry_point_against_numpy_with_blas_conventions(standin):
     worst = exercise(standin, np.random.default_rng(3), [(70, 40, 33), (130, 129, 64), (257, 96, 300), (1, 1, 1), (5, 300, 2)])
     assert set(worst) == {"dgemm", "dsyrk", "dtrmm", "dpotrf", "dtrtri"}
     assert max(worst.values()) < 5e-14, worst
+
+
+def test_a_legal_blas_form_the_library_does_not_implement_ends_the_process_loudly(standin):
+    """a Lower / Unit TRMM or a row-major call is LEGAL BLAS; the offload library used to print one line and return with the
+    output untouched - a program linked with it in MKL's place would have computed on with wrong numbers.  Now it aborts with the reason.
+    (Run in a child process under the same CPU stand-in the fixture installs.)"""
+    import subprocess, sys
+    code = ("import ctypes as C, numpy as np, os, sys\n"
+            "L = C.CDLL(os.environ['CAPCB_TEST_LIB'], mode=C.RTLD_GLOBAL)\n"
+            "a = np.asfortranarray(np.eye(8)); b = np.asfortranarray(np.ones((8, 8)))\n"
+            "p = lambda x: x.ctypes.data_as(C.c_void_p)\n"
+            "form = sys.argv[1]\n"
+            "if form == 'lower': L.cblas_dtrmm(102, 141, 122, 111, 131, 8, 8, C.c_double(1.0), p(a), 8, p(b), 8)\n"
+            "if form == 'unit': L.cblas_dtrmm(102, 141, 121, 111, 132, 8, 8, C.c_double(1.0), p(a), 8, p(b), 8)\n"
+            "if form == 'rowmajor': L.cblas_dgemm(101, 111, 111, 8, 8, 8, C.c_double(1.0), p(a), 8, p(b), 8, C.c_double(0.0), p(b), 8)\n"
+            "print('returned')\n")
+    env = dict(os.environ, CAPCB_TEST_LIB=standin._name)
+    for form in ("lower", "unit", "rowmajor"):
+        r = subprocess.run([sys.executable, "-c", code, form], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "returned" not in r.stdout, (form, r.returncode, r.stdout)
+        assert "does not implement" in r.stderr, (form, r.stderr[-500:])
 
 
 def build_and_run_demo(tmp_path, libdir, run_dirs, extra_env, n):
