@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-Rpass-analysis=kernel-resource-usage", "-I" + os.path.join(os.path.dirname(HERE), "include")]
 # Kernels of the hot path that must live in registers: a silent scratch allocation (seen once: accumulators captured by a
 # lambda) costs 5-7x and nothing else reports it.  Checked after every build against the compiler's own resource remarks.
-NO_SCRATCH = ("dgemm_tn_dma_kernel", "gram256_kernel", "qrapply256_kernel", "bf16_tn_kernel", "bf16_tn_v2_kernel", "bf16_tn3_kernel", "bf16_tn3w_kernel", "leaf_cholinv_kernel",
+NO_SCRATCH = ("dgemm_tn_dma_kernel", "gram256_kernel", "qrapply256_kernel", "bf16_tn_kernel", "bf16_tn_v2_kernel", "bf16_tn3_kernel", "bf16_tn3w_kernel", "bf16_tn3x_kernel", "leaf_cholinv_kernel",
               "panel64_solve_update_kernel", "chain64_coop_kernel")
 
 

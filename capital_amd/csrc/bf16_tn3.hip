@@ -332,6 +332,109 @@ __global__ void __launch_bounds__(512, 2) bf16_tn3w_kernel(const BfArgs g) {
   if (DBG & 8) { CAP_ACC3_KEEP() return; }
   tn3_epilogue(g, acc, ti, tj, grp, w4, r32, kg);
 }
+
+// Long phases (variant 6): the wide staging with ONE load phase and ONE compute phase per 64-k stage - 32 MFMAs (1024 matrix-pipe cycles) between
+// barriers instead of 16.  The MFMA + barrier skeleton of the 16-MFMA phases reaches 0.72 of peak: ~ 200 cycles per phase are hand-over (the two
+// wave groups alternate strictly), and they halve here; the price is 96 fragment registers (4 k-steps) instead of 48.  Group 0 moves ALL of B and its
+// own A rows (12 pieces per wave) at the start of its load phase 2t (flight: 2 phases = 2048 cycles until group 0 reads them in phase 2t + 2);
+// group 1 moves only its own A rows (4 pieces per wave) in phase 2t + 1 and reads them in phase 2t + 3.
+template <int DBG = 0>
+__global__ void __launch_bounds__(512, 2) bf16_tn3x_kernel(const BfArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  char* lds = reinterpret_cast<char*>(smem);
+  int ti, tj;
+  if (!tn3_tile(g, ti, tj)) return;
+  const int64_t i0 = (int64_t)ti * T3, j0 = (int64_t)tj * T3;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wid >> 2, w4 = wid & 3;
+  const int r32 = lane & 31, kg = lane >> 5;
+  const int nk = (int)(g.K / K3W);
+
+  const int rsub = lane >> 3, p8 = lane & 7;
+  const uint32_t rbA = (uint32_t)(g.lda * 2), rbB = (uint32_t)(g.ldb * 2);
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + i0 * g.lda), 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)(g.B + j0 * g.ldb), 0, (int)0xffffffffu, 0x00020000);
+  const uint32_t sw_e = (uint32_t)((p8 ^ (rsub >> 1)) << 4), sw_o = (uint32_t)((p8 ^ ((rsub >> 1) ^ 4)) << 4);
+  const uint32_t vA_e = rsub * rbA + sw_e, vA_o = rsub * rbA + sw_o, vB_e = rsub * rbB + sw_e, vB_o = rsub * rbB + sw_o;
+  auto issue = [&](int st) {
+    char* dst = lds + (st & 1) * STAGE3W;
+    if (grp == 0) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) {                     // B: pieces 8 w4 .. 8 w4 + 7 of 32
+        const uint32_t p = (uint32_t)(w4 * 8 + q);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(dst + IMG3W + p * 1024), 16, (int)((q & 1) ? vB_o : vB_e),
+                                                 (int)(p * 8u * rbB + (uint32_t)st * RB3W), 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {                       // A: my group's rows, pieces grp * 16 + 4 w4 + q
+      const uint32_t p = (uint32_t)(grp * 16 + w4 * 4 + q);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, (int)((q & 1) ? vA_o : vA_e),
+                                               (int)(p * 8u * rbA + (uint32_t)st * RB3W), 0, 0);
+    }
+  };
+  const int t = kg ^ ((r32 >> 1) & 7);
+  const int a_row = (grp * 128 + r32) * RB3W, b_row = IMG3W + (w4 * 64 + r32) * RB3W;
+  bf16x8 fa[4][4], fb[4][2];
+  auto read_frags = [&](int st) {
+    const char* base = lds + (st & 1) * STAGE3W;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int o = ((2 * s) ^ t) << 4;
+#pragma unroll
+      for (int i = 0; i < 4; i++) fa[s][i] = *reinterpret_cast<const bf16x8*>(base + a_row + o + i * 32 * RB3W);
+#pragma unroll
+      for (int j = 0; j < 2; j++) fb[s][j] = *reinterpret_cast<const bf16x8*>(base + b_row + o + j * 32 * RB3W);
+    }
+  };
+  f32x16 acc[4][2];
+  CAP_ACC3_ZERO()
+#define CAP_MMA3X()                                                                                                  \
+  if (DBG & 4) {                                                                                                     \
+    _Pragma("unroll") for (int s = 0; s < 4; s++) {                                                                  \
+      _Pragma("unroll") for (int i = 0; i < 4; i++) asm volatile("" ::"v"(fa[s][i]));                                \
+      _Pragma("unroll") for (int j = 0; j < 2; j++) asm volatile("" ::"v"(fb[s][j]));                                \
+    }                                                                                                                \
+  } else {                                                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                                   \
+    _Pragma("unroll") for (int s = 0; s < 4; s++)                                                                    \
+      _Pragma("unroll") for (int i = 0; i < 4; i++)                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 2; j++)                                                                \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s][j], fa[s][i], acc[i][j], 0, 0, 0);               \
+    __builtin_amdgcn_s_setprio(0);                                                                                   \
+  }
+  issue(0);
+  CAP_VMCNT(0);
+  __builtin_amdgcn_s_barrier();
+  if (grp == 0) {
+    for (int tt = 0; tt < nk; tt++) {
+      if (!(DBG & 1) && tt + 1 < nk) issue(tt + 1);   // phase 2 tt: the slot was read for the last time (group 1, phase 2 tt - 1) before the barrier just passed
+      if (!(DBG & 2) || tt == 0) read_frags(tt);
+      CAP_VMCNT_LGKM0(63);
+      __builtin_amdgcn_s_barrier();
+      CAP_MMA3X()                                     // phase 2 tt + 1
+      CAP_VMCNT(0);                                   // my 12 pieces of stage tt + 1 have landed
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    __builtin_amdgcn_s_barrier();
+    for (int tt = 0; tt < nk; tt++) {
+      if (!(DBG & 1) && tt + 1 < nk) issue(tt + 1);   // phase 2 tt + 1: my A rows of stage tt + 1 (read by me in phase 2 tt + 3)
+      if (!(DBG & 2) || tt == 0) read_frags(tt);
+      CAP_VMCNT_LGKM0(63);
+      __builtin_amdgcn_s_barrier();
+      CAP_MMA3X()                                     // phase 2 tt + 2
+      if (tt + 1 < nk) {
+        CAP_VMCNT(0);                                 // my A pieces of stage tt + 1
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  }
+#undef CAP_MMA3X
+  if (DBG & 8) { CAP_ACC3_KEEP() return; }
+  tn3_epilogue(g, acc, ti, tj, grp, w4, r32, kg);
+}
 #undef CAP_MMA3
 #undef CAP_ACC3_ZERO
 #undef CAP_ACC3_KEEP
@@ -356,6 +459,14 @@ int launch_tn3(const BfArgs& g, unsigned grid, hipStream_t s) {
   return launch_tn3_any(bf16_tn3_kernel<NST, DBG>, NST * STAGE3, (dev >= 0 && dev < 16) ? attr_set[dev] : scratch, g, grid, s);
 }
 template <int DBG = 0>
+int launch_tn3x(const BfArgs& g, unsigned grid, hipStream_t s) {
+  static bool attr_set[16] = {};
+  int dev = 0;
+  CAP_HIP(hipGetDevice(&dev));
+  bool scratch = false;
+  return launch_tn3_any(bf16_tn3x_kernel<DBG>, 2 * STAGE3W, (dev >= 0 && dev < 16) ? attr_set[dev] : scratch, g, grid, s);
+}
+template <int DBG = 0>
 int launch_tn3w(const BfArgs& g, unsigned grid, hipStream_t s) {
   static bool attr_set[16] = {};
   int dev = 0;
@@ -368,7 +479,7 @@ int launch_tn3w(const BfArgs& g, unsigned grid, hipStream_t s) {
 
 // nst 3 / 4: narrow staging (K % 32 == 0); nst 5: wide staging (K % 64 == 0)
 bool cap_bf16_tn3_applies(int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb, int tri, int nst) {
-  return m > 0 && n > 0 && k > 0 && m % T3 == 0 && n % T3 == 0 && k % (nst == 5 ? K3W : K3) == 0 && lda % 8 == 0 && ldb % 8 == 0 && (!tri || m <= n) &&
+  return m > 0 && n > 0 && k > 0 && m % T3 == 0 && n % T3 == 0 && k % (nst >= 5 ? K3W : K3) == 0 && lda % 8 == 0 && ldb % 8 == 0 && (!tri || m <= n) &&
          256 * lda * 2 + k * 2 < 0xfffffff0LL && 256 * ldb * 2 + k * 2 < 0xfffffff0LL;
 }
 
@@ -392,6 +503,14 @@ int cap_bf16_tn3_launch(int64_t m, int64_t n, int64_t k, float alpha, const void
   const unsigned grid = (unsigned)(g.chunk * 8);
   if constexpr (CAP_EXPERIMENTS) {
     const bool wide = nst == 5;
+    if (nst == 6) switch (dbg) {
+      case 1: return launch_tn3x<1>(g, grid, s);
+      case 8: return launch_tn3x<8>(g, grid, s);
+      case 9: return launch_tn3x<9>(g, grid, s);
+      case 11: return launch_tn3x<11>(g, grid, s);
+      case 12: return launch_tn3x<12>(g, grid, s);
+      default: break;
+    }
     switch (dbg) {
       case 1: return wide ? launch_tn3w<1>(g, grid, s) : launch_tn3<3, 1>(g, grid, s);
       case 2: return wide ? launch_tn3w<2>(g, grid, s) : launch_tn3<3, 2>(g, grid, s);
@@ -405,6 +524,7 @@ int cap_bf16_tn3_launch(int64_t m, int64_t n, int64_t k, float alpha, const void
     }
   }
   if (dbg) return CAP_ERR_UNSUPPORTED;
+  if (nst == 6) return launch_tn3x<0>(g, grid, s);
   if (nst == 5) return launch_tn3w<0>(g, grid, s);
   return nst >= 4 ? launch_tn3<4>(g, grid, s) : launch_tn3<3>(g, grid, s);
 }

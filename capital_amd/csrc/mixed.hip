@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(512, 2) bf16_tn_v2_kernel(const Bf2Args g) {
 // against 630 for the old one, but its workgroups hold 145 KiB of LDS for a whole chunk, the diagonal-block chain finds no CU to
 // start on, and the factorization - bound by that chain (panel stream) at every strip - gets 5 % SLOWER (211 vs 199 ms).  Stand-alone
 // (update-bound callers, K >= 2048) it is the faster kernel: 855 vs 770 TF at K = 2048, 1017 vs 894 at K = 4096.
-static int g_bf16_variant = CAP_ENV("CAP_BF16_V2") ? atoi(CAP_ENV("CAP_BF16_V2")) : 5;
+static int g_bf16_variant = CAP_ENV("CAP_BF16_V2") ? atoi(CAP_ENV("CAP_BF16_V2")) : 6;
 static int g_bf16_tpw = CAP_ENV("CAP_BF16_TPW") ? atoi(CAP_ENV("CAP_BF16_TPW")) : 8;
 static int64_t g_bf16_min_tiles = CAP_ENV("CAP_BF16_V2_MIN") ? atoll(CAP_ENV("CAP_BF16_V2_MIN")) : 1024;
 
@@ -525,17 +525,19 @@ int launch_bf16_head(int64_t m, int64_t n, int64_t k, float alpha, const __bf16*
 extern "C" int cap_bf16_update(int variant, int64_t m, int64_t n, int64_t k, float alpha, const void* A16, int64_t lda, const void* B16, int64_t ldb,
                                float* C, int64_t ldc, int tri, int tpw, void* stream) {
   if (!A16 || !B16 || !C || m < 0 || n < 0 || k < 0) return CAP_ERR_ARG;
-  if (tpw > 0 && (variant < 3 || (variant > 5 && variant < 300))) g_bf16_tpw = tpw;
+  if (tpw > 0 && (variant < 3 || (variant > 6 && variant < 300))) g_bf16_tpw = tpw;
   const __bf16* A = (const __bf16*)A16; const __bf16* B = (const __bf16*)B16;
   hipStream_t s = cap_stream(stream);
   if (variant < 0) return launch_bf16_update(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
   if (variant == 0) return launch_bf16_tn(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, s);
-  if (variant >= 3 && variant <= 5)      // third generation: LDS ring of 3 / 4 stages of 32 k, 5 = two stages of 64 k; tpw carries the supertile edge here (0: default)
+  if (variant >= 3 && variant <= 6)      // third generation (6: wide staging with 32-MFMA phases): LDS ring of 3 / 4 stages of 32 k, 5 = two stages of 64 k; tpw carries the supertile edge here (0: default)
     return cap_bf16_tn3_launch(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, variant, tpw > 0 ? tpw : g_bf16_v3_st, s);
   if (variant >= 300 && variant < 316)   // timing surgery on the third generation (experiment builds only): 300 + DBG; 500 + DBG: wide staging
     return cap_bf16_tn3_launch(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, 3, tpw > 0 ? tpw : g_bf16_v3_st, s, variant - 300);
   if (variant >= 500 && variant < 516)
     return cap_bf16_tn3_launch(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, 5, tpw > 0 ? tpw : g_bf16_v3_st, s, variant - 500);
+  if (variant >= 600 && variant < 616)
+    return cap_bf16_tn3_launch(m, n, k, alpha, A, lda, B, ldb, C, ldc, tri, 6, tpw > 0 ? tpw : g_bf16_v3_st, s, variant - 600);
   if (m % 256 || n % 128 || k % 64 || lda % 8 || ldb % 8 || (tri && m != n) || m == 0 || n == 0 || k == 0) return CAP_ERR_UNSUPPORTED;
   // variant 1: the production schedule; 2: without the forced read-ahead; 100 + DBG: timing surgery (experiment builds only)
   g_bf16_sched = variant == 2 ? 0 : 1;
@@ -1048,7 +1050,7 @@ int cap_mpchol_set_option(cap_mpchol_plan* p, const char* key, int64_t value) {
   if (!strcmp(key, "chain_coop")) { if (value < -1 || value > 256) return CAP_ERR_ARG; p->chain_coop = (int)value; return CAP_OK; }   // per plan, see cap_cholinv_set_option
   if (!strcmp(key, "solve3")) { p->solve3 = value != 0; return CAP_OK; }   // block-row solves on the bf16 pipe with split operands (split schedule)
   // process-wide A/B switches of the bf16 update (see launch_bf16_update): which kernel, chunk length, smallest launch for the new one
-  if (!strcmp(key, "update_kernel")) { if (value < 0 || value > 5 || value == 2) return CAP_ERR_ARG; g_bf16_variant = (int)value; return CAP_OK; }
+  if (!strcmp(key, "update_kernel")) { if (value < 0 || value > 6 || value == 2) return CAP_ERR_ARG; g_bf16_variant = (int)value; return CAP_OK; }
   if (!strcmp(key, "update_v3_min_tiles")) { if (value < 0) return CAP_ERR_ARG; g_bf16_v3_min = value; return CAP_OK; }
   if (!strcmp(key, "update_v3_head_min_tiles")) { if (value < -1) return CAP_ERR_ARG; g_bf16_head_min = value; return CAP_OK; }
   if (!strcmp(key, "update_v3_st")) { if (value < 1 || value > 64) return CAP_ERR_ARG; g_bf16_v3_st = (int)value; return CAP_OK; }

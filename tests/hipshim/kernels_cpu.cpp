@@ -781,7 +781,7 @@ static int dispatch(const char* mangled, void** args, unsigned gx, unsigned gy, 
   if (has("scatter_rows_bc_kernel")) { k_scatter_rows_bc(args, gy); return 1; }
   if (has("bf16_tn_kernel")) { k_bf16_tn(args, gx); return 1; }
   if (has("bf16_tn3_kernel")) { k_bf16_tn(args, gx, 256, 32); return 1; }
-  if (has("bf16_tn3w_kernel")) { k_bf16_tn(args, gx, 256, 64); return 1; }      // third generation: the same walk on 256 x 256 tiles, K in stages of 32
+  if (has("bf16_tn3w_kernel") || has("bf16_tn3x_kernel")) { k_bf16_tn(args, gx, 256, 64); return 1; }      // third generation: the same walk on 256 x 256 tiles, K in stages of 32
   if (has("fill_symmetric_bc2d_kernel")) { k_fill_symmetric_bc2d(args); return 1; }
   if (has("fill_symmetric_bc_kernel")) { k_fill_symmetric_bc(args); return 1; }
   if (has("pad_identity_kernel")) { k_pad_identity(args); return 1; }

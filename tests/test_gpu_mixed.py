@@ -216,10 +216,10 @@ def test_bf16_update_third_generation(m, n, k, tri, st):
     mask = torch.triu(torch.ones(m, n, dtype=torch.bool, device="cuda")) if tri else torch.ones(m, n, dtype=torch.bool, device="cuda")
     scale = float(ref.abs().max())
     outs = {}
-    for variant in (0, 3, 4, 5):
+    for variant in (0, 3, 4, 5, 6):
         c = c0.clone()
         rc = _bf16_update(variant, a16, b16, c, -0.5, tri, st if variant else 0)
-        if variant in (0, 5) and rc != 0:
+        if variant in (0, 5, 6) and rc != 0:
             assert k % 64, rc                                  # the 128-tile kernel and the wide staging take K in steps of 64
             continue
         assert rc == 0, (variant, rc)
@@ -234,7 +234,7 @@ def test_bf16_update_third_generation(m, n, k, tri, st):
     assert torch.equal(outs[3][mask], outs[4][mask])
     if 0 in outs:
         assert torch.equal(outs[0][mask], outs[3][mask]), "same k order, one final add: the generations must agree bit for bit"
-        assert torch.equal(outs[5][mask], outs[3][mask])
+        assert torch.equal(outs[5][mask], outs[3][mask]) and torch.equal(outs[6][mask], outs[3][mask])
 
 
 def test_bf16_update_third_generation_refusals():

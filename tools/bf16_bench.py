@@ -16,13 +16,14 @@ for m in sizes:
     a16 = torch.randn(m, K, device="cuda").to(torch.bfloat16)
     c = torch.zeros(m, m, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
-    variants = [(0, 0, "v1 128x128"), (1, 8, "v2 tpw=8"), (3, 8, "v3 nst=3 st=8"), (4, 8, "v3 nst=4 st=8"), (3, 4, "v3 nst=3 st=4"), (5, 8, "v3w st=8"), (5, 4, "v3w st=4"), (116, 8, "v2 pfC/2"), (117, 8, "v2 pfC/4"), (118, 8, "v2 pfC/8"), (104, 8, "v2 -mfma"),
+    variants = [(0, 0, "v1 128x128"), (1, 8, "v2 tpw=8"), (3, 8, "v3 nst=3 st=8"), (4, 8, "v3 nst=4 st=8"), (3, 4, "v3 nst=3 st=4"), (5, 8, "v3w st=8"), (5, 4, "v3w st=4"), (6, 4, "v3x st=4"), (116, 8, "v2 pfC/2"), (117, 8, "v2 pfC/4"), (118, 8, "v2 pfC/8"), (104, 8, "v2 -mfma"),
                 (120, 8, "v2 pfC/4 -mfma"), (101, 8, "v2 -atomics"),
                 (301, 8, "v3 -dma"), (302, 8, "v3 -reads"), (303, 8, "v3 -dma -reads"), (304, 8, "v3 -mfma"), (308, 8, "v3 -epilogue"), (309, 8, "v3 -dma -epi"),
                 (311, 8, "v3 mfma only"), (312, 8, "v3 dma+reads only"),
-                (501, 4, "v3w -dma"), (502, 4, "v3w -reads"), (508, 4, "v3w -epilogue"), (509, 4, "v3w -dma -epi"), (511, 4, "v3w mfma only"), (512, 4, "v3w dma+reads only")]
+                (501, 4, "v3w -dma"), (502, 4, "v3w -reads"), (508, 4, "v3w -epilogue"), (509, 4, "v3w -dma -epi"), (511, 4, "v3w mfma only"), (512, 4, "v3w dma+reads only"),
+                (608, 4, "v3x -epilogue"), (609, 4, "v3x -dma -epi"), (611, 4, "v3x mfma only"), (612, 4, "v3x dma+reads only")]
     if os.environ.get("BF16_V3_ONLY"):
-        variants = [v for v in variants if v[0] in (0, 3, 5) or v[0] >= 300]
+        variants = [v for v in variants if v[0] in (0, 3, 5, 6) or v[0] >= 300]
     if os.environ.get("BF16_PLAIN"):
         variants = [v for v in variants if v[0] < 100]
     times = {v[2]: [] for v in variants}

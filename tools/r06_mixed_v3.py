@@ -16,7 +16,7 @@ def t(f, reps=3):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
 ref = None
 for rnd in range(2):
-    for uk, mt, st in [(0, 0, 8), (5, 64, 4)] + [(5, 64, 1000 + m) for m in mins]:
+    for uk, mt, st in [(0, 0, 8), (5, 64, 1032), (6, 64, 1032)] + [(6, 64, 1000 + m) for m in mins]:
         p.set_option("update_kernel", uk)
         p.set_option("update_v3_head_min_tiles", st - 1000 if st >= 1000 else -1)
         if uk: p.set_option("update_v3_min_tiles", mt); p.set_option("update_v3_st", 4)
