@@ -165,9 +165,24 @@ __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {
                                        (__attribute__((address_space(3))) void*)(st + kr * 128), 16, 0, 0);
     }
   };
-  auto issue_b = [&](int u) {       // all 256 columns of Rinv for this K tile; never skipped: every wave's vmcnt stays uniform
-    const int uc = u < U ? u : U - 1;
-    dma_tile_buf<0, 4>(dB, wid, (uint32_t)(uc & 15) * BK * 8, sBbase + (u % B_NST) * TB);
+  // K tile kt of the upper-triangular Rinv is zero in the columns < 16 kt: only the pieces (8 columns each) p >= 2 kt are moved, dealt
+  // round-robin over the 8 waves - wave w takes p = 2 kt + w + 8 q, q < 4 - (kt >> 2), clamped to 31 (the few duplicates rewrite the same
+  // bytes) - so every wave issues the SAME number of pieces per step and the counted vmcnt below stays wave-uniform.  37 % fewer LDS-DMA
+  // pieces of B (40 instead of 64 per wave and row tile); the stale columns of a stage are never used (CQR_MMA skips their blocks).
+  auto nbp_of = [&](int u) { return 4 - ((((u < U ? u : U - 1)) & 15) >> 2); };
+  auto issue_b = [&](int u) {
+    const int uc = u < U ? u : U - 1, kt = uc & 15;
+    const int nbp = 4 - (kt >> 2);
+    double* st = sBbase + (u % B_NST) * TB;
+    const uint32_t voff = (wid & 1) ? dB.voff_odd : dB.voff_even;      // piece parity = wave parity (2 kt and 8 q are even)
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (q < nbp) {
+        const int pp = 2 * kt + wid + 8 * q;
+        const uint32_t g8 = (uint32_t)(pp < 31 ? pp : (31 - ((31 - wid) & 1)));   // clamp to the last piece of MY parity (30 or 31)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dB.rsrc, (__attribute__((address_space(3))) void*)(st + g8 * 8 * 16), 16, (int)voff,
+                                                 (int)(g8 * dB.rowgrp + (uint32_t)kt * BK * 8), 0, 0);
+      }
   };
   d4 acc[4][4];
 #pragma unroll
@@ -200,10 +215,13 @@ __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {
   // vmcnt retires loads and stores in issue order (the compiler itself counts past younger stores on gfx950), so "tile t has
   // landed" = at most the younger pieces outstanding: 8 DMA pieces (A(t+1), B(t+1), A(t+2)) plus the 16 stores of the two steps
   // before the wait, if this wave finished a block column there (it does every 4th step: kt % 4 == wn)
-  auto wait_tile = [&](int ulast) {        // ulast = the last step whose stores were issued before this wait
+  // nby = B pieces of the ONE younger B tile in flight at this wait (1 .. 4): the younger loads are 4 pieces of A + nby of B
+  auto wait_tile = [&](int ulast, int nby) {        // ulast = the last step whose stores were issued before this wait
     const bool st_young = !(DIAG & 1) && ((ulast >= 0 && (ulast & 3) == wn) || (ulast >= 1 && ((ulast - 1) & 3) == wn));
-    if (st_young) __builtin_amdgcn_s_waitcnt((24 & 15) | (7 << 4) | (0 << 8) | ((24 >> 4) << 14));
-    else __builtin_amdgcn_s_waitcnt(8 | (7 << 4) | (0 << 8));
+#define CQR_WAITV(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (0 << 8) | (((n) >> 4) << 14))
+    if (st_young) { if (nby >= 4) CQR_WAITV(24); else if (nby == 3) CQR_WAITV(23); else if (nby == 2) CQR_WAITV(22); else CQR_WAITV(21); }
+    else { if (nby >= 4) CQR_WAITV(8); else if (nby == 3) CQR_WAITV(7); else if (nby == 2) CQR_WAITV(6); else CQR_WAITV(5); }
+#undef CQR_WAITV
     __builtin_amdgcn_s_barrier();
   };
   // Block column kt = wn + 4 j is complete after K tile kt (K tiles beyond it only meet zeros of Rinv): store it right away, so
@@ -226,11 +244,11 @@ __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {
       }                                                                                                                        \
   }
   issue_a(0); issue_b(0); issue_a(1); issue_b(1); issue_a(2);
-  if (PIPE == 1) {
+  {
     // The tile hand-over (wait + barrier + refill + first fragment reads of the NEXT tile) sits in the middle of a step, between
     // the two k-halves of the current tile, so every wave has half a step of MFMAs queued behind its LDS reads.
     d2 fa0[4], fb0[4], fa1[4], fb1[4];
-    wait_tile(-1);
+    wait_tile(-1, nbp_of(1));                 // tile 0 has landed: younger A(1), A(2), B(1)
     issue_b(2); issue_a(3);
     frags(0, 0, fa0, fb0);
     for (int u = 0; u < U; u++) {
@@ -239,28 +257,11 @@ __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {
       frags(u, 1, fa1, fb1);
       CQR_MMA(fa0, fb0, jlo)
       __builtin_amdgcn_s_waitcnt(63 | (7 << 4) | (0 << 8) | (3 << 14));   // lgkmcnt(0): my reads of tile u are done -> its stages may be refilled
-      wait_tile(u - 1);
+      wait_tile(u - 1, nbp_of(u + 2));        // tile u + 1 has landed: younger A(u + 2), A(u + 3), B(u + 2)
       issue_b(u + 3);
       issue_a(u + 4);
       frags(u + 1, 0, fa0, fb0);
       CQR_MMA(fa1, fb1, jlo)
-      CQR_STORE_COL(u)
-    }
-  } else {
-    for (int u = 0; u < U; u++) {
-      const int kt = u & 15;
-      const int jlo = kt > wn ? (kt - wn + 3) >> 2 : 0;
-      wait_tile(u - 1);
-      issue_b(u + 2);                                          // into the stages of step u-1: consumed before this barrier
-      issue_a(u + 3);
-      if (jlo < 4) {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          d2 fa[4], fb[4];
-          frags(u, h, fa, fb);
-          CQR_MMA(fa, fb, jlo)
-        }
-      }
       CQR_STORE_COL(u)
     }
   }
@@ -309,20 +310,18 @@ int cap_qrapply256_launch(const double* Qin, int64_t ldin, const double* Ri, dou
   static const int contig = CAP_ENV("CAP_CQR_CONTIG") ? atoi(CAP_ENV("CAP_CQR_CONTIG")) : 1;
   ApplyArgs g{Qin, ldin, Ri, Qout, ldout, (int)(m / 128), contig};
   const int grid = (int)std::min<int64_t>(cus, g.ntiles);
-  // CAP_CQR_DIAG is timing surgery only (1 = no stores, 2 = no MFMA: results are wrong); CAP_CQR_PIPE picks the loop form
-  static const int pipe = CAP_ENV("CAP_CQR_PIPE") ? atoi(CAP_ENV("CAP_CQR_PIPE")) : 1;
+  // CAP_CQR_DIAG is timing surgery only (1 = no stores, 2 = no MFMA: results are wrong)
   const size_t lds = (A_NST * TA + B_NST * TB) * sizeof(double);
   const dim3 gr((unsigned)grid), bl(512);
   cap_acc_r(Qin, ldin, m, 256); cap_acc_r(Ri, 256, 256, 256, 1); cap_acc_w(Qout, ldout, m, 256);
   if constexpr (CAP_EXPERIMENTS) {
     static const int diag = CAP_ENV("CAP_CQR_DIAG") ? atoi(CAP_ENV("CAP_CQR_DIAG")) : 0;
-    if (diag == 1) hipLaunchKernelGGL((qrapply256_kernel<1, 0>), gr, bl, lds, s, g);
-    else if (diag == 2) hipLaunchKernelGGL((qrapply256_kernel<2, 0>), gr, bl, lds, s, g);
-    else if (diag == 3) hipLaunchKernelGGL((qrapply256_kernel<3, 0>), gr, bl, lds, s, g);
+    if (diag == 1) hipLaunchKernelGGL((qrapply256_kernel<1, 1>), gr, bl, lds, s, g);
+    else if (diag == 2) hipLaunchKernelGGL((qrapply256_kernel<2, 1>), gr, bl, lds, s, g);
+    else if (diag == 3) hipLaunchKernelGGL((qrapply256_kernel<3, 1>), gr, bl, lds, s, g);
     if (diag >= 1 && diag <= 3) { CAP_HIP(hipGetLastError()); return CAP_OK; }
   }
-  if (pipe == 1) hipLaunchKernelGGL((qrapply256_kernel<0, 1>), gr, bl, lds, s, g);
-  else hipLaunchKernelGGL((qrapply256_kernel<0, 0>), gr, bl, lds, s, g);
+  hipLaunchKernelGGL((qrapply256_kernel<0, 1>), gr, bl, lds, s, g);
   CAP_HIP(hipGetLastError());
   return CAP_OK;
 }
