@@ -249,6 +249,9 @@ def reference_on_operators(n=8192, iters=3, limit_s=90.0, libdirs=None, extra_en
          "residual": float(mr.group(1)), "residual_kind": "the reference's own validator (test/cholesky/validate.hpp:33-46)", "wall_s": time.time() - t0}
     if ms:   # whole process: generation, warm-up, `iters` timed factors and the validator's products
         e["blas_lapack_calls_served"] = int(ms.group(1)); e["bytes_host_to_device"] = int(ms.group(2)); e["bytes_device_to_host"] = int(ms.group(3))
+        mi = re.search(r"([\d.]+) ms inside the entry points", se)
+        if mi:   # (whole process too) - what is NOT inside them is the reference's own host code: serialize / swap / zero-fill loops on one core
+            e["ms_inside_blas_lapack_entry_points_whole_process"] = float(mi.group(1))
     return e
 
 

@@ -4,20 +4,24 @@
 #include "capital_amd.h"
 #include <hip/hip_runtime_api.h>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 
 namespace {
 
-std::atomic<long long> g_calls{0}, g_in{0}, g_out{0};
+std::atomic<long long> g_calls{0}, g_in{0}, g_out{0}, g_us{0};
+// host microseconds spent inside the entry points (staging + operator + copy back): what the seam costs a program, next to the program's own time
+struct Tick { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  ~Tick() { g_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); } };
 
 // CAPCB_REPORT=1: one line on stderr when the process ends - how many calls were served, how many bytes crossed
 void report() {
   int dev = -1;
   (void)hipGetDevice(&dev);
-  fprintf(stderr, "capital_amd_cblas: %lld calls served, %lld bytes host -> device, %lld bytes device -> host, device %d\n", g_calls.load(), g_in.load(),
-          g_out.load(), dev);
+  fprintf(stderr, "capital_amd_cblas: %lld calls served, %lld bytes host -> device, %lld bytes device -> host, device %d, %.1f ms inside the entry points\n",
+          g_calls.load(), g_in.load(), g_out.load(), dev, g_us.load() / 1e3);
 }
 struct Reporter { Reporter() { const char* e = getenv("CAPCB_REPORT"); if (e && *e && *e != '0') atexit(report); } } reporter;
 
@@ -103,6 +107,7 @@ extern "C" {
 void cblas_dgemm(int layout, int transa, int transb, int m, int n, int k, double alpha, const double* A, int lda, const double* B, int ldb,
                  double beta, double* C, int ldc) {
   const char* fn = "cblas_dgemm";
+  Tick whole;
   if (layout != CAPCB_COL_MAJOR && layout != CAPCB_ROW_MAJOR && bad_arg(fn, "layout")) return;
   if (layout != CAPCB_COL_MAJOR) unsupported(fn, "row-major (the reference passes AblasColumnMajor everywhere)");
   if ((!valid_trans(transa) || !valid_trans(transb)) && bad_arg(fn, "transpose flag")) return;
@@ -124,6 +129,7 @@ void cblas_dgemm(int layout, int transa, int transb, int m, int n, int k, double
 void cblas_dtrmm(int layout, int side, int uplo, int transa, int diag, int m, int n, double alpha, const double* A, int lda, double* B,
                  int ldb) {
   const char* fn = "cblas_dtrmm";
+  Tick whole;
   if (layout != CAPCB_COL_MAJOR && layout != CAPCB_ROW_MAJOR && bad_arg(fn, "layout")) return;
   if (side != CAPCB_LEFT && side != CAPCB_RIGHT && bad_arg(fn, "side")) return;
   if (uplo != CAPCB_UPPER && uplo != CAPCB_LOWER && bad_arg(fn, "uplo")) return;
@@ -148,6 +154,7 @@ void cblas_dtrmm(int layout, int side, int uplo, int transa, int diag, int m, in
 
 void cblas_dsyrk(int layout, int uplo, int trans, int n, int k, double alpha, const double* A, int lda, double beta, double* C, int ldc) {
   const char* fn = "cblas_dsyrk";
+  Tick whole;
   if (layout != CAPCB_COL_MAJOR && layout != CAPCB_ROW_MAJOR && bad_arg(fn, "layout")) return;
   if (uplo != CAPCB_UPPER && uplo != CAPCB_LOWER && bad_arg(fn, "uplo")) return;
   if (!valid_trans(trans) && bad_arg(fn, "transpose flag")) return;
@@ -167,6 +174,7 @@ void cblas_dsyrk(int layout, int uplo, int trans, int n, int k, double alpha, co
 
 int LAPACKE_dpotrf(int layout, char uplo, int n, double* a, int lda) {
   const char* fn = "LAPACKE_dpotrf";
+  Tick whole;
   if (layout != CAPCB_COL_MAJOR) { fprintf(stderr, "capital_amd_cblas: %s: row-major is not taken\n", fn); return -1; }
   if (uplo != 'U' && uplo != 'u') { fprintf(stderr, "capital_amd_cblas: %s: uplo '%c' is not taken (the reference removed 'L', cholinv.hpp:9)\n", fn, uplo); return -2; }
   if (n < 0) return -3;
@@ -186,6 +194,7 @@ int LAPACKE_dpotrf(int layout, char uplo, int n, double* a, int lda) {
 
 int LAPACKE_dtrtri(int layout, char uplo, char diag, int n, double* a, int lda) {
   const char* fn = "LAPACKE_dtrtri";
+  Tick whole;
   if (layout != CAPCB_COL_MAJOR) { fprintf(stderr, "capital_amd_cblas: %s: row-major is not taken\n", fn); return -1; }
   if (uplo != 'U' && uplo != 'u') { fprintf(stderr, "capital_amd_cblas: %s: uplo '%c' is not taken\n", fn, uplo); return -2; }
   if (diag != 'N' && diag != 'n') { fprintf(stderr, "capital_amd_cblas: %s: diag '%c' is not taken\n", fn, diag); return -3; }
