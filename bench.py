@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--of", type=int, default=8, help="--replay-rank: ranks of the replayed schedule")
     ap.add_argument("--link-gbps", type=float, default=100.0, help="--replay-rank: modelled bandwidth per xGMI link")
     ap.add_argument("--lat-us", type=float, default=10.0, help="--replay-rank: modelled latency per collective")
+    ap.add_argument("--channels", type=int, default=0, help="--replay-rank: workgroups a collective's stand-in kernel occupies for its modelled time (the CU share of an "
+                                                             "RCCL kernel; 0: none, like the IPC / copy-engine exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs runs")
     ap.add_argument("--no-check", action="store_true", help="skip the residual checks (profiling runs)")
@@ -382,14 +384,14 @@ def main():
         import replay
         ranks = None if args.replay_rank < 0 else [args.replay_rank]
         res = replay.run(args.n, args.of, ranks, 512, args.steps or 3, args.warmup, args.link_gbps, args.lat_us, "auto",
-                         args.occ1_m if args.occ1_m >= 0 else None, args.strip or None)
+                         args.occ1_m if args.occ1_m >= 0 else None, args.strip or None, channels=args.channels)
         print(json.dumps({
             "metric": "PROJECTED fp64 Cholesky TFLOP/s on %d MI355X (max over the replayed ranks of N^3/3 per second of one rank's schedule on ONE GPU; "
                       "peers' data from a finished factor behind a link model) - not a multi-GPU measurement" % args.of,
             "value": res["projected_tf_whole_job"], "unit": "TFLOP/s", "n_gpus": 1, "projection_of_gpus": args.of, "steps": args.steps or 3, "warmup": args.warmup,
             "ms_per_step": res["projected_ms_max_over_ranks"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "N=%d fp64 Cholesky, rank(s) %s of the 1 x %d block-column-cyclic plan replayed on one GPU (tools/replay.py)" % (
-                args.n, "all" if ranks is None else ranks, args.of), "link_GBps_per_link": args.link_gbps, "lat_us": args.lat_us,
+                args.n, "all" if ranks is None else ranks, args.of), "link_GBps_per_link": args.link_gbps, "lat_us": args.lat_us, "collective_kernel_workgroups": args.channels,
                 "projected_frac_of_node_fp64_mfma_peak": res["projected_frac_of_P_gpu_peak"], "projected_speedup_vs_1gpu": res["projected_speedup_vs_1gpu"],
                 "single_gpu_tf_same_box": res["single_gpu_tf"]},
             "ranks": res["ranks"]}))

@@ -24,7 +24,7 @@ struct ReplayCtx {
   int rank, size;
   const double* R; int64_t ldr, n, nb, nblk; int strip;
   const double* Dinv;                         // nblk blocks of nb x nb (ld nb): inverses of R's diagonal blocks
-  double link_GBps, lat_us;
+  double link_GBps, lat_us; int channels;
   int64_t nbcast, ngather;                    // position in the factor call's sequence
   int64_t bytes_in; double model_us; int64_t calls;   // totals since the last reset (what the link model charged)
 };
@@ -32,7 +32,11 @@ struct ReplayCtx {
 inline int64_t lbfirst(int64_t r, int64_t k, int64_t P) { return k >= r ? (k - r) / P + 1 : 0; }
 inline int64_t nblocks_of(int64_t r, int64_t nblk, int64_t P) { return r < nblk ? (nblk - 1 - r) / P + 1 : 0; }
 
+// the stand-in for a collective's kernel: `channels` workgroups of 512 threads holding 32 KiB of LDS each (what an RCCL channel occupies) for the
+// modelled duration; one workgroup of 64 threads when channels <= 1 (copy engines / IPC pushes: no CU share)
 __global__ void replay_spin_kernel(int us) {
+  __shared__ char hold[32768];
+  if (blockDim.x > 64) hold[threadIdx.x] = 0;
   const uint64_t t0 = wall_clock64();
   while (wall_clock64() - t0 < (uint64_t)us * 100ull) __builtin_amdgcn_s_sleep(32);
 }
@@ -55,7 +59,7 @@ __global__ void replay_fill1_kernel(double* recv, const double* send, int P) { i
 int spin(ReplayCtx* c, double bytes, hipStream_t s) {
   const double us = c->lat_us + (c->link_GBps > 0 ? bytes / (c->link_GBps * 1e3) : 0.0);
   c->model_us += us; c->calls++;
-  if (us >= 1.0) hipLaunchKernelGGL(replay_spin_kernel, dim3(1), dim3(64), 0, s, (int)(us + 0.5));
+  if (us >= 1.0) hipLaunchKernelGGL(replay_spin_kernel, dim3(c->channels > 1 ? c->channels : 1), dim3(c->channels > 1 ? 512 : 64), 0, s, (int)(us + 0.5));
   return 0;
 }
 
@@ -116,7 +120,7 @@ int cap_replay_create(cap_comm** comm, void** ctx_out, int rank, int size, const
   ReplayCtx* c = new (std::nothrow) ReplayCtx();
   if (!c) return CAP_ERR_ALLOC;
   c->rank = rank; c->size = size; c->R = R; c->ldr = ldr; c->n = n; c->nb = nb; c->nblk = n / nb; c->strip = strip; c->Dinv = Dinv;
-  c->link_GBps = link_GBps; c->lat_us = lat_us; c->nbcast = c->ngather = 0; c->bytes_in = 0; c->model_us = 0; c->calls = 0;
+  c->link_GBps = link_GBps; c->lat_us = lat_us; c->channels = 0; c->nbcast = c->ngather = 0; c->bytes_in = 0; c->model_us = 0; c->calls = 0;
   const int st = cap_comm_create_callbacks(comm, rank, size, cb_allgather, cb_bcast, cb_allreduce, c);
   if (st != CAP_OK) { delete c; return st; }
   *ctx_out = c;
@@ -130,6 +134,8 @@ int cap_replay_stats(void* ctx, double* out3) {
   c->bytes_in = 0; c->model_us = 0; c->calls = 0;
   return CAP_OK;
 }
+// channels > 1: the link-time spin of every collective occupies that many workgroups (the CU share of an RCCL kernel); <= 1: one small workgroup
+int cap_replay_set_channels(void* ctx, int channels) { ReplayCtx* c = (ReplayCtx*)ctx; if (!c || channels < 0 || channels > 64) return CAP_ERR_ARG; c->channels = channels; return CAP_OK; }
 int cap_replay_set_strip(void* ctx, int strip) { ReplayCtx* c = (ReplayCtx*)ctx; if (!c || (strip != 1 && strip != 2)) return CAP_ERR_ARG; c->strip = strip; c->nbcast = c->ngather = 0; return CAP_OK; }
 void cap_replay_destroy(void* ctx) { delete (ReplayCtx*)ctx; }
 }

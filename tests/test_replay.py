@@ -18,7 +18,7 @@ def test_replay_library_builds_beside_the_product_and_exports_its_entry_points()
     assert os.path.exists(lib) and os.path.basename(lib) == "libcap_replay.so"
     L = ctypes.CDLL(build.LIB, mode=ctypes.RTLD_GLOBAL)      # the product first: the harness links against it
     R = ctypes.CDLL(lib)
-    for name in ("cap_replay_create", "cap_replay_stats", "cap_replay_set_strip", "cap_replay_destroy"):
+    for name in ("cap_replay_create", "cap_replay_stats", "cap_replay_set_strip", "cap_replay_set_channels", "cap_replay_destroy"):
         assert hasattr(R, name), name
         assert not hasattr(L, name), "the replay harness must stay out of the product library: " + name
     # the product-side aid it relies on is an ordinary plan option

@@ -35,6 +35,8 @@ def _replay_lib():
     R.cap_replay_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     R.cap_replay_set_strip.restype = C.c_int
     R.cap_replay_set_strip.argtypes = [C.c_void_p, C.c_int]
+    R.cap_replay_set_channels.restype = C.c_int
+    R.cap_replay_set_channels.argtypes = [C.c_void_p, C.c_int]
     R.cap_replay_destroy.restype = None
     R.cap_replay_destroy.argtypes = [C.c_void_p]
     return R
@@ -97,7 +99,7 @@ def reference_factor(n, nb):
     return Rm, R, dinv, t1
 
 
-def run(n=65536, P=8, ranks=None, nb=512, steps=3, warmup=1, link_GBps=100.0, lat_us=10.0, chain_us="auto", occ1_m=None, strip=None, verbose=False):
+def run(n=65536, P=8, ranks=None, nb=512, steps=3, warmup=1, link_GBps=100.0, lat_us=10.0, chain_us="auto", occ1_m=None, strip=None, verbose=False, channels=0):
     import torch
     from capital_amd import dist_cholesky, _lib
     L = _lib.lib()
@@ -105,7 +107,7 @@ def run(n=65536, P=8, ranks=None, nb=512, steps=3, warmup=1, link_GBps=100.0, la
     assert n % nb == 0
     Rm, Rref, dinv, t_single = reference_factor(n, nb)
     ranks = list(range(P)) if ranks is None else list(ranks)
-    out = {"n": n, "P": P, "nb": nb, "link_GBps_per_link": link_GBps, "lat_us": lat_us, "single_gpu_ms": t_single * 1e3,
+    out = {"n": n, "P": P, "nb": nb, "link_GBps_per_link": link_GBps, "lat_us": lat_us, "collective_kernel_workgroups": channels, "single_gpu_ms": t_single * 1e3,
            "single_gpu_tf": n ** 3 / 3 / t_single / 1e12, "ranks": []}
     names = ["chains", "row_solves", "head_updates", "msg_broadcasts", "strip_exchanges", "bulk_updates"]
     for r in ranks:
@@ -115,6 +117,7 @@ def run(n=65536, P=8, ranks=None, nb=512, steps=3, warmup=1, link_GBps=100.0, la
         if strip: ctx.set_option("strip", strip)
         if occ1_m is not None: ctx.set_option("occ1_m", occ1_m)
         RL.cap_replay_set_strip(comm.ctx, ctx.get_option("strip"))
+        RL.cap_replay_set_channels(comm.ctx, int(channels))
         ctx.fill_symmetric(True)
 
         launches = []
@@ -190,6 +193,7 @@ if __name__ == "__main__":
     ap.add_argument("--n", type=int, default=65536); ap.add_argument("--of", type=int, default=8); ap.add_argument("--ranks", default="")
     ap.add_argument("--steps", type=int, default=3); ap.add_argument("--link-gbps", type=float, default=100.0); ap.add_argument("--lat-us", type=float, default=10.0)
     ap.add_argument("--chain-us", default="auto"); ap.add_argument("--occ1-m", type=int, default=None); ap.add_argument("--strip", type=int, default=None)
+    ap.add_argument("--channels", type=int, default=0, help="workgroups (512 threads, 32 KiB LDS) a collective's stand-in occupies for its modelled time: the CU share of an RCCL kernel (0: none)")
     a = ap.parse_args()
-    res = run(a.n, a.of, [int(x) for x in a.ranks.split(",")] if a.ranks else None, 512, a.steps, 1, a.link_gbps, a.lat_us, a.chain_us, a.occ1_m, a.strip, verbose=True)
+    res = run(a.n, a.of, [int(x) for x in a.ranks.split(",")] if a.ranks else None, 512, a.steps, 1, a.link_gbps, a.lat_us, a.chain_us, a.occ1_m, a.strip, verbose=True, channels=a.channels)
     print(json.dumps({k: v for k, v in res.items() if k != "ranks"}))
