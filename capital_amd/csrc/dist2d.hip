@@ -62,6 +62,9 @@ struct cap_dist2d_plan {
   hipEvent_t ev_init, ev_join_p, ev_join_c, ev_join_m, ev_join_i;
   int strip, depth2, safe;
   int64_t occ1_m;
+  // replay aids (single-GPU replay of one rank, tools/replay.py): what a foreign owner's diagonal-block chain / a foreign process row's block-row
+  // solve take, spun on the message / communication stream behind my own panel stream's position (0: off)
+  int remote_chain_us, remote_solve_us;
   int64_t cnt_gemm, cnt_chain, cnt_copy, cnt_coll;      // launches / collectives of the LAST factor call (this rank)
   // R^-1 streamed with the sweep (complete_inv = 0 / 1): see inverse_step2d
   int complete_inv; int64_t split;
@@ -81,6 +84,11 @@ struct cap_dist2d_plan {
 };
 
 namespace {
+// busy-wait for about `us` microseconds (wall_clock64 ticks at 100 MHz): the replay aids' stand-in for work another rank does
+__global__ void spin_kernel_2d(int us) {
+  const uint64_t t0 = wall_clock64();
+  while (wall_clock64() - t0 < (uint64_t)us * 100ull) __builtin_amdgcn_s_sleep(32);
+}
 __host__ __device__ inline int64_t lbfirst2(int64_t r, int64_t k, int64_t P) { return k >= r ? (k - r) / P + 1 : 0; }   // blocks J <= k owned by r
 __host__ __device__ inline int64_t nblocks_of2(int64_t r, int64_t nblk, int64_t P) { return r < nblk ? (nblk - 1 - r) / P + 1 : 0; }
 
@@ -367,6 +375,7 @@ int cap_dist2d_plan_create(cap_dist2d_plan** plan, int64_t n, int64_t nb, cap_co
   for (int i = 0; i < 4; i++) d->msg[i] = nullptr;
   d->Ri = d->Dall = nullptr;
   d->s_panel = d->s_comm = d->s_msg = d->s_inv = nullptr;
+  d->remote_chain_us = d->remote_solve_us = 0;
   d->occ1_m = 16384 * (int64_t)(P > 1 ? P : 1);        // grows with the rank count like the 1 x P plan's (dist.hip: measured by the single-GPU replay)
   d->strip = d->nblk >= 8 ? 2 : 1; d->depth2 = 1; d->safe = 0; d->complete_inv = -1; d->split = 1;
   d->ipc = 0; d->ipc_ready = d->ipc_failed = false; d->tok = nullptr; d->ev_px = nullptr;
@@ -560,8 +569,13 @@ int cap_dist2d_factor(cap_dist2d_plan* d, const double* Aloc, int64_t lda, void*
         if (inv) { CAP_TRY(cap_copy_rect(Dinv, nb, d->Dall + k * nb2, nb, nb, nb, s1)); d->cnt_copy++; }
         CAP_HIP(hipEventRecord(d->ev_fact[k], s1));
         CAP_HIP(hipStreamWaitEvent(sm, d->ev_fact[k], 0));
-      } else if (in_row && k >= 4) {
-        CAP_HIP(hipStreamWaitEvent(sm, d->ev_rowdone[k - 4], 0));  // the broadcast overwrites the message block row k - 4 was solved with
+      } else if (in_row) {
+        if (k >= 4) CAP_HIP(hipStreamWaitEvent(sm, d->ev_rowdone[k - 4], 0));  // the broadcast overwrites the message block row k - 4 was solved with
+        if (d->remote_chain_us > 0) {     // replay: the owner reaches this point when I do and then needs its chain (see dist.hip, remote_chain_us)
+          CAP_HIP(hipEventRecord(d->ev_fact[k], s1));
+          CAP_HIP(hipStreamWaitEvent(sm, d->ev_fact[k], 0));
+          cap_acc_none(); hipLaunchKernelGGL(spin_kernel_2d, dim3(1), dim3(64), 0, sm, d->remote_chain_us); CAP_HIP(hipGetLastError());
+        }
       }
       // ---- 2. msg(k) = [ R(a, b) | Dinv(k) ] along process row prk
       if (in_row) {
@@ -594,6 +608,10 @@ int cap_dist2d_factor(cap_dist2d_plan* d, const double* Aloc, int64_t lda, void*
       CAP_HIP(hipEventRecord(d->ev_rowdone[k], s1));
       // ---- 4. S_k's piece down my process column (root: process row prk), then into the strip buffer (rows r nb .., ld = q nb)
       CAP_HIP(hipStreamWaitEvent(sc, d->ev_rowdone[k], 0));
+      if (!in_row && ncols > 0 && Pr > 1 && d->remote_chain_us + d->remote_solve_us > 0) {
+        // replay: the process row that owns block row k needs its chain, the message and its row solve before the payload can leave
+        cap_acc_none(); hipLaunchKernelGGL(spin_kernel_2d, dim3(1), dim3(64), 0, sc, d->remote_chain_us + d->remote_solve_us); CAP_HIP(hipGetLastError());
+      }
       if (ncols > 0 && Pr > 1) {
         if (ipc) CAP_TRY(push_move(d, d->col, Pr, pr, pr == prk, Bt, d->peerBt, (int)(k & 1), 0, nb * ncols, d->s_pcol, d->ev_pcol, sc));
         else { CAP_TRY(cap_comm_bcast(d->col, Bt, nb * ncols, prk, (void*)sc)); d->cnt_coll++; }
@@ -780,6 +798,8 @@ int cap_dist2d_set_option(cap_dist2d_plan* d, const char* key, int64_t value) {
     return CAP_OK;
   }
   if (!strcmp(key, "split")) { if (value <= 0) return CAP_ERR_ARG; d->split = value; return CAP_OK; }
+  if (!strcmp(key, "remote_chain_us")) { if (value < 0 || value > 1000000) return CAP_ERR_ARG; d->remote_chain_us = (int)value; return CAP_OK; }
+  if (!strcmp(key, "remote_solve_us")) { if (value < 0 || value > 1000000) return CAP_ERR_ARG; d->remote_solve_us = (int)value; return CAP_OK; }
   return CAP_ERR_ARG;
 }
 

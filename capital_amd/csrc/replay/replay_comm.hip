@@ -15,7 +15,9 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <algorithm>
 #include <new>
+#include <vector>
 
 #include "../../../include/capital_amd.h"
 
@@ -138,4 +140,139 @@ int cap_replay_stats(void* ctx, double* out3) {
 int cap_replay_set_channels(void* ctx, int channels) { ReplayCtx* c = (ReplayCtx*)ctx; if (!c || channels < 0 || channels > 64) return CAP_ERR_ARG; c->channels = channels; return CAP_OK; }
 int cap_replay_set_strip(void* ctx, int strip) { ReplayCtx* c = (ReplayCtx*)ctx; if (!c || (strip != 1 && strip != 2)) return CAP_ERR_ARG; c->strip = strip; c->nbcast = c->ngather = 0; return CAP_OK; }
 void cap_replay_destroy(void* ctx) { delete (ReplayCtx*)ctx; }
+}
+
+// ================================================================================================================================ 2D
+// The same for the Pr x Pc block-cyclic plan (csrc/dist2d.hip, safe mode): three communicators - world (only cap_dist2d_info), my
+// process row, my process column - whose broadcasts follow the plan's loop exactly, so the callbacks GENERATE that sequence and check
+// every call against it:
+//   row:     M(k) = msg(k) = [ R(a,b) | Dinv(k) ] for the block rows k of MY process row (root k % Pc), then per strip the A-operand
+//            pieces A(t, m) of the contributors pcs = pr % Pr + m Pr (the strip's rows at THEIR columns J >= e, ld = q nb)
+//   column:  C(k) = the solved block row k at MY columns J > k (nb x ncols, ld = nb), root k % Pr
+// Foreign roots: the payload is gathered out of R (the table of inverses for Dinv) behind the link model; my own roots: nothing.
+namespace {
+struct Replay2D;
+struct View2D { Replay2D* c; int kind; };      // 0 world, 1 row, 2 column
+struct Ev2D { int type; int64_t k, t; int m; };  // type 0 M(k), 1 A(t, m), 2 C(k)
+struct Replay2D {
+  int rank, Pr, Pc, pr, pc; const double* R; int64_t ldr, n, nb, nblk; int strip; const double* Dinv; double link_GBps, lat_us;
+  std::vector<Ev2D> row, col; size_t irow, icol;
+  int64_t bytes_in; double model_us; int64_t calls;
+  View2D view[3];
+};
+inline int64_t nlc_of(const Replay2D* c, int q) { return nblocks_of(q, c->nblk, c->Pc); }
+void build_sequences(Replay2D* c) {
+  c->row.clear(); c->col.clear(); c->irow = c->icol = 0;
+  const int ncon = c->Pc / c->Pr;
+  for (int64_t a = 0, t = 0; a < c->nblk; a += c->strip, t++) {
+    const int64_t q = std::min<int64_t>(c->strip, c->nblk - a), b = a + q - 1, e = b + 1;
+    for (int64_t r = 0; r < q; r++) {
+      const int64_t k = a + r;
+      if (c->pr == (int)(k % c->Pr) && c->Pc > 1) c->row.push_back(Ev2D{0, k, t, 0});
+      const int64_t ncols = (nlc_of(c, c->pc) - lbfirst(c->pc, k, c->Pc)) * c->nb;
+      if (ncols > 0 && c->Pr > 1) c->col.push_back(Ev2D{2, k, t, 0});
+    }
+    if (e >= c->nblk || c->Pc == 1) continue;
+    for (int m = 0; m < ncon; m++) {
+      const int pcs = c->pr % c->Pr + m * c->Pr;
+      const int64_t cs = (nlc_of(c, pcs) - lbfirst(pcs, b, c->Pc)) * c->nb;
+      if (cs > 0) c->row.push_back(Ev2D{1, a, t, m});
+    }
+  }
+}
+int spin2(Replay2D* c, double bytes, hipStream_t s) {
+  const double us = c->lat_us + (c->link_GBps > 0 ? bytes / (c->link_GBps * 1e3) : 0.0);
+  c->model_us += us; c->calls++;
+  if (us >= 1.0) hipLaunchKernelGGL(replay_spin_kernel, dim3(1), dim3(64), 0, s, (int)(us + 0.5));
+  return 0;
+}
+// piece (ld = ldp) = rows [row0, row0 + rows) of R at the columns of process column q's local blocks lb0 ..: global block lb Pc + q
+__global__ void replay_gather2d_kernel(const double* R, int64_t ldr, double* piece, int64_t ldp, int64_t row0, int64_t rows, int64_t nb, int Pc, int q, int64_t lb0) {
+  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 2, c = blockIdx.y, lb = blockIdx.z;
+  if (i >= rows) return;
+  const int64_t gcol = ((lb0 + lb) * Pc + q) * nb + c;
+  *reinterpret_cast<double2*>(piece + i + (lb * nb + c) * ldp) = *reinterpret_cast<const double2*>(R + row0 + i + gcol * ldr);
+}
+int cb2_bcast(void* vctx, double* buf, int64_t count, int root, void* stream) {
+  View2D* v = (View2D*)vctx; Replay2D* c = v->c;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nb = c->nb, nb2 = nb * nb;
+  if (v->kind == 1) {
+    if (c->irow >= c->row.size()) { fprintf(stderr, "replay2d: row broadcast beyond the sequence\n"); return 1; }
+    const Ev2D ev = c->row[c->irow++];
+    if (ev.type == 0) {
+      const int64_t k = ev.k;
+      if (count != 2 * nb2 || root != (int)(k % c->Pc)) { fprintf(stderr, "replay2d: msg(%lld) out of sequence (count %lld root %d)\n", (long long)k, (long long)count, root); return 1; }
+      if (root != c->pc) {
+        spin2(c, (double)count * 8.0, s); c->bytes_in += count * 8;
+        const dim3 grid((unsigned)((nb / 2 + 255) / 256), (unsigned)nb);
+        if (c->strip == 2 && (k & 1)) hipLaunchKernelGGL(replay_copy_kernel, grid, dim3(256), 0, s, c->R + (k - 1) * nb + k * nb * c->ldr, c->ldr, buf, nb, nb, nb);
+        hipLaunchKernelGGL(replay_copy_kernel, grid, dim3(256), 0, s, c->Dinv + k * nb2, nb, buf + nb2, nb, nb, nb);
+      }
+    } else {
+      const int64_t a = ev.k, q = std::min<int64_t>(c->strip, c->nblk - a), b = a + q - 1, ldS = q * nb;
+      const int pcs = c->pr % c->Pr + ev.m * c->Pr;
+      const int64_t lbs = lbfirst(pcs, b, c->Pc), nbl = nlc_of(c, pcs) - lbs;
+      if (count != ldS * nbl * nb || root != pcs) { fprintf(stderr, "replay2d: A(%lld, %d) out of sequence (count %lld root %d)\n", (long long)ev.t, ev.m, (long long)count, root); return 1; }
+      if (pcs != c->pc) {
+        spin2(c, (double)count * 8.0, s); c->bytes_in += count * 8;
+        hipLaunchKernelGGL(replay_gather2d_kernel, dim3((unsigned)((ldS / 2 + 255) / 256), (unsigned)nb, (unsigned)nbl), dim3(256), 0, s, c->R, c->ldr, buf, ldS, a * nb, ldS, nb,
+                           c->Pc, pcs, lbs);
+      }
+    }
+    if (c->irow == c->row.size() && c->icol == c->col.size()) { c->irow = c->icol = 0; }
+  } else if (v->kind == 2) {
+    if (c->icol >= c->col.size()) { fprintf(stderr, "replay2d: column broadcast beyond the sequence\n"); return 1; }
+    const Ev2D ev = c->col[c->icol++];
+    const int64_t k = ev.k, lbk = lbfirst(c->pc, k, c->Pc), nbl = nlc_of(c, c->pc) - lbk;
+    if (count != nb * nbl * nb || root != (int)(k % c->Pr)) { fprintf(stderr, "replay2d: C(%lld) out of sequence (count %lld root %d)\n", (long long)k, (long long)count, root); return 1; }
+    if (root != c->pr) {
+      spin2(c, (double)count * 8.0, s); c->bytes_in += count * 8;
+      hipLaunchKernelGGL(replay_gather2d_kernel, dim3((unsigned)((nb / 2 + 255) / 256), (unsigned)nb, (unsigned)nbl), dim3(256), 0, s, c->R, c->ldr, buf, nb, k * nb, nb, nb, c->Pc,
+                         c->pc, lbk);
+    }
+    if (c->irow == c->row.size() && c->icol == c->col.size()) { c->irow = c->icol = 0; }
+  } else {
+    fprintf(stderr, "replay2d: unexpected broadcast on the world communicator\n"); return 1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int cb2_allgather(void* vctx, const double* send, double* recv, int64_t cpr, void* stream) {
+  View2D* v = (View2D*)vctx;
+  if (cpr != 1) { fprintf(stderr, "replay2d: unexpected all-gather of %lld doubles per rank\n", (long long)cpr); return 1; }
+  const int np = v->kind == 0 ? v->c->Pr * v->c->Pc : (v->kind == 1 ? v->c->Pc : v->c->Pr);
+  hipLaunchKernelGGL(replay_fill1_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, recv, send, np);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int cb2_allreduce(void*, double*, int64_t, void*) { return 0; }
+}  // namespace
+
+extern "C" {
+// three communicators of rank `rank` = pr Pc + pc of a Pr x Pc grid (Pr | Pc) for cap_dist2d_plan_create(world, Pr, row, col); one context
+int cap_replay2d_create(cap_comm** world, cap_comm** row, cap_comm** col, void** ctx_out, int rank, int Pr, int Pc, const double* R, int64_t ldr, int64_t n, int64_t nb,
+                        int strip, const double* Dinv, double link_GBps, double lat_us) {
+  if (!world || !row || !col || !ctx_out || !R || !Dinv || Pr < 1 || Pc < 1 || Pr * Pc > 8 || Pc % Pr || rank < 0 || rank >= Pr * Pc || n <= 0 || nb <= 0 || n % nb ||
+      (strip != 1 && strip != 2)) return CAP_ERR_ARG;
+  Replay2D* c = new (std::nothrow) Replay2D();
+  if (!c) return CAP_ERR_ALLOC;
+  c->rank = rank; c->Pr = Pr; c->Pc = Pc; c->pr = rank / Pc; c->pc = rank % Pc; c->R = R; c->ldr = ldr; c->n = n; c->nb = nb; c->nblk = n / nb; c->strip = strip;
+  c->Dinv = Dinv; c->link_GBps = link_GBps; c->lat_us = lat_us; c->bytes_in = 0; c->model_us = 0; c->calls = 0;
+  for (int i = 0; i < 3; i++) { c->view[i].c = c; c->view[i].kind = i; }
+  build_sequences(c);
+  int st = cap_comm_create_callbacks(world, rank, Pr * Pc, cb2_allgather, cb2_bcast, cb2_allreduce, &c->view[0]);
+  if (st == CAP_OK) st = cap_comm_create_callbacks(row, c->pc, Pc, cb2_allgather, cb2_bcast, cb2_allreduce, &c->view[1]);
+  if (st == CAP_OK) st = cap_comm_create_callbacks(col, c->pr, Pr, cb2_allgather, cb2_bcast, cb2_allreduce, &c->view[2]);
+  if (st != CAP_OK) { delete c; return st; }
+  *ctx_out = c;
+  return CAP_OK;
+}
+int cap_replay2d_stats(void* ctx, double* out3) {
+  Replay2D* c = (Replay2D*)ctx;
+  if (!c || !out3) return CAP_ERR_ARG;
+  out3[0] = (double)c->bytes_in; out3[1] = c->model_us; out3[2] = (double)c->calls;
+  c->bytes_in = 0; c->model_us = 0; c->calls = 0;
+  return CAP_OK;
+}
+int cap_replay2d_set_strip(void* ctx, int strip) { Replay2D* c = (Replay2D*)ctx; if (!c || (strip != 1 && strip != 2)) return CAP_ERR_ARG; c->strip = strip; build_sequences(c); return CAP_OK; }
+void cap_replay2d_destroy(void* ctx) { delete (Replay2D*)ctx; }
 }

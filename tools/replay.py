@@ -39,6 +39,15 @@ def _replay_lib():
     R.cap_replay_set_channels.argtypes = [C.c_void_p, C.c_int]
     R.cap_replay_destroy.restype = None
     R.cap_replay_destroy.argtypes = [C.c_void_p]
+    R.cap_replay2d_create.restype = C.c_int
+    R.cap_replay2d_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                      C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_double, C.c_double]
+    R.cap_replay2d_stats.restype = C.c_int
+    R.cap_replay2d_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    R.cap_replay2d_set_strip.restype = C.c_int
+    R.cap_replay2d_set_strip.argtypes = [C.c_void_p, C.c_int]
+    R.cap_replay2d_destroy.restype = None
+    R.cap_replay2d_destroy.argtypes = [C.c_void_p]
     return R
 
 
@@ -188,12 +197,89 @@ def run(n=65536, P=8, ranks=None, nb=512, steps=3, warmup=1, link_GBps=100.0, la
     return out
 
 
+class _Comm:
+    def __init__(self, handle, rank, size):
+        self.handle, self.rank, self.size = handle, rank, size
+
+
+def run2d(n=65536, Pr=2, Pc=4, ranks=None, nb=512, steps=3, warmup=1, link_GBps=100.0, lat_us=10.0, chain_us=500, solve_us=300, occ1_m=None, verbose=False):
+    """The same projection for the Pr x Pc block-cyclic plan (csrc/dist2d.hip, safe mode): three replay communicators (world, my process row,
+    my process column) whose broadcasts are generated from the plan's own loop; a foreign owner's chain (chain_us) and a foreign process row's
+    block-row solve (solve_us) are spins behind my panel stream's position (plan options remote_chain_us / remote_solve_us; the defaults are what
+    the 1 x 8 replay measured for a rank's own chain and row solve)."""
+    import torch
+    from capital_amd import dist_cholesky, _lib
+    L = _lib.lib()
+    RL = _replay_lib()
+    assert n % nb == 0 and Pc % Pr == 0
+    Rm, Rref, dinv, t_single = reference_factor(n, nb)
+    P = Pr * Pc
+    ranks = list(range(P)) if ranks is None else list(ranks)
+    out = {"n": n, "grid": "%d x %d" % (Pr, Pc), "nb": nb, "link_GBps_per_link": link_GBps, "lat_us": lat_us, "remote_chain_us": chain_us, "remote_solve_us": solve_us,
+           "single_gpu_ms": t_single * 1e3, "single_gpu_tf": n ** 3 / 3 / t_single / 1e12, "ranks": []}
+    for r in ranks:
+        hw, hr, hc, ctxp = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(RL.cap_replay2d_create(C.byref(hw), C.byref(hr), C.byref(hc), C.byref(ctxp), r, Pr, Pc, Rref.data_ptr(), n, n, nb, 2, dinv.data_ptr(), link_GBps, lat_us),
+                   "cap_replay2d_create")
+        world, row, col = _Comm(hw, r, P), _Comm(hr, r % Pc, Pc), _Comm(hc, r // Pc, Pr)
+        ctx = dist_cholesky.Context2D(n, nb, world, Pr, row, col)
+        ctx.set_option("safe", 1)
+        ctx.set_option("remote_chain_us", int(chain_us)); ctx.set_option("remote_solve_us", int(solve_us))
+        if occ1_m is not None: ctx.set_option("occ1_m", occ1_m)
+        ctx.fill_symmetric(True)
+
+        def timed(k):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(k): ctx.factor()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / k
+        for _ in range(warmup): ctx.factor()
+        assert ctx.last_info() == 0
+        st0 = (C.c_double * 3)(); RL.cap_replay2d_stats(ctxp, st0)
+        t = timed(steps)
+        st = (C.c_double * 3)(); RL.cap_replay2d_stats(ctxp, st)
+        assert ctx.last_info() == 0
+        # my piece of R against the single-GPU factor
+        Rl = ctx.local_R_device()[: ctx.local_cols, : ctx.local_rows]                      # [local col, local row]
+        rows = torch.from_numpy(dist_cholesky.global_index_2d(n, nb, Pr, ctx.pr)).to(Rl.device)
+        cols = torch.from_numpy(dist_cholesky.global_index_2d(n, nb, Pc, ctx.pc)).to(Rl.device)
+        err, ref = 0.0, 0.0
+        for c0 in range(0, cols.numel(), 4096):                                            # in slabs of columns: Rref[cols] would copy 8 GiB at once
+            cc = cols[c0:c0 + 4096]
+            want = Rref[cc][:, rows]
+            err = max(err, float((Rl[c0:c0 + 4096] - want).abs().max())); ref = max(ref, float(want.abs().max()))
+            del want
+        del Rl
+        rec = {"rank": r, "pr": ctx.pr, "pc": ctx.pc, "ms": t * 1e3, "link_model_ms_per_step": st[1] / 1e3 / steps, "GB_from_peers_per_step": st[0] / steps / 1e9,
+               "launch_counts": ctx.launch_counts(), "R_max_abs_diff_vs_single_gpu": err, "R_max_abs": ref}
+        if verbose: print(json.dumps(rec), flush=True)
+        out["ranks"].append(rec)
+        ctx.close()
+        for h in (hw, hr, hc): L.cap_comm_destroy(h)
+        RL.cap_replay2d_destroy(ctxp)
+        del ctx
+        torch.cuda.empty_cache()
+    worst = max(x["ms"] for x in out["ranks"])
+    out["projected_ms_max_over_ranks"] = worst
+    out["projected_tf_whole_job"] = n ** 3 / 3 / (worst * 1e-3) / 1e12
+    out["projected_frac_of_P_gpu_peak"] = out["projected_tf_whole_job"] / (78.6 * P)
+    out["projected_speedup_vs_1gpu"] = t_single * 1e3 / worst
+    del Rm
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=65536); ap.add_argument("--of", type=int, default=8); ap.add_argument("--ranks", default="")
     ap.add_argument("--steps", type=int, default=3); ap.add_argument("--link-gbps", type=float, default=100.0); ap.add_argument("--lat-us", type=float, default=10.0)
     ap.add_argument("--chain-us", default="auto"); ap.add_argument("--occ1-m", type=int, default=None); ap.add_argument("--strip", type=int, default=None)
     ap.add_argument("--channels", type=int, default=0, help="workgroups (512 threads, 32 KiB LDS) a collective's stand-in occupies for its modelled time: the CU share of an RCCL kernel (0: none)")
+    ap.add_argument("--grid-rows", type=int, default=1, help="Pr of the Pr x Pc block-cyclic plan (1: the 1 x P plan)")
     a = ap.parse_args()
+    if a.grid_rows > 1:
+        res = run2d(a.n, a.grid_rows, a.of // a.grid_rows, [int(x) for x in a.ranks.split(",")] if a.ranks else None, 512, a.steps, 1, a.link_gbps, a.lat_us,
+                    500 if a.chain_us == "auto" else int(a.chain_us), 300, a.occ1_m, verbose=True)
+        print(json.dumps({k: v for k, v in res.items() if k != "ranks"}))
+        sys.exit(0)
     res = run(a.n, a.of, [int(x) for x in a.ranks.split(",")] if a.ranks else None, 512, a.steps, 1, a.link_gbps, a.lat_us, a.chain_us, a.occ1_m, a.strip, verbose=True, channels=a.channels)
     print(json.dumps({k: v for k, v in res.items() if k != "ranks"}))
