@@ -383,6 +383,19 @@ def main():
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
         import replay
         ranks = None if args.replay_rank < 0 else [args.replay_rank]
+        if str(args.grid_rows) not in ("auto", "1"):
+            Pr = int(args.grid_rows)
+            res = replay.run2d(args.n, Pr, args.of // Pr, ranks, 512, args.steps or 3, args.warmup, args.link_gbps, args.lat_us, 500, 300, args.occ1_m if args.occ1_m >= 0 else None)
+            print(json.dumps({
+                "metric": "PROJECTED fp64 Cholesky TFLOP/s on %d MI355X, %s block-cyclic plan (max over the replayed ranks of N^3/3 per second of one rank's schedule on ONE GPU; "
+                          "peers' data from a finished factor behind a link model) - not a multi-GPU measurement" % (args.of, res["grid"]),
+                "value": res["projected_tf_whole_job"], "unit": "TFLOP/s", "n_gpus": 1, "projection_of_gpus": args.of, "steps": args.steps or 3, "warmup": args.warmup,
+                "ms_per_step": res["projected_ms_max_over_ranks"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "N=%d fp64 Cholesky, rank(s) %s of the %s block-cyclic plan replayed on one GPU (tools/replay.py run2d)" % (args.n, "all" if ranks is None else ranks, res["grid"]),
+                           "link_GBps_per_link": args.link_gbps, "lat_us": args.lat_us, "projected_frac_of_node_fp64_mfma_peak": res["projected_frac_of_P_gpu_peak"],
+                           "projected_speedup_vs_1gpu": res["projected_speedup_vs_1gpu"], "single_gpu_tf_same_box": res["single_gpu_tf"]},
+                "ranks": res["ranks"]}))
+            return
         res = replay.run(args.n, args.of, ranks, 512, args.steps or 3, args.warmup, args.link_gbps, args.lat_us, "auto",
                          args.occ1_m if args.occ1_m >= 0 else None, args.strip or None, channels=args.channels)
         print(json.dumps({
