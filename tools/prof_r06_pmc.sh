@@ -36,7 +36,7 @@ for r in rows("mp2"):
     if int(r["Grid_Size"]) >= 1024 * 512: a2[r["Counter_Name"]] += float(r["Counter_Value"])
 if a1.get("SQ_VALU_MFMA_BUSY_CYCLES") and a2.get("GRBM_GUI_ACTIVE"):
     print("   matrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8) = %.3f" % (a1["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (a2["GRBM_GUI_ACTIVE"] / 8)))
-print("== CholeskyQR2 2^21 x 256 (tools/cqr_bench.py): per kernel, averages per dispatch (qrapply256 now moves only the non-zero pieces of R^-1)")
+print("== CholeskyQR2 2^21 x 256 (tools/cqr_bench.py): per kernel, averages per dispatch (qrapply256: row-sliced waves, hand-over work inside the MFMA stream)")
 acc = collections.defaultdict(list)
 for r in rows("cqr1"):
     k = "qrapply256" if "qrapply256" in r["Kernel_Name"] else "gram256"
