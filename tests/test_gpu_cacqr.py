@@ -54,7 +54,9 @@ def test_matches_multirank_reference_dump(golden_dir, name):
     assert validate.qr.orthogonality(A, pack) < max(1e-15, 10 * float(g["ref_orthogonality"]))
 
 
-@pytest.mark.parametrize("m,n,variant", [(4096, 64, 2), (5000, 37, 2), (8192, 256, 1), (8192, 256, 2), (100000, 128, 2), (130, 130, 2)])
+# (n = 256, m % 128 == 0 runs the dedicated gram256 / qrapply256 kernels: 8192 = one row tile per workgroup, 33024 = 258 row tiles (two per
+#  workgroup on 129 workgroups), 70272 = 549 row tiles (three per workgroup, the last workgroup short) - the persistent K loop across row tiles)
+@pytest.mark.parametrize("m,n,variant", [(4096, 64, 2), (5000, 37, 2), (8192, 256, 1), (8192, 256, 2), (33024, 256, 1), (70272, 256, 2), (100000, 128, 2), (130, 130, 2)])
 def test_matches_oracle(m, n, variant):
     from capital_amd import cacqr, validate
     A, pack = _run(m, n, variant)
