@@ -889,7 +889,7 @@ def bench_mixed(args, torch, L, C, rank, world, timed):
           and (x_diff is None or x_diff <= 1e-12))
     # roofline of the dominant kernel (bf16 trailing update), measured live with HIP events on its launch stream
     nl, ms, fl, by = p.profile_update(A)
-    roof = {"bound": "hbm", "kernel": "bf16_tn_kernel (trailing update C32 -= S16^T S16: fp32 C read-modify-write, K/4 flop per byte)",
+    roof = {"bound": "hbm", "kernel": "bf16_tn3x_kernel (csrc/bf16_tn3.hip; trailing update C32 -= S16^T S16: fp32 C read-modify-write, K/4 flop per byte)",
             "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
     if nl:
         gbs, tf16 = by / (ms * 1e-3) / 1e9, fl / (ms * 1e-3) / 1e12
