@@ -98,6 +98,7 @@ SIGNATURES = {
     "cap_cholinv_set_option": (cint, [ptr, C.c_char_p, i64]),
     "cap_cholinv_get_option": (i64, [ptr, C.c_char_p]),
     "cap_cholinv_profile": (cint, [ptr, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]),
+    "cap_cholinv_profile_launches": (cint, [ptr, C.POINTER(dbl), C.POINTER(dbl), i64, C.POINTER(i64)]),
     "cap_dist_plan_create": (cint, [C.POINTER(ptr), i64, i64, ptr]),
     "cap_dist_plan_destroy": (cint, [ptr]),
     "cap_dist_local_cols": (i64, [ptr]),

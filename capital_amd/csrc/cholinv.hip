@@ -1404,6 +1404,22 @@ int cap_cholinv_profile(cap_cholinv_plan* p, int64_t* launches, double* ms_total
   return CAP_OK;
 }
 
+// the trailing-update launches of the LAST factor call in profile mode, one by one: up to cap entries of (ms, algorithmic flops); *count = launches
+int cap_cholinv_profile_launches(cap_cholinv_plan* p, double* ms_out, double* flops_out, int64_t cap, int64_t* count) {
+  if (!p || !ms_out || !flops_out || !count || cap < 0) return CAP_ERR_ARG;
+  if (p->dist) return cap_dist_profile_launches(p->dist, ms_out, flops_out, cap, count);
+  *count = 0;
+  if (!p->prof_ev) return CAP_OK;
+  for (int i = 0; i + 1 < p->prof_used; i += 2) {
+    CAP_HIP(hipEventSynchronize((*p->prof_ev)[i + 1]));
+    float ms = 0;
+    CAP_HIP(hipEventElapsedTime(&ms, (*p->prof_ev)[i], (*p->prof_ev)[i + 1]));
+    if (*count < cap) { ms_out[*count] = ms; flops_out[*count] = (*p->prof_flops)[i / 2]; }
+    (*count)++;
+  }
+  return CAP_OK;
+}
+
 // -------------------------------------------------------------------------------------------------
 // operator seam built from the same blocks (lapack::engine::_potrf/_trtri, blas::engine::_trmm, DTRSM)
 // -------------------------------------------------------------------------------------------------

@@ -353,6 +353,8 @@ int cap_chain_inject_timeouts(int count);
  * (HIP events recorded on the stream each launch went to) and summed algorithmic flops
  * (m(m+1)k per launch).  Synchronises on the recorded events.                               */
 int cap_cholinv_profile(cap_cholinv_plan* plan, int64_t* launches, double* ms_total, double* flops_total);
+/* the same launches of the LAST factor call one by one: up to cap entries of (ms, algorithmic flops); *count = launches */
+int cap_cholinv_profile_launches(cap_cholinv_plan* plan, double* ms_out, double* flops_out, int64_t cap, int64_t* count);
 
 /* Multi-GPU blocked Cholesky on a 1 x P block-column-cyclic matrix (the 2D block-cyclic descriptor with
  * Pr = 1): global block column J (width nb) lives on rank J % P as local block J / P; rows are not
