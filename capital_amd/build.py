@@ -71,6 +71,7 @@ def build(force=False, verbose=True):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     check_no_scratch()
+    check_qrapply_requests()
     return LIB
 
 
@@ -160,6 +161,48 @@ def check_no_scratch():
     if bad:
         raise RuntimeError("hot kernels use scratch memory: " + ", ".join("%s (%s B/lane)" % (k, v.get("ScratchSize")) for k, v in bad))
     return res
+
+
+def check_qrapply_requests():
+    """qrapply256_kernel (csrc/cqr_kernels.hip) certifies "K tile u + 1 has landed" with a COUNTED s_waitcnt vmcnt: the count is the number of
+    younger requests by construction - per half step [nq pieces of R^-1 + 2 rows of Q as LDS-DMA, THEN the 8 stores of a finished block column].
+    The order and the counts are the compiler's to keep (sched_group_barrier only asks); this check reads the kernel's machine code and fails
+    when a region between two barriers does not hold exactly the expected requests in that order.  Returns the number of regions checked."""
+    src = os.path.join(CSRC, "cqr_kernels.hip")
+    asm = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(os.path.dirname(HERE), "include"), "-S",
+                          "--cuda-device-only", "-o", "-", src], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
+    m = re.search(r"^(_ZN\S*qrapply256_kernelILi0E\S*):[^\n]*\n(.*?)\.end_amdhsa_kernel", asm, re.S | re.M)
+    if not m:
+        raise RuntimeError("qrapply256_kernel<0> not found in the device assembly")
+    regions, cur = [], []
+    for line in m.group(2).splitlines():
+        t = line.strip()
+        if t.startswith("s_barrier"):
+            regions.append(cur); cur = []
+        elif t.startswith("buffer_load_dwordx4") and " lds" in t:
+            cur.append("L")
+        elif t.startswith("buffer_store_dwordx2"):
+            cur.append("S")
+        elif t.startswith(("buffer_", "global_", "flat_", "scratch_")):
+            cur.append("?")                      # any other vector memory instruction would break the count
+    regions.append(cur)
+    # straight-line steps: prologue (A0 B0 A1 B1 A2 | B2 A3), then for parity 0 and parity 1 the 16 steps of a row tile (second half of every step)
+    nq = lambda kt: 4 - ((kt & 15) >> 2)
+    expect = []
+    for par in (0, 1):
+        for kt in range(16):
+            expect.append("L" * (nq(kt + 3) + 2) + ("S" * 8 if (kt & 1) == par else ""))
+    got = ["".join(r) for r in regions if r]
+    body = list(got)
+    for pro in ("L" * 14, "L" * 6):               # the prologue's two request groups (A0 B0 A1 B1 A2 | B2 A3)
+        if pro not in body:
+            raise RuntimeError("qrapply256_kernel: prologue requests not found: %s" % got)
+        body.remove(pro)
+    if any("?" in g for g in got):
+        raise RuntimeError("qrapply256_kernel: unexpected vector memory instruction next to the counted requests: %s" % got)
+    if sorted(body) != sorted(expect) or any(("S" in g and "L" in g[g.index("S"):]) for g in body):
+        raise RuntimeError("qrapply256_kernel: requests per half step are not [LDS-DMA ..., stores ...] as the counted vmcnt assumes:\n got %s\n expected %s" % (body, expect))
+    return len(body)
 
 
 if __name__ == "__main__":

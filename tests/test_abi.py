@@ -103,6 +103,13 @@ def test_hot_kernels_use_no_scratch(built):
         assert int(res[k]["ScratchSize"]) == 0 and int(res[k]["VGPRs Spill"]) == 0, k
 
 
+def test_qrapply_counted_requests_match_the_machine_code():
+    """qrapply256_kernel waits for 'K tile u + 1 has landed' with a counted vmcnt; the count assumes, per half step, [nq + 2 LDS-DMA requests, then
+    the 8 stores of a finished block column] and nothing else.  The build checks the kernel's machine code against that; so does this test."""
+    from capital_amd import build as b
+    assert b.check_qrapply_requests() == 32          # 16 K steps x 2 column parities
+
+
 def test_no_cpu_fallback():
     """CPU tensors are rejected before any native call; there is no host path to fall back to."""
     import torch
