@@ -223,7 +223,8 @@ __global__ void __launch_bounds__(512, 2) qrapply256_kernel(const ApplyArgs g) {
     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                                         \
   }
   // the finished block column is the FIRST of the half step's MFMA order (4 MFMAs); its 8 stores follow the LDS-DMA requests (the counted
-  // vmcnt of the hand-over relies on this order: requests, then stores)
+  // vmcnt of the hand-over relies on this order: requests, then stores - capital_amd/build.py check_qrapply_requests() reads the kernel's
+  // machine code after every build and fails if a half step holds anything else)
 #define CQY_SCHED_ST()                                                                                                         \
   _Pragma("unroll") for (int q_ = 0; q_ < 8; q_++) {                                                                           \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                         \
