@@ -526,3 +526,27 @@ def test_workspace_follows_the_path_taken():
     cholinv.factor(A, pack, None)
     assert relerr(cholinv.construct_Rinv(pack).to_numpy(), ri_ref) < 1e-12
     assert relerr(cholinv.construct_R(pack).to_numpy(), r_ref) < 1e-13
+
+
+def test_profile_launch_by_launch_agrees_with_the_sums():
+    """cap_cholinv_profile_launches (one entry per trailing-update launch of the last factor call) against cap_cholinv_profile's totals."""
+    import ctypes as C
+    from capital_amd import _lib, cholinv
+    n = 8192
+    A, pack = _factor(n, -1, 1, -5, opts={"profile": 1})
+    assert pack.last_info() == 0
+    L = _lib.lib()
+    nl, ms, fl = C.c_int64(0), C.c_double(0), C.c_double(0)
+    _lib.check(L.cap_cholinv_profile(pack._plan, C.byref(nl), C.byref(ms), C.byref(fl)), "cap_cholinv_profile")
+    cap = 256
+    msv, flv, cnt = (C.c_double * cap)(), (C.c_double * cap)(), C.c_int64(0)
+    _lib.check(L.cap_cholinv_profile_launches(pack._plan, msv, flv, cap, C.byref(cnt)), "cap_cholinv_profile_launches")
+    assert cnt.value == nl.value and 0 < cnt.value <= cap
+    assert abs(sum(flv[i] for i in range(cnt.value)) - fl.value) <= 1e-9 * fl.value
+    assert abs(sum(msv[i] for i in range(cnt.value)) - ms.value) <= 1e-3 * ms.value + 1e-3
+    assert all(msv[i] > 0 and flv[i] > 0 for i in range(cnt.value))
+    # a too small capacity still reports the count and fills what fits
+    cnt2 = C.c_int64(0)
+    _lib.check(L.cap_cholinv_profile_launches(pack._plan, msv, flv, 1, C.byref(cnt2)), "cap_cholinv_profile_launches")
+    assert cnt2.value == cnt.value
+    assert L.cap_cholinv_profile_launches(pack._plan, None, flv, cap, C.byref(cnt)) != 0       # argument check
