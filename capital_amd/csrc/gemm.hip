@@ -726,29 +726,46 @@ __global__ void __launch_bounds__(256) dgemm_tn_skinny_kernel(const SkinnyArgs g
   }
 }
 
-__global__ void __launch_bounds__(256) dgemm_nn_skinny_kernel(const SkinnyArgs g) {
-  __shared__ double part[4][8][64];
+// (round 6: sixteen waves split K instead of four and every wave requests its next 8 k while it multiplies the current 8 - the first version
+//  waited for each group of 8 loads before it asked for the next: 40 of the 50 us of a 1024 x 1024 block step were load latency in series)
+#ifndef NNS_CFG
+#define NNS_CFG 1608
+#endif
+constexpr int NNS_W = NNS_CFG / 100, NNS_U = NNS_CFG % 100;
+__global__ void __launch_bounds__(64 * NNS_W) dgemm_nn_skinny_kernel(const SkinnyArgs g) {
+  __shared__ double part[NNS_W][8][64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 64 + lane;
-  const int64_t kq = ((g.K + 31) / 32) * 8;                       // K quarter, multiple of 8
-  const int64_t kb = wid * kq, ke = (kb + kq < g.K) ? kb + kq : g.K;
+  const int64_t kq = ((g.K + 8 * NNS_W - 1) / (8 * NNS_W)) * 8;   // K share of a wave, multiple of 8
+  const int64_t kb = std::min<int64_t>(wid * kq, g.K), ke = std::min<int64_t>(kb + kq, g.K);
   const double* __restrict__ pa = g.A + row;
   const double* __restrict__ pb = g.B;
   double acc[8];
 #pragma unroll
   for (int c = 0; c < 8; c++) acc[c] = 0.0;
   int64_t k = kb;
-  for (; k + 8 <= ke; k += 8) {
-    double a[8];
+  double a0[NNS_U], a1[NNS_U];
+  auto load = [&](double (&a)[NNS_U], int64_t kk) {
 #pragma unroll
-    for (int u = 0; u < 8; u++) a[u] = pa[(k + u) * g.lda];
+    for (int u = 0; u < NNS_U; u++) a[u] = pa[(kk + u) * g.lda];
+  };
+  auto fma = [&](const double (&a)[NNS_U], int64_t kk) {
 #pragma unroll
     for (int c = 0; c < 8; c++) {
       if (c < g.N) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) acc[c] += a[u] * pb[k + u + (int64_t)c * g.ldb];        // wave-uniform operand
+        for (int u = 0; u < NNS_U; u++) acc[c] += a[u] * pb[kk + u + (int64_t)c * g.ldb];  // wave-uniform operand; k ascending per accumulator
       }
     }
+  };
+  if (k + NNS_U <= ke) {
+    load(a0, k);
+    for (; k + 3 * NNS_U <= ke; k += 2 * NNS_U) {         // two groups per trip: the buffers swap roles without register copies
+      load(a1, k + NNS_U); fma(a0, k);
+      load(a0, k + 2 * NNS_U); fma(a1, k + NNS_U);
+    }
+    if (k + 2 * NNS_U <= ke) { load(a1, k + NNS_U); fma(a0, k); fma(a1, k + NNS_U); k += 2 * NNS_U; }
+    else { fma(a0, k); k += NNS_U; }
   }
   for (; k < ke; k++) {
     const double a = pa[k * g.lda];
@@ -758,16 +775,16 @@ __global__ void __launch_bounds__(256) dgemm_nn_skinny_kernel(const SkinnyArgs g
 #pragma unroll
   for (int c = 0; c < 8; c++) part[wid][c][lane] = acc[c];
   __syncthreads();
-  // thread t: row t & 63, right-hand sides 2 (t >> 6), + 1
-  const int rr = threadIdx.x & 63, c0 = (threadIdx.x >> 6) * 2;
+  // thread t: row t & 63, right-hand side t >> 6; the waves' partial sums are added in wave order (deterministic)
+  const int rr = threadIdx.x & 63, c = threadIdx.x >> 6;
+  if (c < g.N) {
+    double* pc = g.C + (int64_t)blockIdx.x * 64 + rr + (int64_t)c * g.ldc;
+    double sum = part[0][c][rr];
 #pragma unroll
-  for (int c = c0; c < c0 + 2; c++) {
-    if (c < g.N) {
-      double* pc = g.C + (int64_t)blockIdx.x * 64 + rr + (int64_t)c * g.ldc;
-      double v = g.alpha * (part[0][c][rr] + part[1][c][rr] + part[2][c][rr] + part[3][c][rr]);
-      if (g.beta != 0.0) v += g.beta * (*pc);
-      *pc = v;
-    }
+    for (int w = 1; w < NNS_W; w++) sum += part[w][c][rr];
+    double v = g.alpha * sum;
+    if (g.beta != 0.0) v += g.beta * (*pc);
+    *pc = v;
   }
 }
 
@@ -784,7 +801,7 @@ int launch_skinny(int transa, int64_t m, int64_t n, int64_t k, double alpha, con
   } else {
     if (m % 64) return CAP_ERR_UNSUPPORTED;
     note_product(transa, CAP_NOTRANS, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0);
-    hipLaunchKernelGGL(dgemm_nn_skinny_kernel, dim3((unsigned)(m / 64)), dim3(256), 0, stream, g);
+    hipLaunchKernelGGL(dgemm_nn_skinny_kernel, dim3((unsigned)(m / 64)), dim3(64 * NNS_W), 0, stream, g);
   }
   CAP_HIP(hipGetLastError());
   return CAP_OK;
