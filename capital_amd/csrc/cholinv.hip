@@ -1570,7 +1570,7 @@ int cap_trsm_prepare(const double* T, int64_t ldt, int64_t td, int64_t tb, doubl
 }
 
 int cap_trsm_apply(int side, int trans, int64_t m, int64_t n, const double* T, int64_t ldt, const double* Inv, int64_t tb, double* B,
-                   int64_t ldb, double* X, hipStream_t s, int ctag) {
+                   int64_t ldb, double* X, hipStream_t s, int ctag, const float* T32, int64_t ldt32) {
   const bool left = side == CAP_LEFT, tr = trans == CAP_TRANS;
   const int64_t td = left ? m : n;
   const int64_t nblk = cap_ceil_div(td, tb);
@@ -1583,11 +1583,20 @@ int cap_trsm_apply(int side, int trans, int64_t m, int64_t n, const double* T, i
       // X_i = op(Tii^-1) * B_i   (w x n)
       CAP_TRY(cap_gemm_launch(trans, CAP_NOTRANS, w, n, w, 1.0, Ii, tb, B + o, ldb, 0.0, X, w, 0, s, tr ? 16 : 32));
       CAP_TRY(cap_copy_rect(X, w, B + o, ldb, w, n, s));
+      // (with an fp32 copy of T and a few right-hand sides the update streams THAT: same sums, half the bytes; shapes it does not take fall through)
       if (tr) {          // rows below: B_r -= T(i, r)^T X_i
         const int64_t r0 = o + w, rows = td - r0;
-        if (rows > 0) CAP_TRY(cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows, n, w, -1.0, T + o + r0 * ldt, ldt, X, w, 1.0, B + r0, ldb, 0, s, ctag));
+        if (rows > 0) {
+          int st = T32 ? cap_skinny_f32a_launch(CAP_TRANS, rows, n, w, -1.0, T32 + o + r0 * ldt32, ldt32, X, w, 1.0, B + r0, ldb, s) : CAP_ERR_UNSUPPORTED;
+          if (st == CAP_ERR_UNSUPPORTED) st = cap_gemm_launch(CAP_TRANS, CAP_NOTRANS, rows, n, w, -1.0, T + o + r0 * ldt, ldt, X, w, 1.0, B + r0, ldb, 0, s, ctag);
+          CAP_TRY(st);
+        }
       } else {           // rows above: B_r -= T(r, i) X_i
-        if (o > 0) CAP_TRY(cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, o, n, w, -1.0, T + o * ldt, ldt, X, w, 1.0, B, ldb, 0, s, ctag));
+        if (o > 0) {
+          int st = T32 ? cap_skinny_f32a_launch(CAP_NOTRANS, o, n, w, -1.0, T32 + o * ldt32, ldt32, X, w, 1.0, B, ldb, s) : CAP_ERR_UNSUPPORTED;
+          if (st == CAP_ERR_UNSUPPORTED) st = cap_gemm_launch(CAP_NOTRANS, CAP_NOTRANS, o, n, w, -1.0, T + o * ldt, ldt, X, w, 1.0, B, ldb, 0, s, ctag);
+          CAP_TRY(st);
+        }
       }
     } else {
       // X_j = B_j * op(Tjj^-1)   (m x w)

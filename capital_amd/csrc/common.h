@@ -174,8 +174,12 @@ int cap_gemm_small_batched(int transa, int transb, int64_t m, int64_t n, int64_t
 int64_t cap_trsm_block(int64_t td);
 int64_t cap_trsm_prepare_work(int64_t tb);
 int cap_trsm_prepare(const double* T, int64_t ldt, int64_t td, int64_t tb, double* Inv, double* W, hipStream_t s);
+// T32 (optional, LEFT side, n <= 8): the same triangle in fp32 (ld ldt32) - the block updates then stream it instead of T (identical sums when T is its promotion)
 int cap_trsm_apply(int side, int trans, int64_t m, int64_t n, const double* T, int64_t ldt, const double* Inv, int64_t tb, double* B,
-                   int64_t ldb, double* X, hipStream_t s, int ctag = 0);
+                   int64_t ldb, double* X, hipStream_t s, int ctag = 0, const float* T32 = nullptr, int64_t ldt32 = 0);
+// gemm.hip: the streaming product with an fp32 operand (n <= 8, m >= 1024)
+int cap_skinny_f32a_launch(int transa, int64_t m, int64_t n, int64_t k, double alpha, const float* A32, int64_t lda, const double* B, int64_t ldb,
+                           double beta, double* C, int64_t ldc, hipStream_t stream);
 int cap_rec_cholinv_full(double* R, int64_t ldr, double* Ri, int64_t ldi, int64_t n, double* W, int64_t wcap, int* info,
                          hipStream_t s, int64_t info_base);
 int64_t cap_rec_work_size(int64_t n);

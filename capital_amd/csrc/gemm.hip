@@ -669,12 +669,19 @@ int launch_small(int transa, int transb, int64_t m, int64_t n, int64_t k, double
 // ---------------------------------------------------------------------------------------------
 // struct SkinnyArgs: csrc/kargs.h (shared with the CPU kernel models of tests/hipshim)
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <bool F32>
 __global__ void __launch_bounds__(256) dgemm_tn_skinny_kernel(const SkinnyArgs g) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int lr = lane & 15, kg = lane >> 4;
   const int64_t j0 = ((int64_t)blockIdx.x * 4 + wid) * 16;
   if (j0 >= g.M) return;
   const double* __restrict__ pa = g.A + (j0 + lr) * g.lda + 2 * kg;
+  const float* __restrict__ pa32 = g.A32 + (j0 + lr) * g.lda + 2 * kg;          // (F32 only)
+  auto lda2 = [&](int64_t k) -> d2 {                                          // op(A)[k, k + 1] of my column, widened when it is stored in fp32
+    if (F32) { const f2 v = *reinterpret_cast<const f2*>(pa32 + k); return (d2){(double)v.x, (double)v.y}; }
+    return *reinterpret_cast<const d2*>(pa + k);
+  };
   const double* __restrict__ pb = g.B + (int64_t)(lr < g.N ? lr : 0) * g.ldb + 2 * kg;
   const bool bon = lr < g.N;
   // Blocked, compensated summation: every 64 k start from zero accumulators (chains of 8 MFMAs) and are added to the running
@@ -695,7 +702,7 @@ __global__ void __launch_bounds__(256) dgemm_tn_skinny_kernel(const SkinnyArgs g
   for (; k0 + 64 <= g.K; k0 += 64) {          // 8 x (8 k): sixteen 16-byte loads in flight per lane
     d2 a[8], b[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) a[u] = *reinterpret_cast<const d2*>(pa + k0 + 8 * u);
+    for (int u = 0; u < 8; u++) a[u] = lda2(k0 + 8 * u);
 #pragma unroll
     for (int u = 0; u < 8; u++) b[u] = bon ? *reinterpret_cast<const d2*>(pb + k0 + 8 * u) : (d2){0.0, 0.0};
     d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
@@ -709,7 +716,7 @@ __global__ void __launch_bounds__(256) dgemm_tn_skinny_kernel(const SkinnyArgs g
   if (k0 < g.K) {
     d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     for (; k0 < g.K; k0 += 8) {
-      const d2 a = *reinterpret_cast<const d2*>(pa + k0);
+      const d2 a = lda2(k0);
       const d2 b = bon ? *reinterpret_cast<const d2*>(pb + k0) : (d2){0.0, 0.0};
       acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, acc1, 0, 0, 0);
@@ -732,6 +739,7 @@ __global__ void __launch_bounds__(256) dgemm_tn_skinny_kernel(const SkinnyArgs g
 #define NNS_CFG 1608
 #endif
 constexpr int NNS_W = NNS_CFG / 100, NNS_U = NNS_CFG % 100;
+template <bool F32>
 __global__ void __launch_bounds__(64 * NNS_W) dgemm_nn_skinny_kernel(const SkinnyArgs g) {
   __shared__ double part[NNS_W][8][64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -739,6 +747,7 @@ __global__ void __launch_bounds__(64 * NNS_W) dgemm_nn_skinny_kernel(const Skinn
   const int64_t kq = ((g.K + 8 * NNS_W - 1) / (8 * NNS_W)) * 8;   // K share of a wave, multiple of 8
   const int64_t kb = std::min<int64_t>(wid * kq, g.K), ke = std::min<int64_t>(kb + kq, g.K);
   const double* __restrict__ pa = g.A + row;
+  const float* __restrict__ pa32 = g.A32 + row;                                // (F32 only)
   const double* __restrict__ pb = g.B;
   double acc[8];
 #pragma unroll
@@ -747,7 +756,7 @@ __global__ void __launch_bounds__(64 * NNS_W) dgemm_nn_skinny_kernel(const Skinn
   double a0[NNS_U], a1[NNS_U];
   auto load = [&](double (&a)[NNS_U], int64_t kk) {
 #pragma unroll
-    for (int u = 0; u < NNS_U; u++) a[u] = pa[(kk + u) * g.lda];
+    for (int u = 0; u < NNS_U; u++) a[u] = F32 ? (double)pa32[(kk + u) * g.lda] : pa[(kk + u) * g.lda];
   };
   auto fma = [&](const double (&a)[NNS_U], int64_t kk) {
 #pragma unroll
@@ -768,7 +777,7 @@ __global__ void __launch_bounds__(64 * NNS_W) dgemm_nn_skinny_kernel(const Skinn
     else { fma(a0, k); k += NNS_U; }
   }
   for (; k < ke; k++) {
-    const double a = pa[k * g.lda];
+    const double a = F32 ? (double)pa32[k * g.lda] : pa[k * g.lda];
 #pragma unroll
     for (int c = 0; c < 8; c++) if (c < g.N) acc[c] += a * pb[k + (int64_t)c * g.ldb];
   }
@@ -790,18 +799,26 @@ __global__ void __launch_bounds__(64 * NNS_W) dgemm_nn_skinny_kernel(const Skinn
 
 // returns CAP_ERR_UNSUPPORTED when the shape does not qualify (the caller then takes the tile kernels)
 int launch_skinny(int transa, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda, const double* B, int64_t ldb,
-                  double beta, double* C, int64_t ldc, hipStream_t stream) {
+                  double beta, double* C, int64_t ldc, hipStream_t stream, const float* A32 = nullptr) {
   static const int on = CAP_ENV("CAP_SKINNY") ? atoi(CAP_ENV("CAP_SKINNY")) : 1;
   if (!on || n < 1 || n > 8 || m < 64 || k < 8 || (k % 8)) return CAP_ERR_UNSUPPORTED;
-  SkinnyArgs g{A, B, C, lda, ldb, ldc, m, k, (int)n, alpha, beta};
+  SkinnyArgs g{A, B, C, lda, ldb, ldc, m, k, (int)n, alpha, beta, A32};
+  auto note = [&]() {                                     // access notes of the stand-in's race checker (op(A) in fp32: 4-byte elements)
+    if (!A32) { note_product(transa, CAP_NOTRANS, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0); return; }
+    if (!cap_acc_on()) return;
+    if (transa == CAP_TRANS) cap_acc_r(A32, lda, k, m, 0, 4); else cap_acc_r(A32, lda, m, k, 0, 4);
+    cap_acc_r(B, ldb, k, n); cap_acc(beta != 0.0 ? CAP_ACC_RW : CAP_ACC_W, C, ldc, m, n, 0);
+  };
   if (transa == CAP_TRANS) {
-    if ((m % 16) || (lda & 1) || (ldb & 1) || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15)) return CAP_ERR_UNSUPPORTED;
-    note_product(transa, CAP_NOTRANS, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0);
-    hipLaunchKernelGGL(dgemm_tn_skinny_kernel, dim3((unsigned)cap_ceil_div(m, 64)), dim3(256), 0, stream, g);
+    if ((m % 16) || (lda & 1) || (ldb & 1) || (((uintptr_t)(A32 ? (const void*)A32 : (const void*)A)) & (A32 ? 7 : 15)) || (((uintptr_t)B) & 15)) return CAP_ERR_UNSUPPORTED;
+    note();
+    if (A32) hipLaunchKernelGGL(dgemm_tn_skinny_kernel<true>, dim3((unsigned)cap_ceil_div(m, 64)), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL(dgemm_tn_skinny_kernel<false>, dim3((unsigned)cap_ceil_div(m, 64)), dim3(256), 0, stream, g);
   } else {
     if (m % 64) return CAP_ERR_UNSUPPORTED;
-    note_product(transa, CAP_NOTRANS, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0);
-    hipLaunchKernelGGL(dgemm_nn_skinny_kernel, dim3((unsigned)(m / 64)), dim3(64 * NNS_W), 0, stream, g);
+    note();
+    if (A32) hipLaunchKernelGGL(dgemm_nn_skinny_kernel<true>, dim3((unsigned)(m / 64)), dim3(64 * NNS_W), 0, stream, g);
+    else hipLaunchKernelGGL(dgemm_nn_skinny_kernel<false>, dim3((unsigned)(m / 64)), dim3(64 * NNS_W), 0, stream, g);
   }
   CAP_HIP(hipGetLastError());
   return CAP_OK;
@@ -863,6 +880,14 @@ void cap_scratch_release(hipStream_t stream) {
       g_scratch.erase(it);
       return;
     }
+}
+
+// C[m x n] = alpha op(A32) B + beta C with op(A) stored in fp32 (lda in elements) and n <= 8: the streaming kernels with the operand widened in
+// registers - the same fp64 sums as on the promoted copy, half the bytes.  CAP_ERR_UNSUPPORTED when the shape does not qualify.
+int cap_skinny_f32a_launch(int transa, int64_t m, int64_t n, int64_t k, double alpha, const float* A32, int64_t lda, const double* B, int64_t ldb,
+                           double beta, double* C, int64_t ldc, hipStream_t stream) {
+  if (!A32 || m < 1024) return CAP_ERR_UNSUPPORTED;
+  return launch_skinny(transa, m, n, k, alpha, nullptr, lda, B, ldb, beta, C, ldc, stream, A32);
 }
 
 int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,

@@ -65,7 +65,8 @@ struct SmallArgs {
 };
 
 // ---- gemm.hip
-struct SkinnyArgs { const double* A; const double* B; double* C; int64_t lda, ldb, ldc; int64_t M, K; int N; double alpha, beta; };
+// A32 != nullptr: op(A) is read from an fp32 array of the same shape (lda in ELEMENTS) and widened in registers - the same fp64 arithmetic on half the bytes
+struct SkinnyArgs { const double* A; const double* B; double* C; int64_t lda, ldb, ldc; int64_t M, K; int N; double alpha, beta; const float* A32; };
 
 // ---- leaf.hip
 struct Panel64Fold {

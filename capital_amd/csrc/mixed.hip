@@ -1100,8 +1100,10 @@ int cap_mpchol_solve(cap_mpchol_plan* p, const double* A, int64_t lda, const dou
   // 128-wide tile - the residual and every block step of the two substitutions are then bound by HBM, not by 16 x padded flops)
   const int64_t n = p->n, w = nrhs <= 8 ? 8 : cap_round_up(nrhs, 128);
   auto apply_Ainv = [&](double* V) -> int {      // V <- R^-1 R^-T V  (n x w)
-    CAP_TRY(cap_trsm_apply(CAP_LEFT, CAP_TRANS, n, w, p->R64, n, p->Inv, p->tb, V, n, p->Xt, s));
-    return cap_trsm_apply(CAP_LEFT, CAP_NOTRANS, n, w, p->R64, n, p->Inv, p->tb, V, n, p->Xt, s);
+    // up to 8 right-hand sides: the block updates stream the fp32 factor itself (R64 is its exact promotion: the same sums, half the bytes)
+    const float* T32 = w <= 8 ? p->R32 : nullptr;
+    CAP_TRY(cap_trsm_apply(CAP_LEFT, CAP_TRANS, n, w, p->R64, n, p->Inv, p->tb, V, n, p->Xt, s, 0, T32, n));
+    return cap_trsm_apply(CAP_LEFT, CAP_NOTRANS, n, w, p->R64, n, p->Inv, p->tb, V, n, p->Xt, s, 0, T32, n);
   };
   // zero-padded working copies: B, X (= first solve), residual
   CAP_HIP(hipMemsetAsync(p->Bw, 0, sizeof(double) * n * w, s));

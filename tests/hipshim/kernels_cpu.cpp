@@ -203,14 +203,14 @@ void k_dgemm_small(const std::string& name, void** a, unsigned gx, unsigned gy, 
 void k_skinny(void** a, bool tn, unsigned gx) {
   const SkinnyArgs g = arg<SkinnyArgs>(a, 0);
   const int64_t rows = std::min<int64_t>(g.M, (int64_t)gx * 64);
+  auto A = [&](int64_t idx) -> double { return g.A32 ? (double)g.A32[idx] : g.A[idx]; };      // op(A) may live in fp32 (widened, same sums)
   if (tn) {
 #pragma omp parallel for schedule(static)
     for (int64_t r = 0; r < rows; r++)
       for (int c = 0; c < g.N; c++) {
-        const double* x = g.A + r * g.lda; const double* y = g.B + (int64_t)c * g.ldb;
+        const double* y = g.B + (int64_t)c * g.ldb;
         double s = 0.0;
-#pragma omp simd reduction(+ : s)
-        for (int64_t k = 0; k < g.K; k++) s += x[k] * y[k];
+        for (int64_t k = 0; k < g.K; k++) s += A(r * g.lda + k) * y[k];
         double* pc = g.C + r + (int64_t)c * g.ldc;
         *pc = g.beta != 0.0 ? g.alpha * s + g.beta * (*pc) : g.alpha * s;
       }
@@ -222,8 +222,7 @@ void k_skinny(void** a, bool tn, unsigned gx) {
     const int64_t nr = std::min(RB, rows - r0);
     std::vector<double> acc((size_t)nr * g.N, 0.0);
     for (int64_t k = 0; k < g.K; k++) {
-      const double* col = g.A + r0 + k * g.lda;
-      for (int c = 0; c < g.N; c++) { const double b = g.B[k + (int64_t)c * g.ldb]; double* ac = acc.data() + (size_t)c * nr; for (int64_t r = 0; r < nr; r++) ac[r] += col[r] * b; }
+      for (int c = 0; c < g.N; c++) { const double b = g.B[k + (int64_t)c * g.ldb]; double* ac = acc.data() + (size_t)c * nr; for (int64_t r = 0; r < nr; r++) ac[r] += A(r0 + r + k * g.lda) * b; }
     }
     for (int c = 0; c < g.N; c++)
       for (int64_t r = 0; r < nr; r++) { double* pc = g.C + r0 + r + (int64_t)c * g.ldc; const double v = g.alpha * acc[(size_t)c * nr + r]; *pc = g.beta != 0.0 ? v + g.beta * (*pc) : v; }
