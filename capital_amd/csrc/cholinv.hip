@@ -103,11 +103,12 @@ std::mutex g_coop_mu;
 std::vector<CoopSlot>* g_coop_slots = nullptr;
 int* g_coop_fallbacks[16] = {};           // per device: how many chains were re-run after a workgroup gave up waiting (device word)
 hipEvent_t g_coop_fb_zeroed[16] = {};     // recorded behind the one memset that zeroes those words
+hipStream_t g_coop_init_stream[16] = {};  // ... on a stream that lives as long as the process (never the caller's: plans come and go)
 long long* g_coop_trace = nullptr;
 int64_t g_coop_trace_at = -1;
 // (no host synchronisation in here: the first chain of a rank is enqueued in the middle of a multi-stream, multi-rank schedule, and a
 // host that waits for its device there waits for collectives whose partners may not have been enqueued yet.)  The fallback words of a
-// device are zeroed ONCE, on the stream that asks first; every stream that is handed them - this one included, through stream order -
+// device are zeroed ONCE, on a stream of this module; every stream that is handed them
 // waits for that memset's event when its slot is created (chains on other streams read fallbacks[1] with no ordering
 // against the memset; hipMalloc does not zero).  A failing memset leaves nothing published.
 int coop_slot(int** ctr, double** backup, int** fallbacks, hipStream_t s) {
@@ -117,10 +118,14 @@ int coop_slot(int** ctr, double** backup, int** fallbacks, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_coop_mu);
   if (!g_coop_slots) g_coop_slots = new std::vector<CoopSlot>();
   if (!g_coop_fallbacks[dev]) {
+    // The memset and its event live on a stream of THIS module that is never destroyed: the event used to be recorded on the asking plan's
+    // stream, and querying it after that plan (and its streams) had been destroyed failed once in a full suite run with "operation not
+    // permitted on an event last recorded in a capturing stream" (round 6, profiles/r06_experiments.md section 9).
     int* fb = nullptr; hipEvent_t ev = nullptr;
+    if (!g_coop_init_stream[dev]) CAP_HIP(hipStreamCreateWithFlags(&g_coop_init_stream[dev], hipStreamNonBlocking));
     CAP_HIP(hipMalloc((void**)&fb, 4 * sizeof(int)));
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipMemsetAsync(fb, 0, 4 * sizeof(int), s) != hipSuccess ||
-        hipEventRecord(ev, s) != hipSuccess) {
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipMemsetAsync(fb, 0, 4 * sizeof(int), g_coop_init_stream[dev]) != hipSuccess ||
+        hipEventRecord(ev, g_coop_init_stream[dev]) != hipSuccess) {
       (void)hipGetLastError();
       if (ev) (void)hipEventDestroy(ev);
       (void)hipFree(fb);

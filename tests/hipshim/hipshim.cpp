@@ -372,7 +372,9 @@ hipError_t hipEventDestroy(hipEvent_t e) { std::lock_guard<std::mutex> lk(mu); n
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { std::lock_guard<std::mutex> lk(mu); orphan_check("hipEventRecord"); note("RECORD %d %d", sid(s), eid(e)); return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { std::lock_guard<std::mutex> lk(mu); orphan_check("hipStreamWaitEvent"); note("WAIT %d %d", sid(s), eid(e)); return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t e) { std::lock_guard<std::mutex> lk(mu); note("HOSTSYNC event %d", eid(e)); return hipSuccess; }
-hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+// (the stand-in runs everything at once, so a query always finds the event complete - and a successful query IS host knowledge of that: what the
+//  host enqueues afterwards is ordered behind the event, exactly like after hipEventSynchronize)
+hipError_t hipEventQuery(hipEvent_t e) { std::lock_guard<std::mutex> lk(mu); note("HOSTSYNC event %d", eid(e)); return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 1.0f; return hipSuccess; }
 
 // ---------------------------------------------------------------- RCCL: one-rank communicators only; every collective is a traced op
