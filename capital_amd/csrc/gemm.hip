@@ -16,7 +16,7 @@
 //   holds C[i = lane&15][j = (lane>>4)+4r]: 16 consecutive rows of a column -> 128-byte
 //   store segments in column-major C.
 //   Blocks are remapped XCD-aware: block b runs on XCD b%8; each XCD walks a contiguous
-//   range of 8x8-tile supertiles so its private L2 sees compact A/B panels.
+//   range of supertiles (2x2 tiles; 8x8 for the NN products with a triangular operand) so its private L2 sees compact A/B panels.
 #include <algorithm>
 #include <cstdlib>
 #include <map>
@@ -36,7 +36,8 @@ constexpr int LDK = BK + 2;       // K-contiguous LDS row stride (doubles)
 constexpr int LDO = 128 + 16;     // outer-contiguous LDS row stride (doubles)
 constexpr int TILE_ELEMS = 128 * LDK;  // == BK * LDO == 2304 doubles
 static_assert(128 * LDK == BK * LDO, "both LDS layouts use the same footprint");
-constexpr int ST = 8;             // supertile edge (tiles)
+constexpr int ST = 8;             // supertile edge (tiles) of the NN products with a triangular operand
+constexpr int ST_SMALL = 2;       // ... of everything else, see cap_gemm_launch
 
 // struct GemmArgs: csrc/kargs.h (shared with the CPU kernel models of tests/hipshim)
 
@@ -933,8 +934,13 @@ int cap_gemm_launch(int transa, int transb, int64_t m, int64_t n, int64_t k, dou
   g.stair = 0; g.gather = 0; g.sP = 1; g.sp = 0; g.snbT = 1; g.sJ0 = 0; g.slb0 = 0; g.gpiece = 0; g.rP = 1; g.rp = 0; g.rlb0 = 0;
   for (int i = 0; i < 8; i++) g.gstart[i] = 0;
   g.tm = (int)cap_ceil_div(m, BM); g.tn = (int)cap_ceil_div(n, BN);
-  static const int st_env = CAP_ENV("CAP_ST") ? atoi(CAP_ENV("CAP_ST")) : ST;
-  g.st = st_env; g.stm = g.st; g.stn = g.st; g.sorder = 0;
+  // Supertile edge.  Round 6 (profiles/r06_experiments.md section 10): edge 2 instead of 8 makes the factorizations 0.7 - 2 % faster (N = 65536 / 32768:
+  // the XCDs' slot ranges end more evenly and the diagonal supertiles carry 1 empty slot of 4 instead of 28 of 64), edge 4 would cut the
+  // operand re-fetch by 30 % for half of that gain; the NN products with a triangular operand (the inverse tree) keep 8 - their band mapping
+  // below is built on it and they lose 5 % without it.
+  static const int st_env = CAP_ENV("CAP_ST") ? atoi(CAP_ENV("CAP_ST")) : 0;
+  g.st = st_env > 0 ? st_env : ((g.bupper || g.aupn) ? ST : ST_SMALL);
+  g.stm = g.st; g.stn = g.st; g.sorder = 0;
   g.nsm = (int)cap_ceil_div(g.tm, g.st); g.nsn = (int)cap_ceil_div(g.tn, g.st);
   int64_t nsuper;
   g.etri = (tri != 0 && g.nsm == g.nsn) ? tri : 0;

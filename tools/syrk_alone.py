@@ -4,7 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from capital_amd import _lib
 L = _lib.lib()
-for n, K in ((57344, 2048), (57344, 1024), (32768, 2048), (16384, 2048), (8192, 2048), (8192, 8192)):
+shapes = ((57344, 2048), (57344, 1024), (32768, 2048), (16384, 2048), (8192, 2048), (8192, 8192))
+if os.environ.get("SYRK_ONLY"): shapes = shapes[:1]
+for n, K in shapes:
     a = torch.randn(n, K, dtype=torch.float64, device="cuda")       # column-major K x n (ld = K)
     c = torch.zeros(n, n, dtype=torch.float64, device="cuda")
     def run(): 
