@@ -1037,9 +1037,12 @@ int cap_dist_update_launch(int64_t m, int64_t nloc, int64_t k, const double* G, 
   g.A = G; g.B = B; g.C = C; g.lda = k; g.ldb = k; g.ldc = ldc;
   g.M = m; g.N = nloc; g.K = k; g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.etri = 0;
   g.tm = (int)(m / BM); g.tn = (int)(nloc / BN);
-  g.st = ST; g.stm = ST; g.stn = ST; g.sorder = 0;
+  // (round 6: 16 tiles per supertile instead of 64 - the distributed update alone gains 3 - 4 % in rank shapes of a 1 x 8 plan, the replayed rank 1.7 %;
+  //  the one-rank plans do not care; profiles/r06_experiments.md section 10)
+  constexpr int DIST_ST = 4;
+  g.st = DIST_ST; g.stm = DIST_ST; g.stn = DIST_ST; g.sorder = 0;
   // block-column-shaped supertiles where the staircase is steep (1 x P with P >= 4: P row tiles per local column tile), see stair_cnt
-  if (Pr == 1 && P >= 4 && nb / 128 >= 2 && nb / 128 <= 8 && (ST * ST) % (nb / 128) == 0) { g.stn = nb / 128; g.stm = ST * ST / g.stn; }
+  if (Pr == 1 && P >= 4 && nb / 128 >= 2 && nb / 128 <= 8 && (DIST_ST * DIST_ST) % (nb / 128) == 0 && DIST_ST * DIST_ST >= nb / 128) { g.stn = nb / 128; g.stm = DIST_ST * DIST_ST / g.stn; }
   g.nsm = (int)cap_ceil_div(g.tm, g.stm); g.nsn = (int)cap_ceil_div(g.tn, g.stn);
   g.ksplit = 1; g.kchunk = k; g.P = nullptr; g.slab = 0;
   g.hiprio = 0; g.ctr = nullptr; g.bupper = 0; g.aupt = 0; g.aupn = 0;
